@@ -1,0 +1,263 @@
+"""Golden-vector generator.  Runs ONLY in the build container (needs /root/reference); its outputs
+(``tests/golden/*.npz``, ``*.json``) are committed and are the only thing that travels.
+
+What it does:
+  * registers a stub ``sam2_train`` package so the reference's ``__init__`` (Hydra) is skipped, then imports the
+    reference's own modules from /root/reference on CPU;
+  * builds ``SAM2Base`` directly from the YAML leaves of ``sam2_train/sam2_hiera_{s,t}.yaml`` (+ the overrides of
+    ``build_sam.py:26-31,56-65``);
+  * shims: S1 ``model.image_size = N; model._build_sam_heads()``; S2 dense prompt embedding returned at
+    ``image_embedding_size`` (undoes prompt_encoder.py:189-190); S3 ``cell_nums=None`` default for
+    ``MaskDecoder.forward``; S5 ``Tensor.cuda`` -> identity on this CPU-only box;
+  * loads the build-owned name-keyed weights with ``load_state_dict(strict=True)`` (which also pins
+    ``medical-sam2_amd/weights.py``'s key/shape table against the reference);
+  * runs the reference on seeded synthetic inputs and stores inputs-by-seed + expected outputs.
+
+Usage:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tests", "golden")
+
+pkg = types.ModuleType("sam2_train")
+pkg.__path__ = ["/root/reference/sam2_train"]
+sys.modules["sam2_train"] = pkg
+
+import torch.nn.functional as F  # noqa: E402
+from sam2_train.modeling.backbones.hieradet import Hiera  # noqa: E402
+from sam2_train.modeling.backbones.image_encoder import FpnNeck, ImageEncoder  # noqa: E402
+from sam2_train.modeling.memory_attention import MemoryAttention, MemoryAttentionLayer  # noqa: E402
+from sam2_train.modeling.memory_encoder import CXBlock, Fuser, MaskDownSampler, MemoryEncoder  # noqa: E402
+from sam2_train.modeling.position_encoding import PositionEmbeddingSine  # noqa: E402
+from sam2_train.modeling.sam import mask_decoder as ref_md  # noqa: E402
+from sam2_train.modeling.sam import prompt_encoder as ref_pe  # noqa: E402
+from sam2_train.modeling.sam.transformer import RoPEAttention  # noqa: E402
+from sam2_train.modeling.sam2_base import SAM2Base  # noqa: E402
+
+import medical_sam2_amd.synthetic as syn  # noqa: E402
+import medical_sam2_amd.weights as wts  # noqa: E402
+
+torch.Tensor.cuda = lambda self, *a, **k: self  # S5
+
+
+def _pe_forward_s2(self, points, boxes, masks, batch_size=-1):  # S2
+    bs = self._get_batch_size(points, boxes, masks)
+    sparse = torch.empty((bs, 0, self.embed_dim), device=self._get_device())
+    if points is not None:
+        coords, labels = points
+        sparse = torch.cat([sparse, self._embed_points(coords, labels, pad=(boxes is None))], dim=1)
+    if boxes is not None:
+        sparse = torch.cat([sparse, self._embed_boxes(boxes)], dim=1)
+    if masks is not None:
+        dense = self._embed_masks(masks)
+    else:
+        dense = self.no_mask_embed.weight.reshape(1, -1, 1, 1).expand(
+            bs, -1, self.image_embedding_size[0], self.image_embedding_size[1])
+    return sparse, dense
+
+
+ref_pe.PromptEncoder.forward = _pe_forward_s2
+_md_forward = ref_md.MaskDecoder.forward
+
+
+def _md_forward_s3(self, image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings, multimask_output,
+                   repeat_image, cell_nums=None, high_res_features=None):  # S3
+    return _md_forward(self, image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings,
+                       multimask_output, repeat_image, cell_nums, high_res_features)
+
+
+ref_md.MaskDecoder.forward = _md_forward_s3
+
+
+def build_reference(model: str, image_size: int, seed: int = 0) -> SAM2Base:
+    tc = wts.trunk_config(model)
+    trunk = Hiera(embed_dim=tc["embed_dim"], num_heads=tc["num_heads"], stages=tc["stages"],
+                  global_att_blocks=tc["global_att_blocks"], window_pos_embed_bkg_spatial_size=tc["bkg"])
+    neck = FpnNeck(position_encoding=PositionEmbeddingSine(num_pos_feats=256, normalize=True, scale=None, temperature=10000),
+                   d_model=256, backbone_channel_list=trunk.channel_list, fpn_top_down_levels=[2, 3],
+                   fpn_interp_model="nearest")
+    enc = ImageEncoder(trunk=trunk, neck=neck, scalp=1)
+
+    def rope(**kw):
+        return RoPEAttention(rope_theta=10000.0, feat_sizes=[32, 32], embedding_dim=256, num_heads=1, downsample_rate=1,
+                             dropout=0.1, **kw)
+
+    layer = MemoryAttentionLayer(activation="relu", dim_feedforward=2048, dropout=0.1, pos_enc_at_attn=False,
+                                 self_attention=rope(), d_model=256, pos_enc_at_cross_attn_keys=True,
+                                 pos_enc_at_cross_attn_queries=False,
+                                 cross_attention=rope(rope_k_repeat=True, kv_in_dim=64))
+    mem_attn = MemoryAttention(d_model=256, pos_enc_at_input=True, layer=layer, num_layers=4)
+    mem_enc = MemoryEncoder(out_dim=64,
+                            position_encoding=PositionEmbeddingSine(num_pos_feats=64, normalize=True, scale=None,
+                                                                    temperature=10000),
+                            mask_downsampler=MaskDownSampler(kernel_size=3, stride=2, padding=1),
+                            fuser=Fuser(layer=CXBlock(dim=256, kernel_size=7, padding=3, layer_scale_init_value=1e-6,
+                                                      use_dwconv=True), num_layers=2))
+    m = SAM2Base(image_encoder=enc, memory_attention=mem_attn, memory_encoder=mem_enc, num_maskmem=7, image_size=1024,
+                 sigmoid_scale_for_mem_enc=20.0, sigmoid_bias_for_mem_enc=-10.0, use_mask_input_as_output_without_sam=True,
+                 directly_add_no_mem_embed=True, use_high_res_features_in_sam=True, multimask_output_in_sam=True,
+                 iou_prediction_use_sigmoid=True, use_obj_ptrs_in_encoder=True, add_tpos_enc_to_obj_ptrs=False,
+                 only_obj_ptrs_in_the_past_for_eval=True, pred_obj_scores=True, pred_obj_scores_mlp=True,
+                 fixed_no_obj_ptr=True, multimask_output_for_tracking=True, use_multimask_token_for_obj_ptr=True,
+                 multimask_min_pt_num=0, multimask_max_pt_num=1, use_mlp_for_obj_ptr_proj=True,
+                 compile_image_encoder=False, binarize_mask_from_pts_for_mem_enc=True,
+                 sam_mask_decoder_extra_args=dict(dynamic_multimask_via_stability=True,
+                                                  dynamic_multimask_stability_delta=0.05,
+                                                  dynamic_multimask_stability_thresh=0.98))
+    m.image_size = image_size  # S1
+    m._build_sam_heads()
+    sd = wts.init_weights(model, seed)
+    m.load_state_dict(sd, strict=True)
+    return m.eval()
+
+
+def stats(t: torch.Tensor, stride: int = 0):
+    t = t.detach().float().contiguous()
+    d = {"shape": list(t.shape), "sum": float(t.double().sum()), "abs_sum": float(t.double().abs().sum())}
+    return d
+
+
+def sub(t: torch.Tensor, n: int = 4096) -> np.ndarray:
+    """Deterministic strided subsample of the flattened tensor (index i*step for i<n)."""
+    f = t.detach().float().contiguous().flatten()
+    step = max(1, f.numel() // n)
+    return f[::step][:n].numpy().copy()
+
+
+def run_slice_chain(model: str, image_size: int, n_slices: int, tag: str, store_full: bool):
+    """cond slice 0 (point prompt) then n_slices-1 propagated slices through the reference's forward_image/track_step."""
+    m = build_reference(model, image_size)
+    out = {}
+    meta = {"model": model, "image_size": image_size, "n_slices": n_slices, "weights_seed": 0}
+    output_dict = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
+    with torch.no_grad():
+        for t in range(n_slices):
+            img, pts, labels = syn.image_batch([10 + t], image_size)
+            # keep the click inside the same blob layout for every slice: reuse slice-0 click on slice 0 only
+            bo = m.forward_image(img)
+            _, feats, pos, sizes = m._prepare_backbone_features(bo)
+            if t == 0:
+                trunk_blocks = {}
+                x = m.image_encoder.trunk.patch_embed(img)
+                x = x + m.image_encoder.trunk._get_pos_embed(x.shape[1:3])
+                out[f"{tag}_pos_embed_sub"] = sub(m.image_encoder.trunk._get_pos_embed(x.shape[1:3]))
+                for i, blk in enumerate(m.image_encoder.trunk.blocks):
+                    x = blk(x)
+                    trunk_blocks[f"block{i}"] = stats(x)
+                    out[f"{tag}_block{i}_sub"] = sub(x)
+                meta["trunk_blocks"] = trunk_blocks
+                for lvl in range(3):
+                    key = f"{tag}_fpn{lvl}"
+                    if store_full:
+                        out[key] = bo["backbone_fpn"][lvl].numpy().copy()
+                    out[key + "_sub"] = sub(bo["backbone_fpn"][lvl])
+                    meta[key] = stats(bo["backbone_fpn"][lvl])
+                    out[f"{tag}_pos{lvl}_sub"] = sub(bo["vision_pos_enc"][lvl])
+            point_inputs = {"point_coords": pts, "point_labels": labels} if t == 0 else None
+            cur = m.track_step(frame_idx=t, is_init_cond_frame=(t == 0), current_vision_feats=feats,
+                               current_vision_pos_embeds=pos, feat_sizes=sizes, point_inputs=point_inputs,
+                               mask_inputs=None, output_dict=output_dict, num_frames=n_slices, run_mem_encoder=True)
+            (output_dict["cond_frame_outputs"] if t == 0 else output_dict["non_cond_frame_outputs"])[t] = cur
+            out[f"{tag}_t{t}_pred_masks"] = cur["pred_masks"].numpy().copy()
+            out[f"{tag}_t{t}_obj_ptr"] = cur["obj_ptr"].numpy().copy()
+            if store_full:
+                out[f"{tag}_t{t}_maskmem_features"] = cur["maskmem_features"].numpy().copy()
+            out[f"{tag}_t{t}_maskmem_features_sub"] = sub(cur["maskmem_features"])
+            out[f"{tag}_t{t}_maskmem_pos_sub"] = sub(cur["maskmem_pos_enc"][0])
+            meta[f"t{t}"] = {"pred_masks": stats(cur["pred_masks"]), "fg_frac": float((cur["pred_masks"] > 0).float().mean()),
+                             "maskmem_features": stats(cur["maskmem_features"])}
+    return out, meta
+
+
+def run_modules(model: str, image_size: int, tag: str):
+    """Module-level vectors at a small size: memory attention, SAM heads (multi/single, points/box/mask prompt),
+    memory encoder, dynamic multimask, use_mask_as_output."""
+    m = build_reference(model, image_size)
+    E = image_size // 16
+    g = torch.Generator().manual_seed(77)
+    out, meta = {}, {"model": model, "image_size": image_size}
+    with torch.no_grad():
+        B = 2
+        curr = torch.randn(E * E, B, 256, generator=g)
+        curr_pos = torch.randn(E * E, B, 256, generator=g)
+        n_mem, n_ptr = 3, 2
+        memory = torch.randn(n_mem * E * E + 4 * n_ptr, B, 64, generator=g)
+        memory_pos = torch.randn(n_mem * E * E + 4 * n_ptr, B, 64, generator=g)
+        memory_pos[-4 * n_ptr:] = 0
+        y = m.memory_attention(curr=[curr], curr_pos=[curr_pos], memory=memory, memory_pos=memory_pos,
+                               num_obj_ptr_tokens=4 * n_ptr)
+        out[f"{tag}_memattn_out"] = y.numpy().copy()
+        # no pointer tokens, single memory (2D path, func_2d/function.py:119-125)
+        y2 = m.memory_attention(curr=[curr], curr_pos=[curr_pos], memory=memory[: E * E], memory_pos=memory_pos[: E * E],
+                                num_obj_ptr_tokens=0)
+        out[f"{tag}_memattn_out_noptr"] = y2.numpy().copy()
+        # SAM heads
+        feat = torch.randn(B, 256, E, E, generator=g)
+        hr = [torch.randn(B, 32, 4 * E, 4 * E, generator=g), torch.randn(B, 64, 2 * E, 2 * E, generator=g)]
+        pts = torch.rand(B, 2, 2, generator=g) * image_size
+        labs = torch.tensor([[1, 0], [1, 1]], dtype=torch.int32)
+        for mm in (True, False):
+            r = m._forward_sam_heads(backbone_features=feat, point_inputs={"point_coords": pts, "point_labels": labs},
+                                     mask_inputs=None, high_res_features=hr, multimask_output=mm)
+            k = f"{tag}_heads_mm{int(mm)}"
+            out[k + "_low_multi"], out[k + "_ious"] = r[0].numpy().copy(), r[2].numpy().copy()
+            out[k + "_low"], out[k + "_ptr"], out[k + "_obj"] = r[3].numpy().copy(), r[5].numpy().copy(), r[6].numpy().copy()
+            out[k + "_high_sub"] = sub(r[4])
+        # no prompt (tracking), single-mask branch exercised through dynamic multimask
+        r = m._forward_sam_heads(backbone_features=feat, point_inputs=None, mask_inputs=None, high_res_features=hr,
+                                 multimask_output=True)
+        out[f"{tag}_heads_noprompt_low"], out[f"{tag}_heads_noprompt_ptr"] = r[3].numpy().copy(), r[5].numpy().copy()
+        # box prompt through the prompt encoder alone + dense pe
+        boxes = torch.tensor([[10.0, 20.0, 100.0, 120.0], [30.0, 40.0, 200.0, 220.0]])
+        sp, de = m.sam_prompt_encoder(points=None, boxes=boxes, masks=None)
+        out[f"{tag}_pe_box_sparse"] = sp.numpy().copy()
+        out[f"{tag}_pe_dense_pe_sub"] = sub(m.sam_prompt_encoder.get_dense_pe())
+        # mask prompt
+        mask_in = (torch.rand(B, 1, image_size, image_size, generator=g) > 0.5).float()
+        r = m._use_mask_as_output(feat, hr, mask_in)
+        out[f"{tag}_maskout_low_sub"], out[f"{tag}_maskout_ptr"] = sub(r[0]), r[5].numpy().copy()
+        out[f"{tag}_maskout_obj"] = r[6].numpy().copy()
+        # memory encoder
+        top = torch.randn(E * E, B, 256, generator=g)
+        high = torch.randn(B, 1, image_size, image_size, generator=g) * 3
+        for pts_flag in (True, False):
+            f, p = m._encode_new_memory([top], [(E, E)], high, is_mask_from_pts=pts_flag)
+            out[f"{tag}_memenc_pts{int(pts_flag)}"] = f.numpy().copy()
+        out[f"{tag}_memenc_pos_sub"] = sub(p[0])
+    return out, meta
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    spec = {m: {k: list(v.shape) for k, v in build_reference(m, 256).state_dict().items()} for m in ("hiera_t", "hiera_s")}
+    with open(os.path.join(OUT, "state_dict_keys.json"), "w") as f:
+        json.dump(spec, f)
+    allmeta = {}
+    o, meta = run_modules("hiera_s", 256, "mod256")
+    np.savez_compressed(os.path.join(OUT, "modules_256.npz"), **o)
+    allmeta["modules_256"] = meta
+    o, meta = run_slice_chain("hiera_s", 256, 4, "s256", store_full=True)
+    np.savez_compressed(os.path.join(OUT, "chain_hiera_s_256.npz"), **o)
+    allmeta["chain_hiera_s_256"] = meta
+    o, meta = run_slice_chain("hiera_t", 256, 2, "t256", store_full=False)
+    np.savez_compressed(os.path.join(OUT, "chain_hiera_t_256.npz"), **o)
+    allmeta["chain_hiera_t_256"] = meta
+    o, meta = run_slice_chain("hiera_s", 1024, 3, "s1024", store_full=False)
+    np.savez_compressed(os.path.join(OUT, "chain_hiera_s_1024.npz"), **o)
+    allmeta["chain_hiera_s_1024"] = meta
+    with open(os.path.join(OUT, "meta.json"), "w") as f:
+        json.dump(allmeta, f, indent=1)
+    for fn in sorted(os.listdir(OUT)):
+        print(fn, os.path.getsize(os.path.join(OUT, fn)))
+
+
+if __name__ == "__main__":
+    main()
