@@ -1,0 +1,475 @@
+// Fused (flash-style) non-causal attention forward for gfx950, bf16 in / fp32 softmax + accumulate / bf16 out.
+//
+// Replaces the reference's three F.scaled_dot_product_attention call sites:
+//   hieradet.py:72-76      Hiera windowed / global MHA        (D=96; windows gathered in-kernel, pad keys = qkv bias)
+//   transformer.py:318     RoPEAttention in memory attention  (D=256, 1 head, N_k up to ~1e6 -> split-KV + merge)
+//   transformer.py:258     two-way decoder Attention          (D=16/32 -> attn_small kernel below, not MFMA-shaped)
+//
+// MFMA kernel structure (per wave: 32 queries; per workgroup NW waves share K/V tiles of 32 keys in LDS):
+//   S^T = K * Q^T   via mfma_f32_32x32x16_bf16(A = K rows from LDS (ds_read_b128), B = Q rows held in registers)
+//                   -> lane owns one query column: 16 keys in registers, softmax statistics are lane-local
+//   O^T += V^T * P^T via mfma(A = V^T fragments read with ds_read_b64_tr_b16 from the row-major V tile,
+//                   B = the S^T accumulator itself converted to bf16: its k-order is what the tr-read reproduces)
+//   so the query stays on the lane for both products and the O rescale needs no cross-lane traffic.
+#include "common.h"
+
+struct AttnParams {
+  const bf16 *q, *k, *v;
+  bf16* o;
+  int64_t q_bs, q_hs, q_ts, k_bs, k_hs, k_ts, v_bs, v_hs, v_ts, o_bs, o_hs, o_ts;  // element strides
+  int B, H, Lq, Lk;
+  float scale_log2;
+  // window gather (win=1): batch index z = b * (nwy*nwx) + window; tokens are ws x ws patches of an h x w token image
+  int win, ws_q, ws_k, hq, wq, hk, wk, nwy, nwx;
+  const float *kpad, *vpad;  // [H*D] fp32 rows standing in for zero-padded tokens (the qkv bias slices)
+  // split-KV
+  int splits;
+  float* o_part;   // [splits][Bz][H][Lq][D] fp32, unnormalised
+  float* ml_part;  // [splits][Bz][H][Lq][2]  (running max in log2 domain, partial sum)
+};
+
+template <int D>
+struct AttnCfg {
+  static constexpr int BK = 32;
+  static constexpr int KS = D * 2 + 16;                                  // K tile row stride (bytes)
+  static constexpr int VS = D * 2 + (((D * 2) % 128 == 64) ? 0 : 64);    // V tile row stride: VS % 128 == 64
+  static constexpr int STAGE = BK * (KS + VS);
+  static constexpr int LDS_BYTES = 2 * STAGE;
+};
+
+__device__ __forceinline__ int64_t win_token_offset(int t, int ws, int wy, int wx, int himg, int wimg, bool& valid) {
+  const int ty = t / ws, tx = t - ty * ws;
+  const int y = wy * ws + ty, x = wx * ws + tx;
+  valid = (y < himg) && (x < wimg);
+  return (int64_t)y * wimg + x;
+}
+
+template <int D, int NW, bool WIN>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
+  using C = AttnCfg<D>;
+  constexpr int NT = NW * 64;
+  constexpr int DSTEPS = D / 16;   // k-steps of the QK^T product
+  constexpr int DBLK = D / 32;     // 32-row blocks of O^T
+  constexpr int CPR = D / 8;       // 16-byte chunks per K/V row
+  constexpr int CHUNKS = C::BK * CPR;
+  constexpr int PER = (CHUNKS + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y;
+  const int zz = blockIdx.z;
+  const int split = zz % p.splits;
+  const int z = zz / p.splits;  // batch (x window) index
+  int b = z, wy = 0, wx = 0;
+  if (WIN) {
+    const int nw = p.nwy * p.nwx;
+    b = z / nw;
+    const int w = z - b * nw;
+    wy = w / p.nwx;
+    wx = w - wy * p.nwx;
+  }
+  const bf16* qb = p.q + (int64_t)b * p.q_bs + (int64_t)head * p.q_hs;
+  const bf16* kb = p.k + (int64_t)b * p.k_bs + (int64_t)head * p.k_hs;
+  const bf16* vb = p.v + (int64_t)b * p.v_bs + (int64_t)head * p.v_hs;
+
+  // ---- this lane's query row -> B-operand fragments kept in registers
+  const int qi = blockIdx.x * (NW * 32) + wave * 32 + r;
+  bool qvalid = qi < p.Lq;
+  int64_t qtok = qi;
+  if (WIN && qvalid) qtok = win_token_offset(qi, p.ws_q, wy, wx, p.hq, p.wq, qvalid);
+  bf16x8 qf[DSTEPS];
+#pragma unroll
+  for (int s = 0; s < DSTEPS; ++s) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (qvalid) v = *reinterpret_cast<const uint4*>(qb + qtok * p.q_ts + s * 16 + h * 8);
+    qf[s] = __builtin_bit_cast(bf16x8, v);
+  }
+
+  // ---- key range of this split (multiple of BK per split except the tail)
+  const int tiles_total = (p.Lk + C::BK - 1) / C::BK;
+  const int tiles_per = (tiles_total + p.splits - 1) / p.splits;
+  const int t_begin = split * tiles_per;
+  const int t_end = min(tiles_total, t_begin + tiles_per);
+
+  uint4 rk[PER], rv[PER];
+  auto gload = [&](int tile) {
+    const int key0 = tile * C::BK;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid + i * NT;
+      uint4 kk = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+      if (c < CHUNKS) {
+        const int key = key0 + c / CPR, dc = (c % CPR) * 8;
+        if (key < p.Lk) {
+          bool valid = true;
+          int64_t tok = key;
+          if (WIN) tok = win_token_offset(key, p.ws_k, wy, wx, p.hk, p.wk, valid);
+          if (valid) {
+            kk = *reinterpret_cast<const uint4*>(kb + tok * p.k_ts + dc);
+            vv = *reinterpret_cast<const uint4*>(vb + tok * p.v_ts + dc);
+          } else {
+            bf16x8 a, bb;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              a[e] = f2bf(p.kpad[head * D + dc + e]);
+              bb[e] = f2bf(p.vpad[head * D + dc + e]);
+            }
+            kk = __builtin_bit_cast(uint4, a);
+            vv = __builtin_bit_cast(uint4, bb);
+          }
+        }
+      }
+      rk[i] = kk;
+      rv[i] = vv;
+    }
+  };
+  auto lstore = [&](int buf) {
+    unsigned char* base = smem + buf * C::STAGE;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid + i * NT;
+      if (c < CHUNKS) {
+        const int row = c / CPR, dc = (c % CPR) * 16;
+        *reinterpret_cast<uint4*>(base + row * C::KS + dc) = rk[i];
+        *reinterpret_cast<uint4*>(base + C::BK * C::KS + row * C::VS + dc) = rv[i];
+      }
+    }
+  };
+
+  f32x16 o[DBLK];
+#pragma unroll
+  for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // per-lane LDS byte offsets
+  const int k_off = r * C::KS + h * 16;                                  // + s*32 per k-step
+  const int li = lane & 15;
+  const int v_off = (4 * h + (li >> 2)) * C::VS + (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;  // + (16 s + 8 u) rows + dblk*64 B
+
+  if (t_begin < t_end) {
+    gload(t_begin);
+    lstore(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    if (tile + 1 < t_end) gload(tile + 1);
+    const unsigned char* kbase = smem + cur * C::STAGE;
+    const unsigned char* vbase = kbase + C::BK * C::KS;
+    // S^T[key][query]
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < DSTEPS; ++st) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kbase + k_off + st * 32);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s, 0, 0, 0);
+    }
+    // online softmax (log2 domain); keys of register e: (e&3) + 8*(e>>2) + 4*h
+    const int key0 = tile * C::BK;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      s[e] = (key < p.Lk) ? s[e] * p.scale_log2 : -INFINITY;
+      mx = fmaxf(mx, s[e]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    if (__any(m_new > m_run)) {
+      const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+      m_run = m_new;
+    }
+    float psum = 0.f;
+    bf16x8 pf[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pe = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(s[e] - m_run);
+      psum += pe;
+      pf[e >> 3][e & 7] = f2bf(pe);
+    }
+    l_run += psum;
+    // O^T[d][query] += V^T[d][key] P^T[key][query]
+#pragma unroll
+    for (int d = 0; d < DBLK; ++d) {
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const unsigned char* a0 = vbase + v_off + (16 * st) * C::VS + d * 64;
+        const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (short4_t __attribute__((address_space(3)))*)(a0));
+        const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (short4_t __attribute__((address_space(3)))*)(a0 + 8 * C::VS));
+        typedef __attribute__((ext_vector_type(8))) short short8_t;
+        short8_t vv8;
+        vv8[0] = lo[0]; vv8[1] = lo[1]; vv8[2] = lo[2]; vv8[3] = lo[3];
+        vv8[4] = hi[0]; vv8[5] = hi[1]; vv8[6] = hi[2]; vv8[7] = hi[3];
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv8), pf[st], o[d], 0, 0, 0);
+      }
+    }
+    if (tile + 1 < t_end) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (!qvalid) return;
+  if (p.splits == 1) {
+    const float inv = 1.f / l_tot;
+    bf16* ob = p.o + (int64_t)b * p.o_bs + (int64_t)head * p.o_hs + qtok * p.o_ts;
+#pragma unroll
+    for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = f2bf(o[d][4 * g + e] * inv);
+        *reinterpret_cast<bf16x4*>(ob + d * 32 + 8 * g + 4 * h) = w;
+      }
+  } else {
+    const int64_t Bz = gridDim.z / p.splits;
+    const int64_t row = (((int64_t)split * Bz + z) * p.H + head) * p.Lq + qi;
+    float* op = p.o_part + row * D;
+#pragma unroll
+    for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = o[d][4 * g + e];
+        *reinterpret_cast<f32x4*>(op + d * 32 + 8 * g + 4 * h) = w;
+      }
+    if (h == 0) {
+      p.ml_part[row * 2 + 0] = m_run;
+      p.ml_part[row * 2 + 1] = l_tot;
+    }
+  }
+}
+
+// merge split-KV partials: one wave per (z, head, query); lanes stride over D
+template <int D>
+__global__ void attn_merge_kernel(AttnParams p, int Bz) {
+  const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int64_t rows = (int64_t)Bz * p.H * p.Lq;
+  if (gw >= rows) return;
+  const int qi = gw % p.Lq;
+  const int head = (gw / p.Lq) % p.H;
+  const int z = gw / ((int64_t)p.Lq * p.H);
+  float M = -INFINITY;
+  for (int s = 0; s < p.splits; ++s) M = fmaxf(M, p.ml_part[((int64_t)s * rows + gw) * 2]);
+  float L = 0.f;
+  for (int s = 0; s < p.splits; ++s) {
+    const float m = p.ml_part[((int64_t)s * rows + gw) * 2], l = p.ml_part[((int64_t)s * rows + gw) * 2 + 1];
+    L += (m == -INFINITY) ? 0.f : l * __builtin_amdgcn_exp2f(m - M);
+  }
+  const float inv = 1.f / L;
+  bf16* ob = p.o + (int64_t)z * p.o_bs + (int64_t)head * p.o_hs + (int64_t)qi * p.o_ts;
+  for (int d = lane; d < D; d += 64) {
+    float acc = 0.f;
+    for (int s = 0; s < p.splits; ++s) {
+      const float m = p.ml_part[((int64_t)s * rows + gw) * 2];
+      if (m != -INFINITY) acc += p.o_part[((int64_t)s * rows + gw) * D + d] * __builtin_amdgcn_exp2f(m - M);
+    }
+    ob[d] = f2bf(acc * inv);
+  }
+}
+
+template <int D, int NW, bool WIN>
+static int launch_attn(const AttnParams& p, int Bz, hipStream_t s) {
+  using C = AttnCfg<D>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)attn_fwd_kernel<D, NW, WIN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    attr_set = true;
+  }
+  dim3 grid(cdiv(p.Lq, NW * 32), p.H, Bz * p.splits);
+  hipLaunchKernelGGL((attn_fwd_kernel<D, NW, WIN>), grid, dim3(NW * 64), C::LDS_BYTES, s, p);
+  if (p.splits > 1) {
+    const int64_t rows = (int64_t)Bz * p.H * p.Lq;
+    hipLaunchKernelGGL((attn_merge_kernel<D>), dim3(cdiv(rows * 64, 256)), dim3(256), 0, s, p, Bz);
+  }
+  return msam2_check_launch("attention_fwd");
+}
+
+template <int D, bool WIN>
+static int dispatch_nw(const AttnParams& p, int Bz, hipStream_t s) {
+  if (p.Lq <= 32) return launch_attn<D, 1, WIN>(p, Bz, s);
+  if (p.Lq <= 64) return launch_attn<D, 2, WIN>(p, Bz, s);
+  return launch_attn<D, 4, WIN>(p, Bz, s);
+}
+
+extern "C" size_t msam2_attention_workspace_bytes(int64_t Bz, int64_t H, int64_t Lq, int64_t D, int splits) {
+  if (splits <= 1) return 0;
+  return (size_t)splits * Bz * H * Lq * (D + 2) * sizeof(float);
+}
+
+// q,k,v,o: bf16 with element strides {batch, head, token}; the head dim D is contiguous.
+extern "C" int msam2_attention_fwd(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
+                                   const void* v, const int64_t* v_strides, void* o, const int64_t* o_strides, int64_t B,
+                                   int64_t H, int64_t Lq, int64_t Lk, int64_t D, float scale, int splits, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  MSAM2_REQUIRE(q && k && v && o, "attention: null tensor");
+  MSAM2_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attention: empty problem");
+  MSAM2_REQUIRE(D == 96 || D == 256 || D == 64 || D == 128, "attention: head dim %lld not built (96/256/64/128)", (long long)D);
+  MSAM2_REQUIRE(splits >= 1 && splits <= 64, "attention: bad split count %d", splits);
+  for (int i = 0; i < 3; ++i)
+    MSAM2_REQUIRE(q_strides[i] % 8 == 0 && k_strides[i] % 8 == 0 && v_strides[i] % 8 == 0 && o_strides[i] % 4 == 0,
+                  "attention: strides must keep 16-byte row alignment");
+  const int tiles = (int)((Lk + 31) / 32);
+  if (splits > tiles) splits = tiles;
+  // every split must own at least one tile
+  while (splits > 1 && (int64_t)(splits - 1) * ((tiles + splits - 1) / splits) >= tiles) --splits;
+  MSAM2_REQUIRE(workspace_bytes >= msam2_attention_workspace_bytes(B, H, Lq, D, splits), "attention: workspace too small");
+  AttnParams p = {};
+  p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (bf16*)o;
+  p.q_bs = q_strides[0]; p.q_hs = q_strides[1]; p.q_ts = q_strides[2];
+  p.k_bs = k_strides[0]; p.k_hs = k_strides[1]; p.k_ts = k_strides[2];
+  p.v_bs = v_strides[0]; p.v_hs = v_strides[1]; p.v_ts = v_strides[2];
+  p.o_bs = o_strides[0]; p.o_hs = o_strides[1]; p.o_ts = o_strides[2];
+  p.B = (int)B; p.H = (int)H; p.Lq = (int)Lq; p.Lk = (int)Lk;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  p.splits = splits;
+  p.o_part = (float*)workspace;
+  p.ml_part = p.o_part ? p.o_part + (size_t)splits * B * H * Lq * D : nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  switch (D) {
+    case 96: return dispatch_nw<96, false>(p, (int)B, s);
+    case 256: return dispatch_nw<256, false>(p, (int)B, s);
+    case 64: return dispatch_nw<64, false>(p, (int)B, s);
+    default: return dispatch_nw<128, false>(p, (int)B, s);
+  }
+}
+
+// Windowed attention straight from the un-partitioned token image (replaces window_partition + SDPA +
+// window_unpartition, backbones/utils.py:16-62 + hieradet.py:72-76).  qkv tokens live at
+// base + ((b*h + y)*w + x)*token_stride + head*head_stride; windows are ws x ws, zero-padded at the bottom/right, where a
+// padded token's key/value rows are kpad/vpad (the qkv bias slices, because LayerNorm'ed input was zero-padded).
+extern "C" int msam2_window_attention_fwd(const void* q, int64_t q_token_stride, int64_t q_head_stride, int64_t hq, int64_t wq,
+                                          int64_t ws_q, const void* k, const void* v, int64_t kv_token_stride,
+                                          int64_t kv_head_stride, int64_t hk, int64_t wk, int64_t ws_k, const float* kpad,
+                                          const float* vpad, void* o, int64_t o_token_stride, int64_t o_head_stride, int64_t B,
+                                          int64_t H, int64_t D, float scale, void* stream) {
+  MSAM2_REQUIRE(q && k && v && o && kpad && vpad, "window_attention: null tensor");
+  MSAM2_REQUIRE(D == 96 || D == 64 || D == 128, "window_attention: head dim %lld not built", (long long)D);
+  MSAM2_REQUIRE(ws_q > 0 && ws_k > 0 && hq > 0 && wq > 0 && hk > 0 && wk > 0, "window_attention: bad geometry");
+  const int nwy = (int)((hk + ws_k - 1) / ws_k), nwx = (int)((wk + ws_k - 1) / ws_k);
+  MSAM2_REQUIRE((hq + ws_q - 1) / ws_q == nwy && (wq + ws_q - 1) / ws_q == nwx, "window_attention: q/kv window grids differ");
+  MSAM2_REQUIRE(q_token_stride % 8 == 0 && kv_token_stride % 8 == 0 && q_head_stride % 8 == 0 && kv_head_stride % 8 == 0 &&
+                    o_token_stride % 4 == 0 && o_head_stride % 4 == 0, "window_attention: strides must keep 16-byte alignment");
+  AttnParams p = {};
+  p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (bf16*)o;
+  p.q_bs = hq * wq * q_token_stride; p.q_hs = q_head_stride; p.q_ts = q_token_stride;
+  p.k_bs = hk * wk * kv_token_stride; p.k_hs = kv_head_stride; p.k_ts = kv_token_stride;
+  p.v_bs = p.k_bs; p.v_hs = kv_head_stride; p.v_ts = kv_token_stride;
+  p.o_bs = hq * wq * o_token_stride; p.o_hs = o_head_stride; p.o_ts = o_token_stride;
+  p.B = (int)B; p.H = (int)H; p.Lq = (int)(ws_q * ws_q); p.Lk = (int)(ws_k * ws_k);
+  p.scale_log2 = scale * 1.4426950408889634f;
+  p.win = 1; p.ws_q = (int)ws_q; p.ws_k = (int)ws_k; p.hq = (int)hq; p.wq = (int)wq; p.hk = (int)hk; p.wk = (int)wk;
+  p.nwy = nwy; p.nwx = nwx; p.kpad = kpad; p.vpad = vpad; p.splits = 1;
+  hipStream_t s = (hipStream_t)stream;
+  const int Bz = (int)B * nwy * nwx;
+  switch (D) {
+    case 96: return dispatch_nw<96, true>(p, Bz, s);
+    case 64: return dispatch_nw<64, true>(p, Bz, s);
+    default: return dispatch_nw<128, true>(p, Bz, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Small-head attention for the two-way decoder (transformer.py:239-263): D in {16, 32}, 8 heads, either very few
+// queries (tokens -> image, Lq ~ 8, Lk = 4096) or very few keys (image -> tokens).  One wave per (batch, head, query);
+// lanes stride over the keys with a private online softmax, then a butterfly merge.  fp32 math, bf16 I/O.
+// ------------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ void attn_small_kernel(const bf16* q, const bf16* k, const bf16* v, bf16* o, int64_t q_bs, int64_t q_ts,
+                                  int64_t k_bs, int64_t k_ts, int64_t v_bs, int64_t v_ts, int64_t o_bs, int64_t o_ts, int B,
+                                  int H, int Lq, int Lk, float scale_log2) {
+  const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (gw >= (int64_t)B * H * Lq) return;
+  const int qi = gw % Lq;
+  const int head = (gw / Lq) % H;
+  const int b = gw / ((int64_t)Lq * H);
+  float qv[D];
+  const bf16* qp = q + b * q_bs + (int64_t)qi * q_ts + head * D;
+#pragma unroll
+  for (int d = 0; d < D; d += 8) {
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>(qp + d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[d + e] = bf2f(t[e]) * scale_log2;
+  }
+  float m = -INFINITY, l = 0.f, acc[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) acc[d] = 0.f;
+  for (int key = lane; key < Lk; key += 64) {
+    const bf16* kp = k + b * k_bs + (int64_t)key * k_ts + head * D;
+    const bf16* vp = v + b * v_bs + (int64_t)key * v_ts + head * D;
+    float s = 0.f;
+    float vv[D];
+#pragma unroll
+    for (int d = 0; d < D; d += 8) {
+      const bf16x8 t = *reinterpret_cast<const bf16x8*>(kp + d);
+      const bf16x8 u = *reinterpret_cast<const bf16x8*>(vp + d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s += qv[d + e] * bf2f(t[e]);
+        vv[d + e] = bf2f(u[e]);
+      }
+    }
+    const float mn = fmaxf(m, s);
+    const float a = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - mn);
+    const float pe = __builtin_amdgcn_exp2f(s - mn);
+    l = l * a + pe;
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] = acc[d] * a + pe * vv[d];
+    m = mn;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float m2 = __shfl_xor(m, off, 64), l2 = __shfl_xor(l, off, 64);
+    const float mn = fmaxf(m, m2);
+    const float a1 = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - mn);
+    const float a2 = (m2 == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m2 - mn);
+    l = l * a1 + l2 * a2;
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] = acc[d] * a1 + __shfl_xor(acc[d], off, 64) * a2;
+    m = mn;
+  }
+  if (lane == 0) {
+    bf16* op = o + b * o_bs + (int64_t)qi * o_ts + head * D;
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int d = 0; d < D; ++d) op[d] = f2bf(acc[d] * inv);
+  }
+}
+
+// q/k/v/o: bf16 [B, L, H*D] with element strides {batch, token}
+extern "C" int msam2_attention_small_fwd(const void* q, int64_t q_bs, int64_t q_ts, const void* k, int64_t k_bs, int64_t k_ts,
+                                         const void* v, int64_t v_bs, int64_t v_ts, void* o, int64_t o_bs, int64_t o_ts,
+                                         int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t D, float scale, void* stream) {
+  MSAM2_REQUIRE(q && k && v && o, "attention_small: null tensor");
+  MSAM2_REQUIRE(D == 16 || D == 32, "attention_small: head dim %lld not built (16/32)", (long long)D);
+  MSAM2_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attention_small: empty problem");
+  MSAM2_REQUIRE(q_ts % 8 == 0 && k_ts % 8 == 0 && v_ts % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 && v_bs % 8 == 0,
+                "attention_small: strides must keep 16-byte alignment");
+  const int64_t waves = B * H * Lq;
+  dim3 grid(cdiv(waves * 64, 256));
+  const float sl = scale * 1.4426950408889634f;
+  hipStream_t s = (hipStream_t)stream;
+  if (D == 16)
+    hipLaunchKernelGGL((attn_small_kernel<16>), grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o,
+                       q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts, (int)B, (int)H, (int)Lq, (int)Lk, sl);
+  else
+    hipLaunchKernelGGL((attn_small_kernel<32>), grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o,
+                       q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts, (int)B, (int)H, (int)Lq, (int)Lk, sl);
+  return msam2_check_launch("attention_small");
+}

@@ -1,0 +1,46 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of libmsam2_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define MSAM2_OK 0
+#define MSAM2_ERR_ARG -1
+#define MSAM2_ERR_LAUNCH -2
+
+// error string shared by every translation unit (api.hip owns it)
+void msam2_set_error(const char* fmt, ...);
+int msam2_check_launch(const char* what);
+
+#define MSAM2_REQUIRE(cond, ...)          \
+  do {                                    \
+    if (!(cond)) {                        \
+      msam2_set_error(__VA_ARGS__);       \
+      return MSAM2_ERR_ARG;               \
+    }                                     \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+__device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,384 @@
+// Convolution-shaped pieces of the path (gfx950).  GEMM-shaped convs are lowered to im2col + msam2_gemm_bf16; the
+// small-channel mask down-sampler and the depth-wise 7x7 are direct kernels with their LayerNorm2d(+GELU) fused.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------------------------
+// PatchEmbed (backbones/utils.py:84-95): Conv2d(3,E,k7,s4,p3) as im2col -> [B*(S/4)^2, 160] bf16 (147 taps + zero pad),
+// column order (c, ky, kx) to match weight.reshape(E, 147).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void im2col_patch_kernel(const float* __restrict__ img, bf16* __restrict__ out, int B, int S) {
+  const int So = S / 4;
+  const int64_t total = (int64_t)B * So * So * 160;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int col = i % 160;
+    int64_t t = i / 160;
+    const int xo = t % So;
+    t /= So;
+    const int yo = t % So;
+    const int b = t / So;
+    float v = 0.f;
+    if (col < 147) {
+      const int c = col / 49, k = col % 49, ky = k / 7, kx = k % 7;
+      const int y = yo * 4 - 3 + ky, x = xo * 4 - 3 + kx;
+      if (y >= 0 && y < S && x >= 0 && x < S) v = img[(((int64_t)b * 3 + c) * S + y) * S + x];
+    }
+    out[i] = f2bf(v);
+  }
+}
+
+extern "C" int msam2_im2col_patch7x7s4(const float* img, void* out, int64_t B, int64_t S, void* stream) {
+  MSAM2_REQUIRE(img && out && B > 0 && S > 0 && S % 4 == 0, "im2col_patch: bad arguments");
+  const int64_t total = B * (S / 4) * (S / 4) * 160;
+  hipLaunchKernelGGL(im2col_patch_kernel, dim3((unsigned)min((int64_t)16384, (total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, img, (bf16*)out, (int)B, (int)S);
+  return msam2_check_launch("im2col_patch7x7s4");
+}
+
+// 3x3 / stride 2 / pad 1 im2col on NHWC bf16: [B,H,W,C] -> [B*(H/2)*(W/2), 9*C], column order (ky, kx, c)
+__global__ void im2col3x3s2_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, int B, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)B * Ho * Wo * 9 * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    int64_t t = i / C;
+    const int k = t % 9;
+    t /= 9;
+    const int xo = t % Wo;
+    t /= Wo;
+    const int yo = t % Ho;
+    const int b = t / Ho;
+    const int y = 2 * yo - 1 + k / 3, xx = 2 * xo - 1 + k % 3;
+    bf16 v = f2bf(0.f);
+    if (y >= 0 && y < H && xx >= 0 && xx < W) v = x[(((int64_t)b * H + y) * W + xx) * C + c];
+    out[i] = v;
+  }
+}
+
+extern "C" int msam2_im2col3x3s2(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, void* stream) {
+  MSAM2_REQUIRE(x && out && B > 0 && C > 0 && H % 2 == 0 && W % 2 == 0, "im2col3x3s2: bad arguments");
+  const int64_t total = B * (H / 2) * (W / 2) * 9 * C;
+  hipLaunchKernelGGL(im2col3x3s2_kernel, dim3((unsigned)min((int64_t)16384, (total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16*)x, (bf16*)out, (int)B, (int)H, (int)W, (int)C);
+  return msam2_check_launch("im2col3x3s2");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// MaskDownSampler stage (memory_encoder.py:37-54): Conv2d(CIN, COUT=4*CIN, k3, s2, p1) + LayerNorm2d(eps 1e-6) + GELU,
+// one thread per output pixel holding all COUT channels.  When `mask_mode` != 0 the (single-channel fp32) input is the
+// raw high-res mask logits and the scaled sigmoid / binarisation of sam2_base.py:686-696 is applied on the fly:
+//   mode 1: sigmoid(x) * scale + bias      mode 2: (x > 0) * scale + bias
+// weights: fp32 [COUT][CIN][3][3] (nn.Conv2d layout); output NHWC bf16.
+// ------------------------------------------------------------------------------------------------------------------
+template <int CIN, int COUT, typename TI>
+__global__ void conv3x3s2_ln_gelu_kernel(const TI* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                         const float* __restrict__ ln_w, const float* __restrict__ ln_b, bf16* __restrict__ y,
+                                         int B, int H, int W, int mask_mode, float mscale, float mbias) {
+  __shared__ float ws[COUT * CIN * 9];
+  for (int i = threadIdx.x; i < COUT * CIN * 9; i += blockDim.x) ws[i] = w[i];
+  __syncthreads();
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)B * Ho * Wo;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int xo = i % Wo;
+    int64_t t = i / Wo;
+    const int yo = t % Ho;
+    const int b = t / Ho;
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = bias[co];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = 2 * yo - 1 + ky;
+      if (yy < 0 || yy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int xx = 2 * xo - 1 + kx;
+        if (xx < 0 || xx >= W) continue;
+        const TI* px = x + (((int64_t)b * H + yy) * W + xx) * CIN;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+          float v = (float)px[ci];
+          if (mask_mode == 1) v = mscale / (1.f + __expf(-v)) + mbias;
+          else if (mask_mode == 2) v = (v > 0.f ? mscale : 0.f) + mbias;
+#pragma unroll
+          for (int co = 0; co < COUT; ++co) acc[co] += v * ws[(co * CIN + ci) * 9 + ky * 3 + kx];
+        }
+      }
+    }
+    float mean = 0.f;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) mean += acc[co];
+    mean /= COUT;
+    float var = 0.f;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) var += (acc[co] - mean) * (acc[co] - mean);
+    const float rstd = 1.f / sqrtf(var / COUT + 1e-6f);
+    bf16* py = y + i * COUT;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) py[co] = f2bf(gelu_erf((acc[co] - mean) * rstd * ln_w[co] + ln_b[co]));
+  }
+}
+
+extern "C" int msam2_conv3x3s2_ln_gelu(const void* x, int in_is_bf16, const float* weight, const float* bias, const float* ln_w,
+                                       const float* ln_b, void* y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                                       int mask_mode, float mask_scale, float mask_bias, void* stream) {
+  MSAM2_REQUIRE(x && weight && bias && ln_w && ln_b && y, "conv3x3s2_ln_gelu: null tensor");
+  MSAM2_REQUIRE(H % 2 == 0 && W % 2 == 0 && B > 0, "conv3x3s2_ln_gelu: bad shape");
+  MSAM2_REQUIRE(Cout == 4 * Cin && (Cin == 1 || Cin == 4 || Cin == 16), "conv3x3s2_ln_gelu: built for 1->4, 4->16, 16->64");
+  MSAM2_REQUIRE(mask_mode == 0 || (Cin == 1 && !in_is_bf16), "conv3x3s2_ln_gelu: mask transform needs the fp32 1-channel input");
+  MSAM2_REQUIRE(Cin == 1 ? !in_is_bf16 : in_is_bf16, "conv3x3s2_ln_gelu: layer 1 takes fp32, later layers bf16");
+  const int64_t total = B * (H / 2) * (W / 2);
+  dim3 grid((unsigned)min((int64_t)8192, (total + 127) / 128)), block(128);
+  hipStream_t s = (hipStream_t)stream;
+  if (Cin == 1)
+    hipLaunchKernelGGL((conv3x3s2_ln_gelu_kernel<1, 4, float>), grid, block, 0, s, (const float*)x, weight, bias, ln_w, ln_b,
+                       (bf16*)y, (int)B, (int)H, (int)W, mask_mode, mask_scale, mask_bias);
+  else if (Cin == 4)
+    hipLaunchKernelGGL((conv3x3s2_ln_gelu_kernel<4, 16, bf16>), grid, block, 0, s, (const bf16*)x, weight, bias, ln_w, ln_b,
+                       (bf16*)y, (int)B, (int)H, (int)W, 0, 0.f, 0.f);
+  else
+    hipLaunchKernelGGL((conv3x3s2_ln_gelu_kernel<16, 64, bf16>), grid, block, 0, s, (const bf16*)x, weight, bias, ln_w, ln_b,
+                       (bf16*)y, (int)B, (int)H, (int)W, 0, 0.f, 0.f);
+  return msam2_check_launch("conv3x3s2_ln_gelu");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// CXBlock head (memory_encoder.py:99-101): depth-wise Conv2d(C, C, k7, p3, groups=C) + LayerNorm2d(eps 1e-6) on NHWC
+// fp32 -> normalised bf16 (the A operand of pwconv1).  One wave per pixel, C = 256 -> 4 channels per lane.
+// weights: fp32 [49][C] (tap-major, prepared from [C,1,7,7]).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void dwconv7x7_ln_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                    const float* __restrict__ ln_w, const float* __restrict__ ln_b, bf16* __restrict__ y, int B,
+                                    int H, int W, int C) {
+  const int64_t pix = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (pix >= (int64_t)B * H * W) return;
+  const int xx = pix % W;
+  const int yy = (pix / W) % H;
+  const int b = pix / ((int64_t)W * H);
+  const int c0 = lane * 4;
+  f32x4 acc = *reinterpret_cast<const f32x4*>(bias + c0);
+  for (int ky = 0; ky < 7; ++ky) {
+    const int y2 = yy - 3 + ky;
+    if (y2 < 0 || y2 >= H) continue;
+    for (int kx = 0; kx < 7; ++kx) {
+      const int x2 = xx - 3 + kx;
+      if (x2 < 0 || x2 >= W) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((int64_t)b * H + y2) * W + x2) * C + c0);
+      const f32x4 ww = *reinterpret_cast<const f32x4*>(w + (ky * 7 + kx) * C + c0);
+      acc += v * ww;
+    }
+  }
+  const float mean = wave_sum(acc[0] + acc[1] + acc[2] + acc[3]) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) q += (acc[e] - mean) * (acc[e] - mean);
+  const float rstd = 1.f / sqrtf(wave_sum(q) / C + 1e-6f);
+  bf16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = f2bf((acc[e] - mean) * rstd * ln_w[c0 + e] + ln_b[c0 + e]);
+  *reinterpret_cast<bf16x4*>(y + pix * C + c0) = o;
+}
+
+extern "C" int msam2_dwconv7x7_ln(const float* x, const float* weight_tap_major, const float* bias, const float* ln_w,
+                                  const float* ln_b, void* y, int64_t B, int64_t H, int64_t W, int64_t C, void* stream) {
+  MSAM2_REQUIRE(x && weight_tap_major && bias && ln_w && ln_b && y, "dwconv7x7_ln: null tensor");
+  MSAM2_REQUIRE(C == 256, "dwconv7x7_ln: built for C=256 (one wave per pixel, 4 channels per lane)");
+  const int64_t pix = B * H * W;
+  hipLaunchKernelGGL(dwconv7x7_ln_kernel, dim3(cdiv(pix * 64, 256)), dim3(256), 0, (hipStream_t)stream, x, weight_tap_major, bias,
+                     ln_w, ln_b, (bf16*)y, (int)B, (int)H, (int)W, (int)C);
+  return msam2_check_launch("dwconv7x7_ln");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// ConvTranspose2d(k2, s2) tail (mask_decoder.py:244-247): the GEMM produced g[token(y,x)][(ky*2+kx)*C + co]; this kernel
+// scatters it to pixel (2y+ky, 2x+kx), adds the conv bias and the high-res skip feature, then LayerNorm2d + GELU
+// (first up-scaling) or GELU alone (second).  One wave per output pixel, lane = channel (C <= 64).  All NHWC.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void pixel_shuffle_kernel(const bf16* __restrict__ g, const float* __restrict__ bias, const bf16* __restrict__ skip,
+                                     const float* __restrict__ ln_w, const float* __restrict__ ln_b, bf16* __restrict__ y, int B,
+                                     int h, int w, int C) {
+  const int64_t pix = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int H = 2 * h, W = 2 * w;
+  if (pix >= (int64_t)B * H * W) return;
+  const int X = pix % W;
+  const int Y = (pix / W) % H;
+  const int b = pix / ((int64_t)W * H);
+  const int64_t tok = ((int64_t)b * h + Y / 2) * w + X / 2;
+  const int sub = (Y & 1) * 2 + (X & 1);
+  float v = 0.f;
+  if (lane < C) v = bf2f(g[tok * 4 * C + sub * C + lane]) + bias[lane] + bf2f(skip[pix * C + lane]);
+  if (ln_w) {
+    const float mean = wave_sum(lane < C ? v : 0.f) / C;
+    const float d = lane < C ? v - mean : 0.f;
+    const float rstd = 1.f / sqrtf(wave_sum(d * d) / C + 1e-6f);
+    v = d * rstd * (lane < C ? ln_w[lane] : 0.f) + (lane < C ? ln_b[lane] : 0.f);
+  }
+  if (lane < C) y[pix * C + lane] = f2bf(gelu_erf(v));
+}
+
+extern "C" int msam2_convt2x2_shuffle(const void* gemm_out, const float* bias, const void* skip, const float* ln_w,
+                                      const float* ln_b, void* y, int64_t B, int64_t h, int64_t w, int64_t C, void* stream) {
+  MSAM2_REQUIRE(gemm_out && bias && skip && y, "convt2x2_shuffle: null tensor");
+  MSAM2_REQUIRE(C > 0 && C <= 64, "convt2x2_shuffle: C must be <= 64");
+  const int64_t pix = B * 4 * h * w;
+  hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(cdiv(pix * 64, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)gemm_out,
+                     bias, (const bf16*)skip, ln_w, ln_b, (bf16*)y, (int)B, (int)h, (int)w, (int)C);
+  return msam2_check_launch("convt2x2_shuffle");
+}
+
+// masks[n, k, p] = sum_c hyper[n, k, c] * up[n, p, c]   (mask_decoder.py:249-256), C = 32, K mask tokens; fp32 out
+__global__ void hyper_masks_kernel(const float* __restrict__ hyper, const bf16* __restrict__ up, float* __restrict__ masks, int n,
+                                   int K, int P, int C) {
+  __shared__ float hs[8 * 32];
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < K * C; i += blockDim.x) hs[i] = hyper[(int64_t)b * K * C + i];
+  __syncthreads();
+  for (int64_t pidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pidx < P; pidx += (int64_t)gridDim.x * blockDim.x) {
+    float u[32];
+    const bf16* pu = up + ((int64_t)b * P + pidx) * C;
+#pragma unroll
+    for (int c = 0; c < 32; c += 8) {
+      const bf16x8 t = *reinterpret_cast<const bf16x8*>(pu + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) u[c + e] = bf2f(t[e]);
+    }
+    for (int k = 0; k < K; ++k) {
+      float a = 0.f;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) a += hs[k * 32 + c] * u[c];
+      masks[((int64_t)b * K + k) * P + pidx] = a;
+    }
+  }
+}
+
+extern "C" int msam2_hyper_masks(const float* hyper, const void* upscaled, float* masks, int64_t n, int64_t K, int64_t P, int64_t C,
+                                 void* stream) {
+  MSAM2_REQUIRE(hyper && upscaled && masks, "hyper_masks: null tensor");
+  MSAM2_REQUIRE(C == 32 && K > 0 && K <= 8 && n > 0 && P > 0, "hyper_masks: built for C=32, K<=8");
+  hipLaunchKernelGGL(hyper_masks_kernel, dim3(cdiv(P, 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, hyper,
+                     (const bf16*)upscaled, masks, (int)n, (int)K, (int)P, (int)C);
+  return msam2_check_launch("hyper_masks");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Prompt embeddings (prompt_encoder.py:79-114; position_encoding.py:130-158): random-Fourier PE of (x+0.5, y+0.5)/S plus
+// the per-label learned vector; label -1 -> not_a_point_embed only.  One block per point, thread = channel pair.
+// tables: point_emb [4][C], not_a_point [C], gauss [2][C/2]; out fp32 [n_points_total, C]
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void prompt_points_kernel(const float* __restrict__ xy, const int* __restrict__ labels, const float* __restrict__ gauss,
+                                     const float* __restrict__ point_emb, const float* __restrict__ not_a_point,
+                                     float* __restrict__ out, int n_pts, int C, float inv_size) {
+  const int pt = blockIdx.x;
+  if (pt >= n_pts) return;
+  const int nf = C / 2;
+  const int lab = labels[pt];
+  const float cx = 2.f * ((xy[2 * pt] + 0.5f) * inv_size) - 1.f, cy = 2.f * ((xy[2 * pt + 1] + 0.5f) * inv_size) - 1.f;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int f = c % nf;
+    const float a = 6.283185307179586f * (cx * gauss[f] + cy * gauss[nf + f]);
+    float v = (c < nf) ? sinf(a) : cosf(a);
+    if (lab == -1) v = not_a_point[c];
+    else if (lab >= 0 && lab < 4) v += point_emb[lab * C + c];
+    out[(int64_t)pt * C + c] = v;
+  }
+}
+
+extern "C" int msam2_prompt_points(const float* xy, const int* labels, const float* gauss, const float* point_emb,
+                                   const float* not_a_point, float* out, int64_t n_points, int64_t C, float image_size,
+                                   void* stream) {
+  MSAM2_REQUIRE(xy && labels && gauss && point_emb && not_a_point && out, "prompt_points: null tensor");
+  MSAM2_REQUIRE(n_points > 0 && C % 2 == 0, "prompt_points: bad shape");
+  hipLaunchKernelGGL(prompt_points_kernel, dim3((unsigned)n_points), dim3(128), 0, (hipStream_t)stream, xy, labels, gauss,
+                     point_emb, not_a_point, out, (int)n_points, (int)C, 1.0f / image_size);
+  return msam2_check_launch("prompt_points");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Mask selection (sam2_base.py:354-385, mask_decoder.py:147-168,269-317) without a host round trip.
+//   multimask=1: candidates are tokens 1..3, best = argmax IoU
+//   multimask=0: token 0 unless its stability score < thresh, then best-IoU of tokens 1..3 (dynamic multimask, eval)
+// gated by the object score (<= 0 -> NO_OBJ_SCORE).  Writes low_res [n,1,h,w], sel[n] (chosen token index 0..3),
+// iou_sel[n].  masks: fp32 [n,4,h,w]; ious: [n,4]; obj: [n].
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void select_mask_kernel(const float* __restrict__ masks, const float* __restrict__ ious, const float* __restrict__ obj,
+                                   float* __restrict__ low, int* __restrict__ sel, float* __restrict__ iou_sel, int P, int multimask,
+                                   int dynamic, float delta, float thresh) {
+  __shared__ int s_sel;
+  __shared__ float red_i[256], red_u[256];
+  const int b = blockIdx.x;
+  const float* m = masks + (int64_t)b * 4 * P;
+  int best = 1;
+  float bi = ious[b * 4 + 1];
+  for (int k = 2; k < 4; ++k)
+    if (ious[b * 4 + k] > bi) { bi = ious[b * 4 + k]; best = k; }
+  int choice = best;
+  if (!multimask) {
+    choice = 0;
+    if (dynamic) {
+      float ai = 0.f, au = 0.f;
+      for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        ai += m[i] > delta ? 1.f : 0.f;
+        au += m[i] > -delta ? 1.f : 0.f;
+      }
+      red_i[threadIdx.x] = ai;
+      red_u[threadIdx.x] = au;
+      __syncthreads();
+      for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { red_i[threadIdx.x] += red_i[threadIdx.x + o]; red_u[threadIdx.x] += red_u[threadIdx.x + o]; }
+        __syncthreads();
+      }
+      const float stab = red_u[0] > 0.f ? red_i[0] / red_u[0] : 1.f;
+      if (!(stab >= thresh)) choice = best;
+    }
+  }
+  if (threadIdx.x == 0) {
+    s_sel = choice;
+    sel[b] = choice;
+    iou_sel[b] = ious[b * 4 + choice];
+  }
+  __syncthreads();
+  const bool appearing = obj[b] > 0.f;
+  const float* src = m + (int64_t)s_sel * P;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) low[(int64_t)b * P + i] = appearing ? src[i] : -1024.0f;
+}
+
+extern "C" int msam2_select_mask(const float* masks, const float* ious, const float* obj_scores, float* low_res, int* sel,
+                                 float* iou_sel, int64_t n, int64_t P, int multimask, int dynamic_stability, float delta,
+                                 float thresh, void* stream) {
+  MSAM2_REQUIRE(masks && ious && obj_scores && low_res && sel && iou_sel && n > 0 && P > 0, "select_mask: bad arguments");
+  hipLaunchKernelGGL(select_mask_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, masks, ious, obj_scores, low_res, sel,
+                     iou_sel, (int)P, multimask, dynamic_stability, delta, thresh);
+  return msam2_check_launch("select_mask");
+}
+
+// Gather row sel[b] (+offset) of a [n, T, C] tensor -> [n, C]  (sam2_base.py:375-383 token pick), fp32
+__global__ void gather_rows_kernel(const float* __restrict__ x, const int* __restrict__ sel, float* __restrict__ y, int T, int C,
+                                   int offset) {
+  const int b = blockIdx.x;
+  const int row = (sel ? sel[b] : 0) + offset;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) y[(int64_t)b * C + c] = x[((int64_t)b * T + row) * C + c];
+}
+
+extern "C" int msam2_gather_rows(const float* x, const int* sel, float* y, int64_t n, int64_t T, int64_t C, int64_t offset,
+                                 void* stream) {
+  MSAM2_REQUIRE(x && y && n > 0 && T > 0 && C > 0, "gather_rows: bad arguments");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, x, sel, y, (int)T, (int)C, (int)offset);
+  return msam2_check_launch("gather_rows");
+}
+
+// obj_ptr = lam * ptr + (1 - lam) * no_obj_ptr, lam = obj_score > 0   (sam2_base.py:389-400, fixed_no_obj_ptr)
+__global__ void obj_ptr_mix_kernel(float* __restrict__ ptr, const float* __restrict__ obj, const float* __restrict__ no_obj_ptr,
+                                   int C) {
+  const int b = blockIdx.x;
+  const bool app = obj[b] > 0.f;
+  for (int c = threadIdx.x; c < C; c += blockDim.x)
+    if (!app) ptr[(int64_t)b * C + c] = no_obj_ptr[c];
+}
+
+extern "C" int msam2_obj_ptr_mix(float* ptr, const float* obj_scores, const float* no_obj_ptr, int64_t n, int64_t C, void* stream) {
+  MSAM2_REQUIRE(ptr && obj_scores && no_obj_ptr && n > 0, "obj_ptr_mix: bad arguments");
+  hipLaunchKernelGGL(obj_ptr_mix_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, ptr, obj_scores, no_obj_ptr, (int)C);
+  return msam2_check_launch("obj_ptr_mix");
+}

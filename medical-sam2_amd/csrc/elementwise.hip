@@ -1,0 +1,351 @@
+// HBM-bound row / elementwise kernels of the per-slice forward (gfx950): LayerNorm, strided add+cast, 2x2 max-pool,
+// nearest-2x add, axial RoPE, bilinear up-sampling, and the input-independent position tables.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (nn.LayerNorm / LayerNorm2d on NHWC tokens): hieradet.py:138,166; memory_attention.py:
+// 60,73,94,162; transformer.py:173-194; sam2_utils.py:137-149.  One wave per row, fp32 statistics (two-pass on
+// registers), optional exact-erf GELU on the way out.  C <= 1024.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ void layernorm_kernel(const TI* __restrict__ x, int64_t ldx, const float* __restrict__ w, const float* __restrict__ b,
+                                 TO* __restrict__ y, int64_t ldy, int64_t rows, int C, float eps, int act) {
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const TI* xr = x + row * ldx;
+  float v[16];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + i * 64;
+    v[i] = (c < C) ? (float)xr[c] : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + i * 64;
+    const float d = (c < C) ? v[i] - mean : 0.f;
+    q += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / C + eps);
+  TO* yr = y + row * ldy;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + i * 64;
+    if (c < C) {
+      float o = (v[i] - mean) * rstd * w[c] + b[c];
+      if (act == 1) o = gelu_erf(o);
+      yr[c] = (TO)o;
+    }
+  }
+}
+
+extern "C" int msam2_layernorm(const void* x, int in_is_bf16, int64_t ldx, const float* weight, const float* bias, void* y,
+                               int out_is_bf16, int64_t ldy, int64_t rows, int64_t C, float eps, int act, void* stream) {
+  MSAM2_REQUIRE(x && y && weight && bias, "layernorm: null tensor");
+  MSAM2_REQUIRE(rows > 0 && C > 0 && C <= 1024, "layernorm: rows=%lld C=%lld unsupported (C<=1024)", (long long)rows, (long long)C);
+  dim3 grid(cdiv(rows * 64, 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define LN_LAUNCH(TI, TO) \
+  hipLaunchKernelGGL((layernorm_kernel<TI, TO>), grid, block, 0, s, (const TI*)x, ldx, weight, bias, (TO*)y, ldy, rows, (int)C, eps, act)
+  if (in_is_bf16 && out_is_bf16) LN_LAUNCH(bf16, bf16);
+  else if (in_is_bf16) LN_LAUNCH(bf16, float);
+  else if (out_is_bf16) LN_LAUNCH(float, bf16);
+  else LN_LAUNCH(float, float);
+#undef LN_LAUNCH
+  return msam2_check_launch("layernorm");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// out[i,j,c] = a[i,j,c] + alpha * b[i,j,c]   on a logical [D0, D1, C] volume; a and b carry arbitrary element strides
+// for the two outer dims (0 stride = broadcast), the channel dim is contiguous; out is contiguous.  Covers every
+// "x + pos" / cast / seq-first<->batch-first move of the path (memory_attention.py:139-147, 74-76; transformer.py:
+// 175-190; mask_decoder.py:231; sam2_base.py:642).
+// ------------------------------------------------------------------------------------------------------------------
+template <typename TA, typename TB, typename TO>
+__global__ void add_cast_kernel(const TA* __restrict__ a, int64_t a_s0, int64_t a_s1, const TB* __restrict__ b, int64_t b_s0,
+                                int64_t b_s1, float alpha, TO* __restrict__ out, int64_t D0, int64_t D1, int C) {
+  const int64_t total = D0 * D1 * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    const int64_t rj = i / C;
+    const int64_t j = rj % D1, r = rj / D1;
+    float v = (float)a[r * a_s0 + j * a_s1 + c];
+    if (b) v += alpha * (float)b[r * b_s0 + j * b_s1 + c];
+    out[i] = (TO)v;
+  }
+}
+
+extern "C" int msam2_add_cast(const void* a, int a_is_bf16, int64_t a_s0, int64_t a_s1, const void* b, int b_is_bf16, int64_t b_s0,
+                              int64_t b_s1, float alpha, void* out, int out_is_bf16, int64_t D0, int64_t D1, int64_t C,
+                              void* stream) {
+  MSAM2_REQUIRE(a && out, "add_cast: null tensor");
+  MSAM2_REQUIRE(D0 > 0 && D1 > 0 && C > 0, "add_cast: empty volume");
+  const int64_t total = D0 * D1 * C;
+  dim3 grid((unsigned)min((int64_t)8192, (total + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define AC(TA, TB, TO)                                                                                                   \
+  hipLaunchKernelGGL((add_cast_kernel<TA, TB, TO>), grid, block, 0, s, (const TA*)a, a_s0, a_s1, (const TB*)b, b_s0, b_s1, \
+                     alpha, (TO*)out, D0, D1, (int)C)
+  const int key = (a_is_bf16 ? 4 : 0) | (b_is_bf16 ? 2 : 0) | (out_is_bf16 ? 1 : 0);
+  switch (key) {
+    case 0: AC(float, float, float); break;
+    case 1: AC(float, float, bf16); break;
+    case 2: AC(float, bf16, float); break;
+    case 3: AC(float, bf16, bf16); break;
+    case 4: AC(bf16, float, float); break;
+    case 5: AC(bf16, float, bf16); break;
+    case 6: AC(bf16, bf16, float); break;
+    default: AC(bf16, bf16, bf16); break;
+  }
+#undef AC
+  return msam2_check_launch("add_cast");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 2x2/stride-2 max pool on NHWC tokens (do_pool, hieradet.py:23-34): x [B,H,W,C] with token stride ldx -> [B,H/2,W/2,C]
+// ------------------------------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ void maxpool2x2_kernel(const TI* __restrict__ x, int64_t ldx, TO* __restrict__ y, int64_t ldy, int B, int H, int W,
+                                  int C) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)B * Ho * Wo * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    int64_t t = i / C;
+    const int xo = t % Wo;
+    t /= Wo;
+    const int yo = t % Ho;
+    const int b = t / Ho;
+    const int64_t base = ((int64_t)b * H + 2 * yo) * W + 2 * xo;
+    const float v0 = (float)x[base * ldx + c], v1 = (float)x[(base + 1) * ldx + c];
+    const float v2 = (float)x[(base + W) * ldx + c], v3 = (float)x[(base + W + 1) * ldx + c];
+    y[(((int64_t)b * Ho + yo) * Wo + xo) * ldy + c] = (TO)fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+  }
+}
+
+extern "C" int msam2_maxpool2x2(const void* x, int in_is_bf16, int64_t ldx, void* y, int out_is_bf16, int64_t ldy, int64_t B,
+                                int64_t H, int64_t W, int64_t C, void* stream) {
+  MSAM2_REQUIRE(x && y, "maxpool2x2: null tensor");
+  MSAM2_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "maxpool2x2: H, W must be even");
+  const int64_t total = B * (H / 2) * (W / 2) * C;
+  dim3 grid((unsigned)min((int64_t)8192, (total + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define MP(TI, TO) \
+  hipLaunchKernelGGL((maxpool2x2_kernel<TI, TO>), grid, block, 0, s, (const TI*)x, ldx, (TO*)y, ldy, (int)B, (int)H, (int)W, (int)C)
+  if (in_is_bf16 && out_is_bf16) MP(bf16, bf16);
+  else if (in_is_bf16) MP(bf16, float);
+  else if (out_is_bf16) MP(float, bf16);
+  else MP(float, float);
+#undef MP
+  return msam2_check_launch("maxpool2x2");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// FPN top-down step (image_encoder.py:113-124, nearest, scale 2, sum fuse): y[b,i,j,c] += top[b,i/2,j/2,c], fp32 NHWC
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void upsample2x_add_kernel(float* __restrict__ y, const float* __restrict__ top, int B, int H, int W, int C) {
+  const int64_t total = (int64_t)B * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    int64_t t = i / C;
+    const int xx = t % W;
+    t /= W;
+    const int yy = t % H;
+    const int b = t / H;
+    y[i] += top[(((int64_t)b * (H / 2) + yy / 2) * (W / 2) + xx / 2) * C + c];
+  }
+}
+
+extern "C" int msam2_upsample2x_add(void* y, const void* top, int64_t B, int64_t H, int64_t W, int64_t C, void* stream) {
+  MSAM2_REQUIRE(y && top, "upsample2x_add: null tensor");
+  MSAM2_REQUIRE(H % 2 == 0 && W % 2 == 0 && B > 0 && C > 0, "upsample2x_add: bad shape");
+  const int64_t total = B * H * W * C;
+  hipLaunchKernelGGL(upsample2x_add_kernel, dim3((unsigned)min((int64_t)8192, (total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, (float*)y, (const float*)top, (int)B, (int)H, (int)W, (int)C);
+  return msam2_check_launch("upsample2x_add");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Axial RoPE (position_encoding.py:174-216; transformer.py:299-315).  Table: cos/sin [n_pos, D/2] fp32 where pair i
+// < D/4 rotates with x = pos % side and the rest with y = pos / side.  In-place on bf16 rows [B, L, ld]: rows
+// l < n_rope of every batch are rotated with position l % n_pos (rope_k_repeat tiles the table over the keys).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void rope_table_kernel(float* __restrict__ cs, float* __restrict__ sn, int side, int D, float theta) {
+  const int n_pairs = D / 2, nq = D / 4;
+  const int64_t total = (int64_t)side * side * n_pairs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int pr = i % n_pairs;
+    const int pos = i / n_pairs;
+    const int f = pr % nq;
+    const float freq = 1.0f / powf(theta, (float)(4 * f) / (float)D);
+    const float t = (pr < nq) ? (float)(pos % side) : (float)(pos / side);
+    const float ang = t * freq;
+    cs[i] = cosf(ang);
+    sn[i] = sinf(ang);
+  }
+}
+
+extern "C" int msam2_rope_table(float* cos_out, float* sin_out, int64_t side, int64_t D, float theta, void* stream) {
+  MSAM2_REQUIRE(cos_out && sin_out && side > 0 && D % 4 == 0, "rope_table: bad arguments");
+  hipLaunchKernelGGL(rope_table_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, cos_out, sin_out, (int)side, (int)D, theta);
+  return msam2_check_launch("rope_table");
+}
+
+__global__ void rope_inplace_kernel(bf16* __restrict__ x, int64_t bs, int64_t ld, int B, int L, int n_rope, int n_pos, int D,
+                                    const float* __restrict__ cs, const float* __restrict__ sn) {
+  const int hp = D / 2;
+  const int64_t total = (int64_t)B * n_rope * hp;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int pr = i % hp;
+    int64_t t = i / hp;
+    const int l = t % n_rope;
+    const int b = t / n_rope;
+    bf16x2* px = reinterpret_cast<bf16x2*>(x + b * bs + (int64_t)l * ld) + pr;
+    const bf16x2 v = *px;
+    const float re = (float)v[0], im = (float)v[1];
+    const int pos = l % n_pos;
+    const float c = cs[(int64_t)pos * hp + pr], s = sn[(int64_t)pos * hp + pr];
+    bf16x2 o;
+    o[0] = (bf16)(re * c - im * s);
+    o[1] = (bf16)(re * s + im * c);
+    *px = o;
+  }
+}
+
+extern "C" int msam2_rope_inplace(void* x, int64_t batch_stride, int64_t ld, int64_t B, int64_t L, int64_t n_rope, int64_t n_pos,
+                                  int64_t D, const float* cos_t, const float* sin_t, void* stream) {
+  MSAM2_REQUIRE(x && cos_t && sin_t, "rope: null tensor");
+  MSAM2_REQUIRE(D % 4 == 0 && ld % 2 == 0 && batch_stride % 2 == 0 && n_rope >= 0 && n_rope <= L && n_pos > 0, "rope: bad shape");
+  if (n_rope == 0) return MSAM2_OK;
+  const int64_t total = B * n_rope * (D / 2);
+  hipLaunchKernelGGL(rope_inplace_kernel, dim3((unsigned)min((int64_t)8192, (total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, (bf16*)x, batch_stride, ld, (int)B, (int)L, (int)n_rope, (int)n_pos, (int)D, cos_t, sin_t);
+  return msam2_check_launch("rope_inplace");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Bilinear resize, align_corners=False, fp32 planes [P, h, w] -> [P, H, W] (F.interpolate at sam2_base.py:368-373)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void bilinear_kernel(const float* __restrict__ x, float* __restrict__ y, int P, int h, int w, int H, int W) {
+  const float sy = (float)h / H, sx = (float)w / W;
+  const int64_t total = (int64_t)P * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int X = i % W;
+    int64_t t = i / W;
+    const int Y = t % H;
+    const int pl = t / H;
+    float fy = fmaxf((Y + 0.5f) * sy - 0.5f, 0.f), fx = fmaxf((X + 0.5f) * sx - 0.5f, 0.f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float ly = fy - y0, lx = fx - x0;
+    const float* p = x + (int64_t)pl * h * w;
+    const float v = (1.f - ly) * ((1.f - lx) * p[y0 * w + x0] + lx * p[y0 * w + x1]) +
+                    ly * ((1.f - lx) * p[y1 * w + x0] + lx * p[y1 * w + x1]);
+    y[i] = v;
+  }
+}
+
+extern "C" int msam2_bilinear_upsample(const float* x, float* y, int64_t planes, int64_t h, int64_t w, int64_t H, int64_t W,
+                                       void* stream) {
+  MSAM2_REQUIRE(x && y && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bilinear: bad arguments");
+  const int64_t total = planes * H * W;
+  hipLaunchKernelGGL(bilinear_kernel, dim3((unsigned)min((int64_t)16384, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     x, y, (int)planes, (int)h, (int)w, (int)H, (int)W);
+  return msam2_check_launch("bilinear_upsample");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Input-independent tables, generated once per (model, size) on the device.
+//  * sine_pos_2d: PositionEmbeddingSine.forward (position_encoding.py:78-112) -> token-major [h*w, C] fp32
+//  * fourier_pe_grid: PromptEncoder.get_dense_pe (prompt_encoder.py:68-77, position_encoding.py:130-151) -> [h*w, C]
+//  * hiera_pos_embed: Hiera._get_pos_embed (hieradet.py:269-277): bicubic (A=-0.75, align_corners=False, clamped
+//    taps) resize of pos_embed [C, bh, bw] to h x w + tiled pos_embed_window [C, 8, 8] -> token-major [h*w, C] fp32
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void sine_pos_kernel(float* __restrict__ out, int h, int w, int C, float temperature) {
+  const int npf = C / 2;
+  const float two_pi = 6.283185307179586f, eps = 1e-6f;
+  const int64_t total = (int64_t)h * w * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    const int64_t t = i / C;
+    const int xx = t % w, yy = t / w;
+    const bool is_y = c < npf;
+    const int k = is_y ? c : c - npf;
+    const float e = is_y ? (yy + 1) / ((float)h + eps) * two_pi : (xx + 1) / ((float)w + eps) * two_pi;
+    const float dim_t = powf(temperature, (float)(2 * (k / 2)) / (float)npf);
+    const float a = e / dim_t;
+    out[i] = (k & 1) ? cosf(a) : sinf(a);
+  }
+}
+
+extern "C" int msam2_sine_pos_2d(float* out, int64_t h, int64_t w, int64_t C, float temperature, void* stream) {
+  MSAM2_REQUIRE(out && h > 0 && w > 0 && C % 4 == 0, "sine_pos_2d: bad arguments");
+  hipLaunchKernelGGL(sine_pos_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, out, (int)h, (int)w, (int)C, temperature);
+  return msam2_check_launch("sine_pos_2d");
+}
+
+__global__ void fourier_grid_kernel(float* __restrict__ out, const float* __restrict__ G, int h, int w, int C) {
+  const int nf = C / 2;
+  const int64_t total = (int64_t)h * w * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    const int64_t t = i / C;
+    const int xx = t % w, yy = t / w;
+    const float cx = 2.f * ((xx + 0.5f) / w) - 1.f, cy = 2.f * ((yy + 0.5f) / h) - 1.f;
+    const int f = c % nf;
+    const float a = 6.283185307179586f * (cx * G[f] + cy * G[nf + f]);
+    out[i] = (c < nf) ? sinf(a) : cosf(a);
+  }
+}
+
+extern "C" int msam2_fourier_pe_grid(float* out, const float* gauss, int64_t h, int64_t w, int64_t C, void* stream) {
+  MSAM2_REQUIRE(out && gauss && h > 0 && w > 0 && C % 2 == 0, "fourier_pe_grid: bad arguments");
+  hipLaunchKernelGGL(fourier_grid_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, out, gauss, (int)h, (int)w, (int)C);
+  return msam2_check_launch("fourier_pe_grid");
+}
+
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+__global__ void hiera_pos_kernel(float* __restrict__ out, const float* __restrict__ bkg, const float* __restrict__ win, int C,
+                                 int bh, int bw, int h, int w, int wsz) {
+  const float A = -0.75f;
+  const float sy = (float)bh / h, sx = (float)bw / w;
+  const int64_t total = (int64_t)h * w * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    const int64_t t = i / C;
+    const int xx = t % w, yy = t / w;
+    const float fy = (yy + 0.5f) * sy - 0.5f, fx = (xx + 0.5f) * sx - 0.5f;
+    const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+    const float ty = fy - iy, tx = fx - ix;
+    float wy[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
+    float wx[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int y = min(max(iy - 1 + a, 0), bh - 1);
+      float rowv = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int x = min(max(ix - 1 + b, 0), bw - 1);
+        rowv += wx[b] * bkg[((int64_t)c * bh + y) * bw + x];
+      }
+      acc += wy[a] * rowv;
+    }
+    out[i] = acc + win[((int64_t)c * wsz + (yy % wsz)) * wsz + (xx % wsz)];
+  }
+}
+
+extern "C" int msam2_hiera_pos_embed(float* out, const float* pos_embed, const float* pos_embed_window, int64_t C, int64_t bh,
+                                     int64_t bw, int64_t h, int64_t w, int64_t window, void* stream) {
+  MSAM2_REQUIRE(out && pos_embed && pos_embed_window, "hiera_pos_embed: null tensor");
+  MSAM2_REQUIRE(h % window == 0 && w % window == 0, "hiera_pos_embed: token grid must be a multiple of the window embedding");
+  hipLaunchKernelGGL(hiera_pos_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, out, pos_embed, pos_embed_window, (int)C,
+                     (int)bh, (int)bw, (int)h, (int)w, (int)window);
+  return msam2_check_launch("hiera_pos_embed");
+}

@@ -1,0 +1,354 @@
+"""torch-tensor front end of the C-ABI (include/msam2_hip.h): every function extracts raw device pointers, sizes and
+strides and calls libmsam2_hip.so on torch's current HIP stream.  PyTorch provides memory and streams only.
+
+Layout conventions: activations are token-major ("NHWC") ``[rows, C]`` with C contiguous; bf16 for MFMA operands,
+fp32 for residual streams / logits.  Weights follow nn.Linear (``[out, in]``).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import check, lib
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _is_bf16(t: torch.Tensor) -> int:
+    if t.dtype == BF16:
+        return 1
+    if t.dtype == F32:
+        return 0
+    raise TypeError(f"expected bf16 or fp32 tensor, got {t.dtype}")
+
+
+def _req(cond: bool, msg: str):
+    if not cond:
+        raise ValueError(msg)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = ACT_NONE,
+         colscale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, res_mod: int = 0,
+         out_dtype: torch.dtype = BF16, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M,N] = residual + colscale * act(a[M,K] @ w[N,K]^T + bias).  a, w bf16; bias/colscale fp32."""
+    _req(a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1], f"gemm shapes {tuple(a.shape)} x {tuple(w.shape)}")
+    _req(a.dtype == BF16 and w.dtype == BF16, "gemm operands must be bf16")
+    _req(a.stride(1) == 1 and w.stride(1) == 1, "gemm operands must be K-contiguous")
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    _req(out.stride(1) == 1 and out.shape == (M, N), "gemm out must be [M,N] row-major")
+    if residual is not None:
+        _req(residual.dim() == 2 and residual.stride(1) == 1 and residual.shape[1] == N, "gemm residual must be [*,N]")
+    check(lib().msam2_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(colscale), _p(residual),
+                                residual.stride(0) if residual is not None else 0,
+                                _is_bf16(residual) if residual is not None else 0, res_mod, _p(out), out.stride(0),
+                                _is_bf16(out), M, N, K, act, _stream()))
+    return out
+
+
+def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float, *, act: int = ACT_NONE,
+              out_dtype: torch.dtype = BF16) -> torch.Tensor:
+    """Row LayerNorm over the last dim of a [rows, C] tensor (C contiguous)."""
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C)
+    _req(x2.stride(1) == 1, "layernorm input rows must be contiguous")
+    y = torch.empty(x2.shape, dtype=out_dtype, device=x.device)
+    check(lib().msam2_layernorm(_p(x2), _is_bf16(x2), x2.stride(0), _p(weight), _p(bias), _p(y), _is_bf16(y), y.stride(0),
+                                x2.shape[0], C, eps, act, _stream()))
+    return y.reshape(x.shape)
+
+
+def _strides3(t: torch.Tensor) -> "ctypes.Array":
+    return (ctypes.c_int64 * 3)(t.stride(0), t.stride(1), t.stride(2))
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, splits: int = 1,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(q k^T / sqrt(D)) v.  q [B,H,Lq,D], k/v [B,H,Lk,D] as (possibly strided) bf16 views with D contiguous.
+    Returns [B,H,Lq,D] view of a [B,Lq,H,D] buffer (heads recombined for the following out-projection)."""
+    B, H, Lq, D = q.shape
+    Lk = k.shape[2]
+    for t in (q, k, v):
+        _req(t.dtype == BF16 and t.stride(3) == 1, "attention tensors must be bf16 with contiguous head dim")
+    if out is None:
+        out = torch.empty(B, Lq, H, D, dtype=BF16, device=q.device).permute(0, 2, 1, 3)
+    ws_bytes = lib().msam2_attention_workspace_bytes(B, H, Lq, D, splits)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=q.device) if splits > 1 else None
+    check(lib().msam2_attention_fwd(_p(q), _strides3(q), _p(k), _strides3(k), _p(v), _strides3(v), _p(out), _strides3(out),
+                                    B, H, Lq, Lk, D, 1.0 / math.sqrt(D), splits, _p(ws), ws_bytes if ws is not None else 0,
+                                    _stream()))
+    return out
+
+
+def window_attention(qkv: torch.Tensor, B: int, H: int, W: int, heads: int, ws: int, qkv_bias: torch.Tensor,
+                     q_pooled: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Hiera windowed MHA straight from the fused qkv tokens [B*H*W, 3*heads*D] (bf16); if q_pooled is given
+    ([B*(H/2)*(W/2), heads*D]) queries come from it with window ws/2.  Returns o [B*Hq*Wq, heads*D] bf16."""
+    dim_out = qkv.shape[1] // 3
+    D = dim_out // heads
+    _req(qkv.dtype == BF16 and qkv.stride(1) == 1, "qkv must be bf16 row-major")
+    if q_pooled is None:
+        qt, q_ts, hq, wq, ws_q = qkv, qkv.stride(0), H, W, ws
+    else:
+        qt, q_ts, hq, wq, ws_q = q_pooled, q_pooled.stride(0), H // 2, W // 2, ws // 2
+    o = torch.empty(B * hq * wq, dim_out, dtype=BF16, device=qkv.device)
+    kpad = qkv_bias[dim_out:2 * dim_out]
+    vpad = qkv_bias[2 * dim_out:]
+    kptr = qkv.data_ptr() + dim_out * 2
+    vptr = qkv.data_ptr() + 2 * dim_out * 2
+    check(lib().msam2_window_attention_fwd(_p(qt), q_ts, D, hq, wq, ws_q, kptr, vptr, qkv.stride(0), D, H, W, ws, _p(kpad),
+                                           _p(vpad), _p(o), o.stride(0), D, B, heads, D, 1.0 / math.sqrt(D), _stream()))
+    return o
+
+
+def attention_small(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int) -> torch.Tensor:
+    """Decoder attention with head dim 16/32: q [B,Lq,C], k/v [B,Lk,C] bf16 (C = heads*D contiguous) -> [B,Lq,C] bf16."""
+    B, Lq, C = q.shape
+    Lk = k.shape[1]
+    D = C // heads
+    for t in (q, k, v):
+        _req(t.dtype == BF16 and t.stride(2) == 1, "attention_small tensors must be bf16, channel-contiguous")
+    o = torch.empty(B, Lq, C, dtype=BF16, device=q.device)
+    check(lib().msam2_attention_small_fwd(_p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0),
+                                          v.stride(1), _p(o), o.stride(0), o.stride(1), B, heads, Lq, Lk, D,
+                                          1.0 / math.sqrt(D), _stream()))
+    return o
+
+
+def add_cast(a: torch.Tensor, b: Optional[torch.Tensor] = None, alpha: float = 1.0, out_dtype: torch.dtype = BF16) -> torch.Tensor:
+    """out = a + alpha*b over a logical [D0, D1, C] volume (C contiguous in a and b; outer dims may be strided or, for b,
+    broadcast with stride 0).  Result is contiguous."""
+    _req(a.dim() == 3 and a.stride(2) == 1, "add_cast: a must be [D0,D1,C] with contiguous C")
+    D0, D1, C = a.shape
+    bs0 = bs1 = 0
+    if b is not None:
+        b = b.expand(D0, D1, C)
+        _req(b.stride(2) == 1 or C == 1, "add_cast: b must have contiguous C")
+        bs0, bs1 = b.stride(0), b.stride(1)
+    out = torch.empty(D0, D1, C, dtype=out_dtype, device=a.device)
+    check(lib().msam2_add_cast(_p(a), _is_bf16(a), a.stride(0), a.stride(1), _p(b), _is_bf16(b) if b is not None else 0, bs0,
+                               bs1, alpha, _p(out), _is_bf16(out), D0, D1, C, _stream()))
+    return out
+
+
+def maxpool2x2(x: torch.Tensor, B: int, H: int, W: int, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """x: [B*H*W, C] token-major view (row stride may exceed C) -> [B*(H/2)*(W/2), C]."""
+    C = x.shape[1]
+    _req(x.stride(1) == 1, "maxpool2x2: channel dim must be contiguous")
+    y = torch.empty(B * (H // 2) * (W // 2), C, dtype=out_dtype or x.dtype, device=x.device)
+    check(lib().msam2_maxpool2x2(_p(x), _is_bf16(x), x.stride(0), _p(y), _is_bf16(y), y.stride(0), B, H, W, C, _stream()))
+    return y
+
+
+def upsample2x_add_(y: torch.Tensor, top: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
+    """y[B,H,W,C] += nearest2x(top[B,H/2,W/2,C]) in place (fp32, contiguous)."""
+    _req(y.dtype == F32 and top.dtype == F32 and y.is_contiguous() and top.is_contiguous(), "upsample2x_add: fp32 contiguous")
+    check(lib().msam2_upsample2x_add(_p(y), _p(top), B, H, W, y.shape[-1], _stream()))
+    return y
+
+
+def rope_table(side: int, D: int, theta: float, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    cs = torch.empty(side * side, D // 2, dtype=F32, device=device)
+    sn = torch.empty_like(cs)
+    check(lib().msam2_rope_table(_p(cs), _p(sn), side, D, theta, _stream()))
+    return cs, sn
+
+
+def rope_(x: torch.Tensor, n_rope: int, table: Tuple[torch.Tensor, torch.Tensor]) -> torch.Tensor:
+    """Rotate rows l < n_rope of every batch of x [B, L, D] (bf16 view, D contiguous) in place."""
+    B, L, D = x.shape
+    _req(x.dtype == BF16 and x.stride(2) == 1, "rope: bf16 with contiguous D")
+    cs, sn = table
+    check(lib().msam2_rope_inplace(_p(x), x.stride(0), x.stride(1), B, L, n_rope, cs.shape[0], D, _p(cs), _p(sn), _stream()))
+    return x
+
+
+def bilinear_upsample(x: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """fp32 [..., h, w] -> [..., H, W], align_corners=False."""
+    _req(x.dtype == F32 and x.is_contiguous(), "bilinear: fp32 contiguous")
+    h, w = x.shape[-2:]
+    planes = x.numel() // (h * w)
+    y = torch.empty(*x.shape[:-2], H, W, dtype=F32, device=x.device)
+    check(lib().msam2_bilinear_upsample(_p(x), _p(y), planes, h, w, H, W, _stream()))
+    return y
+
+
+def sine_pos_2d(h: int, w: int, C: int, device, temperature: float = 10000.0) -> torch.Tensor:
+    out = torch.empty(h * w, C, dtype=F32, device=device)
+    check(lib().msam2_sine_pos_2d(_p(out), h, w, C, temperature, _stream()))
+    return out
+
+
+def fourier_pe_grid(gauss: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    C = 2 * gauss.shape[1]
+    out = torch.empty(h * w, C, dtype=F32, device=gauss.device)
+    check(lib().msam2_fourier_pe_grid(_p(out), _p(gauss.contiguous()), h, w, C, _stream()))
+    return out
+
+
+def hiera_pos_embed(pos_embed: torch.Tensor, pos_embed_window: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    _, C, bh, bw = pos_embed.shape
+    out = torch.empty(h * w, C, dtype=F32, device=pos_embed.device)
+    check(lib().msam2_hiera_pos_embed(_p(out), _p(pos_embed.contiguous()), _p(pos_embed_window.contiguous()), C, bh, bw, h, w,
+                                      pos_embed_window.shape[-1], _stream()))
+    return out
+
+
+def im2col_patch(img: torch.Tensor) -> torch.Tensor:
+    """img fp32 [B,3,S,S] -> bf16 [B*(S/4)^2, 160]."""
+    _req(img.dtype == F32 and img.is_contiguous() and img.shape[1] == 3 and img.shape[2] == img.shape[3], "im2col_patch: [B,3,S,S] fp32")
+    B, _, S, _ = img.shape
+    out = torch.empty(B * (S // 4) ** 2, 160, dtype=BF16, device=img.device)
+    check(lib().msam2_im2col_patch7x7s4(_p(img), _p(out), B, S, _stream()))
+    return out
+
+
+def im2col3x3s2(x: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
+    C = x.shape[-1]
+    _req(x.dtype == BF16 and x.is_contiguous(), "im2col3x3s2: bf16 contiguous NHWC")
+    out = torch.empty(B * (H // 2) * (W // 2), 9 * C, dtype=BF16, device=x.device)
+    check(lib().msam2_im2col3x3s2(_p(x), _p(out), B, H, W, C, _stream()))
+    return out
+
+
+def conv3x3s2_ln_gelu(x: torch.Tensor, B: int, H: int, W: int, weight, bias, ln_w, ln_b, mask_mode: int = 0,
+                      mask_scale: float = 0.0, mask_bias: float = 0.0) -> torch.Tensor:
+    cout, cin = weight.shape[0], weight.shape[1]
+    y = torch.empty(B * (H // 2) * (W // 2), cout, dtype=BF16, device=x.device)
+    check(lib().msam2_conv3x3s2_ln_gelu(_p(x), _is_bf16(x), _p(weight), _p(bias), _p(ln_w), _p(ln_b), _p(y), B, H, W, cin, cout,
+                                        mask_mode, mask_scale, mask_bias, _stream()))
+    return y
+
+
+def dwconv7x7_ln(x: torch.Tensor, B: int, H: int, W: int, w_tap_major, bias, ln_w, ln_b) -> torch.Tensor:
+    _req(x.dtype == F32 and x.is_contiguous(), "dwconv7x7_ln: fp32 contiguous NHWC")
+    C = x.shape[-1]
+    y = torch.empty(B * H * W, C, dtype=BF16, device=x.device)
+    check(lib().msam2_dwconv7x7_ln(_p(x), _p(w_tap_major), _p(bias), _p(ln_w), _p(ln_b), _p(y), B, H, W, C, _stream()))
+    return y
+
+
+def convt2x2_shuffle(g: torch.Tensor, bias, skip: torch.Tensor, ln_w, ln_b, B: int, h: int, w: int) -> torch.Tensor:
+    C = g.shape[1] // 4
+    _req(g.dtype == BF16 and skip.dtype == BF16 and g.is_contiguous() and skip.is_contiguous(), "convt2x2_shuffle: bf16 contiguous")
+    y = torch.empty(B * 4 * h * w, C, dtype=BF16, device=g.device)
+    check(lib().msam2_convt2x2_shuffle(_p(g), _p(bias), _p(skip), _p(ln_w), _p(ln_b), _p(y), B, h, w, C, _stream()))
+    return y
+
+
+def hyper_masks(hyper: torch.Tensor, up: torch.Tensor, n: int, P: int) -> torch.Tensor:
+    K, C = hyper.shape[1], hyper.shape[2]
+    masks = torch.empty(n, K, P, dtype=F32, device=up.device)
+    check(lib().msam2_hyper_masks(_p(hyper.contiguous()), _p(up), _p(masks), n, K, P, C, _stream()))
+    return masks
+
+
+def prompt_points(xy: torch.Tensor, labels: torch.Tensor, gauss, point_emb, not_a_point, image_size: float) -> torch.Tensor:
+    """xy fp32 [n,P,2], labels int32 [n,P] -> fp32 [n,P,C]."""
+    n, P = labels.shape
+    C = point_emb.shape[1]
+    out = torch.empty(n, P, C, dtype=F32, device=xy.device)
+    check(lib().msam2_prompt_points(_p(xy.contiguous()), _p(labels.contiguous()), _p(gauss), _p(point_emb), _p(not_a_point), _p(out),
+                                    n * P, C, float(image_size), _stream()))
+    return out
+
+
+def select_mask(masks: torch.Tensor, ious: torch.Tensor, obj: torch.Tensor, multimask: bool, dynamic: bool, delta: float,
+                thresh: float):
+    n, K, h, w = masks.shape
+    low = torch.empty(n, 1, h, w, dtype=F32, device=masks.device)
+    sel = torch.empty(n, dtype=torch.int32, device=masks.device)
+    iou_sel = torch.empty(n, 1, dtype=F32, device=masks.device)
+    check(lib().msam2_select_mask(_p(masks), _p(ious), _p(obj), _p(low), _p(sel), _p(iou_sel), n, h * w, int(multimask), int(dynamic),
+                                  delta, thresh, _stream()))
+    return low, sel, iou_sel
+
+
+def gather_rows(x: torch.Tensor, sel: Optional[torch.Tensor], offset: int = 0) -> torch.Tensor:
+    n, T, C = x.shape
+    y = torch.empty(n, C, dtype=F32, device=x.device)
+    check(lib().msam2_gather_rows(_p(x.contiguous()), _p(sel), _p(y), n, T, C, offset, _stream()))
+    return y
+
+
+def obj_ptr_mix_(ptr: torch.Tensor, obj: torch.Tensor, no_obj_ptr: torch.Tensor) -> torch.Tensor:
+    check(lib().msam2_obj_ptr_mix(_p(ptr), _p(obj), _p(no_obj_ptr), ptr.shape[0], ptr.shape[1], _stream()))
+    return ptr
+
+
+def connected_components(mask_u8: torch.Tensor):
+    """Drop-in for ``sam2_train._C.get_connected_componnets`` (connected_components.cu:213-282)."""
+    if not mask_u8.is_cuda:
+        raise RuntimeError("inputs must be a CUDA tensor")
+    if mask_u8.dim() != 4 or mask_u8.shape[1] != 1:
+        raise RuntimeError("inputs must be [N, 1, H, W] shape")
+    if mask_u8.dtype != torch.uint8:
+        raise RuntimeError("inputs must be a uint8 type")
+    N, _, H, W = mask_u8.shape
+    if H % 2:
+        raise RuntimeError("height must be a even number")
+    if W % 2:
+        raise RuntimeError("width must be a even number")
+    m = mask_u8.contiguous()
+    labels = torch.empty(N, 1, H, W, dtype=torch.int32, device=m.device)
+    counts = torch.empty_like(labels)
+    nb = lib().msam2_cc_workspace_bytes(N, H, W)
+    ws = torch.empty(nb, dtype=torch.uint8, device=m.device)
+    check(lib().msam2_cc_label(_p(m), _p(labels), _p(counts), N, H, W, _p(ws), nb, _stream()))
+    return [labels, counts]
+
+
+def fill_holes_(mask: torch.Tensor, max_area: int) -> torch.Tensor:
+    """fill_holes_in_mask_scores (utils/misc.py:247-258), in place on an fp32 [N,1,H,W] tensor."""
+    _req(mask.dtype == F32 and mask.is_contiguous(), "fill_holes: fp32 contiguous")
+    N, _, H, W = mask.shape
+    nb = lib().msam2_fill_holes_workspace_bytes(N, H, W)
+    ws = torch.empty(nb, dtype=torch.uint8, device=mask.device)
+    check(lib().msam2_fill_holes(_p(mask), N, H, W, max_area, _p(ws), nb, _stream()))
+    return mask
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class HipGraph:
+    """Capture everything enqueued on the current stream inside the ``with`` block; ``replay()`` relaunches it."""
+
+    def __init__(self):
+        self._exec = ctypes.c_void_p()
+        self._stream = None
+
+    def __enter__(self):
+        self._stream = _stream()
+        check(lib().msam2_graph_begin(self._stream))
+        return self
+
+    def __exit__(self, et, ev, tb):
+        rc = lib().msam2_graph_end(self._stream, ctypes.byref(self._exec))
+        if et is None:
+            check(rc)
+        return False
+
+    def replay(self):
+        check(lib().msam2_graph_launch(self._exec, _stream()))
+
+    def __del__(self):
+        try:
+            if self._exec:
+                lib().msam2_graph_destroy(self._exec)
+        except Exception:
+            pass
