@@ -41,6 +41,10 @@ SIGNATURES = {
     "msam2_conv3x3s2_ln_gelu": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_i, c_f, c_f, c_p]),
     "msam2_dwconv7x7_ln": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_p]),
     "msam2_convt2x2_shuffle": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_p]),
+    "msam2_space_to_depth": (c_i, [c_p, c_i, c_p, c_l, c_l, c_l, c_l, c_l, c_l, c_p]),
+    "msam2_aa_downsample": (c_i, [c_p, c_p, c_l, c_l, c_l, c_l, c_f, c_f, c_p]),
+    "msam2_gate_rows": (c_i, [c_p, c_p, c_f, c_l, c_l, c_p]),
+    "msam2_any_positive": (c_i, [c_p, c_p, c_l, c_l, c_p]),
     "msam2_hyper_masks": (c_i, [c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_p]),
     "msam2_prompt_points": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_f, c_p]),
     "msam2_select_mask": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_f, c_f, c_p]),

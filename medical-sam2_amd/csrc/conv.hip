@@ -382,3 +382,43 @@ extern "C" int msam2_obj_ptr_mix(float* ptr, const float* obj_scores, const floa
   hipLaunchKernelGGL(obj_ptr_mix_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, ptr, obj_scores, no_obj_ptr, (int)C);
   return msam2_check_launch("obj_ptr_mix");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Non-overlapping k x k / stride k patches (PromptEncoder.mask_downscaling convs k2 s2, prompt_encoder.py:58-66; and
+// SAM2Base.mask_downsample k4 s4, sam2_base.py:108): NHWC [B,H,W,C] -> bf16 [B*(H/k)*(W/k), ld] with columns
+// (ky, kx, c) and zero fill up to ld (>= k*k*C, multiple of 8 for the GEMM).
+// ------------------------------------------------------------------------------------------------------------------
+template <typename TI>
+__global__ void space_to_depth_kernel(const TI* __restrict__ x, bf16* __restrict__ out, int B, int H, int W, int C, int k, int ld) {
+  const int Ho = H / k, Wo = W / k;
+  const int64_t total = (int64_t)B * Ho * Wo * ld;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int col = i % ld;
+    int64_t t = i / ld;
+    const int xo = t % Wo;
+    t /= Wo;
+    const int yo = t % Ho;
+    const int b = t / Ho;
+    float v = 0.f;
+    if (col < k * k * C) {
+      const int c = col % C, kk = col / C, ky = kk / k, kx = kk % k;
+      v = (float)x[(((int64_t)b * H + yo * k + ky) * W + xo * k + kx) * C + c];
+    }
+    out[i] = f2bf(v);
+  }
+}
+
+extern "C" int msam2_space_to_depth(const void* x, int in_is_bf16, void* out, int64_t B, int64_t H, int64_t W, int64_t C, int64_t k,
+                                    int64_t ld, void* stream) {
+  MSAM2_REQUIRE(x && out && B > 0 && C > 0 && k > 0 && H % k == 0 && W % k == 0 && ld >= k * k * C && ld % 8 == 0,
+                "space_to_depth: bad arguments");
+  const int64_t total = B * (H / k) * (W / k) * ld;
+  dim3 grid((unsigned)min((int64_t)8192, (total + 255) / 256)), block(256);
+  if (in_is_bf16)
+    hipLaunchKernelGGL((space_to_depth_kernel<bf16>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out, (int)B, (int)H,
+                       (int)W, (int)C, (int)k, (int)ld);
+  else
+    hipLaunchKernelGGL((space_to_depth_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, (bf16*)out, (int)B, (int)H,
+                       (int)W, (int)C, (int)k, (int)ld);
+  return msam2_check_launch("space_to_depth");
+}

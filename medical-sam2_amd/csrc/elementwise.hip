@@ -349,3 +349,74 @@ extern "C" int msam2_hiera_pos_embed(float* out, const float* pos_embed, const f
                      (int)bh, (int)bw, (int)h, (int)w, (int)window);
   return msam2_check_launch("hiera_pos_embed");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Anti-aliased bilinear down-sampling by an integer factor (F.interpolate(..., mode="bilinear", antialias=True,
+// align_corners=False) at sam2_base.py:321-327,421-427): separable triangle filter of half-width `f` source pixels,
+// weights renormalised at the borders.  Optional affine on the input: v = x * in_scale + in_bias (mask -> +-10 logits).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void aa_downsample_kernel(const float* __restrict__ x, float* __restrict__ y, int P, int H, int W, int f, float in_scale,
+                                     float in_bias) {
+  const int Ho = H / f, Wo = W / f;
+  const int64_t total = (int64_t)P * Ho * Wo;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int xo = i % Wo;
+    int64_t t = i / Wo;
+    const int yo = t % Ho;
+    const int pl = t / Ho;
+    const float cy = (yo + 0.5f) * f, cx = (xo + 0.5f) * f;
+    const int y0 = max((int)(cy - f + 0.5f), 0), y1 = min((int)(cy + f + 0.5f), H);
+    const int x0 = max((int)(cx - f + 0.5f), 0), x1 = min((int)(cx + f + 0.5f), W);
+    float wys = 0.f, wxs = 0.f;
+    for (int yy = y0; yy < y1; ++yy) wys += fmaxf(0.f, 1.f - fabsf((yy + 0.5f - cy) / f));
+    for (int xx = x0; xx < x1; ++xx) wxs += fmaxf(0.f, 1.f - fabsf((xx + 0.5f - cx) / f));
+    float acc = 0.f;
+    const float* p = x + (int64_t)pl * H * W;
+    for (int yy = y0; yy < y1; ++yy) {
+      const float wy = fmaxf(0.f, 1.f - fabsf((yy + 0.5f - cy) / f)) / wys;
+      float rowv = 0.f;
+      for (int xx = x0; xx < x1; ++xx) rowv += (fmaxf(0.f, 1.f - fabsf((xx + 0.5f - cx) / f)) / wxs) * (p[yy * W + xx] * in_scale + in_bias);
+      acc += wy * rowv;
+    }
+    y[i] = acc;
+  }
+}
+
+extern "C" int msam2_aa_downsample(const float* x, float* y, int64_t planes, int64_t H, int64_t W, int64_t factor, float in_scale,
+                                   float in_bias, void* stream) {
+  MSAM2_REQUIRE(x && y && planes > 0 && factor >= 1 && H % factor == 0 && W % factor == 0, "aa_downsample: bad arguments");
+  const int64_t total = planes * (H / factor) * (W / factor);
+  hipLaunchKernelGGL(aa_downsample_kernel, dim3((unsigned)min((int64_t)8192, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     y, (int)planes, (int)H, (int)W, (int)factor, in_scale, in_bias);
+  return msam2_check_launch("aa_downsample");
+}
+
+// rows[b, :] = value where score[b] <= 0   (object-score gating of the mask logits, sam2_base.py:354-363)
+__global__ void gate_rows_kernel(float* __restrict__ x, const float* __restrict__ score, float value, int64_t row_len) {
+  const int b = blockIdx.y;
+  if (score[b] > 0.f) return;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_len; i += (int64_t)gridDim.x * blockDim.x)
+    x[(int64_t)b * row_len + i] = value;
+}
+
+extern "C" int msam2_gate_rows(float* x, const float* score, float value, int64_t B, int64_t row_len, void* stream) {
+  MSAM2_REQUIRE(x && score && B > 0 && row_len > 0, "gate_rows: bad arguments");
+  hipLaunchKernelGGL(gate_rows_kernel, dim3((unsigned)min((int64_t)1024, (row_len + 255) / 256), (unsigned)B), dim3(256), 0,
+                     (hipStream_t)stream, x, score, value, row_len);
+  return msam2_check_launch("gate_rows");
+}
+
+// out[b] = 1.0 if any x[b, :] > 0 else 0.0   (sam2_base.py:445-447)
+__global__ void any_positive_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t row_len) {
+  const int b = blockIdx.x;
+  int found = 0;
+  for (int64_t i = threadIdx.x; i < row_len; i += blockDim.x) found |= x[(int64_t)b * row_len + i] > 0.f;
+  found = __syncthreads_or(found);
+  if (threadIdx.x == 0) out[b] = found ? 1.f : 0.f;
+}
+
+extern "C" int msam2_any_positive(const float* x, float* out, int64_t B, int64_t row_len, void* stream) {
+  MSAM2_REQUIRE(x && out && B > 0 && row_len > 0, "any_positive: bad arguments");
+  hipLaunchKernelGGL(any_positive_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, x, out, row_len);
+  return msam2_check_launch("any_positive");
+}

@@ -20,7 +20,7 @@ struct GemmParams {
   int64_t lda, ldw, ldr, ldc;
   int64_t res_mod;
   int M, N, K;
-  int act;          // 0 none, 1 gelu(erf), 2 relu
+  int act;          // 0 none, 1 gelu(erf), 2 relu, 3 sigmoid
   int res_is_bf16;  // residual dtype
   int out_is_bf16;  // output dtype
 };
@@ -135,6 +135,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmParams p) {
         float v = acc[i][j][e] + bias;
         if (p.act == 1) v = gelu_erf(v);
         else if (p.act == 2) v = fmaxf(v, 0.f);
+        else if (p.act == 3) v = 1.f / (1.f + __expf(-v));
         v *= cs;
         if (p.res) {
           const int64_t rr = p.res_mod > 0 ? (m % p.res_mod) : m;
@@ -163,7 +164,7 @@ extern "C" int msam2_gemm_bf16(const void* A, int64_t lda, const void* W, int64_
   MSAM2_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0, "gemm: K, lda, ldw must be multiples of 8 (16-byte rows)");
   MSAM2_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "gemm: A and W must be 16-byte aligned");
   MSAM2_REQUIRE(M < (1ll << 31) && N < (1ll << 31), "gemm: M/N too large");
-  MSAM2_REQUIRE(act >= 0 && act <= 2, "gemm: bad activation %d", act);
+  MSAM2_REQUIRE(act >= 0 && act <= 3, "gemm: bad activation %d", act);
   GemmParams p;
   p.A = (const bf16*)A; p.W = (const bf16*)W; p.bias = bias; p.colscale = colscale; p.res = residual; p.C = C;
   p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldc = ldc; p.res_mod = res_mod;

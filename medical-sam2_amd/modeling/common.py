@@ -1,0 +1,71 @@
+"""Shared host-side helpers for the drop-in modules: a version-checked cache of kernel-ready (bf16 / repacked) weights
+and tiny tensor-view utilities.  Nothing here computes on activations."""
+from __future__ import annotations
+
+from typing import Callable, Dict, Sequence, Tuple
+
+import torch
+
+from .. import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+class WeightCache:
+    """Kernel-ready copies of parameters (bf16 casts, fused/concatenated or permuted layouts), rebuilt only when the
+    source parameter storage or its in-place version counter changes (i.e. after load_state_dict / an optimizer step).
+    The repacking is pure data movement done once per weight update -- not part of the per-slice path."""
+
+    def __init__(self):
+        self._c: Dict[str, Tuple[tuple, object]] = {}
+
+    def get(self, key: str, params: Sequence[torch.Tensor], build: Callable[[], object]):
+        sig = tuple((p.data_ptr(), p._version, str(p.device), p.dtype) for p in params)
+        hit = self._c.get(key)
+        if hit is None or hit[0] != sig:
+            with torch.no_grad():
+                hit = (sig, build())
+            self._c[key] = hit
+        return hit[1]
+
+    def clear(self):
+        self._c.clear()
+
+
+def w_bf16(cache: WeightCache, key: str, *weights: torch.Tensor) -> torch.Tensor:
+    """bf16 [sum(out_i), in] matrix from one or more nn.Linear / 1x1-conv weights stacked along the output dim."""
+    return cache.get(key, weights, lambda: torch.cat([w.detach().reshape(w.shape[0], -1) for w in weights], 0).to(BF16).contiguous())
+
+
+def v_f32(cache: WeightCache, key: str, *vecs: torch.Tensor) -> torch.Tensor:
+    return cache.get(key, vecs, lambda: torch.cat([v.detach().reshape(-1) for v in vecs], 0).to(F32).contiguous())
+
+
+def tokens_of(x_nchw: torch.Tensor) -> torch.Tensor:
+    """[B,C,H,W] -> token-major [B*H*W, C].  Free when the tensor is an NCHW view of NHWC memory (what this package's
+    modules return); foreign channels-first tensors are re-laid-out once by torch (data movement only)."""
+    B, C, H, W = x_nchw.shape
+    t = x_nchw.permute(0, 2, 3, 1)
+    if not t.is_contiguous():
+        t = t.contiguous()
+    return t.reshape(B * H * W, C)
+
+
+def nchw_view(tokens: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
+    """token-major [B*H*W, C] -> [B,C,H,W] view (no copy)."""
+    return tokens.reshape(B, H, W, tokens.shape[-1]).permute(0, 3, 1, 2)
+
+
+def to_bf16(x2d: torch.Tensor) -> torch.Tensor:
+    """bf16 copy of a [rows, C] tensor through the add_cast kernel (no-op for bf16 input)."""
+    if x2d.dtype == BF16:
+        return x2d
+    return ops.add_cast(x2d.unsqueeze(0), None, 1.0, BF16)[0]
+
+
+def attn_splits(B: int, H: int, Lq: int, Lk: int) -> int:
+    """Split-KV factor: enough workgroups (128 queries each) to cover the 256 CUs twice, at least 8 key tiles per split."""
+    wgs = B * H * ((Lq + 127) // 128)
+    if wgs >= 512 or Lk < 1024:
+        return 1
+    return max(1, min((512 + wgs - 1) // wgs, Lk // 256, 16))

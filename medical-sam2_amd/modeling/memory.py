@@ -1,0 +1,336 @@
+"""Drop-in memory attention and memory encoder (sam2_train/modeling/{memory_attention,memory_encoder}.py and the
+RoPEAttention of sam/transformer.py:266-331), routed through the MI355X kernels.
+
+Memory attention runs batch-first internally: fp32 residual stream [B*L, 256], fused q|k|v projection for the self
+attention, per-layer K/V projection of the 64-channel memory bank, in-place axial RoPE on the bf16 q/k rows, and the
+D=256 single-head flash kernel with split-KV sized to fill the 256 CUs.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .common import BF16, F32, WeightCache, attn_splits, nchw_view, to_bf16, tokens_of, v_f32, w_bf16
+from .encoder import MLP  # noqa: F401  (re-export for the registry)
+
+
+class LayerNorm2d(nn.Module):
+    """sam2_utils.py:137-149 -- parameters only; the kernels normalise NHWC tokens over the channel dim."""
+
+    def __init__(self, num_channels: int, eps: float = 1e-6) -> None:
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(num_channels))
+        self.bias = nn.Parameter(torch.zeros(num_channels))
+        self.eps = eps
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        B, C, H, W = x.shape
+        y = ops.layernorm(tokens_of(x), self.weight.detach().float(), self.bias.detach().float(), self.eps, out_dtype=F32)
+        return nchw_view(y, B, H, W)
+
+
+class Attention(nn.Module):
+    """sam/transformer.py:199-263.  `forward(q,k,v)` takes [B, L, C] tensors like the reference."""
+
+    def __init__(self, embedding_dim: int, num_heads: int, downsample_rate: int = 1, dropout: float = 0.0, kv_in_dim: int = None):
+        super().__init__()
+        self.embedding_dim = embedding_dim
+        self.kv_in_dim = kv_in_dim if kv_in_dim is not None else embedding_dim
+        self.internal_dim = embedding_dim // downsample_rate
+        self.num_heads = num_heads
+        assert self.internal_dim % num_heads == 0, "num_heads must divide embedding_dim."
+        self.q_proj = nn.Linear(embedding_dim, self.internal_dim)
+        self.k_proj = nn.Linear(self.kv_in_dim, self.internal_dim)
+        self.v_proj = nn.Linear(self.kv_in_dim, self.internal_dim)
+        self.out_proj = nn.Linear(self.internal_dim, embedding_dim)
+        self.dropout_p = dropout
+        self._wc = WeightCache()
+
+    # -- kernel-ready pieces -------------------------------------------------------------------------------------
+    def proj(self, which: str, x_bf16: torch.Tensor) -> torch.Tensor:
+        lin = getattr(self, which + "_proj")
+        return ops.gemm(x_bf16, w_bf16(self._wc, which + "w", lin.weight), v_f32(self._wc, which + "b", lin.bias))
+
+    def out(self, o_bf16: torch.Tensor, residual: Optional[torch.Tensor], out_dtype=F32) -> torch.Tensor:
+        return ops.gemm(o_bf16, w_bf16(self._wc, "ow", self.out_proj.weight), v_f32(self._wc, "ob", self.out_proj.bias),
+                        residual=residual, out_dtype=out_dtype)
+
+    def core(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+        """projected bf16 [B, L, internal] -> attention output [B*Lq, internal] bf16."""
+        B, Lq, C = q.shape
+        D = C // self.num_heads
+        if D in (16, 32):
+            return ops.attention_small(q, k, v, self.num_heads).reshape(B * Lq, C)
+        H = self.num_heads
+        sp = lambda t: t.view(B, t.shape[1], H, D).permute(0, 2, 1, 3)
+        o = ops.attention(sp(q), sp(k), sp(v), splits=attn_splits(B, H, Lq, k.shape[1]))
+        return o.permute(0, 2, 1, 3).reshape(B * Lq, C)
+
+    def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+        assert not (self.training and self.dropout_p > 0.0), "attention dropout (train mode) is outside the forward hot path"
+        B, Lq, _ = q.shape
+        f = lambda t, n: self.proj(n, to_bf16(t.reshape(-1, t.shape[-1]).contiguous())).view(B, t.shape[1], -1)
+        o = self.core(f(q, "q"), f(k, "k"), f(v, "v"))
+        return self.out(o, None).view(B, Lq, -1)
+
+
+class RoPEAttention(Attention):
+    """sam/transformer.py:266-331."""
+
+    def __init__(self, *args, rope_theta=10000.0, rope_k_repeat=False, feat_sizes=(32, 32), **kwargs):
+        super().__init__(*args, **kwargs)
+        self.rope_theta = rope_theta
+        self.rope_k_repeat = rope_k_repeat
+        self.feat_sizes = feat_sizes
+        self._tables = {}
+
+    def table(self, n_q: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+        """axial cos/sin table for a sqrt(n_q) x sqrt(n_q) query grid (transformer.py:299-305), generated on device once."""
+        side = int(round(math.sqrt(n_q)))
+        assert side * side == n_q, "RoPE attention expects a square token grid"
+        key = (side, str(device))
+        if key not in self._tables:
+            self._tables[key] = ops.rope_table(side, self.internal_dim // self.num_heads, float(self.rope_theta), device)
+        return self._tables[key]
+
+    def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_k_exclude_rope: int = 0) -> torch.Tensor:
+        assert not (self.training and self.dropout_p > 0.0), "attention dropout (train mode) is outside the forward hot path"
+        B, Lq, _ = q.shape
+        f = lambda t, n: self.proj(n, to_bf16(t.reshape(-1, t.shape[-1]).contiguous())).view(B, t.shape[1], -1)
+        qp, kp, vp = f(q, "q"), f(k, "k"), f(v, "v")
+        if qp.shape[1] != kp.shape[1]:
+            assert self.rope_k_repeat
+        tab = self.table(Lq, q.device)
+        ops.rope_(qp, Lq, tab)
+        ops.rope_(kp, kp.shape[1] - num_k_exclude_rope, tab)
+        return self.out(self.core(qp, kp, vp), None).view(B, Lq, -1)
+
+
+class MemoryAttentionLayer(nn.Module):
+    """memory_attention.py:17-99 (pre-LN: RoPE self-attn, RoPE cross-attn to the memory bank, ReLU FFN)."""
+
+    def __init__(self, activation: str, cross_attention: nn.Module, d_model: int, dim_feedforward: int, dropout: float,
+                 pos_enc_at_attn: bool, pos_enc_at_cross_attn_keys: bool, pos_enc_at_cross_attn_queries: bool,
+                 self_attention: nn.Module):
+        super().__init__()
+        assert activation == "relu" and not pos_enc_at_attn and pos_enc_at_cross_attn_keys and not pos_enc_at_cross_attn_queries, \
+            "HIP path implements the YAML's layer wiring (relu; pos enc only on cross-attn keys)"
+        self.d_model, self.dim_feedforward, self.dropout_value = d_model, dim_feedforward, dropout
+        self.self_attn = self_attention
+        self.cross_attn_image = cross_attention
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d_model), nn.LayerNorm(d_model), nn.LayerNorm(d_model)
+        self.dropout1, self.dropout2, self.dropout3 = nn.Dropout(dropout), nn.Dropout(dropout), nn.Dropout(dropout)
+        self.activation_str = activation
+        self.pos_enc_at_attn = pos_enc_at_attn
+        self.pos_enc_at_cross_attn_queries = pos_enc_at_cross_attn_queries
+        self.pos_enc_at_cross_attn_keys = pos_enc_at_cross_attn_keys
+        self._wc = WeightCache()
+
+    def _ln(self, name: str, x: torch.Tensor) -> torch.Tensor:
+        n = getattr(self, name)
+        return ops.layernorm(x, v_f32(self._wc, name + "w", n.weight), v_f32(self._wc, name + "b", n.bias), n.eps)
+
+    def run(self, x: torch.Tensor, mem_k: torch.Tensor, mem_v: torch.Tensor, B: int, L: int, n_ptr_tokens: int) -> torch.Tensor:
+        """x fp32 [B*L, C]; mem_k (= memory + pos) / mem_v (= memory) bf16 [B, Nk, 64]."""
+        wc, sa, ca = self._wc, self.self_attn, self.cross_attn_image
+        C = self.d_model
+        Nk = mem_k.shape[1]
+        tab = sa.table(L, x.device)
+        # self attention: fused q|k|v projection, RoPE on q and k rows in place
+        t = self._ln("norm1", x)
+        qkv = ops.gemm(t, w_bf16(wc, "sqkv", sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight),
+                       v_f32(wc, "sqkvb", sa.q_proj.bias, sa.k_proj.bias, sa.v_proj.bias)).view(B, L, 3 * C)
+        q, k, v = qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
+        ops.rope_(q, L, tab)
+        ops.rope_(k, L, tab)
+        x = sa.out(sa.core(q, k, v), x)
+        # cross attention to the memory bank (keys carry the position encoding, values do not)
+        t = self._ln("norm2", x)
+        q = ca.proj("q", t).view(B, L, C)
+        ops.rope_(q, L, tab)
+        kk = ca.proj("k", mem_k.reshape(B * Nk, -1)).view(B, Nk, C)
+        ops.rope_(kk, Nk - n_ptr_tokens, tab)
+        vv = ca.proj("v", mem_v.reshape(B * Nk, -1)).view(B, Nk, C)
+        x = ca.out(ca.core(q, kk, vv), x)
+        # FFN
+        t = self._ln("norm3", x)
+        h = ops.gemm(t, w_bf16(wc, "f1", self.linear1.weight), v_f32(wc, "f1b", self.linear1.bias), act=ops.ACT_RELU)
+        return ops.gemm(h, w_bf16(wc, "f2", self.linear2.weight), v_f32(wc, "f2b", self.linear2.bias), residual=x, out_dtype=F32)
+
+    def forward(self, tgt, memory, pos: Optional[torch.Tensor] = None, query_pos: Optional[torch.Tensor] = None,
+                num_k_exclude_rope: int = 0) -> torch.Tensor:
+        assert not self.training or self.dropout_value == 0.0, "dropout (train mode) is outside the forward hot path"
+        B, L, C = tgt.shape
+        mem_k = ops.add_cast(memory, pos, 1.0, BF16)
+        mem_v = ops.add_cast(memory, None, 1.0, BF16)
+        x = ops.add_cast(tgt, None, 1.0, F32).reshape(B * L, C)
+        return self.run(x, mem_k, mem_v, B, L, num_k_exclude_rope).view(B, L, C)
+
+
+class MemoryAttention(nn.Module):
+    """memory_attention.py:102-169; seq-first [L, B, C] in and out, like the reference."""
+
+    def __init__(self, d_model: int, pos_enc_at_input: bool, layer: nn.Module, num_layers: int, batch_first: bool = True):
+        super().__init__()
+        assert batch_first
+        self.d_model = d_model
+        self.layers = nn.ModuleList([copy.deepcopy(layer) for _ in range(num_layers)])
+        self.num_layers = num_layers
+        self.norm = nn.LayerNorm(d_model)
+        self.pos_enc_at_input = pos_enc_at_input
+        self.batch_first = batch_first
+        self._wc = WeightCache()
+
+    def forward(self, curr: torch.Tensor, memory: torch.Tensor, curr_pos: Optional[torch.Tensor] = None,
+                memory_pos: Optional[torch.Tensor] = None, num_obj_ptr_tokens: int = 0):
+        if isinstance(curr, list):
+            assert isinstance(curr_pos, list) and len(curr) == len(curr_pos) == 1
+            curr, curr_pos = curr[0], curr_pos[0]
+        assert curr.shape[1] == memory.shape[1], "Batch size must be the same for curr and memory"
+        L, B, C = curr.shape
+        # seq-first -> batch-first happens inside the add/cast kernels (strided reads), no separate transpose
+        use_pos = self.pos_enc_at_input and curr_pos is not None
+        x = ops.add_cast(curr.transpose(0, 1), curr_pos.transpose(0, 1) if use_pos else None, 0.1, F32).reshape(B * L, C)
+        mem_bf = memory.transpose(0, 1)
+        mem_k = ops.add_cast(mem_bf, memory_pos.transpose(0, 1), 1.0, BF16)
+        mem_v = ops.add_cast(mem_bf, None, 1.0, BF16)
+        for layer in self.layers:
+            x = layer.run(x, mem_k, mem_v, B, L, num_obj_ptr_tokens)
+        y = ops.layernorm(x, v_f32(self._wc, "nw", self.norm.weight), v_f32(self._wc, "nb", self.norm.bias), self.norm.eps,
+                          out_dtype=F32)
+        return y.view(B, L, C).transpose(0, 1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class MaskDownSampler(nn.Module):
+    """memory_encoder.py:17-58 (conv k3 s2 p1 + LayerNorm2d + GELU, x4, then 1x1 to embed_dim)."""
+
+    def __init__(self, embed_dim=256, kernel_size=4, stride=4, padding=0, total_stride=16, activation=nn.GELU):
+        super().__init__()
+        assert (kernel_size, stride, padding, total_stride) == (3, 2, 1, 16) and activation is nn.GELU, \
+            "HIP path implements the YAML's k3/s2/p1 mask down-sampler"
+        num_layers = int(math.log2(total_stride) // math.log2(stride))
+        self.encoder = nn.Sequential()
+        cin = 1
+        for _ in range(num_layers):
+            cout = cin * (stride ** 2)
+            self.encoder.append(nn.Conv2d(cin, cout, kernel_size=kernel_size, stride=stride, padding=padding))
+            self.encoder.append(LayerNorm2d(cout))
+            self.encoder.append(activation())
+            cin = cout
+        self.encoder.append(nn.Conv2d(cin, embed_dim, kernel_size=1))
+        self._wc = WeightCache()
+
+    def run(self, mask: torch.Tensor, mode: int, scale: float, bias: float) -> torch.Tensor:
+        """fp32 mask [n,1,S,S] (raw logits when mode != 0) -> fp32 tokens [n*(S/16)^2, embed_dim]."""
+        n, _, S, _ = mask.shape
+        wc, enc = self._wc, self.encoder
+        f = lambda key, p: v_f32(wc, key, p)
+        h = mask.to(F32).contiguous().reshape(n * S * S, 1)
+        side = S
+        for j in range(3):
+            conv, ln = enc[3 * j], enc[3 * j + 1]
+            h = ops.conv3x3s2_ln_gelu(h, n, side, side, wc.get(f"cw{j}", [conv.weight], lambda c=conv: c.weight.detach().float().contiguous()),
+                                      f(f"cb{j}", conv.bias), f(f"lw{j}", ln.weight), f(f"lb{j}", ln.bias),
+                                      mode if j == 0 else 0, scale, bias)
+            side //= 2
+        conv, ln = enc[9], enc[10]
+        cols = ops.im2col3x3s2(h, n, side, side)
+        wmat = wc.get("cw3", [conv.weight], lambda: conv.weight.detach().permute(0, 2, 3, 1).reshape(conv.weight.shape[0], -1).to(BF16).contiguous())
+        h = ops.gemm(cols, wmat, f("cb3", conv.bias), out_dtype=F32)
+        h = ops.layernorm(h, f("lw3", ln.weight), f("lb3", ln.bias), ln.eps, act=ops.ACT_GELU)
+        return ops.gemm(h, w_bf16(wc, "pw", enc[12].weight), f("pb", enc[12].bias), out_dtype=F32)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        n, _, S, _ = x.shape
+        return nchw_view(self.run(x, 0, 0.0, 0.0), n, S // 16, S // 16)
+
+
+class CXBlock(nn.Module):
+    """memory_encoder.py:62-117 (ConvNeXt block: dw 7x7 -> LN -> 1x1 -> GELU -> 1x1 -> layer scale -> residual)."""
+
+    def __init__(self, dim, kernel_size=7, padding=3, drop_path=0.0, layer_scale_init_value=1e-6, use_dwconv=True):
+        super().__init__()
+        assert kernel_size == 7 and padding == 3 and use_dwconv and drop_path == 0.0 and layer_scale_init_value > 0
+        self.dwconv = nn.Conv2d(dim, dim, kernel_size=7, padding=3, groups=dim)
+        self.norm = LayerNorm2d(dim, eps=1e-6)
+        self.pwconv1 = nn.Linear(dim, 4 * dim)
+        self.act = nn.GELU()
+        self.pwconv2 = nn.Linear(4 * dim, dim)
+        self.gamma = nn.Parameter(layer_scale_init_value * torch.ones(dim), requires_grad=True)
+        self._wc = WeightCache()
+
+    def run(self, x: torch.Tensor, n: int, H: int, W: int) -> torch.Tensor:
+        """fp32 tokens [n*H*W, C] -> same."""
+        wc = self._wc
+        C = x.shape[1]
+        wt = wc.get("dw", [self.dwconv.weight], lambda: self.dwconv.weight.detach().reshape(C, 49).t().float().contiguous())
+        h = ops.dwconv7x7_ln(x, n, H, W, wt, v_f32(wc, "dwb", self.dwconv.bias), v_f32(wc, "lw", self.norm.weight),
+                             v_f32(wc, "lb", self.norm.bias))
+        h = ops.gemm(h, w_bf16(wc, "w1", self.pwconv1.weight), v_f32(wc, "b1", self.pwconv1.bias), act=ops.ACT_GELU)
+        return ops.gemm(h, w_bf16(wc, "w2", self.pwconv2.weight), v_f32(wc, "b2", self.pwconv2.bias),
+                        colscale=v_f32(wc, "g", self.gamma), residual=x, out_dtype=F32)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        n, C, H, W = x.shape
+        return nchw_view(self.run(tokens_of(x.to(F32)), n, H, W), n, H, W)
+
+
+class Fuser(nn.Module):
+    """memory_encoder.py:120-135."""
+
+    def __init__(self, layer, num_layers, dim=None, input_projection=False):
+        super().__init__()
+        assert not input_projection, "SAM2 configs use no input projection in the fuser"
+        self.proj = nn.Identity()
+        self.layers = nn.ModuleList([copy.deepcopy(layer) for _ in range(num_layers)])
+
+    def run(self, x, n, H, W):
+        for layer in self.layers:
+            x = layer.run(x, n, H, W)
+        return x
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        n, C, H, W = x.shape
+        return nchw_view(self.run(tokens_of(x.to(F32)), n, H, W), n, H, W)
+
+
+class MemoryEncoder(nn.Module):
+    """memory_encoder.py:138-181."""
+
+    def __init__(self, out_dim, mask_downsampler, fuser, position_encoding, in_dim=256):
+        super().__init__()
+        self.mask_downsampler = mask_downsampler
+        self.pix_feat_proj = nn.Conv2d(in_dim, in_dim, kernel_size=1)
+        self.fuser = fuser
+        self.position_encoding = position_encoding
+        self.out_proj = nn.Identity()
+        if out_dim != in_dim:
+            self.out_proj = nn.Conv2d(in_dim, out_dim, kernel_size=1)
+        self._wc = WeightCache()
+
+    def run(self, pix_tokens: torch.Tensor, mask: torch.Tensor, mode: int, scale: float, bias: float, n: int, H: int, W: int):
+        """pix_tokens [n*H*W, C] (fp32 or bf16), mask fp32 [n,1,16H,16W] -> (fp32 tokens [n*H*W, out_dim])."""
+        wc = self._wc
+        m = self.mask_downsampler.run(mask, mode, scale, bias)
+        x = ops.gemm(to_bf16(pix_tokens), w_bf16(wc, "pw", self.pix_feat_proj.weight), v_f32(wc, "pb", self.pix_feat_proj.bias),
+                     residual=m, out_dtype=F32)
+        x = self.fuser.run(x, n, H, W)
+        if isinstance(self.out_proj, nn.Identity):
+            return x
+        return ops.gemm(to_bf16(x), w_bf16(wc, "ow", self.out_proj.weight), v_f32(wc, "ob", self.out_proj.bias), out_dtype=F32)
+
+    def forward(self, pix_feat: torch.Tensor, masks: torch.Tensor, skip_mask_sigmoid: bool = False):
+        n, C, H, W = pix_feat.shape
+        y = self.run(tokens_of(pix_feat), masks, 0 if skip_mask_sigmoid else 1, 1.0, 0.0, n, H, W)
+        x = nchw_view(y, n, H, W)
+        pos = self.position_encoding(x).to(x.dtype)
+        return {"vision_features": x, "vision_pos_enc": [pos]}

@@ -1,0 +1,318 @@
+"""Drop-in SAM prompt encoder, two-way transformer and mask decoder (sam2_train/modeling/sam/{prompt_encoder,transformer,
+mask_decoder}.py) on the MI355X kernels.  Token-side tensors are a handful of rows; image-side tensors are token-major
+[B*h*w, C] (fp32 residual stream + bf16 operand copies)."""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple, Type
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .common import BF16, F32, WeightCache, nchw_view, to_bf16, tokens_of, v_f32, w_bf16
+from .encoder import MLP
+from .memory import Attention, LayerNorm2d
+from .position import PositionEmbeddingRandom
+
+
+class PromptEncoder(nn.Module):
+    """prompt_encoder.py:15-190.  Dense embeddings are returned at `image_embedding_size` (the upstream behaviour that the
+    fork's hard-coded 16x16 resize at 189-190 reproduces only for 256-pixel inputs; SURVEY.md shim S2)."""
+
+    def __init__(self, embed_dim: int, image_embedding_size: Tuple[int, int], input_image_size: Tuple[int, int],
+                 mask_in_chans: int, activation: Type[nn.Module] = nn.GELU) -> None:
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.input_image_size = input_image_size
+        self.image_embedding_size = image_embedding_size
+        self.pe_layer = PositionEmbeddingRandom(embed_dim // 2)
+        self.num_point_embeddings: int = 4
+        self.point_embeddings = nn.ModuleList([nn.Embedding(1, embed_dim) for _ in range(self.num_point_embeddings)])
+        self.not_a_point_embed = nn.Embedding(1, embed_dim)
+        self.mask_input_size = (4 * image_embedding_size[0], 4 * image_embedding_size[1])
+        self.mask_downscaling = nn.Sequential(
+            nn.Conv2d(1, mask_in_chans // 4, kernel_size=2, stride=2), LayerNorm2d(mask_in_chans // 4), activation(),
+            nn.Conv2d(mask_in_chans // 4, mask_in_chans, kernel_size=2, stride=2), LayerNorm2d(mask_in_chans), activation(),
+            nn.Conv2d(mask_in_chans, embed_dim, kernel_size=1))
+        self.no_mask_embed = nn.Embedding(1, embed_dim)
+        self._wc = WeightCache()
+
+    def dense_pe_tokens(self) -> torch.Tensor:
+        g = self.pe_layer.positional_encoding_gaussian_matrix
+        return self._wc.get("dense_pe", [g], lambda: self.pe_layer.grid_tokens(self.image_embedding_size))
+
+    def get_dense_pe(self) -> torch.Tensor:
+        h, w = self.image_embedding_size
+        return nchw_view(self.dense_pe_tokens(), 1, h, w)
+
+    def _points(self, xy: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        assert self.input_image_size[0] == self.input_image_size[1]
+        wc = self._wc
+        emb = wc.get("pemb", [m.weight for m in self.point_embeddings],
+                     lambda: torch.cat([m.weight.detach() for m in self.point_embeddings], 0).float().contiguous())
+        return ops.prompt_points(xy.to(F32), labels.to(torch.int32), self.pe_layer.positional_encoding_gaussian_matrix.to(F32), emb,
+                                 v_f32(wc, "nap", self.not_a_point_embed.weight), float(self.input_image_size[0]))
+
+    def _embed_masks_tokens(self, masks: torch.Tensor) -> torch.Tensor:
+        """mask_downscaling (two k2/s2 convs + LN + GELU, then 1x1) -> fp32 tokens [n*h*w, embed_dim]."""
+        n, _, H, W = masks.shape
+        wc, md = self._wc, self.mask_downscaling
+        f = lambda key, p: v_f32(wc, key, p)
+
+        def patch_w(conv, key):
+            def build():
+                w = conv.weight.detach().permute(0, 2, 3, 1).reshape(conv.weight.shape[0], -1)
+                ld = (w.shape[1] + 7) // 8 * 8
+                out = torch.zeros(w.shape[0], ld, dtype=BF16, device=w.device)
+                out[:, : w.shape[1]] = w.to(BF16)
+                return out
+            return wc.get(key, [conv.weight], build)
+
+        h = ops.space_to_depth(masks.to(F32).contiguous().reshape(n * H * W, 1), n, H, W, 2)
+        h = ops.gemm(h, patch_w(md[0], "w0"), f("b0", md[0].bias), out_dtype=F32)
+        h = ops.layernorm(h, f("lw0", md[1].weight), f("lb0", md[1].bias), md[1].eps, act=ops.ACT_GELU)
+        h = ops.space_to_depth(h, n, H // 2, W // 2, 2)
+        h = ops.gemm(h, patch_w(md[3], "w1"), f("b1", md[3].bias), out_dtype=F32)
+        h = ops.layernorm(h, f("lw1", md[4].weight), f("lb1", md[4].bias), md[4].eps, act=ops.ACT_GELU)
+        return ops.gemm(h, w_bf16(wc, "w2", md[6].weight), f("b2", md[6].bias), out_dtype=F32)
+
+    def _get_batch_size(self, points, boxes, masks) -> int:
+        if points is not None:
+            return points[0].shape[0]
+        if boxes is not None:
+            return boxes.shape[0]
+        if masks is not None:
+            return masks.shape[0]
+        return 1
+
+    def forward(self, points: Optional[Tuple[torch.Tensor, torch.Tensor]], boxes: Optional[torch.Tensor],
+                masks: Optional[torch.Tensor], batch_size=-1) -> Tuple[torch.Tensor, torch.Tensor]:
+        bs = self._get_batch_size(points, boxes, masks)
+        dev = self.no_mask_embed.weight.device
+        xy_parts, lab_parts = [], []
+        if points is not None:
+            coords, labels = points
+            xy_parts.append(coords.to(F32))
+            lab_parts.append(labels.to(torch.int32))
+            if boxes is None:  # padding point, label -1 (prompt_encoder.py:87-91)
+                xy_parts.append(torch.zeros(bs, 1, 2, device=dev))
+                lab_parts.append(torch.full((bs, 1), -1, dtype=torch.int32, device=dev))
+        if boxes is not None:  # box corners are points with labels 2 / 3 (prompt_encoder.py:103-112)
+            xy_parts.append(boxes.to(F32).reshape(-1, 2, 2))
+            lab_parts.append(torch.tensor([[2, 3]], dtype=torch.int32, device=dev).expand(bs, 2))
+        if xy_parts:
+            sparse = self._points(torch.cat(xy_parts, 1).contiguous(), torch.cat(lab_parts, 1).contiguous())
+        else:
+            sparse = torch.empty((bs, 0, self.embed_dim), device=dev)
+        h, w = self.image_embedding_size
+        if masks is not None:
+            dense = nchw_view(self._embed_masks_tokens(masks), bs, h, w)
+        else:
+            dense = self.no_mask_embed.weight.reshape(1, -1, 1, 1).expand(bs, -1, h, w)
+        return sparse, dense
+
+
+class TwoWayAttentionBlock(nn.Module):
+    """transformer.py:121-196."""
+
+    def __init__(self, embedding_dim: int, num_heads: int, mlp_dim: int = 2048, activation: Type[nn.Module] = nn.ReLU,
+                 attention_downsample_rate: int = 2, skip_first_layer_pe: bool = False) -> None:
+        super().__init__()
+        self.self_attn = Attention(embedding_dim, num_heads)
+        self.norm1 = nn.LayerNorm(embedding_dim)
+        self.cross_attn_token_to_image = Attention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
+        self.norm2 = nn.LayerNorm(embedding_dim)
+        self.mlp = MLP(embedding_dim, mlp_dim, embedding_dim, num_layers=2, activation=activation)
+        self.norm3 = nn.LayerNorm(embedding_dim)
+        self.norm4 = nn.LayerNorm(embedding_dim)
+        self.cross_attn_image_to_token = Attention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
+        self.skip_first_layer_pe = skip_first_layer_pe
+        self._wc = WeightCache()
+
+    def _ln(self, name, x):
+        n = getattr(self, name)
+        return ops.layernorm(x, v_f32(self._wc, name + "w", n.weight), v_f32(self._wc, name + "b", n.bias), n.eps, out_dtype=F32)
+
+    def run(self, queries, keys, query_pe, key_pe, B, T, L):
+        """queries/query_pe fp32 [B*T, C]; keys fp32 [B*L, C]; key_pe fp32 [L, C] (shared over the batch)."""
+        C = queries.shape[1]
+        q3 = lambda t, n: t.view(B, n, -1)
+        sa = self.self_attn
+        if self.skip_first_layer_pe:
+            qb = to_bf16(queries)
+            queries = sa.out(sa.core(q3(sa.proj("q", qb), T), q3(sa.proj("k", qb), T), q3(sa.proj("v", qb), T)), None)
+        else:
+            qb = ops.add_cast(queries.view(1, B * T, C), query_pe.view(1, B * T, C), 1.0, BF16)[0]
+            queries = sa.out(sa.core(q3(sa.proj("q", qb), T), q3(sa.proj("k", qb), T), q3(sa.proj("v", to_bf16(queries)), T)), queries)
+        queries = self._ln("norm1", queries)
+        # tokens -> image
+        ca = self.cross_attn_token_to_image
+        qb = ops.add_cast(queries.view(1, B * T, C), query_pe.view(1, B * T, C), 1.0, BF16)[0]
+        kb = ops.add_cast(keys.view(B, L, C), key_pe.view(1, L, C), 1.0, BF16).view(B * L, C)
+        keys_b = to_bf16(keys)
+        o = ca.core(q3(ca.proj("q", qb), T), q3(ca.proj("k", kb), L), q3(ca.proj("v", keys_b), L))
+        queries = self._ln("norm2", ca.out(o, queries))
+        queries = self._ln("norm3", self.mlp.run(to_bf16(queries), residual=queries, out_dtype=F32))
+        # image -> tokens
+        ia = self.cross_attn_image_to_token
+        qb = ops.add_cast(queries.view(1, B * T, C), query_pe.view(1, B * T, C), 1.0, BF16)[0]
+        o = ia.core(q3(ia.proj("q", kb), L), q3(ia.proj("k", qb), T), q3(ia.proj("v", to_bf16(queries)), T))
+        keys = self._ln("norm4", ia.out(o, keys))
+        return queries, keys
+
+    def forward(self, queries, keys, query_pe, key_pe):
+        B, T, C = queries.shape
+        L = keys.shape[1]
+        assert key_pe.shape[0] == 1 or B == 1, "key_pe is the batch-shared dense position encoding"
+        q, k = self.run(queries.to(F32).reshape(B * T, C).contiguous(), keys.to(F32).reshape(B * L, C).contiguous(),
+                        query_pe.to(F32).reshape(B * T, C).contiguous(), key_pe.to(F32).reshape(-1, C)[:L].contiguous(), B, T, L)
+        return q.view(B, T, C), k.view(B, L, C)
+
+
+class TwoWayTransformer(nn.Module):
+    """transformer.py:28-118."""
+
+    def __init__(self, depth: int, embedding_dim: int, num_heads: int, mlp_dim: int, activation: Type[nn.Module] = nn.ReLU,
+                 attention_downsample_rate: int = 2) -> None:
+        super().__init__()
+        self.depth, self.embedding_dim, self.num_heads, self.mlp_dim = depth, embedding_dim, num_heads, mlp_dim
+        self.layers = nn.ModuleList([
+            TwoWayAttentionBlock(embedding_dim=embedding_dim, num_heads=num_heads, mlp_dim=mlp_dim, activation=activation,
+                                 attention_downsample_rate=attention_downsample_rate, skip_first_layer_pe=(i == 0))
+            for i in range(depth)])
+        self.final_attn_token_to_image = Attention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
+        self.norm_final_attn = nn.LayerNorm(embedding_dim)
+        self._wc = WeightCache()
+
+    def run(self, keys, key_pe, tokens, B, T, L):
+        """keys fp32 [B*L, C] tokens of the image embedding; key_pe fp32 [L, C]; tokens fp32 [B*T, C]."""
+        C = tokens.shape[1]
+        queries, qpe = tokens, tokens
+        for layer in self.layers:
+            queries, keys = layer.run(queries, keys, qpe, key_pe, B, T, L)
+        fa = self.final_attn_token_to_image
+        qb = ops.add_cast(queries.view(1, B * T, C), qpe.view(1, B * T, C), 1.0, BF16)[0]
+        kb = ops.add_cast(keys.view(B, L, C), key_pe.view(1, L, C), 1.0, BF16).view(B * L, C)
+        q3 = lambda t, n: t.view(B, n, -1)
+        o = fa.core(q3(fa.proj("q", qb), T), q3(fa.proj("k", kb), L), q3(fa.proj("v", to_bf16(keys)), L))
+        n = self.norm_final_attn
+        queries = ops.layernorm(fa.out(o, queries), v_f32(self._wc, "nw", n.weight), v_f32(self._wc, "nb", n.bias), n.eps, out_dtype=F32)
+        return queries, keys
+
+    def forward(self, image_embedding, image_pe, point_embedding):
+        B, C, h, w = image_embedding.shape
+        T = point_embedding.shape[1]
+        keys = tokens_of(image_embedding.to(F32))
+        pe = tokens_of(image_pe.to(F32))[: h * w]
+        q, k = self.run(keys, pe, point_embedding.to(F32).reshape(B * T, C).contiguous(), B, T, h * w)
+        return q.view(B, T, C), k.view(B, h * w, C)
+
+
+class MaskDecoder(nn.Module):
+    """mask_decoder.py:15-317.  `cell_nums` keeps its position in the signature (the fork's func_2d call site passes it by
+    keyword) but defaults to None, which is the upstream one-prompt-set-per-image path (SURVEY.md shim S3)."""
+
+    def __init__(self, *, transformer_dim: int, transformer: nn.Module, num_multimask_outputs: int = 3,
+                 activation: Type[nn.Module] = nn.GELU, iou_head_depth: int = 3, iou_head_hidden_dim: int = 256,
+                 use_high_res_features: bool = False, iou_prediction_use_sigmoid=False, dynamic_multimask_via_stability=False,
+                 dynamic_multimask_stability_delta=0.05, dynamic_multimask_stability_thresh=0.98, pred_obj_scores: bool = False,
+                 pred_obj_scores_mlp: bool = False, use_multimask_token_for_obj_ptr: bool = False) -> None:
+        super().__init__()
+        assert num_multimask_outputs == 3 and use_high_res_features and pred_obj_scores and pred_obj_scores_mlp, \
+            "HIP path implements the SAM2 YAML decoder (3 multimasks, high-res skips, object-score MLP)"
+        self.transformer_dim, self.transformer = transformer_dim, transformer
+        self.num_multimask_outputs = num_multimask_outputs
+        self.iou_token = nn.Embedding(1, transformer_dim)
+        self.num_mask_tokens = num_multimask_outputs + 1
+        self.mask_tokens = nn.Embedding(self.num_mask_tokens, transformer_dim)
+        self.pred_obj_scores = pred_obj_scores
+        self.obj_score_token = nn.Embedding(1, transformer_dim)
+        self.use_multimask_token_for_obj_ptr = use_multimask_token_for_obj_ptr
+        self.output_upscaling = nn.Sequential(
+            nn.ConvTranspose2d(transformer_dim, transformer_dim // 4, kernel_size=2, stride=2), LayerNorm2d(transformer_dim // 4),
+            activation(), nn.ConvTranspose2d(transformer_dim // 4, transformer_dim // 8, kernel_size=2, stride=2), activation())
+        self.use_high_res_features = use_high_res_features
+        self.conv_s0 = nn.Conv2d(transformer_dim, transformer_dim // 8, kernel_size=1, stride=1)
+        self.conv_s1 = nn.Conv2d(transformer_dim, transformer_dim // 4, kernel_size=1, stride=1)
+        self.output_hypernetworks_mlps = nn.ModuleList(
+            [MLP(transformer_dim, transformer_dim, transformer_dim // 8, 3) for _ in range(self.num_mask_tokens)])
+        self.iou_prediction_head = MLP(transformer_dim, iou_head_hidden_dim, self.num_mask_tokens, iou_head_depth,
+                                       sigmoid_output=iou_prediction_use_sigmoid)
+        self.pred_obj_score_head = MLP(transformer_dim, transformer_dim, 1, 3)
+        self.dynamic_multimask_via_stability = dynamic_multimask_via_stability
+        self.dynamic_multimask_stability_delta = dynamic_multimask_stability_delta
+        self.dynamic_multimask_stability_thresh = dynamic_multimask_stability_thresh
+        self._wc = WeightCache()
+
+    def conv_s(self, which: int, tokens_bf16: torch.Tensor, out_dtype=BF16) -> torch.Tensor:
+        """conv_s0 / conv_s1 (sam2_base.py:470-475) on token-major bf16 features."""
+        c = self.conv_s0 if which == 0 else self.conv_s1
+        return ops.gemm(tokens_bf16, w_bf16(self._wc, f"cs{which}w", c.weight), v_f32(self._wc, f"cs{which}b", c.bias), out_dtype=out_dtype)
+
+    def predict_masks_tokens(self, src_tokens: torch.Tensor, pe_tokens: torch.Tensor, sparse: torch.Tensor, feat_s0: torch.Tensor,
+                             feat_s1: torch.Tensor, B: int, h: int, w: int):
+        """src_tokens fp32 [B*h*w, C] (= image embedding + dense prompt); pe_tokens fp32 [h*w, C]; sparse fp32 [B,P,C];
+        feat_s0 bf16 [B*16hw, C/8], feat_s1 bf16 [B*4hw, C/4] token-major.  Returns (masks [B,4,4h,4w] fp32, iou [B,4],
+        mask_tokens_out [B,4,C], object_score_logits [B,1])."""
+        wc = self._wc
+        C = self.transformer_dim
+        out_tok = wc.get("otok", [self.obj_score_token.weight, self.iou_token.weight, self.mask_tokens.weight],
+                         lambda: torch.cat([self.obj_score_token.weight, self.iou_token.weight, self.mask_tokens.weight], 0).detach().float())
+        T = out_tok.shape[0] + sparse.shape[1]
+        tokens = torch.empty(B, T, C, dtype=F32, device=src_tokens.device)
+        tokens[:, : out_tok.shape[0]] = out_tok          # data movement: assemble the query token list
+        tokens[:, out_tok.shape[0]:] = sparse
+        hs, keys = self.transformer.run(src_tokens, pe_tokens, tokens.view(B * T, C), B, T, h * w)
+        hs = hs.view(B, T, C)
+        up = self.output_upscaling
+        dc1_w = wc.get("dc1", [up[0].weight], lambda: up[0].weight.detach().permute(2, 3, 1, 0).reshape(-1, C).to(BF16).contiguous())
+        g = ops.gemm(to_bf16(keys), dc1_w)
+        u = ops.convt2x2_shuffle(g, v_f32(wc, "dc1b", up[0].bias), feat_s1, v_f32(wc, "lnw", up[1].weight), v_f32(wc, "lnb", up[1].bias), B, h, w)
+        dc2_w = wc.get("dc2", [up[3].weight], lambda: up[3].weight.detach().permute(2, 3, 1, 0).reshape(-1, C // 4).to(BF16).contiguous())
+        g = ops.gemm(u, dc2_w)
+        u = ops.convt2x2_shuffle(g, v_f32(wc, "dc2b", up[3].bias), feat_s0, None, None, B, 2 * h, 2 * w)  # [B*16hw, C/8] bf16
+        hyper = torch.empty(B, self.num_mask_tokens, C // 8, dtype=F32, device=u.device)
+        for i, m in enumerate(self.output_hypernetworks_mlps):
+            hyper[:, i] = m.run(to_bf16(hs[:, 2 + i].contiguous()))
+        masks = ops.hyper_masks(hyper, u, B, 16 * h * w).view(B, self.num_mask_tokens, 4 * h, 4 * w)
+        iou = self.iou_prediction_head.run(to_bf16(hs[:, 1].contiguous()))
+        obj = self.pred_obj_score_head.run(to_bf16(hs[:, 0].contiguous()))
+        return masks, iou, hs[:, 2:2 + self.num_mask_tokens], obj
+
+    def predict_masks(self, image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings, repeat_image,
+                      cell_nums=None, high_res_features=None):
+        assert cell_nums is None, "per-image prompt repetition (cell_nums) belongs to the fork's nuclei pipeline, outside this path"
+        B, C, h, w = image_embeddings.shape
+        assert sparse_prompt_embeddings.shape[0] == B, "one prompt set per image embedding"
+        emb = image_embeddings.to(F32)
+        dense = dense_prompt_embeddings.to(F32).expand(B, C, h, w)
+        # image embedding + dense prompt embedding -> token-major fp32 (the spatially constant no-mask embedding is read as a
+        # broadcast vector inside the kernel)
+        e3 = tokens_of(emb).view(B, h * w, C)
+        if dense.stride(2) == 0 and dense.stride(3) == 0:
+            d3 = dense[:, :, 0, 0].contiguous().unsqueeze(1).expand(B, h * w, C)
+        else:
+            d3 = tokens_of(dense).view(B, h * w, C)
+        src = ops.add_cast(e3, d3, 1.0, F32).view(B * h * w, C)
+        pe = tokens_of(image_pe.to(F32))[: h * w]
+        f0, f1 = high_res_features
+        return self.predict_masks_tokens(src, pe, sparse_prompt_embeddings.to(F32), to_bf16(tokens_of(f0)), to_bf16(tokens_of(f1)), B, h, w)
+
+    def forward(self, image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings, multimask_output: bool,
+                repeat_image: bool, cell_nums=None, high_res_features: Optional[List[torch.Tensor]] = None):
+        masks, iou_pred, mask_tokens_out, object_score_logits = self.predict_masks(
+            image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings, repeat_image, cell_nums, high_res_features)
+        if multimask_output:
+            masks, iou_pred = masks[:, 1:, :, :], iou_pred[:, 1:]
+        elif self.dynamic_multimask_via_stability and not self.training:
+            obj_pos = torch.ones_like(object_score_logits[:, 0])  # no object gating at this level
+            low, sel, iou_sel = ops.select_mask(masks.contiguous(), iou_pred.contiguous(), obj_pos, False, True,
+                                                self.dynamic_multimask_stability_delta, self.dynamic_multimask_stability_thresh)
+            masks, iou_pred = low, iou_sel
+        else:
+            masks, iou_pred = masks[:, 0:1, :, :], iou_pred[:, 0:1]
+        if multimask_output and self.use_multimask_token_for_obj_ptr:
+            sam_tokens_out = mask_tokens_out[:, 1:]
+        else:
+            sam_tokens_out = mask_tokens_out[:, 0:1]
+        return masks, iou_pred, sam_tokens_out, object_score_logits

@@ -16,7 +16,7 @@ from ._lib import check, lib
 
 BF16 = torch.bfloat16
 F32 = torch.float32
-ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 
 
 def _stream() -> int:
@@ -131,19 +131,44 @@ def attention_small(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: in
     return o
 
 
-def add_cast(a: torch.Tensor, b: Optional[torch.Tensor] = None, alpha: float = 1.0, out_dtype: torch.dtype = BF16) -> torch.Tensor:
+def add_cast(a: torch.Tensor, b: Optional[torch.Tensor] = None, alpha: float = 1.0, out_dtype: torch.dtype = BF16,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = a + alpha*b over a logical [D0, D1, C] volume (C contiguous in a and b; outer dims may be strided or, for b,
-    broadcast with stride 0).  Result is contiguous."""
-    _req(a.dim() == 3 and a.stride(2) == 1, "add_cast: a must be [D0,D1,C] with contiguous C")
+    broadcast with stride 0).  Result is contiguous (or written into the contiguous `out`)."""
+    _req(a.dim() == 3 and (a.stride(2) == 1 or a.shape[2] == 1), "add_cast: a must be [D0,D1,C] with contiguous C")
     D0, D1, C = a.shape
     bs0 = bs1 = 0
     if b is not None:
         b = b.expand(D0, D1, C)
         _req(b.stride(2) == 1 or C == 1, "add_cast: b must have contiguous C")
         bs0, bs1 = b.stride(0), b.stride(1)
-    out = torch.empty(D0, D1, C, dtype=out_dtype, device=a.device)
+    if out is None:
+        out = torch.empty(D0, D1, C, dtype=out_dtype, device=a.device)
+    _req(out.is_contiguous() and out.numel() == D0 * D1 * C, "add_cast: out must be a contiguous [D0,D1,C] buffer")
     check(lib().msam2_add_cast(_p(a), _is_bf16(a), a.stride(0), a.stride(1), _p(b), _is_bf16(b) if b is not None else 0, bs0,
                                bs1, alpha, _p(out), _is_bf16(out), D0, D1, C, _stream()))
+    return out
+
+
+def add_cast_into(out: torch.Tensor, a: torch.Tensor, b: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
+    """Strided gather/copy(+add) of a [D0,D1,C] view into a contiguous slice of a larger buffer (memory-bank assembly)."""
+    return add_cast(a, b, alpha, out=out)
+
+
+def gate_no_obj_(x: torch.Tensor, score: torch.Tensor, value: float) -> torch.Tensor:
+    """x[b] = value where score[b] <= 0 (fp32, contiguous, in place)."""
+    _req(x.dtype == F32 and x.is_contiguous(), "gate_no_obj: fp32 contiguous")
+    B = x.shape[0]
+    check(lib().msam2_gate_rows(_p(x), _p(score), value, B, x.numel() // B, _stream()))
+    return x
+
+
+def any_positive(x: torch.Tensor) -> torch.Tensor:
+    """[B, ...] fp32 -> [B, 1] fp32 (1.0 where any element of the row is > 0)."""
+    _req(x.dtype == F32 and x.is_contiguous(), "any_positive: fp32 contiguous")
+    B = x.shape[0]
+    out = torch.empty(B, 1, dtype=F32, device=x.device)
+    check(lib().msam2_any_positive(_p(x), _p(out), B, x.numel() // B, _stream()))
     return out
 
 
@@ -352,3 +377,21 @@ class HipGraph:
                 lib().msam2_graph_destroy(self._exec)
         except Exception:
             pass
+
+
+def space_to_depth(x: torch.Tensor, B: int, H: int, W: int, k: int) -> torch.Tensor:
+    """NHWC [B*H*W, C] -> bf16 [B*(H/k)*(W/k), ld] patches with columns (ky,kx,c), ld = k*k*C rounded up to 8."""
+    C = x.shape[-1]
+    ld = (k * k * C + 7) // 8 * 8
+    out = torch.empty(B * (H // k) * (W // k), ld, dtype=BF16, device=x.device)
+    check(lib().msam2_space_to_depth(_p(x), _is_bf16(x), _p(out), B, H, W, C, k, ld, _stream()))
+    return out
+
+
+def aa_downsample(x: torch.Tensor, factor: int, in_scale: float = 1.0, in_bias: float = 0.0) -> torch.Tensor:
+    """fp32 [..., H, W] -> [..., H/f, W/f] anti-aliased bilinear (of x*in_scale + in_bias)."""
+    _req(x.dtype == F32 and x.is_contiguous(), "aa_downsample: fp32 contiguous")
+    H, W = x.shape[-2:]
+    y = torch.empty(*x.shape[:-2], H // factor, W // factor, dtype=F32, device=x.device)
+    check(lib().msam2_aa_downsample(_p(x), _p(y), x.numel() // (H * W), H, W, factor, in_scale, in_bias, _stream()))
+    return y

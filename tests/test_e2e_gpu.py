@@ -1,0 +1,157 @@
+"""End-to-end parity (GPU): the drop-in model (HIP kernels behind the reference's module interface) against golden
+vectors captured from the reference's own fp32 modules (tests/golden/make_golden.py) on the same seeded inputs and
+name-keyed weights.
+
+The kernels compute with bf16 MFMA operands and fp32 accumulation / residual streams, so this is the "stated bf16
+tolerance" of BASELINE.json's north_star; the reference itself, run under CPU bf16 autocast, differs from its own
+fp32 run by IoU 0.993-0.996 and max |dlogit| 0.19 on these random weights.  Tolerances below:
+  trunk / FPN features          relative L2 <= 2e-2
+  memory attention output       relative L2 <= 2e-2
+  mask logits (pred_masks)      mean |d| <= 0.08, max |d| <= 0.3   and   IoU >= 0.97 vs the reference fp32 mask
+  obj_ptr / maskmem_features    relative L2 <= 3e-2
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import medical_sam2_amd.synthetic as syn  # noqa: E402
+import medical_sam2_amd.weights as wts  # noqa: E402
+from helpers import load_meta, load_npz, mask_iou, max_abs, rel_err, sub  # noqa: E402
+
+DEV = "cuda"
+REPORT = {}
+
+
+@pytest.fixture(scope="module")
+def build():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import medical_sam2_amd.build_sam as bs
+
+    def make(model, image_size):
+        m = bs.build_sam2("sam2_" + model, device="cpu", hydra_overrides_extra=[f"++model.image_size={image_size}",
+                                                                              "++model.binarize_mask_from_pts_for_mem_enc=true"])
+        m.load_state_dict(wts.init_weights(model, 0), strict=True)
+        return m.to(DEV).eval()
+    return make
+
+
+def _dump():
+    import json, os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/e2e_report.json", "w") as f:
+        json.dump(REPORT, f, indent=1)
+
+
+def _mean_abs(a, b):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).mean())
+
+
+def _chain(build, model, image_size, n_slices, tag, gold):
+    m = build(model, image_size)
+    od = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
+    worst = {"iou": 1.0, "max": 0.0, "mean": 0.0}
+    with torch.no_grad():
+        for t in range(n_slices):
+            img, pts, labels = syn.image_batch([10 + t], image_size)
+            bo = m.forward_image(img.to(DEV))
+            if t == 0:
+                for lvl in range(3):
+                    e = rel_err(sub(bo["backbone_fpn"][lvl].cpu()), gold[f"{tag}_fpn{lvl}_sub"])
+                    REPORT[f"{tag}_fpn{lvl}"] = e
+                    assert e < 2e-2, (lvl, e)
+                    assert rel_err(sub(bo["vision_pos_enc"][lvl].cpu()), gold[f"{tag}_pos{lvl}_sub"]) < 1e-4
+            _, feats, pos, sizes = m._prepare_backbone_features(bo)
+            pin = {"point_coords": pts.to(DEV), "point_labels": labels.to(DEV)} if t == 0 else None
+            cur = m.track_step(frame_idx=t, is_init_cond_frame=(t == 0), current_vision_feats=feats, current_vision_pos_embeds=pos,
+                               feat_sizes=sizes, point_inputs=pin, mask_inputs=None, output_dict=od, num_frames=n_slices)
+            (od["cond_frame_outputs"] if t == 0 else od["non_cond_frame_outputs"])[t] = cur
+            ref = gold[f"{tag}_t{t}_pred_masks"]
+            got = cur["pred_masks"].float().cpu().numpy()
+            iou, mx, mean = mask_iou(got, ref), max_abs(got, ref), _mean_abs(got, ref)
+            REPORT[f"{tag}_t{t}"] = dict(iou=iou, max_abs=mx, mean_abs=mean)
+            worst = {"iou": min(worst["iou"], iou), "max": max(worst["max"], mx), "mean": max(worst["mean"], mean)}
+            assert rel_err(cur["obj_ptr"].cpu(), gold[f"{tag}_t{t}_obj_ptr"]) < 3e-2
+            assert rel_err(sub(cur["maskmem_features"].cpu()), gold[f"{tag}_t{t}_maskmem_features_sub"]) < 3e-2
+            assert rel_err(sub(cur["maskmem_pos_enc"][0].cpu()), gold[f"{tag}_t{t}_maskmem_pos_sub"]) < 1e-4
+            assert cur["pred_masks"].shape == ref.shape and cur["pred_masks_high_res"].shape[-1] == image_size
+    _dump()
+    # measured (round 1): IoU 0.9997 on the prompted slice, 0.983-0.995 on propagated slices whose masks cover only ~2-3 % of
+    # the image (a few pixels flip where |logit| < 0.12); mean |dlogit| 0.02-0.05, max 0.12
+    assert worst["iou"] >= 0.97 and worst["max"] <= 0.3 and worst["mean"] <= 0.08, worst
+
+
+def test_chain_hiera_s_256(build):
+    _chain(build, "hiera_s", 256, 4, "s256", load_npz("chain_hiera_s_256.npz"))
+
+
+def test_chain_hiera_t_256(build):
+    _chain(build, "hiera_t", 256, 2, "t256", load_npz("chain_hiera_t_256.npz"))
+
+
+def test_chain_hiera_s_1024(build):
+    _chain(build, "hiera_s", 1024, 3, "s1024", load_npz("chain_hiera_s_1024.npz"))
+
+
+def test_modules_vs_reference(build):
+    g = load_npz("modules_256.npz")
+    m = build("hiera_s", 256)
+    E = 16
+    gen = torch.Generator().manual_seed(77)
+    B = 2
+    curr = torch.randn(E * E, B, 256, generator=gen)
+    curr_pos = torch.randn(E * E, B, 256, generator=gen)
+    memory = torch.randn(3 * E * E + 8, B, 64, generator=gen)
+    memory_pos = torch.randn(3 * E * E + 8, B, 64, generator=gen)
+    memory_pos[-8:] = 0
+    feat = torch.randn(B, 256, E, E, generator=gen)
+    hr = [torch.randn(B, 32, 4 * E, 4 * E, generator=gen), torch.randn(B, 64, 2 * E, 2 * E, generator=gen)]
+    pts = torch.rand(B, 2, 2, generator=gen) * 256
+    labs = torch.tensor([[1, 0], [1, 1]], dtype=torch.int32)
+    mask_in = (torch.rand(B, 1, 256, 256, generator=gen) > 0.5).float()
+    top = torch.randn(E * E, B, 256, generator=gen)
+    high = torch.randn(B, 1, 256, 256, generator=gen) * 3
+    d = lambda t: t.to(DEV)
+    with torch.no_grad():
+        y = m.memory_attention(curr=[d(curr)], curr_pos=[d(curr_pos)], memory=d(memory), memory_pos=d(memory_pos), num_obj_ptr_tokens=8)
+        assert y.shape == (E * E, B, 256)
+        e = rel_err(y.cpu(), g["mod256_memattn_out"]); REPORT["memattn"] = e; assert e < 2e-2, e
+        y = m.memory_attention(curr=[d(curr)], curr_pos=[d(curr_pos)], memory=d(memory[: E * E]), memory_pos=d(memory_pos[: E * E]),
+                               num_obj_ptr_tokens=0)
+        e = rel_err(y.cpu(), g["mod256_memattn_out_noptr"]); assert e < 2e-2, e
+        for mm in (True, False):
+            r = m._forward_sam_heads(backbone_features=d(feat), point_inputs={"point_coords": d(pts), "point_labels": d(labs)},
+                                     mask_inputs=None, high_res_features=[d(h) for h in hr], multimask_output=mm)
+            k = f"mod256_heads_mm{int(mm)}"
+            assert rel_err(r[0].cpu(), g[k + "_low_multi"]) < 3e-2
+            assert rel_err(r[2].cpu(), g[k + "_ious"]) < 2e-2
+            assert rel_err(r[3].cpu(), g[k + "_low"]) < 3e-2
+            assert rel_err(r[5].cpu(), g[k + "_ptr"]) < 3e-2
+            assert rel_err(r[6].cpu(), g[k + "_obj"]) < 3e-2
+            assert rel_err(sub(r[4].cpu()), g[k + "_high_sub"]) < 3e-2
+        r = m._forward_sam_heads(backbone_features=d(feat), point_inputs=None, mask_inputs=None, high_res_features=[d(h) for h in hr],
+                                 multimask_output=True)
+        assert rel_err(r[3].cpu(), g["mod256_heads_noprompt_low"]) < 3e-2
+        boxes = torch.tensor([[10.0, 20.0, 100.0, 120.0], [30.0, 40.0, 200.0, 220.0]])
+        sp, _ = m.sam_prompt_encoder(points=None, boxes=d(boxes), masks=None)
+        assert rel_err(sp.cpu(), g["mod256_pe_box_sparse"]) < 1e-4
+        assert rel_err(sub(m.sam_prompt_encoder.get_dense_pe().cpu()), g["mod256_pe_dense_pe_sub"]) < 1e-4
+        r = m._use_mask_as_output(d(feat), [d(h) for h in hr], d(mask_in))
+        assert rel_err(sub(r[0].cpu()), g["mod256_maskout_low_sub"]) < 1e-4
+        assert rel_err(r[5].cpu(), g["mod256_maskout_ptr"]) < 3e-2
+        assert max_abs(r[6].cpu(), g["mod256_maskout_obj"]) == 0.0
+        for flag in (True, False):
+            f, p = m._encode_new_memory([d(top)], [(E, E)], d(high), is_mask_from_pts=flag)
+            e = rel_err(f.cpu(), g[f"mod256_memenc_pts{int(flag)}"]); assert e < 3e-2, e
+        assert rel_err(sub(p[0].cpu()), g["mod256_memenc_pos_sub"]) < 1e-4
+    _dump()
+
+
+def test_state_dict_roundtrip_and_reference_yaml(build):
+    m = build("hiera_s", 256)
+    sd = m.state_dict()
+    spec = wts.state_dict_spec("hiera_s")
+    assert list(sd.keys()) == list(spec.keys())
+    assert all(tuple(sd[k].shape) == tuple(v) for k, v in spec.items())
