@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X hot path: BASELINE.json metric "slices/sec @1024^2 (Hiera-S ...)".
+
+Workload at N=1 (BASELINE.json configs[1], the 2D `train_2d.py` SAM2 sub-sequence, func_2d/function.py:70-191, forward only):
+  4 synthetic 1024x1024 slices, bf16 MFMA operands ->  forward_image -> _prepare_backbone_features -> memory_attention against a
+  pre-filled 16-entry memory bank (4 sampled memories per slice, fixed indices instead of torch.multinomial) -> prompt encoder
+  (one click per slice) -> mask decoder (+ high-res features) -> bilinear x4 -> _encode_new_memory.
+One "step" = that sequence for the batch of 4 slices; value = slices / second with inputs resident in HBM.
+The step is captured into one hipGraph (torch.cuda.graph: PyTorch provides the stream + memory pool) and replayed.
+
+N>1 (launched by torch.distributed.run, one rank per GPU): every rank runs the same per-GPU workload on its own slices and
+its own memory bank -- the 2D path shares nothing between replicas -- so there is no data-path collective;
+RCCL is used for the barrier and the max-over-ranks time only.  scaling = "weak".
+
+Extra objects on the JSON line: "roofline" (dominant kernel = D=256 flash attention of memory attention, MFMA-bound; timed with
+HIP events on the launch stream) and "cpu_baseline" (the CPU oracle on a bounded sample, rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def build_model(device):
+    import medical_sam2_amd.build_sam as bs
+    import medical_sam2_amd.weights as wts
+    m = bs.build_sam2("sam2_hiera_s", device="cpu", hydra_overrides_extra=["++model.image_size=1024"])
+    m.load_state_dict(wts.init_weights("hiera_s", 0), strict=True)
+    return m.to(device).eval()
+
+
+def make_inputs(device, batch, rank):
+    import medical_sam2_amd.synthetic as syn
+    imgs, pts, labels = syn.image_batch([rank * 1000 + i for i in range(batch)], 1024)
+    g = torch.Generator().manual_seed(1234 + rank)
+    # 16-entry memory bank (maskmem_features [1,64,64,64] + its position encoding per entry); synthetic values of the scale the
+    # memory encoder produces
+    bank_feats = torch.randn(16, 64, 64, 64, generator=g) * 0.5
+    sampled = torch.tensor([[(3 * b + 5 * j) % 16 for j in range(batch)] for b in range(batch)])  # fixed "multinomial" draw
+    return imgs.to(device), pts.to(device), labels.to(device), bank_feats.to(device), sampled
+
+
+def step_2d(m, imgs, pts, labels, memory, memory_pos):
+    """func_2d/function.py:70-191 restated against the drop-in modules (same calls, same tensor conventions)."""
+    B = imgs.shape[0]
+    backbone_out = m.forward_image(imgs)
+    _, vision_feats, vision_pos_embeds, feat_sizes = m._prepare_backbone_features(backbone_out)
+    vision_feats[-1] = m.memory_attention(curr=[vision_feats[-1]], curr_pos=[vision_pos_embeds[-1]], memory=memory,
+                                          memory_pos=memory_pos, num_obj_ptr_tokens=0)
+    feats = [f.permute(1, 2, 0).view(B, -1, *s) for f, s in zip(vision_feats[::-1], feat_sizes[::-1])][::-1]
+    image_embed, high_res_feats = feats[-1], feats[:-1]
+    se, de = m.sam_prompt_encoder(points=(pts, labels), boxes=None, masks=None, batch_size=B)
+    low_res, iou, tokens, obj = m.sam_mask_decoder(image_embeddings=image_embed, image_pe=m.sam_prompt_encoder.get_dense_pe(),
+                                                   sparse_prompt_embeddings=se, dense_prompt_embeddings=de, multimask_output=False,
+                                                   repeat_image=False, cell_nums=None, high_res_features=high_res_feats)
+    import medical_sam2_amd.ops as ops
+    high_res = ops.bilinear_upsample(low_res.contiguous(), 1024, 1024)
+    maskmem_features, maskmem_pos_enc = m._encode_new_memory(current_vision_feats=vision_feats, feat_sizes=feat_sizes,
+                                                             pred_masks_high_res=high_res, is_mask_from_pts=True)
+    return low_res, iou, maskmem_features
+
+
+def assemble_memory(m, bank_feats, sampled):
+    """func_2d/function.py:92-116 with fixed indices: memory [B*HW, B, 64] (+ position encoding)."""
+    B = sampled.shape[0]
+    pos = m.memory_encoder.position_encoding(bank_feats[:1])  # [1,64,64,64] view, same for every entry
+    mem = bank_feats[sampled.to(bank_feats.device)]            # [B(img), B(samples), 64, 64, 64]
+    memory = mem.flatten(3).permute(1, 3, 0, 2).reshape(-1, B, 64).contiguous()   # (sample, hw) x img x C
+    memory_pos = pos.flatten(2).permute(2, 0, 1).repeat(B, B, 1).contiguous()
+    return memory, memory_pos
+
+
+def time_dominant_kernel(device, batch):
+    """HIP-event timing (on the launch stream) of the D=256 single-head flash attention at the cross-attention shape of this
+    workload: Lq = 4096, Lk = batch*4096 per slice.  Returns (avg seconds per launch, flops per launch, bytes per launch)."""
+    import medical_sam2_amd.ops as ops
+    from medical_sam2_amd._lib import lib, check
+    from medical_sam2_amd.modeling.common import attn_splits
+    B, Lq, Lk, D = batch, 4096, batch * 4096, 256
+    g = torch.Generator().manual_seed(5)
+    q = (torch.randn(B, 1, Lq, D, generator=g)).to(torch.bfloat16).to(device)
+    k = (torch.randn(B, 1, Lk, D, generator=g)).to(torch.bfloat16).to(device)
+    v = (torch.randn(B, 1, Lk, D, generator=g)).to(torch.bfloat16).to(device)
+    splits = attn_splits(B, 1, Lq, Lk)
+    out = torch.empty(B, Lq, 1, D, dtype=torch.bfloat16, device=device).permute(0, 2, 1, 3)
+    for _ in range(3):
+        ops.attention(q, k, v, splits=splits, out=out)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    check(lib().msam2_event_create(ctypes.byref(e0)))
+    check(lib().msam2_event_create(ctypes.byref(e1)))
+    n = 20
+    check(lib().msam2_event_record(e0, stream))
+    for _ in range(n):
+        ops.attention(q, k, v, splits=splits, out=out)
+    check(lib().msam2_event_record(e1, stream))
+    ms = ctypes.c_float()
+    check(lib().msam2_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+    lib().msam2_event_destroy(e0)
+    lib().msam2_event_destroy(e1)
+    flops = 4.0 * B * Lq * Lk * D
+    bytes_ = 2.0 * B * (2 * Lq * D + 2 * Lk * D)
+    return ms.value / 1e3 / n, flops, bytes_, splits
+
+
+def cpu_baseline():
+    """The CPU oracle (fp32 torch restatement, "port") on ONE slice of the same workload (1 memory of the 4 -> scaled
+    honestly: the sample is one slice with its full 4-memory bank), 1 warm-up + 2 timed repetitions."""
+    from oracle import sam2_oracle as O
+    import medical_sam2_amd.synthetic as syn
+    import medical_sam2_amd.weights as wts
+    torch.set_grad_enabled(False)
+    P = wts.init_weights("hiera_s", 0)
+    cfg = O.model_config("hiera_s", 1024)
+    img, pts, labels = syn.image_batch([0], 1024)
+    g = torch.Generator().manual_seed(1234)
+    memory = torch.randn(4 * 4096, 1, 64, generator=g) * 0.5
+    memory_pos = O.sine_pos_2d(64, 64, 64).flatten(1).t()[:, None, :].repeat(4, 1, 1)
+
+    def one():
+        bo = O.forward_image(P, cfg, img)
+        feats, pos, sizes = O.prepare_backbone_features(bo)
+        top = O.memory_attention(P, cfg, feats[-1], memory, pos[-1], memory_pos, 0)
+        emb = top.permute(1, 2, 0).reshape(1, 256, 64, 64)
+        hr = [f.permute(1, 2, 0).reshape(1, -1, *s) for f, s in zip(feats[:-1], sizes[:-1])]
+        sp, de = O.prompt_encoder(P, cfg, (pts, labels), None, None)
+        masks, iou, toks, obj = O.mask_decoder(P, cfg, emb, O.dense_pe(P, 64, 64), sp, de, False, hr)
+        high = torch.nn.functional.interpolate(masks, size=(1024, 1024), mode="bilinear", align_corners=False)
+        return O.encode_new_memory(P, cfg, top, (64, 64), high, True)
+
+    one()
+    reps = 2
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one()
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": 1.0 / dt, "unit": "slices/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 slice (of the 4-slice step) through oracle/sam2_oracle.py fp32, its 4x4096-token memory bank, "
+                      f"1 warm-up + {reps} timed reps, {dt:.2f} s per slice"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP library is the only compute path (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    torch.set_grad_enabled(False)
+    m = build_model(device)
+    imgs, pts, labels, bank_feats, sampled = make_inputs(device, args.batch, rank)
+    memory, memory_pos = assemble_memory(m, bank_feats, sampled)
+
+    run = lambda: step_2d(m, imgs, pts, labels, memory, memory_pos)
+    out = run()  # first call: weight packing, table generation, kernel module load
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            run()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = run()
+        run = graph.replay
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        slices = args.batch * args.steps * world
+        k_s, k_flops, k_bytes, splits = time_dominant_kernel(device, args.batch)
+        achieved = k_flops / k_s / 1e12
+        line = {
+            "metric": "slices/sec @1024^2 (Hiera-S)", "value": slices / dt, "unit": "slices/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[1]: sam2_hiera_s 2D (train_2d SAM2 sub-sequence, forward), b=4 x 1024x1024 per GPU, "
+                                   "16-entry memory bank with 4 sampled memories per slice, one click per slice; "
+                                   "forward_image -> memory_attention -> prompt encoder -> mask decoder -> memory encoder",
+                       "slices_per_step_per_gpu": args.batch, "hip_graph": graph is not None, "weights": "random name-keyed init"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "kernel": f"attn_fwd_kernel<256,4,false> (+merge, split-KV {splits}) at B={args.batch} Lq=4096 Lk={args.batch * 4096}",
+                         "avg_launch_us": k_s * 1e6, "flops_per_launch": k_flops, "algorithmic_bytes_per_launch": k_bytes,
+                         "hbm_GBs_on_algorithmic_bytes": k_bytes / k_s / 1e9, "hbm_frac_of_peak": k_bytes / k_s / 1e9 / HBM_PEAK_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Regenerates include/msam2_hip.h from the `extern "C"` definitions in medical-sam2_amd/csrc (prototypes are taken
+verbatim from the sources; the per-entry documentation below names the reference interface each entry replaces)."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "medical-sam2_amd", "csrc")
+
+DOC = {
+    "msam2_version": "Library version (major*10000 + minor*100 + patch).",
+    "msam2_last_error": "Message of the last failing call on this thread.  Errors never cross the ABI as exceptions: every entry returns\n0 on success, <0 on failure (reference behaviour: AT_ASSERTM -> RuntimeError, connected_components.cu:215-228; the\nPython wrapper re-raises as RuntimeError).",
+    "msam2_gemm_bf16": "C[M,N] = residual[m % res_mod] + colscale[n] * act(A[M,K] W[N,K]^T + bias[n]); A, W bf16 (K contiguous), bias/colscale\nfp32, residual/C bf16 or fp32.  act: 0 none, 1 exact-erf GELU, 2 ReLU, 3 sigmoid.\nReplaces every nn.Linear / 1x1 Conv2d / im2col'ed conv of the path: hieradet.py:61,79,141; sam2_utils.py:127-131;\ntransformer.py:241-243,261; memory_attention.py:96; image_encoder.py:112; mask_decoder.py:240-256;\nmemory_encoder.py:103-105,171-175; sam2_base.py:470-475.",
+    "msam2_layernorm": "Row LayerNorm (fp32 statistics) on [rows, C], optional GELU: nn.LayerNorm at hieradet.py:138,166,\nmemory_attention.py:60,73,94,162, transformer.py:173-194,116; LayerNorm2d (sam2_utils.py:137-149) on NHWC tokens.",
+    "msam2_attention_workspace_bytes": "Scratch needed by msam2_attention_fwd when splits > 1 (fp32 partial O, running max, partial sum).",
+    "msam2_attention_fwd": "softmax(Q K^T * scale) V, non-causal, bf16 in/out, fp32 softmax/accumulate; head dim 64/96/128/256; q/k/v/o given by\nelement strides {batch, head, token}.  splits > 1 = split-KV (flash-decoding) with an in-library merge.\nReplaces F.scaled_dot_product_attention at hieradet.py:72-76 (global blocks) and transformer.py:318 (RoPEAttention,\nmemory attention self/cross).",
+    "msam2_window_attention_fwd": "Windowed Hiera attention straight from un-partitioned qkv tokens: replaces window_partition -> SDPA ->\nwindow_unpartition (backbones/utils.py:16-62 + hieradet.py:138-158,72-76).  Zero-padded window tokens are unmasked keys\nwhose K/V rows are kpad/vpad (= qkv bias), exactly what the reference computes; q may come from a 2x2 max-pooled image\n(q-pool at stage changes, hieradet.py:65-69).",
+    "msam2_attention_small_fwd": "Attention with head dim 16/32 (two-way decoder: transformer.py:239-263 via 165-196, 74-118): tokens->image,\nimage->tokens and token self-attention.  q/k/v/o: bf16 [B, L, heads*D].",
+    "msam2_add_cast": "out = a + alpha * b on a logical [D0,D1,C] volume with arbitrary outer strides (0 = broadcast) and dtype conversion:\nmemory_attention.py:139-147 (+0.1*pos, seq-first -> batch-first), 74-76 (memory + pos), transformer.py:175-190 (q + pe,\nk + pe), mask_decoder.py:231 (src + dense), sam2_base.py:642 (+ no_mem_embed), 571-580,626-635 (memory-bank assembly).",
+    "msam2_maxpool2x2": "MaxPool2d(2,2) on NHWC tokens (do_pool, hieradet.py:23-34: q-pool and pooled shortcut).",
+    "msam2_upsample2x_add": "FPN top-down step y += nearest2x(top) (image_encoder.py:113-124).",
+    "msam2_rope_table": "cos/sin of compute_axial_cis (position_encoding.py:174-183) for a side x side grid.",
+    "msam2_rope_inplace": "apply_rotary_enc (position_encoding.py:194-216) in place on bf16 rows; rows >= n_rope of each batch are left\nuntouched (num_k_exclude_rope, transformer.py:308-315); positions wrap modulo n_pos (rope_k_repeat).",
+    "msam2_bilinear_upsample": "F.interpolate(mode=\"bilinear\", align_corners=False) on fp32 planes (sam2_base.py:367-373).",
+    "msam2_sine_pos_2d": "PositionEmbeddingSine.forward (position_encoding.py:78-112) as a token-major [h*w, C] table.",
+    "msam2_fourier_pe_grid": "PromptEncoder.get_dense_pe (prompt_encoder.py:68-77; position_encoding.py:130-151) as [h*w, C].",
+    "msam2_hiera_pos_embed": "Hiera._get_pos_embed (hieradet.py:269-277): bicubic resize of pos_embed + tiled pos_embed_window.",
+    "msam2_aa_downsample": "F.interpolate(mode=\"bilinear\", antialias=True) by an integer factor (sam2_base.py:321-327, 421-427).",
+    "msam2_gate_rows": "masks[b] = value where object score <= 0 (NO_OBJ_SCORE fill, sam2_base.py:354-363).",
+    "msam2_any_positive": "is_obj_appearing = any(mask > 0) per object (sam2_base.py:445-447).",
+    "msam2_im2col_patch7x7s4": "PatchEmbed Conv2d(3,E,k7,s4,p3) (backbones/utils.py:84-95) lowered to im2col (+ msam2_gemm_bf16).",
+    "msam2_im2col3x3s2": "im2col of the 64->256 k3/s2/p1 mask down-sampler conv (memory_encoder.py:41-49).",
+    "msam2_conv3x3s2_ln_gelu": "One MaskDownSampler stage: Conv2d(k3,s2,p1) + LayerNorm2d + GELU (memory_encoder.py:37-54), with the scaled\nsigmoid / binarisation of the mask logits (sam2_base.py:686-696) fused into the first stage.",
+    "msam2_dwconv7x7_ln": "CXBlock head: depth-wise 7x7 conv + LayerNorm2d (memory_encoder.py:99-101).",
+    "msam2_convt2x2_shuffle": "ConvTranspose2d(k2,s2) tail of the mask decoder up-scaling: pixel shuffle of the GEMM output + bias + high-res\nskip feature, then LayerNorm2d + GELU or GELU (mask_decoder.py:244-247).",
+    "msam2_hyper_masks": "masks = hyper_in @ upscaled_embedding (mask_decoder.py:249-256).",
+    "msam2_prompt_points": "Point / box-corner prompt embeddings (prompt_encoder.py:79-114; position_encoding.py:153-158).",
+    "msam2_select_mask": "Mask selection without a host round trip: best-IoU multimask or dynamic multimask via stability\n(mask_decoder.py:147-168,269-317) and object-score gating (sam2_base.py:354-385).",
+    "msam2_gather_rows": "Pick the SAM output token of the selected mask (sam2_base.py:375-383).",
+    "msam2_obj_ptr_mix": "obj_ptr = lam*obj_ptr + (1-lam)*no_obj_ptr with the hard lam of fixed_no_obj_ptr (sam2_base.py:389-400).",
+    "msam2_space_to_depth": "Non-overlapping k x k patches for the k2/s2 mask_downscaling convs (prompt_encoder.py:58-66) and the k4/s4\nmask_downsample conv (sam2_base.py:108,439).",
+    "msam2_cc_workspace_bytes": "Scratch (union-find parents + area histogram) for msam2_cc_label.",
+    "msam2_cc_label": "Drop-in for the reference's only native op, `_C.get_connected_componnets` (sam2_train/csrc/connected_components.cu:\n213-282; Python wrapper utils/misc.py:47-63): 8-connected labels (1 + smallest 2x2-block corner index of the component)\nand per-pixel component areas for uint8 masks [N,1,H,W], H and W even.  The caller allocates labels/counts/workspace.",
+    "msam2_fill_holes_workspace_bytes": "Scratch for msam2_fill_holes.",
+    "msam2_fill_holes": "fill_holes_in_mask_scores (utils/misc.py:247-258): background components of area <= max_area get score 0.1.",
+    "msam2_graph_begin": "hipGraph capture of everything enqueued on `stream` until msam2_graph_end (the per-slice forward is launch-bound in\nthe reference: ~750 dependent ATen kernels per slice, SURVEY.md section 0.9).",
+    "msam2_graph_end": "Ends the capture and instantiates the executable graph.",
+    "msam2_graph_launch": "Replays a captured graph on `stream`.",
+    "msam2_graph_destroy": "Releases a graph.",
+    "msam2_event_create": "HIP event helpers so callers can time kernels on the launch stream itself.",
+    "msam2_event_record": None, "msam2_event_elapsed_ms": None, "msam2_event_destroy": None,
+}
+
+
+def main():
+    decls = []
+    for f in ["api.hip", "gemm.hip", "attention.hip", "elementwise.hip", "conv.hip", "cc.hip"]:
+        s = open(os.path.join(CSRC, f)).read()
+        for m in re.finditer(r'extern "C" ([^{;]+?)\s*\{', s, re.S):
+            decls.append(" ".join(m.group(1).split()))
+    out = ['/* msam2_hip.h -- C ABI of libmsam2_hip.so: the MI355X (gfx950) hot path of Medical-SAM2.',
+           ' *',
+           ' * GENERATED by tools/gen_header.py from the extern "C" definitions in the .hip sources under medical-sam2_amd/csrc.',
+           ' *',
+           ' * Conventions (SURVEY.md section 8(b)): plain pointers and sizes only -- no torch / ATen types.  Every pointer is a',
+           ' * device pointer unless stated; the CALLER owns all memory (inputs, outputs, workspaces): the library never allocates or',
+           ' * frees device memory and keeps no mutable global state besides lazily loaded code objects.  All work is enqueued on the',
+           ' * `stream` argument (a hipStream_t passed as void*, 0 = default stream) without host synchronisation, so every entry',
+           ' * is hipGraph-capturable and re-entrant.  Return value: 0 = ok, <0 = error (see msam2_last_error).',
+           ' * Tensors: "bf16" = 16-bit brain float, "fp32" = IEEE float; *_is_bf16 flags select between the two.',
+           ' * file:line citations refer to the reference tree (1275468127/Medical-SAM2 @ 2024_10_08).',
+           ' */',
+           '#ifndef MSAM2_HIP_H', '#define MSAM2_HIP_H', '', '#include <stddef.h>', '#include <stdint.h>', '',
+           '#ifdef __cplusplus', 'extern "C" {', '#endif', '']
+    for d in decls:
+        name = re.search(r"(msam2_\w+)\(", d).group(1)
+        doc = DOC.get(name, "")
+        if doc:
+            out.append("/* " + doc.replace("\n", "\n * ") + " */")
+        elif name not in DOC:
+            raise SystemExit(f"undocumented entry point {name}")
+        out.append(d + ";")
+        out.append("")
+    out += ['#ifdef __cplusplus', '}', '#endif', '#endif /* MSAM2_HIP_H */', '']
+    with open(os.path.join(ROOT, "include", "msam2_hip.h"), "w") as f:
+        f.write("\n".join(out))
+    print(f"wrote include/msam2_hip.h with {len(decls)} entry points")
+
+
+if __name__ == "__main__":
+    main()
