@@ -12,6 +12,7 @@
 //                   B = the S^T accumulator itself converted to bf16: its k-order is what the tr-read reproduces)
 //   so the query stays on the lane for both products and the O rescale needs no cross-lane traffic.
 #include "common.h"
+#include <stdlib.h>
 
 struct AttnParams {
   const bf16 *q, *k, *v;
@@ -283,6 +284,253 @@ __global__ void attn_merge_kernel(AttnParams p, int Bz) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant for D = 128 / 256 (memory attention): K/V tiles go global -> LDS with global_load_lds_dwordx4 (no staging
+// registers, no ds_write), which brings the D=256 kernel under 256 registers => 2 workgroups (8 waves) per CU, so one
+// wave's softmax VALU and waits hide behind the other's MFMAs.  The DMA writes LDS linearly, so the conflict-avoiding
+// layouts are XOR swizzles applied to the per-lane SOURCE address and to the fragment reads:
+//   K image [32 keys][2D B]: 16-byte chunk c of key r sits at (c & ~15) | ((c & 15) ^ (r & 15))   (ds_read_b128 rows)
+//   V image [32 keys][2D B]: chunk c of key r sits at c ^ ((r & 3) << 2)                          (ds_read_b64_tr_b16)
+// ------------------------------------------------------------------------------------------------------------------
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_glds_kernel(AttnParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor builtins exist only in the device pass; the host pass just needs the launch stub
+  constexpr int BK = 32, RB = D * 2, CPR = D / 8;            // row bytes, 16-byte chunks per row
+  constexpr int TILE = BK * RB, STAGE = 2 * TILE;
+  constexpr int KI = TILE / 1024;                            // DMA instructions per operand tile
+  constexpr int PW = KI / NW;                                // per wave
+  constexpr int DSTEPS = D / 16, DBLK = D / 32;
+  static_assert(KI % NW == 0, "tile must split evenly over the waves");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  // XCD-aware work mapping.  Workgroups are dealt round-robin over the 8 XCDs (id % 8 share an XCD), each with a private L2;
+  // all query tiles of one (batch, head, split) stream the SAME K/V range, so they are placed on one XCD (a contiguous slice
+  // of the remapped id space per XCD): K/V then comes from that XCD's L2 instead of being re-fetched from the Infinity Cache
+  // by every XCD.  Pure speed: any placement is correct.
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int nwg = gx * gy * gridDim.z;
+  int lid = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  {
+    const int q8 = nwg / 8, rem = nwg % 8, xcd = lid % 8;
+    lid = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + lid / 8;
+  }
+  const int qtile = lid % gx;
+  const int head = (lid / gx) % gy;
+  const int zz = lid / (gx * gy);
+  const int split = zz % p.splits, z = zz / p.splits;
+  const bf16* qb = p.q + (int64_t)z * p.q_bs + (int64_t)head * p.q_hs;
+  const bf16* kb = p.k + (int64_t)z * p.k_bs + (int64_t)head * p.k_hs;
+  const bf16* vb = p.v + (int64_t)z * p.v_bs + (int64_t)head * p.v_hs;
+
+  const int qi = qtile * (NW * 32) + wave * 32 + r;
+  const bool qvalid = qi < p.Lq;
+  bf16x8 qf[DSTEPS];
+#pragma unroll
+  for (int s = 0; s < DSTEPS; ++s) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (qvalid) v = *reinterpret_cast<const uint4*>(qb + (int64_t)qi * p.q_ts + s * 16 + h * 8);
+    qf[s] = __builtin_bit_cast(bf16x8, v);
+  }
+
+  const int tiles_total = (p.Lk + BK - 1) / BK;
+  const int tiles_per = (tiles_total + p.splits - 1) / p.splits;
+  const int t_begin = split * tiles_per;
+  const int t_end = min(tiles_total, t_begin + tiles_per);
+  // full tiles run in the pipelined loop; a partial last tile (only the split that owns it) is handled after the loop so
+  // that the loop body carries no tail logic (and none of its registers)
+  const int t_full_end = min(t_end, p.Lk / BK);
+
+  // DMA sources: buffer descriptors (SGPRs) + loop-invariant 32-bit per-lane byte offsets + a scalar tile offset
+  // (buffer_load_dwordx4 ... offen lds); piece j of this wave covers flat chunks (wave*PW + j)*64 + lane of the [32][CPR] image
+  const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, 0x7fffffff, 0x00020000);
+  const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, 0x7fffffff, 0x00020000);
+  const int k_rb = (int)p.k_ts * 2, v_rb = (int)p.v_ts * 2;   // global row pitch in bytes
+  unsigned koff[PW], voff[PW];
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    const int f = (wave * PW + j) * 64 + lane;
+    const int row = f / CPR, c = f % CPR;
+    koff[j] = (unsigned)(row * k_rb + (((c & ~15) | ((c & 15) ^ (row & 15))) << 4));
+    voff[j] = (unsigned)(row * v_rb + ((c ^ ((row & 3) << 2)) << 4));
+  }
+  auto issue = [&](int tile, int stage) {
+    unsigned char* base = smem + stage * STAGE + wave * PW * 1024;
+    const unsigned ks = (unsigned)(tile * BK) * (unsigned)k_rb, vs = (unsigned)(tile * BK) * (unsigned)v_rb;
+#pragma unroll
+    for (int j = 0; j < PW; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(base + j * 1024), 16, koff[j], ks, 0, 0);
+#pragma unroll
+    for (int j = 0; j < PW; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(base + TILE + j * 1024), 16, voff[j], vs, 0, 0);
+  };
+
+  f32x16 o[DBLK];
+#pragma unroll
+  for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // fragment read offsets.  K: key row r, chunk 2*st + h.  V (transposed read): lane supplies key 4h + q (+16 st, +8 u),
+  // elements d0 + 16*cgrp + 4p .. +3 with q = li>>2, p = li&3.
+  const int k_row = r * RB, k_x = r & 15;
+  const int li = lane & 15, vq = li >> 2, vp = li & 3, cgrp = (lane >> 4) & 1;
+  const int v_row = (4 * h + vq) * RB + ((vp & 1) << 3);
+  const int v_sw = vq << 2, v_c0 = 2 * cgrp + (vp >> 1);
+
+  auto compute = [&](int stage, int key0, const bool masked) __attribute__((always_inline)) {
+    const unsigned char* kbase = smem + stage * STAGE;
+    const unsigned char* vbase = kbase + TILE;
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+    // K fragments two at a time: the scheduling fence keeps the compiler from hoisting all D/16 reads at once, which would
+    // push the kernel over its 256-register budget
+#pragma unroll
+    for (int g2 = 0; g2 < DSTEPS; g2 += 2) {
+      bf16x8 kf[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c = 2 * (g2 + u) + h;
+        kf[u] = *reinterpret_cast<const bf16x8*>(kbase + k_row + (((c & ~15) | ((c & 15) ^ k_x)) << 4));
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[u], qf[g2 + u], s, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      if (masked) {
+        const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        s[e] = (key < p.Lk) ? s[e] * p.scale_log2 : -INFINITY;
+      } else {
+        s[e] *= p.scale_log2;
+      }
+      mx = fmaxf(mx, s[e]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    if (__any(m_new > m_run)) {
+      const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+      m_run = m_new;
+    }
+    float psum = 0.f;
+    bf16x8 pf[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pe = __builtin_amdgcn_exp2f(s[e] - m_run);   // m_run is finite here: every tile holds >= 1 valid key
+      psum += pe;
+      pf[e >> 3][e & 7] = f2bf(pe);
+    }
+    l_run += psum;
+#pragma unroll
+    for (int d = 0; d < DBLK; ++d) {
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        typedef __attribute__((ext_vector_type(8))) short short8_t;
+        const int cch = (d * 4 + v_c0) ^ v_sw;   // swizzled 16-byte chunk; (key & 3) == q for every read below
+        const unsigned char* a0 = vbase + v_row + (16 * st) * RB + (cch << 4);
+        const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0));
+        const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0 + 8 * RB));
+        short8_t vv8;
+        vv8[0] = lo[0]; vv8[1] = lo[1]; vv8[2] = lo[2]; vv8[3] = lo[3];
+        vv8[4] = hi[0]; vv8[5] = hi[1]; vv8[6] = hi[2]; vv8[7] = hi[3];
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv8), pf[st], o[d], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  if (t_begin < t_full_end) issue(t_begin, 0);
+  for (int tile = t_begin; tile < t_full_end; ++tile) {
+    const int st_i = (tile - t_begin) & 1;
+    if (tile + 1 < t_full_end) {
+      issue(tile + 1, st_i ^ 1);
+      if constexpr (2 * PW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if constexpr (2 * PW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if constexpr (2 * PW == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    compute(st_i, tile * BK, false);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  if (t_full_end < t_end) {
+    // partial last tile: rows past Lk re-read the last valid key (their scores are masked to -inf)
+    const int key0 = t_full_end * BK, last = p.Lk - 1 - key0;
+    unsigned char* base = smem + wave * PW * 1024;
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      const int f = (wave * PW + j) * 64 + lane;
+      const int row = f / CPR, c = f % CPR, rr = min(row, last);
+      const unsigned ko = (unsigned)((key0 + rr) * k_rb + (((c & ~15) | ((c & 15) ^ (row & 15))) << 4));
+      const unsigned vo = (unsigned)((key0 + rr) * v_rb + ((c ^ ((row & 3) << 2)) << 4));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(base + j * 1024), 16, ko, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(base + TILE + j * 1024), 16, vo, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    compute(0, key0, true);
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (!qvalid) return;
+  if (p.splits == 1) {
+    const float inv = 1.f / l_tot;
+    bf16* ob = p.o + (int64_t)z * p.o_bs + (int64_t)head * p.o_hs + (int64_t)qi * p.o_ts;
+#pragma unroll
+    for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = f2bf(o[d][4 * g + e] * inv);
+        *reinterpret_cast<bf16x4*>(ob + d * 32 + 8 * g + 4 * h) = w;
+      }
+  } else {
+    const int64_t Bz = gridDim.z / p.splits;
+    const int64_t row = (((int64_t)split * Bz + z) * p.H + head) * p.Lq + qi;
+    float* op = p.o_part + row * D;
+#pragma unroll
+    for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = o[d][4 * g + e];
+        *reinterpret_cast<f32x4*>(op + d * 32 + 8 * g + 4 * h) = w;
+      }
+    if (h == 0) {
+      p.ml_part[row * 2 + 0] = m_run;
+      p.ml_part[row * 2 + 1] = l_tot;
+    }
+  }
+#endif
+}
+
+template <int D>
+static int launch_attn_glds(const AttnParams& p, int Bz, hipStream_t s) {
+  dim3 grid(cdiv(p.Lq, 128), p.H, Bz * p.splits);
+  hipLaunchKernelGGL((attn_glds_kernel<D, 4>), grid, dim3(256), 0, s, p);
+  if (p.splits > 1) {
+    const int64_t rows = (int64_t)Bz * p.H * p.Lq;
+    hipLaunchKernelGGL((attn_merge_kernel<D>), dim3(cdiv(rows * 64, 256)), dim3(256), 0, s, p, Bz);
+  }
+  return msam2_check_launch("attention_fwd(glds)");
+}
+
 template <int D, int NW, bool WIN>
 static int launch_attn(const AttnParams& p, int Bz, hipStream_t s) {
   using C = AttnCfg<D>;
@@ -341,11 +589,13 @@ extern "C" int msam2_attention_fwd(const void* q, const int64_t* q_strides, cons
   p.o_part = (float*)workspace;
   p.ml_part = p.o_part ? p.o_part + (size_t)splits * B * H * Lq * D : nullptr;
   hipStream_t s = (hipStream_t)stream;
+  const char* force = getenv("MSAM2_ATTN_V1");
+  const bool v2 = !(force && force[0] == '1') && Lq > 64;
   switch (D) {
     case 96: return dispatch_nw<96, false>(p, (int)B, s);
-    case 256: return dispatch_nw<256, false>(p, (int)B, s);
+    case 256: return v2 ? launch_attn_glds<256>(p, (int)B, s) : dispatch_nw<256, false>(p, (int)B, s);
     case 64: return dispatch_nw<64, false>(p, (int)B, s);
-    default: return dispatch_nw<128, false>(p, (int)B, s);
+    default: return v2 ? launch_attn_glds<128>(p, (int)B, s) : dispatch_nw<128, false>(p, (int)B, s);
   }
 }
 

@@ -30,7 +30,16 @@ int msam2_check_launch(const char* what);
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU (nn.GELU default).  erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. at fp32 round-off of the
+// surrounding arithmetic and far below the bf16 rounding of every consumer) -- ~4x fewer VALU operations than erff().
+__device__ __forceinline__ float fast_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = 1.0f - poly * __expf(-ax * ax);
+  return copysignf(e, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -34,31 +34,36 @@ extern "C" int msam2_im2col_patch7x7s4(const float* img, void* out, int64_t B, i
   return msam2_check_launch("im2col_patch7x7s4");
 }
 
-// 3x3 / stride 2 / pad 1 im2col on NHWC bf16: [B,H,W,C] -> [B*(H/2)*(W/2), 9*C], column order (ky, kx, c)
-__global__ void im2col3x3s2_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, int B, int H, int W, int C) {
+// 3x3 / stride 2 / pad 1 im2col on NHWC bf16: [B,H,W,C] -> [B*(H/2)*(W/2), ld], column order (ky, kx, c), zero fill
+// up to ld (>= 9*C, multiple of 8).  One thread per 8-byte group of 4 channels (C % 4 == 0).
+__global__ void im2col3x3s2_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, int B, int H, int W, int C, int ld) {
   const int Ho = H / 2, Wo = W / 2;
-  const int64_t total = (int64_t)B * Ho * Wo * 9 * C;
+  const int gpr = ld / 4;  // 4-element groups per output row
+  const int64_t total = (int64_t)B * Ho * Wo * gpr;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = i % C;
-    int64_t t = i / C;
-    const int k = t % 9;
-    t /= 9;
+    const int g = i % gpr;
+    int64_t t = i / gpr;
     const int xo = t % Wo;
     t /= Wo;
     const int yo = t % Ho;
     const int b = t / Ho;
-    const int y = 2 * yo - 1 + k / 3, xx = 2 * xo - 1 + k % 3;
-    bf16 v = f2bf(0.f);
-    if (y >= 0 && y < H && xx >= 0 && xx < W) v = x[(((int64_t)b * H + y) * W + xx) * C + c];
-    out[i] = v;
+    const int col = g * 4;
+    bf16x4 v = {f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+    if (col < 9 * C) {
+      const int k = col / C, c = col % C;
+      const int y = 2 * yo - 1 + k / 3, xx = 2 * xo - 1 + k % 3;
+      if (y >= 0 && y < H && xx >= 0 && xx < W) v = *reinterpret_cast<const bf16x4*>(x + (((int64_t)b * H + y) * W + xx) * C + c);
+    }
+    *reinterpret_cast<bf16x4*>(out + i * 4) = v;
   }
 }
 
-extern "C" int msam2_im2col3x3s2(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, void* stream) {
-  MSAM2_REQUIRE(x && out && B > 0 && C > 0 && H % 2 == 0 && W % 2 == 0, "im2col3x3s2: bad arguments");
-  const int64_t total = B * (H / 2) * (W / 2) * 9 * C;
+extern "C" int msam2_im2col3x3s2(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ld, void* stream) {
+  MSAM2_REQUIRE(x && out && B > 0 && C > 0 && C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && ld >= 9 * C && ld % 8 == 0,
+                "im2col3x3s2: bad arguments");
+  const int64_t total = B * (H / 2) * (W / 2) * (ld / 4);
   hipLaunchKernelGGL(im2col3x3s2_kernel, dim3((unsigned)min((int64_t)16384, (total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, (const bf16*)x, (bf16*)out, (int)B, (int)H, (int)W, (int)C);
+                     (hipStream_t)stream, (const bf16*)x, (bf16*)out, (int)B, (int)H, (int)W, (int)C, (int)ld);
   return msam2_check_launch("im2col3x3s2");
 }
 

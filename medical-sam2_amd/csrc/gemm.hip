@@ -9,6 +9,7 @@
 // staging issued before the MFMA phase and written after it (one barrier per k-step).
 // Epilogue (all optional, fp32): + bias[n] -> activation -> * colscale[n] -> + residual[m % res_mod][n] -> bf16|f32.
 #include "common.h"
+#include <stdlib.h>
 
 struct GemmParams {
   const bf16* A;
@@ -27,6 +28,87 @@ struct GemmParams {
 
 constexpr int GEMM_BK = 32;
 constexpr int GEMM_LDS_STRIDE = 40;  // bf16 elements per LDS row (32 data + 8 pad = 80 B)
+
+// ---- shared epilogue.  Each wave re-lays its accumulators through a private fp32 LDS scratch ([32][TN+4], rows of the C tile
+// contiguous) so that bias / activation / layer-scale / residual and the global stores work on 16-byte row segments
+// (full 128..256-byte lines per 16 lanes) instead of one 2- or 4-byte element per lane.
+template <int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[FM][FN], float* scr, int64_t row0, int64_t col0,
+                                              int lane) {
+  constexpr int TN = FN * 32;
+  constexpr int SLD = TN + 4;                       // scratch row stride in floats
+  constexpr int CPR_ = TN / 4;                      // 4-float chunks per row
+  constexpr int CH_ITERS = (32 * CPR_) / 64;        // chunk iterations per lane
+  const int r = lane & 31, h = lane >> 5;
+  const bool vec_ok = ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                      (!p.res || (((p.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0)));
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) scr[((e & 3) + 8 * (e >> 2) + 4 * h) * SLD + j * 32 + r] = acc[i][j][e];
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's scratch writes have landed (scratch is wave-private)
+#pragma unroll
+    for (int it = 0; it < CH_ITERS; ++it) {
+      const int c = it * 64 + lane;
+      const int row = c / CPR_, col = (c % CPR_) * 4;
+      const int64_t m = row0 + i * 32 + row;
+      const int64_t n = col0 + col;
+      if (m >= p.M || n >= p.N) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * SLD + col);
+      const bool full = vec_ok && (n + 3 < p.N);
+      const int64_t rr = p.res ? (p.res_mod > 0 ? (m % p.res_mod) : m) : 0;
+      float resv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.res) {
+        if (full) {
+          if (p.res_is_bf16) {
+            const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.res) + rr * p.ldr + n);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) resv[q] = bf2f(t[q]);
+          } else {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + rr * p.ldr + n);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) resv[q] = t[q];
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (n + q < p.N)
+              resv[q] = p.res_is_bf16 ? bf2f(reinterpret_cast<const bf16*>(p.res)[rr * p.ldr + n + q])
+                                      : reinterpret_cast<const float*>(p.res)[rr * p.ldr + n + q];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t nn = (n + q < p.N) ? n + q : n;
+        float x = v[q] + (p.bias ? p.bias[nn] : 0.f);
+        if (p.act == 1) x = gelu_erf(x);
+        else if (p.act == 2) x = fmaxf(x, 0.f);
+        else if (p.act == 3) x = 1.f / (1.f + __expf(-x));
+        if (p.colscale) x *= p.colscale[nn];
+        v[q] = x + resv[q];
+      }
+      if (full) {
+        if (p.out_is_bf16) {
+          bf16x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = f2bf(v[q]);
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + m * p.ldc + n) = o;
+        } else {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n) = v;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (n + q < p.N) {
+            if (p.out_is_bf16) reinterpret_cast<bf16*>(p.C)[m * p.ldc + n + q] = f2bf(v[q]);
+            else reinterpret_cast<float*>(p.C)[m * p.ldc + n + q] = v[q];
+          }
+      }
+    }
+  }
+}
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmParams p) {
@@ -119,34 +201,111 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmParams p) {
     cur ^= 1;
   }
 
-  // epilogue: lane owns column n = .. + r and rows (e&3) + 8*(e>>2) + 4*h of each 32x32 tile
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    const int64_t n = n0 + wn * TN + j * 32 + r;
-    if (n >= p.N) continue;
-    const float bias = p.bias ? p.bias[n] : 0.f;
-    const float cs = p.colscale ? p.colscale[n] : 1.f;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int64_t m = m0 + wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (m >= p.M) continue;
-        float v = acc[i][j][e] + bias;
-        if (p.act == 1) v = gelu_erf(v);
-        else if (p.act == 2) v = fmaxf(v, 0.f);
-        else if (p.act == 3) v = 1.f / (1.f + __expf(-v));
-        v *= cs;
-        if (p.res) {
-          const int64_t rr = p.res_mod > 0 ? (m % p.res_mod) : m;
-          v += p.res_is_bf16 ? bf2f(reinterpret_cast<const bf16*>(p.res)[rr * p.ldr + n])
-                             : reinterpret_cast<const float*>(p.res)[rr * p.ldr + n];
-        }
-        if (p.out_is_bf16) reinterpret_cast<bf16*>(p.C)[m * p.ldc + n] = f2bf(v);
-        else reinterpret_cast<float*>(p.C)[m * p.ldc + n] = v;
-      }
-    }
+  // ---- epilogue through wave-private LDS scratch (the operand LDS is free after the barrier)
+  __syncthreads();
+  static_assert(WM * WN * 32 * (TN + 4) * 4 <= 2 * (BM + BN) * GEMM_LDS_STRIDE * 2, "epilogue scratch must fit the operand LDS");
+  gemm_epilogue<FM, FN>(p, acc, reinterpret_cast<float*>(lds) + wave * 32 * (TN + 4), m0 + wm * TM, n0 + wn * TN, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Large-shape variant: 128x128x64 tiles, operands streamed global -> LDS by LDS-DMA (global_load_lds_dwordx4, no staging
+// registers), 2-stage ring per workgroup and 2 workgroups per CU so that a tile is always in flight behind the MFMA phase.
+// LDS image per operand: [128 rows][64 k] bf16 with 128-byte rows; the 16-byte chunk c of row r sits in slot
+// c ^ ((r >> 1) & 7), which makes every ds_read_b128 fragment read (16-lane groups of the 32x32x16 operand map) conflict
+// free.  The DMA writes LDS linearly (wave base + lane*16), so the swizzle is applied to the per-lane SOURCE address.
+// Requires K % 64 == 0; rows beyond M / N are clamped on load and dropped in the epilogue.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
+  constexpr int BM = 128, BN = 128, BK = 64, STAGE_BYTES = (BM + BN) * BK * 2;  // 32 KiB
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE_BYTES];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  // XCD-aware tile order: workgroups that share an XCD (ids congruent mod 8) walk the N tiles of the same M panel
+  const int n_tiles_n = (p.N + BN - 1) / BN, n_tiles_m = (p.M + BM - 1) / BM;
+  const int nwg = n_tiles_n * n_tiles_m;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8;
+    bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + bid / 8;
   }
+  const int64_t m0 = (int64_t)(bid / n_tiles_n) * BM;
+  const int64_t n0 = (int64_t)(bid % n_tiles_n) * BN;
+
+  // this wave's 4 A pieces and 4 W pieces (a piece = 8 rows x 128 B = one DMA instruction): buffer descriptors in SGPRs,
+  // loop-invariant 32-bit per-lane byte offsets, scalar k offset -> no 64-bit per-lane pointer arithmetic in the loop
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+  unsigned offsA[4], offsW[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    const int64_t ga = min(m0 + row, (int64_t)p.M - 1), gw = min(n0 + row, (int64_t)p.N - 1);
+    offsA[i] = (unsigned)(ga * p.lda * 2 + chunk * 16);
+    offsW[i] = (unsigned)(gw * p.ldw * 2 + chunk * 16);
+  }
+  auto issue = [&](int kt, int stage) {
+    unsigned char* base = lds + stage * STAGE_BYTES + wave * 4096;
+    const unsigned so = (unsigned)kt * BK * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(base + i * 1024), 16, offsA[i], so, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(base + BM * BK * 2 + i * 1024), 16, offsW[i], so, 0, 0);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment read offsets (bytes) inside a stage, without the k-substep term
+  int offA[2], offB[2], swz[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ra = wm * 64 + i * 32 + r, rb = wn * 64 + i * 32 + r;
+    offA[i] = ra * 128;
+    offB[i] = BM * BK * 2 + rb * 128;
+    swz[0][i] = (ra >> 1) & 7;
+    swz[1][i] = (rb >> 1) & 7;
+  }
+
+  const int nk = p.K / BK;
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int st = kt & 1;
+    if (kt + 1 < nk) {
+      issue(kt + 1, st ^ 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's 8 DMA pieces of tile kt have landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                        // ... and so have every other wave's
+    const unsigned char* sb = lds + st * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[2], bfr[2];
+      const int c = 2 * ks + h;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8*>(sb + offA[i] + ((c ^ swz[0][i]) << 4));
+        bfr[i] = *reinterpret_cast<const bf16x8*>(sb + offB[i] + ((c ^ swz[1][i]) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // stage st may be overwritten by the next iteration's DMA
+  }
+  gemm_epilogue<2, 2>(p, acc, reinterpret_cast<float*>(lds) + wave * 32 * 68, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -170,7 +329,12 @@ extern "C" int msam2_gemm_bf16(const void* A, int64_t lda, const void* W, int64_
   p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldc = ldc; p.res_mod = res_mod;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act; p.res_is_bf16 = res_is_bf16; p.out_is_bf16 = out_is_bf16;
   hipStream_t s = (hipStream_t)stream;
-  if (M <= 32) launch_gemm<32, 128, 1, 4>(p, s);
+  const char* force = getenv("MSAM2_GEMM_V1");
+  if (!(force && force[0] == '1') && K % 64 == 0 && M >= 256 && N >= 96 && (N % 128 == 0 || N >= 512) &&
+      M * lda * 2 < (1ll << 31) && N * ldw * 2 < (1ll << 31)) {
+    const int tiles = cdiv(p.N, 128) * cdiv(p.M, 128);
+    hipLaunchKernelGGL(gemm_glds_kernel, dim3(tiles), dim3(256), 0, s, p);
+  } else if (M <= 32) launch_gemm<32, 128, 1, 4>(p, s);
   else if (N <= 32) launch_gemm<128, 32, 4, 1>(p, s);
   else if (N <= 64 || (N % 128 != 0 && N % 64 == 0 && N < 512)) launch_gemm<128, 64, 2, 2>(p, s);
   else launch_gemm<128, 128, 2, 2>(p, s);

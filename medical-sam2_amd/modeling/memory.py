@@ -235,18 +235,24 @@ class MaskDownSampler(nn.Module):
         wc, enc = self._wc, self.encoder
         f = lambda key, p: v_f32(wc, key, p)
         h = mask.to(F32).contiguous().reshape(n * S * S, 1)
-        side = S
-        for j in range(3):
+        conv, ln = enc[0], enc[1]
+        # stage 1 (1 -> 4 channels, reads the full-resolution mask once): direct kernel with the mask transform fused in
+        h = ops.conv3x3s2_ln_gelu(h, n, S, S, wc.get("cw0", [conv.weight], lambda: conv.weight.detach().float().contiguous()),
+                                  f("cb0", conv.bias), f("lw0", ln.weight), f("lb0", ln.bias), mode, scale, bias)
+        side = S // 2
+        # stages 2-4 (4->16, 16->64, 64->256): im2col + MFMA GEMM, LayerNorm2d + GELU on the fp32 result
+        for j in range(1, 4):
             conv, ln = enc[3 * j], enc[3 * j + 1]
-            h = ops.conv3x3s2_ln_gelu(h, n, side, side, wc.get(f"cw{j}", [conv.weight], lambda c=conv: c.weight.detach().float().contiguous()),
-                                      f(f"cb{j}", conv.bias), f(f"lw{j}", ln.weight), f(f"lb{j}", ln.bias),
-                                      mode if j == 0 else 0, scale, bias)
+            cols = ops.im2col3x3s2(h, n, side, side)
+
+            def pack(c=conv, ld=cols.shape[1]):
+                w = c.weight.detach().permute(0, 2, 3, 1).reshape(c.weight.shape[0], -1)
+                out = torch.zeros(w.shape[0], ld, dtype=BF16, device=w.device)
+                out[:, : w.shape[1]] = w.to(BF16)
+                return out
+            g = ops.gemm(cols, wc.get(f"cw{j}", [conv.weight], pack), f(f"cb{j}", conv.bias), out_dtype=F32)
+            h = ops.layernorm(g, f(f"lw{j}", ln.weight), f(f"lb{j}", ln.bias), ln.eps, act=ops.ACT_GELU)
             side //= 2
-        conv, ln = enc[9], enc[10]
-        cols = ops.im2col3x3s2(h, n, side, side)
-        wmat = wc.get("cw3", [conv.weight], lambda: conv.weight.detach().permute(0, 2, 3, 1).reshape(conv.weight.shape[0], -1).to(BF16).contiguous())
-        h = ops.gemm(cols, wmat, f("cb3", conv.bias), out_dtype=F32)
-        h = ops.layernorm(h, f("lw3", ln.weight), f("lb3", ln.bias), ln.eps, act=ops.ACT_GELU)
         return ops.gemm(h, w_bf16(wc, "pw", enc[12].weight), f("pb", enc[12].bias), out_dtype=F32)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

@@ -245,10 +245,12 @@ def im2col_patch(img: torch.Tensor) -> torch.Tensor:
 
 
 def im2col3x3s2(x: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
+    """bf16 NHWC -> [B*(H/2)*(W/2), ld] patches, columns (ky,kx,c), ld = 9*C rounded up to a multiple of 8 (zero filled)."""
     C = x.shape[-1]
     _req(x.dtype == BF16 and x.is_contiguous(), "im2col3x3s2: bf16 contiguous NHWC")
-    out = torch.empty(B * (H // 2) * (W // 2), 9 * C, dtype=BF16, device=x.device)
-    check(lib().msam2_im2col3x3s2(_p(x), _p(out), B, H, W, C, _stream()))
+    ld = (9 * C + 7) // 8 * 8
+    out = torch.empty(B * (H // 2) * (W // 2), ld, dtype=BF16, device=x.device)
+    check(lib().msam2_im2col3x3s2(_p(x), _p(out), B, H, W, C, ld, _stream()))
     return out
 
 

@@ -48,7 +48,8 @@ def close(a, b, atol, rtol=0.0, what=""):
 
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (5, 288, 96), (300, 96, 384), (70, 32, 64), (257, 576, 160), (33, 64, 16),
-                                   (1000, 2048, 256), (8, 4, 256), (4096, 768, 256)])
+                                   (1000, 2048, 256), (8, 4, 256), (4096, 768, 256), (300, 128, 64), (257, 640, 192), (4099, 1152, 384),
+                                   (513, 576, 576), (256, 1536, 3072)])
 def test_gemm_exact_integers(ops, M, N, K):
     g = torch.Generator().manual_seed(M * 7 + N)
     a = torch.randint(-3, 4, (M, K), generator=g).float()
