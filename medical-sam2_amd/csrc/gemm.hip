@@ -39,9 +39,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
   constexpr int SLD = TN + 4;                       // scratch row stride in floats
   constexpr int CPR_ = TN / 4;                      // 4-float chunks per row
   constexpr int CH_ITERS = (32 * CPR_) / 64;        // chunk iterations per lane
+  constexpr int ROWS_PER_IT = 64 / CPR_;            // rows covered by one chunk iteration of the wave
+  static_assert(64 % CPR_ == 0, "a lane keeps the same 4 columns in every chunk iteration");
   const int r = lane & 31, h = lane >> 5;
   const bool vec_ok = ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
                       (!p.res || (((p.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0)));
+  // this lane's 4 output columns are the same for every row it touches: bias / layer-scale are loaded once
+  const int col = (lane % CPR_) * 4;
+  const int64_t n = col0 + col;
+  const bool n_in = n < p.N;
+  const bool full = vec_ok && (n + 3 < p.N);
+  float bias4[4], cs4[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool ok = n + q < p.N;
+    bias4[q] = (p.bias && ok) ? p.bias[n + q] : 0.f;
+    cs4[q] = (p.colscale && ok) ? p.colscale[n + q] : 1.f;
+  }
+  const int row_in_it = lane / CPR_;
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -51,16 +66,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's scratch writes have landed (scratch is wave-private)
 #pragma unroll
     for (int it = 0; it < CH_ITERS; ++it) {
-      const int c = it * 64 + lane;
-      const int row = c / CPR_, col = (c % CPR_) * 4;
+      const int row = it * ROWS_PER_IT + row_in_it;
       const int64_t m = row0 + i * 32 + row;
-      const int64_t n = col0 + col;
-      if (m >= p.M || n >= p.N) continue;
+      if (m >= p.M || !n_in) continue;
       f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * SLD + col);
-      const bool full = vec_ok && (n + 3 < p.N);
-      const int64_t rr = p.res ? (p.res_mod > 0 ? (m % p.res_mod) : m) : 0;
       float resv[4] = {0.f, 0.f, 0.f, 0.f};
       if (p.res) {
+        const int64_t rr = p.res_mod > 0 ? (int64_t)((unsigned)m % (unsigned)p.res_mod) : m;
         if (full) {
           if (p.res_is_bf16) {
             const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.res) + rr * p.ldr + n);
@@ -81,13 +93,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int64_t nn = (n + q < p.N) ? n + q : n;
-        float x = v[q] + (p.bias ? p.bias[nn] : 0.f);
+        float x = v[q] + bias4[q];
         if (p.act == 1) x = gelu_erf(x);
         else if (p.act == 2) x = fmaxf(x, 0.f);
         else if (p.act == 3) x = 1.f / (1.f + __expf(-x));
-        if (p.colscale) x *= p.colscale[nn];
-        v[q] = x + resv[q];
+        v[q] = x * cs4[q] + resv[q];
       }
       if (full) {
         if (p.out_is_bf16) {
@@ -277,35 +287,152 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
   }
 
   const int nk = p.K / BK;
+  // one DMA piece of tile kt (i < 4: A piece i, else W piece i-4)
+  auto issue_piece = [&](int kt, int stage, int i) {
+    unsigned char* base = lds + stage * STAGE_BYTES + wave * 4096;
+    const unsigned so = (unsigned)kt * BK * 2;
+    if (i < 4)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(base + i * 1024), 16, offsA[i], so, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(base + BM * BK * 2 + (i - 4) * 1024), 16,
+                                               offsW[i - 4], so, 0, 0);
+  };
   issue(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     const int st = kt & 1;
-    if (kt + 1 < nk) {
-      issue(kt + 1, st ^ 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's 8 DMA pieces of tile kt have landed
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();                        // ... and so have every other wave's
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of tile kt have landed
+    __builtin_amdgcn_s_barrier();                        // ... and so have every other wave's; stage st^1 is free again
     const unsigned char* sb = lds + st * STAGE_BYTES;
+    // all 16 operand fragments of the tile in one burst (64 VGPRs), then 16 MFMAs with the next tile's DMA pieces issued in
+    // their shadow (2 per k-substep): LDS latency is paid once per tile and the DMA issue cost hides under the matrix pipe
+    bf16x8 af[4][2], bfr[4][2];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 af[2], bfr[2];
       const int c = 2 * ks + h;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        af[i] = *reinterpret_cast<const bf16x8*>(sb + offA[i] + ((c ^ swz[0][i]) << 4));
-        bfr[i] = *reinterpret_cast<const bf16x8*>(sb + offB[i] + ((c ^ swz[1][i]) << 4));
+        af[ks][i] = *reinterpret_cast<const bf16x8*>(sb + offA[i] + ((c ^ swz[0][i]) << 4));
+        bfr[ks][i] = *reinterpret_cast<const bf16x8*>(sb + offB[i] + ((c ^ swz[1][i]) << 4));
       }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+      if (kt + 1 < nk) {
+        issue_piece(kt + 1, st ^ 1, 2 * ks);
+        issue_piece(kt + 1, st ^ 1, 2 * ks + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                        // stage st may be overwritten by the next iteration's DMA
   }
+  __builtin_amdgcn_s_barrier();
   gemm_epilogue<2, 2>(p, acc, reinterpret_cast<float*>(lds) + wave * 32 * 68, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 4-stage variant: 128x128x32 tiles, LDS-DMA ring of four 16 KiB stages per workgroup (prefetch distance 3), 2 workgroups
+// per CU, ONE barrier per k-step.  The deeper ring is what hides the L2 -> LDS latency (~1.5-2k cycles under load) that the
+// 2-stage kernel above exposes every step; K only needs to be a multiple of 32, which also brings the K = 96 / 160 layers
+// of Hiera stage 1 onto the DMA path.
+// LDS image per operand: [128 rows][32 k] bf16 = 64-byte rows; chunk c (0..3) of row r sits in slot c ^ ((r >> 2) & 3):
+// every 16-lane ds_read_b128 group of the 32x32x16 operand map then covers 16 distinct (row mod 4, slot) positions of the
+// 256-byte bank rows it touches (conflict free).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void gemm_glds4_kernel(GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 128, BN = 128, BK = 32, NST = 4, STAGE_BYTES = (BM + BN) * BK * 2;  // 16 KiB
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE_BYTES];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int n_tiles_n = (p.N + BN - 1) / BN, n_tiles_m = (p.M + BM - 1) / BM;
+  const int nwg = n_tiles_n * n_tiles_m;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8;
+    bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + bid / 8;
+  }
+  const int64_t m0 = (int64_t)(bid / n_tiles_n) * BM;
+  const int64_t n0 = (int64_t)(bid % n_tiles_n) * BN;
+
+  // a DMA piece = 16 rows x 64 B; the A tile has 8 pieces, so has the W tile: 2 + 2 per wave
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+  unsigned offsA[2], offsW[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave * 2 + i) * 16 + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    const int64_t ga = min(m0 + row, (int64_t)p.M - 1), gw = min(n0 + row, (int64_t)p.N - 1);
+    offsA[i] = (unsigned)(ga * p.lda * 2 + chunk * 16);
+    offsW[i] = (unsigned)(gw * p.ldw * 2 + chunk * 16);
+  }
+  auto issue = [&](int kt) {
+    unsigned char* base = lds + (kt & 3) * STAGE_BYTES + wave * 2048;
+    const unsigned so = (unsigned)kt * BK * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(base + i * 1024), 16, offsA[i], so, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(base + BM * BK * 2 + i * 1024), 16, offsW[i], so, 0, 0);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  int offA[2], offB[2], swz[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ra = wm * 64 + i * 32 + r, rb = wn * 64 + i * 32 + r;
+    offA[i] = ra * 64;
+    offB[i] = BM * BK * 2 + rb * 64;
+    swz[0][i] = (ra >> 2) & 3;
+    swz[1][i] = (rb >> 2) & 3;
+  }
+
+  const int nk = p.K / BK;
+  issue(0);
+  if (nk > 1) issue(1);
+  if (nk > 2) issue(2);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int ahead = min(nk - 1 - kt, 2);               // DMA groups younger than tile kt still allowed in flight
+    if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // tile kt visible to all waves; stage (kt+3)&3 no longer being read
+    if (kt + 3 < nk) issue(kt + 3);
+    const unsigned char* sb = lds + (kt & 3) * STAGE_BYTES;
+    bf16x8 af[2][2], bfr[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = 2 * ks + h;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[ks][i] = *reinterpret_cast<const bf16x8*>(sb + offA[i] + ((c ^ swz[0][i]) << 4));
+        bfr[ks][i] = *reinterpret_cast<const bf16x8*>(sb + offB[i] + ((c ^ swz[1][i]) << 4));
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+  }
+  __builtin_amdgcn_s_barrier();
+  gemm_epilogue<2, 2>(p, acc, reinterpret_cast<float*>(lds) + wave * 32 * 68, m0 + wm * 64, n0 + wn * 64, lane);
+#endif
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -330,10 +457,15 @@ extern "C" int msam2_gemm_bf16(const void* A, int64_t lda, const void* W, int64_
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act; p.res_is_bf16 = res_is_bf16; p.out_is_bf16 = out_is_bf16;
   hipStream_t s = (hipStream_t)stream;
   const char* force = getenv("MSAM2_GEMM_V1");
-  if (!(force && force[0] == '1') && K % 64 == 0 && M >= 256 && N >= 96 && (N % 128 == 0 || N >= 512) &&
-      M * lda * 2 < (1ll << 31) && N * ldw * 2 < (1ll << 31)) {
+  const char* var = getenv("MSAM2_GEMM_VARIANT");  // "4": 4-stage BK=32 DMA kernel (experiment); default: 2-stage BK=64 DMA kernel
+  const bool dma_ok = !(force && force[0] == '1') && M >= 256 && N >= 96 && (N % 128 == 0 || N >= 256 || N % 64 != 0) &&
+                      M * lda * 2 < (1ll << 31) && N * ldw * 2 < (1ll << 31);
+  if (dma_ok && K % 64 == 0 && !(var && var[0] == '4')) {
     const int tiles = cdiv(p.N, 128) * cdiv(p.M, 128);
     hipLaunchKernelGGL(gemm_glds_kernel, dim3(tiles), dim3(256), 0, s, p);
+  } else if (dma_ok && K % 32 == 0 && var && var[0] == '4') {
+    const int tiles = cdiv(p.N, 128) * cdiv(p.M, 128);
+    hipLaunchKernelGGL(gemm_glds4_kernel, dim3(tiles), dim3(256), 0, s, p);
   } else if (M <= 32) launch_gemm<32, 128, 1, 4>(p, s);
   else if (N <= 32) launch_gemm<128, 32, 4, 1>(p, s);
   else if (N <= 64 || (N % 128 != 0 && N % 64 == 0 && N < 512)) launch_gemm<128, 64, 2, 2>(p, s);
