@@ -2,7 +2,7 @@
 """Benchmark of the MI355X hot path: BASELINE.json metric "slices/sec @1024^2 (Hiera-S ...)".
 
 Workload at N=1 (BASELINE.json configs[1], the 2D `train_2d.py` SAM2 sub-sequence, func_2d/function.py:70-191, forward only):
-  4 synthetic 1024x1024 slices, bf16 MFMA operands ->  forward_image -> _prepare_backbone_features -> memory_attention against a
+  4 synthetic 1024x1024 slices, 16-bit MFMA operands (fp16 by default; fp32 accumulate / residual streams) ->  forward_image -> _prepare_backbone_features -> memory_attention against a
   pre-filled 16-entry memory bank (4 sampled memories per slice, fixed indices instead of torch.multinomial) -> prompt encoder
   (one click per slice) -> mask decoder (+ high-res features) -> bilinear x4 -> _encode_new_memory.
 One "step" = that sequence for the batch of 4 slices; value = slices / second with inputs resident in HBM.
@@ -88,11 +88,11 @@ def time_dominant_kernel(device, batch):
     from medical_sam2_amd.modeling.common import attn_splits
     B, Lq, Lk, D = batch, 4096, batch * 4096, 256
     g = torch.Generator().manual_seed(5)
-    q = (torch.randn(B, 1, Lq, D, generator=g)).to(torch.bfloat16).to(device)
-    k = (torch.randn(B, 1, Lk, D, generator=g)).to(torch.bfloat16).to(device)
-    v = (torch.randn(B, 1, Lk, D, generator=g)).to(torch.bfloat16).to(device)
+    q = (torch.randn(B, 1, Lq, D, generator=g)).to(ops.OP16).to(device)
+    k = (torch.randn(B, 1, Lk, D, generator=g)).to(ops.OP16).to(device)
+    v = (torch.randn(B, 1, Lk, D, generator=g)).to(ops.OP16).to(device)
     splits = attn_splits(B, 1, Lq, Lk)
-    out = torch.empty(B, Lq, 1, D, dtype=torch.bfloat16, device=device).permute(0, 2, 1, 3)
+    out = torch.empty(B, Lq, 1, D, dtype=ops.OP16, device=device).permute(0, 2, 1, 3)
     for _ in range(3):
         ops.attention(q, k, v, splits=splits, out=out)
     torch.cuda.synchronize()
@@ -212,6 +212,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    import medical_sam2_amd.ops as ops
     if rank == 0:
         slices = args.batch * args.steps * world
         k_s, k_flops, k_bytes, splits = time_dominant_kernel(device, args.batch)
@@ -219,7 +220,7 @@ def main():
         line = {
             "metric": "slices/sec @1024^2 (Hiera-S)", "value": slices / dt, "unit": "slices/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16" if ops.OP16 == torch.float16 else "bf16", "data": "synthetic",
             "config": {"workload": "configs[1]: sam2_hiera_s 2D (train_2d SAM2 sub-sequence, forward), b=4 x 1024x1024 per GPU, "
                                    "16-entry memory bank with 4 sampled memories per slice, one click per slice; "
                                    "forward_image -> memory_attention -> prompt encoder -> mask decoder -> memory encoder",

@@ -25,6 +25,8 @@ int msam2_check_launch(const char* what) {
 
 extern "C" const char* msam2_last_error(void) { return g_err; }
 extern "C" int msam2_version(void) { return 100; }  // 0.1.0
+// 16-bit operand type the library was built with: 1 = IEEE fp16 (default), 0 = bf16 (-DMSAM2_OPERAND_BF16)
+extern "C" int msam2_operand_is_fp16(void) { return MSAM2_OPERAND_IS_FP16; }
 
 // ---- hipGraph helpers: capture everything enqueued on `stream` between begin/end, replay with launch ----
 extern "C" int msam2_graph_begin(void* stream) {

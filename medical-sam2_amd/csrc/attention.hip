@@ -1,4 +1,4 @@
-// Fused (flash-style) non-causal attention forward for gfx950, bf16 in / fp32 softmax + accumulate / bf16 out.
+// Fused (flash-style) non-causal attention forward for gfx950, op16 in / fp32 softmax + accumulate / op16 out.
 //
 // Replaces the reference's three F.scaled_dot_product_attention call sites:
 //   hieradet.py:72-76      Hiera windowed / global MHA        (D=96; windows gathered in-kernel, pad keys = qkv bias)
@@ -9,14 +9,14 @@
 //   S^T = K * Q^T   via mfma_f32_32x32x16_bf16(A = K rows from LDS (ds_read_b128), B = Q rows held in registers)
 //                   -> lane owns one query column: 16 keys in registers, softmax statistics are lane-local
 //   O^T += V^T * P^T via mfma(A = V^T fragments read with ds_read_b64_tr_b16 from the row-major V tile,
-//                   B = the S^T accumulator itself converted to bf16: its k-order is what the tr-read reproduces)
+//                   B = the S^T accumulator itself converted to op16: its k-order is what the tr-read reproduces)
 //   so the query stays on the lane for both products and the O rescale needs no cross-lane traffic.
 #include "common.h"
 #include <stdlib.h>
 
 struct AttnParams {
-  const bf16 *q, *k, *v;
-  bf16* o;
+  const op16 *q, *k, *v;
+  op16* o;
   int64_t q_bs, q_hs, q_ts, k_bs, k_hs, k_ts, v_bs, v_hs, v_ts, o_bs, o_hs, o_ts;  // element strides
   int B, H, Lq, Lk;
   float scale_log2;
@@ -70,21 +70,21 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
     wy = w / p.nwx;
     wx = w - wy * p.nwx;
   }
-  const bf16* qb = p.q + (int64_t)b * p.q_bs + (int64_t)head * p.q_hs;
-  const bf16* kb = p.k + (int64_t)b * p.k_bs + (int64_t)head * p.k_hs;
-  const bf16* vb = p.v + (int64_t)b * p.v_bs + (int64_t)head * p.v_hs;
+  const op16* qb = p.q + (int64_t)b * p.q_bs + (int64_t)head * p.q_hs;
+  const op16* kb = p.k + (int64_t)b * p.k_bs + (int64_t)head * p.k_hs;
+  const op16* vb = p.v + (int64_t)b * p.v_bs + (int64_t)head * p.v_hs;
 
   // ---- this lane's query row -> B-operand fragments kept in registers
   const int qi = blockIdx.x * (NW * 32) + wave * 32 + r;
   bool qvalid = qi < p.Lq;
   int64_t qtok = qi;
   if (WIN && qvalid) qtok = win_token_offset(qi, p.ws_q, wy, wx, p.hq, p.wq, qvalid);
-  bf16x8 qf[DSTEPS];
+  op16x8 qf[DSTEPS];
 #pragma unroll
   for (int s = 0; s < DSTEPS; ++s) {
     uint4 v = make_uint4(0, 0, 0, 0);
     if (qvalid) v = *reinterpret_cast<const uint4*>(qb + qtok * p.q_ts + s * 16 + h * 8);
-    qf[s] = __builtin_bit_cast(bf16x8, v);
+    qf[s] = __builtin_bit_cast(op16x8, v);
   }
 
   // ---- key range of this split (multiple of BK per split except the tail)
@@ -110,11 +110,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
             kk = *reinterpret_cast<const uint4*>(kb + tok * p.k_ts + dc);
             vv = *reinterpret_cast<const uint4*>(vb + tok * p.v_ts + dc);
           } else {
-            bf16x8 a, bb;
+            op16x8 a, bb;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-              a[e] = f2bf(p.kpad[head * D + dc + e]);
-              bb[e] = f2bf(p.vpad[head * D + dc + e]);
+              a[e] = f2op(p.kpad[head * D + dc + e]);
+              bb[e] = f2op(p.vpad[head * D + dc + e]);
             }
             kk = __builtin_bit_cast(uint4, a);
             vv = __builtin_bit_cast(uint4, bb);
@@ -166,8 +166,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
     for (int e = 0; e < 16; ++e) s[e] = 0.f;
 #pragma unroll
     for (int st = 0; st < DSTEPS; ++st) {
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kbase + k_off + st * 32);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s, 0, 0, 0);
+      const op16x8 kf = *reinterpret_cast<const op16x8*>(kbase + k_off + st * 32);
+      s = MSAM2_MFMA_32x32x16(kf, qf[st], s, 0, 0, 0);
     }
     // online softmax (log2 domain); keys of register e: (e&3) + 8*(e>>2) + 4*h
     const int key0 = tile * C::BK;
@@ -190,12 +190,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
       m_run = m_new;
     }
     float psum = 0.f;
-    bf16x8 pf[2];
+    op16x8 pf[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const float pe = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(s[e] - m_run);
       psum += pe;
-      pf[e >> 3][e & 7] = f2bf(pe);
+      pf[e >> 3][e & 7] = f2op(pe);
     }
     l_run += psum;
     // O^T[d][query] += V^T[d][key] P^T[key][query]
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
         short8_t vv8;
         vv8[0] = lo[0]; vv8[1] = lo[1]; vv8[2] = lo[2]; vv8[3] = lo[3];
         vv8[4] = hi[0]; vv8[5] = hi[1]; vv8[6] = hi[2]; vv8[7] = hi[3];
-        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv8), pf[st], o[d], 0, 0, 0);
+        o[d] = MSAM2_MFMA_32x32x16(__builtin_bit_cast(op16x8, vv8), pf[st], o[d], 0, 0, 0);
       }
     }
     if (tile + 1 < t_end) lstore(cur ^ 1);
@@ -225,15 +225,15 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
   if (!qvalid) return;
   if (p.splits == 1) {
     const float inv = 1.f / l_tot;
-    bf16* ob = p.o + (int64_t)b * p.o_bs + (int64_t)head * p.o_hs + qtok * p.o_ts;
+    op16* ob = p.o + (int64_t)b * p.o_bs + (int64_t)head * p.o_hs + qtok * p.o_ts;
 #pragma unroll
     for (int d = 0; d < DBLK; ++d)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        bf16x4 w;
+        op16x4 w;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = f2bf(o[d][4 * g + e] * inv);
-        *reinterpret_cast<bf16x4*>(ob + d * 32 + 8 * g + 4 * h) = w;
+        for (int e = 0; e < 4; ++e) w[e] = f2op(o[d][4 * g + e] * inv);
+        *reinterpret_cast<op16x4*>(ob + d * 32 + 8 * g + 4 * h) = w;
       }
   } else {
     const int64_t Bz = gridDim.z / p.splits;
@@ -273,14 +273,14 @@ __global__ void attn_merge_kernel(AttnParams p, int Bz) {
     L += (m == -INFINITY) ? 0.f : l * __builtin_amdgcn_exp2f(m - M);
   }
   const float inv = 1.f / L;
-  bf16* ob = p.o + (int64_t)z * p.o_bs + (int64_t)head * p.o_hs + (int64_t)qi * p.o_ts;
+  op16* ob = p.o + (int64_t)z * p.o_bs + (int64_t)head * p.o_hs + (int64_t)qi * p.o_ts;
   for (int d = lane; d < D; d += 64) {
     float acc = 0.f;
     for (int s = 0; s < p.splits; ++s) {
       const float m = p.ml_part[((int64_t)s * rows + gw) * 2];
       if (m != -INFINITY) acc += p.o_part[((int64_t)s * rows + gw) * D + d] * __builtin_amdgcn_exp2f(m - M);
     }
-    ob[d] = f2bf(acc * inv);
+    ob[d] = f2op(acc * inv);
   }
 }
 
@@ -321,18 +321,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_glds_kernel(AttnParams p) {
   const int head = (lid / gx) % gy;
   const int zz = lid / (gx * gy);
   const int split = zz % p.splits, z = zz / p.splits;
-  const bf16* qb = p.q + (int64_t)z * p.q_bs + (int64_t)head * p.q_hs;
-  const bf16* kb = p.k + (int64_t)z * p.k_bs + (int64_t)head * p.k_hs;
-  const bf16* vb = p.v + (int64_t)z * p.v_bs + (int64_t)head * p.v_hs;
+  const op16* qb = p.q + (int64_t)z * p.q_bs + (int64_t)head * p.q_hs;
+  const op16* kb = p.k + (int64_t)z * p.k_bs + (int64_t)head * p.k_hs;
+  const op16* vb = p.v + (int64_t)z * p.v_bs + (int64_t)head * p.v_hs;
 
   const int qi = qtile * (NW * 32) + wave * 32 + r;
   const bool qvalid = qi < p.Lq;
-  bf16x8 qf[DSTEPS];
+  op16x8 qf[DSTEPS];
 #pragma unroll
   for (int s = 0; s < DSTEPS; ++s) {
     uint4 v = make_uint4(0, 0, 0, 0);
     if (qvalid) v = *reinterpret_cast<const uint4*>(qb + (int64_t)qi * p.q_ts + s * 16 + h * 8);
-    qf[s] = __builtin_bit_cast(bf16x8, v);
+    qf[s] = __builtin_bit_cast(op16x8, v);
   }
 
   const int tiles_total = (p.Lk + BK - 1) / BK;
@@ -391,14 +391,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_glds_kernel(AttnParams p) {
     // push the kernel over its 256-register budget
 #pragma unroll
     for (int g2 = 0; g2 < DSTEPS; g2 += 2) {
-      bf16x8 kf[2];
+      op16x8 kf[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int c = 2 * (g2 + u) + h;
-        kf[u] = *reinterpret_cast<const bf16x8*>(kbase + k_row + (((c & ~15) | ((c & 15) ^ k_x)) << 4));
+        kf[u] = *reinterpret_cast<const op16x8*>(kbase + k_row + (((c & ~15) | ((c & 15) ^ k_x)) << 4));
       }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[u], qf[g2 + u], s, 0, 0, 0);
+      for (int u = 0; u < 2; ++u) s = MSAM2_MFMA_32x32x16(kf[u], qf[g2 + u], s, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     float mx = -INFINITY;
@@ -424,12 +424,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_glds_kernel(AttnParams p) {
       m_run = m_new;
     }
     float psum = 0.f;
-    bf16x8 pf[2];
+    op16x8 pf[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const float pe = __builtin_amdgcn_exp2f(s[e] - m_run);   // m_run is finite here: every tile holds >= 1 valid key
       psum += pe;
-      pf[e >> 3][e & 7] = f2bf(pe);
+      pf[e >> 3][e & 7] = f2op(pe);
     }
     l_run += psum;
 #pragma unroll
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_glds_kernel(AttnParams p) {
         short8_t vv8;
         vv8[0] = lo[0]; vv8[1] = lo[1]; vv8[2] = lo[2]; vv8[3] = lo[3];
         vv8[4] = hi[0]; vv8[5] = hi[1]; vv8[6] = hi[2]; vv8[7] = hi[3];
-        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv8), pf[st], o[d], 0, 0, 0);
+        o[d] = MSAM2_MFMA_32x32x16(__builtin_bit_cast(op16x8, vv8), pf[st], o[d], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -489,15 +489,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_glds_kernel(AttnParams p) {
   if (!qvalid) return;
   if (p.splits == 1) {
     const float inv = 1.f / l_tot;
-    bf16* ob = p.o + (int64_t)z * p.o_bs + (int64_t)head * p.o_hs + (int64_t)qi * p.o_ts;
+    op16* ob = p.o + (int64_t)z * p.o_bs + (int64_t)head * p.o_hs + (int64_t)qi * p.o_ts;
 #pragma unroll
     for (int d = 0; d < DBLK; ++d)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        bf16x4 w;
+        op16x4 w;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = f2bf(o[d][4 * g + e] * inv);
-        *reinterpret_cast<bf16x4*>(ob + d * 32 + 8 * g + 4 * h) = w;
+        for (int e = 0; e < 4; ++e) w[e] = f2op(o[d][4 * g + e] * inv);
+        *reinterpret_cast<op16x4*>(ob + d * 32 + 8 * g + 4 * h) = w;
       }
   } else {
     const int64_t Bz = gridDim.z / p.splits;
@@ -560,7 +560,7 @@ extern "C" size_t msam2_attention_workspace_bytes(int64_t Bz, int64_t H, int64_t
   return (size_t)splits * Bz * H * Lq * (D + 2) * sizeof(float);
 }
 
-// q,k,v,o: bf16 with element strides {batch, head, token}; the head dim D is contiguous.
+// q,k,v,o: op16 with element strides {batch, head, token}; the head dim D is contiguous.
 extern "C" int msam2_attention_fwd(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
                                    const void* v, const int64_t* v_strides, void* o, const int64_t* o_strides, int64_t B,
                                    int64_t H, int64_t Lq, int64_t Lk, int64_t D, float scale, int splits, void* workspace,
@@ -578,7 +578,7 @@ extern "C" int msam2_attention_fwd(const void* q, const int64_t* q_strides, cons
   while (splits > 1 && (int64_t)(splits - 1) * ((tiles + splits - 1) / splits) >= tiles) --splits;
   MSAM2_REQUIRE(workspace_bytes >= msam2_attention_workspace_bytes(B, H, Lq, D, splits), "attention: workspace too small");
   AttnParams p = {};
-  p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (bf16*)o;
+  p.q = (const op16*)q; p.k = (const op16*)k; p.v = (const op16*)v; p.o = (op16*)o;
   p.q_bs = q_strides[0]; p.q_hs = q_strides[1]; p.q_ts = q_strides[2];
   p.k_bs = k_strides[0]; p.k_hs = k_strides[1]; p.k_ts = k_strides[2];
   p.v_bs = v_strides[0]; p.v_hs = v_strides[1]; p.v_ts = v_strides[2];
@@ -616,7 +616,7 @@ extern "C" int msam2_window_attention_fwd(const void* q, int64_t q_token_stride,
   MSAM2_REQUIRE(q_token_stride % 8 == 0 && kv_token_stride % 8 == 0 && q_head_stride % 8 == 0 && kv_head_stride % 8 == 0 &&
                     o_token_stride % 4 == 0 && o_head_stride % 4 == 0, "window_attention: strides must keep 16-byte alignment");
   AttnParams p = {};
-  p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (bf16*)o;
+  p.q = (const op16*)q; p.k = (const op16*)k; p.v = (const op16*)v; p.o = (op16*)o;
   p.q_bs = hq * wq * q_token_stride; p.q_hs = q_head_stride; p.q_ts = q_token_stride;
   p.k_bs = hk * wk * kv_token_stride; p.k_hs = kv_head_stride; p.k_ts = kv_token_stride;
   p.v_bs = p.k_bs; p.v_hs = kv_head_stride; p.v_ts = kv_token_stride;
@@ -637,10 +637,10 @@ extern "C" int msam2_window_attention_fwd(const void* q, int64_t q_token_stride,
 // ------------------------------------------------------------------------------------------------------------------
 // Small-head attention for the two-way decoder (transformer.py:239-263): D in {16, 32}, 8 heads, either very few
 // queries (tokens -> image, Lq ~ 8, Lk = 4096) or very few keys (image -> tokens).  One wave per (batch, head, query);
-// lanes stride over the keys with a private online softmax, then a butterfly merge.  fp32 math, bf16 I/O.
+// lanes stride over the keys with a private online softmax, then a butterfly merge.  fp32 math, op16 I/O.
 // ------------------------------------------------------------------------------------------------------------------
 template <int D>
-__global__ void attn_small_kernel(const bf16* q, const bf16* k, const bf16* v, bf16* o, int64_t q_bs, int64_t q_ts,
+__global__ void attn_small_kernel(const op16* q, const op16* k, const op16* v, op16* o, int64_t q_bs, int64_t q_ts,
                                   int64_t k_bs, int64_t k_ts, int64_t v_bs, int64_t v_ts, int64_t o_bs, int64_t o_ts, int B,
                                   int H, int Lq, int Lk, float scale_log2) {
   const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -650,29 +650,29 @@ __global__ void attn_small_kernel(const bf16* q, const bf16* k, const bf16* v, b
   const int head = (gw / Lq) % H;
   const int b = gw / ((int64_t)Lq * H);
   float qv[D];
-  const bf16* qp = q + b * q_bs + (int64_t)qi * q_ts + head * D;
+  const op16* qp = q + b * q_bs + (int64_t)qi * q_ts + head * D;
 #pragma unroll
   for (int d = 0; d < D; d += 8) {
-    const bf16x8 t = *reinterpret_cast<const bf16x8*>(qp + d);
+    const op16x8 t = *reinterpret_cast<const op16x8*>(qp + d);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) qv[d + e] = bf2f(t[e]) * scale_log2;
+    for (int e = 0; e < 8; ++e) qv[d + e] = op2f(t[e]) * scale_log2;
   }
   float m = -INFINITY, l = 0.f, acc[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) acc[d] = 0.f;
   for (int key = lane; key < Lk; key += 64) {
-    const bf16* kp = k + b * k_bs + (int64_t)key * k_ts + head * D;
-    const bf16* vp = v + b * v_bs + (int64_t)key * v_ts + head * D;
+    const op16* kp = k + b * k_bs + (int64_t)key * k_ts + head * D;
+    const op16* vp = v + b * v_bs + (int64_t)key * v_ts + head * D;
     float s = 0.f;
     float vv[D];
 #pragma unroll
     for (int d = 0; d < D; d += 8) {
-      const bf16x8 t = *reinterpret_cast<const bf16x8*>(kp + d);
-      const bf16x8 u = *reinterpret_cast<const bf16x8*>(vp + d);
+      const op16x8 t = *reinterpret_cast<const op16x8*>(kp + d);
+      const op16x8 u = *reinterpret_cast<const op16x8*>(vp + d);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        s += qv[d + e] * bf2f(t[e]);
-        vv[d + e] = bf2f(u[e]);
+        s += qv[d + e] * op2f(t[e]);
+        vv[d + e] = op2f(u[e]);
       }
     }
     const float mn = fmaxf(m, s);
@@ -695,14 +695,14 @@ __global__ void attn_small_kernel(const bf16* q, const bf16* k, const bf16* v, b
     m = mn;
   }
   if (lane == 0) {
-    bf16* op = o + b * o_bs + (int64_t)qi * o_ts + head * D;
+    op16* op = o + b * o_bs + (int64_t)qi * o_ts + head * D;
     const float inv = 1.f / l;
 #pragma unroll
-    for (int d = 0; d < D; ++d) op[d] = f2bf(acc[d] * inv);
+    for (int d = 0; d < D; ++d) op[d] = f2op(acc[d] * inv);
   }
 }
 
-// q/k/v/o: bf16 [B, L, H*D] with element strides {batch, token}
+// q/k/v/o: op16 [B, L, H*D] with element strides {batch, token}
 extern "C" int msam2_attention_small_fwd(const void* q, int64_t q_bs, int64_t q_ts, const void* k, int64_t k_bs, int64_t k_ts,
                                          const void* v, int64_t v_bs, int64_t v_ts, void* o, int64_t o_bs, int64_t o_ts,
                                          int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t D, float scale, void* stream) {
@@ -716,10 +716,10 @@ extern "C" int msam2_attention_small_fwd(const void* q, int64_t q_bs, int64_t q_
   const float sl = scale * 1.4426950408889634f;
   hipStream_t s = (hipStream_t)stream;
   if (D == 16)
-    hipLaunchKernelGGL((attn_small_kernel<16>), grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o,
+    hipLaunchKernelGGL((attn_small_kernel<16>), grid, dim3(256), 0, s, (const op16*)q, (const op16*)k, (const op16*)v, (op16*)o,
                        q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts, (int)B, (int)H, (int)Lq, (int)Lk, sl);
   else
-    hipLaunchKernelGGL((attn_small_kernel<32>), grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o,
+    hipLaunchKernelGGL((attn_small_kernel<32>), grid, dim3(256), 0, s, (const op16*)q, (const op16*)k, (const op16*)v, (op16*)o,
                        q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts, (int)B, (int)H, (int)Lq, (int)Lk, sl);
   return msam2_check_launch("attention_small");
 }

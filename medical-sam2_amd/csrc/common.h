@@ -3,10 +3,21 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef __bf16 bf16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// 16-bit MFMA operand type of the whole library.  Default: IEEE fp16 (11-bit significand -> 8x finer operand rounding than
+// bf16 at the same MFMA rate; every activation of this network sits well inside the fp16 range because residual streams,
+// softmax statistics, LayerNorm and all logits stay fp32).  -DMSAM2_OPERAND_BF16 rebuilds the library on bf16 operands.
+#if defined(MSAM2_OPERAND_BF16)
+typedef __bf16 op16;
+#define MSAM2_OPERAND_IS_FP16 0
+#define MSAM2_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#else
+typedef _Float16 op16;
+#define MSAM2_OPERAND_IS_FP16 1
+#define MSAM2_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#endif
+typedef __attribute__((ext_vector_type(8))) op16 op16x8;
+typedef __attribute__((ext_vector_type(4))) op16 op16x4;
+typedef __attribute__((ext_vector_type(2))) op16 op16x2;
 typedef __attribute__((ext_vector_type(4))) short short4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -27,11 +38,11 @@ int msam2_check_launch(const char* what);
     }                                     \
   } while (0)
 
-__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
-__device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
+__device__ __forceinline__ float op2f(op16 x) { return (float)x; }
+__device__ __forceinline__ op16 f2op(float x) { return (op16)x; }
 
 // exact-erf GELU (nn.GELU default).  erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. at fp32 round-off of the
-// surrounding arithmetic and far below the bf16 rounding of every consumer) -- ~4x fewer VALU operations than erff().
+// surrounding arithmetic and far below the op16 rounding of every consumer) -- ~4x fewer VALU operations than erff().
 __device__ __forceinline__ float fast_erf(float x) {
   const float ax = fabsf(x);
   const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);

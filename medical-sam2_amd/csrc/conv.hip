@@ -3,10 +3,10 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------------------------
-// PatchEmbed (backbones/utils.py:84-95): Conv2d(3,E,k7,s4,p3) as im2col -> [B*(S/4)^2, 160] bf16 (147 taps + zero pad),
+// PatchEmbed (backbones/utils.py:84-95): Conv2d(3,E,k7,s4,p3) as im2col -> [B*(S/4)^2, 160] op16 (147 taps + zero pad),
 // column order (c, ky, kx) to match weight.reshape(E, 147).
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void im2col_patch_kernel(const float* __restrict__ img, bf16* __restrict__ out, int B, int S) {
+__global__ void im2col_patch_kernel(const float* __restrict__ img, op16* __restrict__ out, int B, int S) {
   const int So = S / 4;
   const int64_t total = (int64_t)B * So * So * 160;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -22,7 +22,7 @@ __global__ void im2col_patch_kernel(const float* __restrict__ img, bf16* __restr
       const int y = yo * 4 - 3 + ky, x = xo * 4 - 3 + kx;
       if (y >= 0 && y < S && x >= 0 && x < S) v = img[(((int64_t)b * 3 + c) * S + y) * S + x];
     }
-    out[i] = f2bf(v);
+    out[i] = f2op(v);
   }
 }
 
@@ -30,13 +30,13 @@ extern "C" int msam2_im2col_patch7x7s4(const float* img, void* out, int64_t B, i
   MSAM2_REQUIRE(img && out && B > 0 && S > 0 && S % 4 == 0, "im2col_patch: bad arguments");
   const int64_t total = B * (S / 4) * (S / 4) * 160;
   hipLaunchKernelGGL(im2col_patch_kernel, dim3((unsigned)min((int64_t)16384, (total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, img, (bf16*)out, (int)B, (int)S);
+                     (hipStream_t)stream, img, (op16*)out, (int)B, (int)S);
   return msam2_check_launch("im2col_patch7x7s4");
 }
 
-// 3x3 / stride 2 / pad 1 im2col on NHWC bf16: [B,H,W,C] -> [B*(H/2)*(W/2), ld], column order (ky, kx, c), zero fill
+// 3x3 / stride 2 / pad 1 im2col on NHWC op16: [B,H,W,C] -> [B*(H/2)*(W/2), ld], column order (ky, kx, c), zero fill
 // up to ld (>= 9*C, multiple of 8).  One thread per 8-byte group of 4 channels (C % 4 == 0).
-__global__ void im2col3x3s2_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, int B, int H, int W, int C, int ld) {
+__global__ void im2col3x3s2_kernel(const op16* __restrict__ x, op16* __restrict__ out, int B, int H, int W, int C, int ld) {
   const int Ho = H / 2, Wo = W / 2;
   const int gpr = ld / 4;  // 4-element groups per output row
   const int64_t total = (int64_t)B * Ho * Wo * gpr;
@@ -48,13 +48,13 @@ __global__ void im2col3x3s2_kernel(const bf16* __restrict__ x, bf16* __restrict_
     const int yo = t % Ho;
     const int b = t / Ho;
     const int col = g * 4;
-    bf16x4 v = {f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+    op16x4 v = {f2op(0.f), f2op(0.f), f2op(0.f), f2op(0.f)};
     if (col < 9 * C) {
       const int k = col / C, c = col % C;
       const int y = 2 * yo - 1 + k / 3, xx = 2 * xo - 1 + k % 3;
-      if (y >= 0 && y < H && xx >= 0 && xx < W) v = *reinterpret_cast<const bf16x4*>(x + (((int64_t)b * H + y) * W + xx) * C + c);
+      if (y >= 0 && y < H && xx >= 0 && xx < W) v = *reinterpret_cast<const op16x4*>(x + (((int64_t)b * H + y) * W + xx) * C + c);
     }
-    *reinterpret_cast<bf16x4*>(out + i * 4) = v;
+    *reinterpret_cast<op16x4*>(out + i * 4) = v;
   }
 }
 
@@ -63,7 +63,7 @@ extern "C" int msam2_im2col3x3s2(const void* x, void* out, int64_t B, int64_t H,
                 "im2col3x3s2: bad arguments");
   const int64_t total = B * (H / 2) * (W / 2) * (ld / 4);
   hipLaunchKernelGGL(im2col3x3s2_kernel, dim3((unsigned)min((int64_t)16384, (total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, (const bf16*)x, (bf16*)out, (int)B, (int)H, (int)W, (int)C, (int)ld);
+                     (hipStream_t)stream, (const op16*)x, (op16*)out, (int)B, (int)H, (int)W, (int)C, (int)ld);
   return msam2_check_launch("im2col3x3s2");
 }
 
@@ -72,11 +72,11 @@ extern "C" int msam2_im2col3x3s2(const void* x, void* out, int64_t B, int64_t H,
 // one thread per output pixel holding all COUT channels.  When `mask_mode` != 0 the (single-channel fp32) input is the
 // raw high-res mask logits and the scaled sigmoid / binarisation of sam2_base.py:686-696 is applied on the fly:
 //   mode 1: sigmoid(x) * scale + bias      mode 2: (x > 0) * scale + bias
-// weights: fp32 [COUT][CIN][3][3] (nn.Conv2d layout); output NHWC bf16.
+// weights: fp32 [COUT][CIN][3][3] (nn.Conv2d layout); output NHWC op16.
 // ------------------------------------------------------------------------------------------------------------------
 template <int CIN, int COUT, typename TI>
 __global__ void conv3x3s2_ln_gelu_kernel(const TI* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                         const float* __restrict__ ln_w, const float* __restrict__ ln_b, bf16* __restrict__ y,
+                                         const float* __restrict__ ln_w, const float* __restrict__ ln_b, op16* __restrict__ y,
                                          int B, int H, int W, int mask_mode, float mscale, float mbias) {
   __shared__ float ws[COUT * CIN * 9];
   for (int i = threadIdx.x; i < COUT * CIN * 9; i += blockDim.x) ws[i] = w[i];
@@ -118,42 +118,42 @@ __global__ void conv3x3s2_ln_gelu_kernel(const TI* __restrict__ x, const float* 
 #pragma unroll
     for (int co = 0; co < COUT; ++co) var += (acc[co] - mean) * (acc[co] - mean);
     const float rstd = 1.f / sqrtf(var / COUT + 1e-6f);
-    bf16* py = y + i * COUT;
+    op16* py = y + i * COUT;
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) py[co] = f2bf(gelu_erf((acc[co] - mean) * rstd * ln_w[co] + ln_b[co]));
+    for (int co = 0; co < COUT; ++co) py[co] = f2op(gelu_erf((acc[co] - mean) * rstd * ln_w[co] + ln_b[co]));
   }
 }
 
-extern "C" int msam2_conv3x3s2_ln_gelu(const void* x, int in_is_bf16, const float* weight, const float* bias, const float* ln_w,
+extern "C" int msam2_conv3x3s2_ln_gelu(const void* x, int in_is_16bit, const float* weight, const float* bias, const float* ln_w,
                                        const float* ln_b, void* y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                                        int mask_mode, float mask_scale, float mask_bias, void* stream) {
   MSAM2_REQUIRE(x && weight && bias && ln_w && ln_b && y, "conv3x3s2_ln_gelu: null tensor");
   MSAM2_REQUIRE(H % 2 == 0 && W % 2 == 0 && B > 0, "conv3x3s2_ln_gelu: bad shape");
   MSAM2_REQUIRE(Cout == 4 * Cin && (Cin == 1 || Cin == 4 || Cin == 16), "conv3x3s2_ln_gelu: built for 1->4, 4->16, 16->64");
-  MSAM2_REQUIRE(mask_mode == 0 || (Cin == 1 && !in_is_bf16), "conv3x3s2_ln_gelu: mask transform needs the fp32 1-channel input");
-  MSAM2_REQUIRE(Cin == 1 ? !in_is_bf16 : in_is_bf16, "conv3x3s2_ln_gelu: layer 1 takes fp32, later layers bf16");
+  MSAM2_REQUIRE(mask_mode == 0 || (Cin == 1 && !in_is_16bit), "conv3x3s2_ln_gelu: mask transform needs the fp32 1-channel input");
+  MSAM2_REQUIRE(Cin == 1 ? !in_is_16bit : in_is_16bit, "conv3x3s2_ln_gelu: layer 1 takes fp32, later layers op16");
   const int64_t total = B * (H / 2) * (W / 2);
   dim3 grid((unsigned)min((int64_t)8192, (total + 127) / 128)), block(128);
   hipStream_t s = (hipStream_t)stream;
   if (Cin == 1)
     hipLaunchKernelGGL((conv3x3s2_ln_gelu_kernel<1, 4, float>), grid, block, 0, s, (const float*)x, weight, bias, ln_w, ln_b,
-                       (bf16*)y, (int)B, (int)H, (int)W, mask_mode, mask_scale, mask_bias);
+                       (op16*)y, (int)B, (int)H, (int)W, mask_mode, mask_scale, mask_bias);
   else if (Cin == 4)
-    hipLaunchKernelGGL((conv3x3s2_ln_gelu_kernel<4, 16, bf16>), grid, block, 0, s, (const bf16*)x, weight, bias, ln_w, ln_b,
-                       (bf16*)y, (int)B, (int)H, (int)W, 0, 0.f, 0.f);
+    hipLaunchKernelGGL((conv3x3s2_ln_gelu_kernel<4, 16, op16>), grid, block, 0, s, (const op16*)x, weight, bias, ln_w, ln_b,
+                       (op16*)y, (int)B, (int)H, (int)W, 0, 0.f, 0.f);
   else
-    hipLaunchKernelGGL((conv3x3s2_ln_gelu_kernel<16, 64, bf16>), grid, block, 0, s, (const bf16*)x, weight, bias, ln_w, ln_b,
-                       (bf16*)y, (int)B, (int)H, (int)W, 0, 0.f, 0.f);
+    hipLaunchKernelGGL((conv3x3s2_ln_gelu_kernel<16, 64, op16>), grid, block, 0, s, (const op16*)x, weight, bias, ln_w, ln_b,
+                       (op16*)y, (int)B, (int)H, (int)W, 0, 0.f, 0.f);
   return msam2_check_launch("conv3x3s2_ln_gelu");
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // CXBlock head (memory_encoder.py:99-101): depth-wise Conv2d(C, C, k7, p3, groups=C) + LayerNorm2d(eps 1e-6) on NHWC
-// fp32 -> normalised bf16 (the A operand of pwconv1).  One wave per pixel, C = 256 -> 4 channels per lane.
+// fp32 -> normalised op16 (the A operand of pwconv1).  One wave per pixel, C = 256 -> 4 channels per lane.
 // weights: fp32 [49][C] (tap-major, prepared from [C,1,7,7]).
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void dwconv7x7_ln_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                    const float* __restrict__ ln_w, const float* __restrict__ ln_b, bf16* __restrict__ y, int B,
+                                    const float* __restrict__ ln_w, const float* __restrict__ ln_b, op16* __restrict__ y, int B,
                                     int H, int W, int C) {
   const int64_t pix = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
@@ -179,10 +179,10 @@ __global__ void dwconv7x7_ln_kernel(const float* __restrict__ x, const float* __
 #pragma unroll
   for (int e = 0; e < 4; ++e) q += (acc[e] - mean) * (acc[e] - mean);
   const float rstd = 1.f / sqrtf(wave_sum(q) / C + 1e-6f);
-  bf16x4 o;
+  op16x4 o;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = f2bf((acc[e] - mean) * rstd * ln_w[c0 + e] + ln_b[c0 + e]);
-  *reinterpret_cast<bf16x4*>(y + pix * C + c0) = o;
+  for (int e = 0; e < 4; ++e) o[e] = f2op((acc[e] - mean) * rstd * ln_w[c0 + e] + ln_b[c0 + e]);
+  *reinterpret_cast<op16x4*>(y + pix * C + c0) = o;
 }
 
 extern "C" int msam2_dwconv7x7_ln(const float* x, const float* weight_tap_major, const float* bias, const float* ln_w,
@@ -191,7 +191,7 @@ extern "C" int msam2_dwconv7x7_ln(const float* x, const float* weight_tap_major,
   MSAM2_REQUIRE(C == 256, "dwconv7x7_ln: built for C=256 (one wave per pixel, 4 channels per lane)");
   const int64_t pix = B * H * W;
   hipLaunchKernelGGL(dwconv7x7_ln_kernel, dim3(cdiv(pix * 64, 256)), dim3(256), 0, (hipStream_t)stream, x, weight_tap_major, bias,
-                     ln_w, ln_b, (bf16*)y, (int)B, (int)H, (int)W, (int)C);
+                     ln_w, ln_b, (op16*)y, (int)B, (int)H, (int)W, (int)C);
   return msam2_check_launch("dwconv7x7_ln");
 }
 
@@ -200,8 +200,8 @@ extern "C" int msam2_dwconv7x7_ln(const float* x, const float* weight_tap_major,
 // scatters it to pixel (2y+ky, 2x+kx), adds the conv bias and the high-res skip feature, then LayerNorm2d + GELU
 // (first up-scaling) or GELU alone (second).  One wave per output pixel, lane = channel (C <= 64).  All NHWC.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void pixel_shuffle_kernel(const bf16* __restrict__ g, const float* __restrict__ bias, const bf16* __restrict__ skip,
-                                     const float* __restrict__ ln_w, const float* __restrict__ ln_b, bf16* __restrict__ y, int B,
+__global__ void pixel_shuffle_kernel(const op16* __restrict__ g, const float* __restrict__ bias, const op16* __restrict__ skip,
+                                     const float* __restrict__ ln_w, const float* __restrict__ ln_b, op16* __restrict__ y, int B,
                                      int h, int w, int C) {
   const int64_t pix = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
@@ -213,14 +213,14 @@ __global__ void pixel_shuffle_kernel(const bf16* __restrict__ g, const float* __
   const int64_t tok = ((int64_t)b * h + Y / 2) * w + X / 2;
   const int sub = (Y & 1) * 2 + (X & 1);
   float v = 0.f;
-  if (lane < C) v = bf2f(g[tok * 4 * C + sub * C + lane]) + bias[lane] + bf2f(skip[pix * C + lane]);
+  if (lane < C) v = op2f(g[tok * 4 * C + sub * C + lane]) + bias[lane] + op2f(skip[pix * C + lane]);
   if (ln_w) {
     const float mean = wave_sum(lane < C ? v : 0.f) / C;
     const float d = lane < C ? v - mean : 0.f;
     const float rstd = 1.f / sqrtf(wave_sum(d * d) / C + 1e-6f);
     v = d * rstd * (lane < C ? ln_w[lane] : 0.f) + (lane < C ? ln_b[lane] : 0.f);
   }
-  if (lane < C) y[pix * C + lane] = f2bf(gelu_erf(v));
+  if (lane < C) y[pix * C + lane] = f2op(gelu_erf(v));
 }
 
 extern "C" int msam2_convt2x2_shuffle(const void* gemm_out, const float* bias, const void* skip, const float* ln_w,
@@ -228,13 +228,13 @@ extern "C" int msam2_convt2x2_shuffle(const void* gemm_out, const float* bias, c
   MSAM2_REQUIRE(gemm_out && bias && skip && y, "convt2x2_shuffle: null tensor");
   MSAM2_REQUIRE(C > 0 && C <= 64, "convt2x2_shuffle: C must be <= 64");
   const int64_t pix = B * 4 * h * w;
-  hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(cdiv(pix * 64, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)gemm_out,
-                     bias, (const bf16*)skip, ln_w, ln_b, (bf16*)y, (int)B, (int)h, (int)w, (int)C);
+  hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(cdiv(pix * 64, 256)), dim3(256), 0, (hipStream_t)stream, (const op16*)gemm_out,
+                     bias, (const op16*)skip, ln_w, ln_b, (op16*)y, (int)B, (int)h, (int)w, (int)C);
   return msam2_check_launch("convt2x2_shuffle");
 }
 
 // masks[n, k, p] = sum_c hyper[n, k, c] * up[n, p, c]   (mask_decoder.py:249-256), C = 32, K mask tokens; fp32 out
-__global__ void hyper_masks_kernel(const float* __restrict__ hyper, const bf16* __restrict__ up, float* __restrict__ masks, int n,
+__global__ void hyper_masks_kernel(const float* __restrict__ hyper, const op16* __restrict__ up, float* __restrict__ masks, int n,
                                    int K, int P, int C) {
   __shared__ float hs[8 * 32];
   const int b = blockIdx.y;
@@ -242,12 +242,12 @@ __global__ void hyper_masks_kernel(const float* __restrict__ hyper, const bf16* 
   __syncthreads();
   for (int64_t pidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pidx < P; pidx += (int64_t)gridDim.x * blockDim.x) {
     float u[32];
-    const bf16* pu = up + ((int64_t)b * P + pidx) * C;
+    const op16* pu = up + ((int64_t)b * P + pidx) * C;
 #pragma unroll
     for (int c = 0; c < 32; c += 8) {
-      const bf16x8 t = *reinterpret_cast<const bf16x8*>(pu + c);
+      const op16x8 t = *reinterpret_cast<const op16x8*>(pu + c);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) u[c + e] = bf2f(t[e]);
+      for (int e = 0; e < 8; ++e) u[c + e] = op2f(t[e]);
     }
     for (int k = 0; k < K; ++k) {
       float a = 0.f;
@@ -263,7 +263,7 @@ extern "C" int msam2_hyper_masks(const float* hyper, const void* upscaled, float
   MSAM2_REQUIRE(hyper && upscaled && masks, "hyper_masks: null tensor");
   MSAM2_REQUIRE(C == 32 && K > 0 && K <= 8 && n > 0 && P > 0, "hyper_masks: built for C=32, K<=8");
   hipLaunchKernelGGL(hyper_masks_kernel, dim3(cdiv(P, 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, hyper,
-                     (const bf16*)upscaled, masks, (int)n, (int)K, (int)P, (int)C);
+                     (const op16*)upscaled, masks, (int)n, (int)K, (int)P, (int)C);
   return msam2_check_launch("hyper_masks");
 }
 
@@ -390,11 +390,11 @@ extern "C" int msam2_obj_ptr_mix(float* ptr, const float* obj_scores, const floa
 
 // ------------------------------------------------------------------------------------------------------------------
 // Non-overlapping k x k / stride k patches (PromptEncoder.mask_downscaling convs k2 s2, prompt_encoder.py:58-66; and
-// SAM2Base.mask_downsample k4 s4, sam2_base.py:108): NHWC [B,H,W,C] -> bf16 [B*(H/k)*(W/k), ld] with columns
+// SAM2Base.mask_downsample k4 s4, sam2_base.py:108): NHWC [B,H,W,C] -> op16 [B*(H/k)*(W/k), ld] with columns
 // (ky, kx, c) and zero fill up to ld (>= k*k*C, multiple of 8 for the GEMM).
 // ------------------------------------------------------------------------------------------------------------------
 template <typename TI>
-__global__ void space_to_depth_kernel(const TI* __restrict__ x, bf16* __restrict__ out, int B, int H, int W, int C, int k, int ld) {
+__global__ void space_to_depth_kernel(const TI* __restrict__ x, op16* __restrict__ out, int B, int H, int W, int C, int k, int ld) {
   const int Ho = H / k, Wo = W / k;
   const int64_t total = (int64_t)B * Ho * Wo * ld;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -409,21 +409,21 @@ __global__ void space_to_depth_kernel(const TI* __restrict__ x, bf16* __restrict
       const int c = col % C, kk = col / C, ky = kk / k, kx = kk % k;
       v = (float)x[(((int64_t)b * H + yo * k + ky) * W + xo * k + kx) * C + c];
     }
-    out[i] = f2bf(v);
+    out[i] = f2op(v);
   }
 }
 
-extern "C" int msam2_space_to_depth(const void* x, int in_is_bf16, void* out, int64_t B, int64_t H, int64_t W, int64_t C, int64_t k,
+extern "C" int msam2_space_to_depth(const void* x, int in_is_16bit, void* out, int64_t B, int64_t H, int64_t W, int64_t C, int64_t k,
                                     int64_t ld, void* stream) {
   MSAM2_REQUIRE(x && out && B > 0 && C > 0 && k > 0 && H % k == 0 && W % k == 0 && ld >= k * k * C && ld % 8 == 0,
                 "space_to_depth: bad arguments");
   const int64_t total = B * (H / k) * (W / k) * ld;
   dim3 grid((unsigned)min((int64_t)8192, (total + 255) / 256)), block(256);
-  if (in_is_bf16)
-    hipLaunchKernelGGL((space_to_depth_kernel<bf16>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out, (int)B, (int)H,
+  if (in_is_16bit)
+    hipLaunchKernelGGL((space_to_depth_kernel<op16>), grid, block, 0, (hipStream_t)stream, (const op16*)x, (op16*)out, (int)B, (int)H,
                        (int)W, (int)C, (int)k, (int)ld);
   else
-    hipLaunchKernelGGL((space_to_depth_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, (bf16*)out, (int)B, (int)H,
+    hipLaunchKernelGGL((space_to_depth_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, (op16*)out, (int)B, (int)H,
                        (int)W, (int)C, (int)k, (int)ld);
   return msam2_check_launch("space_to_depth");
 }

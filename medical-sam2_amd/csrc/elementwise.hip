@@ -43,17 +43,17 @@ __global__ void layernorm_kernel(const TI* __restrict__ x, int64_t ldx, const fl
   }
 }
 
-extern "C" int msam2_layernorm(const void* x, int in_is_bf16, int64_t ldx, const float* weight, const float* bias, void* y,
-                               int out_is_bf16, int64_t ldy, int64_t rows, int64_t C, float eps, int act, void* stream) {
+extern "C" int msam2_layernorm(const void* x, int in_is_16bit, int64_t ldx, const float* weight, const float* bias, void* y,
+                               int out_is_16bit, int64_t ldy, int64_t rows, int64_t C, float eps, int act, void* stream) {
   MSAM2_REQUIRE(x && y && weight && bias, "layernorm: null tensor");
   MSAM2_REQUIRE(rows > 0 && C > 0 && C <= 1024, "layernorm: rows=%lld C=%lld unsupported (C<=1024)", (long long)rows, (long long)C);
   dim3 grid(cdiv(rows * 64, 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define LN_LAUNCH(TI, TO) \
   hipLaunchKernelGGL((layernorm_kernel<TI, TO>), grid, block, 0, s, (const TI*)x, ldx, weight, bias, (TO*)y, ldy, rows, (int)C, eps, act)
-  if (in_is_bf16 && out_is_bf16) LN_LAUNCH(bf16, bf16);
-  else if (in_is_bf16) LN_LAUNCH(bf16, float);
-  else if (out_is_bf16) LN_LAUNCH(float, bf16);
+  if (in_is_16bit && out_is_16bit) LN_LAUNCH(op16, op16);
+  else if (in_is_16bit) LN_LAUNCH(op16, float);
+  else if (out_is_16bit) LN_LAUNCH(float, op16);
   else LN_LAUNCH(float, float);
 #undef LN_LAUNCH
   return msam2_check_launch("layernorm");
@@ -79,8 +79,8 @@ __global__ void add_cast_kernel(const TA* __restrict__ a, int64_t a_s0, int64_t 
   }
 }
 
-extern "C" int msam2_add_cast(const void* a, int a_is_bf16, int64_t a_s0, int64_t a_s1, const void* b, int b_is_bf16, int64_t b_s0,
-                              int64_t b_s1, float alpha, void* out, int out_is_bf16, int64_t D0, int64_t D1, int64_t C,
+extern "C" int msam2_add_cast(const void* a, int a_is_16bit, int64_t a_s0, int64_t a_s1, const void* b, int b_is_16bit, int64_t b_s0,
+                              int64_t b_s1, float alpha, void* out, int out_is_16bit, int64_t D0, int64_t D1, int64_t C,
                               void* stream) {
   MSAM2_REQUIRE(a && out, "add_cast: null tensor");
   MSAM2_REQUIRE(D0 > 0 && D1 > 0 && C > 0, "add_cast: empty volume");
@@ -90,16 +90,16 @@ extern "C" int msam2_add_cast(const void* a, int a_is_bf16, int64_t a_s0, int64_
 #define AC(TA, TB, TO)                                                                                                   \
   hipLaunchKernelGGL((add_cast_kernel<TA, TB, TO>), grid, block, 0, s, (const TA*)a, a_s0, a_s1, (const TB*)b, b_s0, b_s1, \
                      alpha, (TO*)out, D0, D1, (int)C)
-  const int key = (a_is_bf16 ? 4 : 0) | (b_is_bf16 ? 2 : 0) | (out_is_bf16 ? 1 : 0);
+  const int key = (a_is_16bit ? 4 : 0) | (b_is_16bit ? 2 : 0) | (out_is_16bit ? 1 : 0);
   switch (key) {
     case 0: AC(float, float, float); break;
-    case 1: AC(float, float, bf16); break;
-    case 2: AC(float, bf16, float); break;
-    case 3: AC(float, bf16, bf16); break;
-    case 4: AC(bf16, float, float); break;
-    case 5: AC(bf16, float, bf16); break;
-    case 6: AC(bf16, bf16, float); break;
-    default: AC(bf16, bf16, bf16); break;
+    case 1: AC(float, float, op16); break;
+    case 2: AC(float, op16, float); break;
+    case 3: AC(float, op16, op16); break;
+    case 4: AC(op16, float, float); break;
+    case 5: AC(op16, float, op16); break;
+    case 6: AC(op16, op16, float); break;
+    default: AC(op16, op16, op16); break;
   }
 #undef AC
   return msam2_check_launch("add_cast");
@@ -127,7 +127,7 @@ __global__ void maxpool2x2_kernel(const TI* __restrict__ x, int64_t ldx, TO* __r
   }
 }
 
-extern "C" int msam2_maxpool2x2(const void* x, int in_is_bf16, int64_t ldx, void* y, int out_is_bf16, int64_t ldy, int64_t B,
+extern "C" int msam2_maxpool2x2(const void* x, int in_is_16bit, int64_t ldx, void* y, int out_is_16bit, int64_t ldy, int64_t B,
                                 int64_t H, int64_t W, int64_t C, void* stream) {
   MSAM2_REQUIRE(x && y, "maxpool2x2: null tensor");
   MSAM2_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "maxpool2x2: H, W must be even");
@@ -136,9 +136,9 @@ extern "C" int msam2_maxpool2x2(const void* x, int in_is_bf16, int64_t ldx, void
   hipStream_t s = (hipStream_t)stream;
 #define MP(TI, TO) \
   hipLaunchKernelGGL((maxpool2x2_kernel<TI, TO>), grid, block, 0, s, (const TI*)x, ldx, (TO*)y, ldy, (int)B, (int)H, (int)W, (int)C)
-  if (in_is_bf16 && out_is_bf16) MP(bf16, bf16);
-  else if (in_is_bf16) MP(bf16, float);
-  else if (out_is_bf16) MP(float, bf16);
+  if (in_is_16bit && out_is_16bit) MP(op16, op16);
+  else if (in_is_16bit) MP(op16, float);
+  else if (out_is_16bit) MP(float, op16);
   else MP(float, float);
 #undef MP
   return msam2_check_launch("maxpool2x2");
@@ -171,7 +171,7 @@ extern "C" int msam2_upsample2x_add(void* y, const void* top, int64_t B, int64_t
 
 // ------------------------------------------------------------------------------------------------------------------
 // Axial RoPE (position_encoding.py:174-216; transformer.py:299-315).  Table: cos/sin [n_pos, D/2] fp32 where pair i
-// < D/4 rotates with x = pos % side and the rest with y = pos / side.  In-place on bf16 rows [B, L, ld]: rows
+// < D/4 rotates with x = pos % side and the rest with y = pos / side.  In-place on op16 rows [B, L, ld]: rows
 // l < n_rope of every batch are rotated with position l % n_pos (rope_k_repeat tiles the table over the keys).
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void rope_table_kernel(float* __restrict__ cs, float* __restrict__ sn, int side, int D, float theta) {
@@ -195,7 +195,7 @@ extern "C" int msam2_rope_table(float* cos_out, float* sin_out, int64_t side, in
   return msam2_check_launch("rope_table");
 }
 
-__global__ void rope_inplace_kernel(bf16* __restrict__ x, int64_t bs, int64_t ld, int B, int L, int n_rope, int n_pos, int D,
+__global__ void rope_inplace_kernel(op16* __restrict__ x, int64_t bs, int64_t ld, int B, int L, int n_rope, int n_pos, int D,
                                     const float* __restrict__ cs, const float* __restrict__ sn) {
   const int hp = D / 2;
   const int64_t total = (int64_t)B * n_rope * hp;
@@ -204,14 +204,14 @@ __global__ void rope_inplace_kernel(bf16* __restrict__ x, int64_t bs, int64_t ld
     int64_t t = i / hp;
     const int l = t % n_rope;
     const int b = t / n_rope;
-    bf16x2* px = reinterpret_cast<bf16x2*>(x + b * bs + (int64_t)l * ld) + pr;
-    const bf16x2 v = *px;
+    op16x2* px = reinterpret_cast<op16x2*>(x + b * bs + (int64_t)l * ld) + pr;
+    const op16x2 v = *px;
     const float re = (float)v[0], im = (float)v[1];
     const int pos = l % n_pos;
     const float c = cs[(int64_t)pos * hp + pr], s = sn[(int64_t)pos * hp + pr];
-    bf16x2 o;
-    o[0] = (bf16)(re * c - im * s);
-    o[1] = (bf16)(re * s + im * c);
+    op16x2 o;
+    o[0] = (op16)(re * c - im * s);
+    o[1] = (op16)(re * s + im * c);
     *px = o;
   }
 }
@@ -223,7 +223,7 @@ extern "C" int msam2_rope_inplace(void* x, int64_t batch_stride, int64_t ld, int
   if (n_rope == 0) return MSAM2_OK;
   const int64_t total = B * n_rope * (D / 2);
   hipLaunchKernelGGL(rope_inplace_kernel, dim3((unsigned)min((int64_t)8192, (total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, (bf16*)x, batch_stride, ld, (int)B, (int)L, (int)n_rope, (int)n_pos, (int)D, cos_t, sin_t);
+                     (hipStream_t)stream, (op16*)x, batch_stride, ld, (int)B, (int)L, (int)n_rope, (int)n_pos, (int)D, cos_t, sin_t);
   return msam2_check_launch("rope_inplace");
 }
 

@@ -1,19 +1,19 @@
-// bf16 MFMA GEMM with fused epilogue for gfx950:   C[M,N] = epi( A[M,K] * W[N,K]^T )
+// op16 MFMA GEMM with fused epilogue for gfx950:   C[M,N] = epi( A[M,K] * W[N,K]^T )
 //
 // Serves every nn.Linear / 1x1 conv / im2col'ed conv on the hot path (reference call sites: hieradet.py:61,79,
 // sam2_utils.py:127-131, transformer.py:241-243,261, memory_attention.py:96, image_encoder.py:112, mask_decoder.py:
 // 240-256, memory_encoder.py:103-105,171-175).  Both operands are K-contiguous (activation rows and nn.Linear weight
-// rows), so the 32x32x16 bf16 MFMA fragments (8 consecutive k per lane) are plain 16-byte LDS reads.
+// rows), so the 32x32x16 op16 MFMA fragments (8 consecutive k per lane) are plain 16-byte LDS reads.
 //
 // Tile: BM x BN x 32, WM x WN waves, double-buffered LDS with 80-byte rows (conflict-free ds_read_b128), register
 // staging issued before the MFMA phase and written after it (one barrier per k-step).
-// Epilogue (all optional, fp32): + bias[n] -> activation -> * colscale[n] -> + residual[m % res_mod][n] -> bf16|f32.
+// Epilogue (all optional, fp32): + bias[n] -> activation -> * colscale[n] -> + residual[m % res_mod][n] -> op16|f32.
 #include "common.h"
 #include <stdlib.h>
 
 struct GemmParams {
-  const bf16* A;
-  const bf16* W;
+  const op16* A;
+  const op16* W;
   const float* bias;
   const float* colscale;
   const void* res;
@@ -22,12 +22,12 @@ struct GemmParams {
   int64_t res_mod;
   int M, N, K;
   int act;          // 0 none, 1 gelu(erf), 2 relu, 3 sigmoid
-  int res_is_bf16;  // residual dtype
-  int out_is_bf16;  // output dtype
+  int res_is_16bit;  // residual dtype
+  int out_is_16bit;  // output dtype
 };
 
 constexpr int GEMM_BK = 32;
-constexpr int GEMM_LDS_STRIDE = 40;  // bf16 elements per LDS row (32 data + 8 pad = 80 B)
+constexpr int GEMM_LDS_STRIDE = 40;  // op16 elements per LDS row (32 data + 8 pad = 80 B)
 
 // ---- shared epilogue.  Each wave re-lays its accumulators through a private fp32 LDS scratch ([32][TN+4], rows of the C tile
 // contiguous) so that bias / activation / layer-scale / residual and the global stores work on 16-byte row segments
@@ -74,10 +74,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
       if (p.res) {
         const int64_t rr = p.res_mod > 0 ? (int64_t)((unsigned)m % (unsigned)p.res_mod) : m;
         if (full) {
-          if (p.res_is_bf16) {
-            const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.res) + rr * p.ldr + n);
+          if (p.res_is_16bit) {
+            const op16x4 t = *reinterpret_cast<const op16x4*>(reinterpret_cast<const op16*>(p.res) + rr * p.ldr + n);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) resv[q] = bf2f(t[q]);
+            for (int q = 0; q < 4; ++q) resv[q] = op2f(t[q]);
           } else {
             const f32x4 t = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + rr * p.ldr + n);
 #pragma unroll
@@ -87,7 +87,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             if (n + q < p.N)
-              resv[q] = p.res_is_bf16 ? bf2f(reinterpret_cast<const bf16*>(p.res)[rr * p.ldr + n + q])
+              resv[q] = p.res_is_16bit ? op2f(reinterpret_cast<const op16*>(p.res)[rr * p.ldr + n + q])
                                       : reinterpret_cast<const float*>(p.res)[rr * p.ldr + n + q];
         }
       }
@@ -100,11 +100,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         v[q] = x * cs4[q] + resv[q];
       }
       if (full) {
-        if (p.out_is_bf16) {
-          bf16x4 o;
+        if (p.out_is_16bit) {
+          op16x4 o;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] = f2bf(v[q]);
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + m * p.ldc + n) = o;
+          for (int q = 0; q < 4; ++q) o[q] = f2op(v[q]);
+          *reinterpret_cast<op16x4*>(reinterpret_cast<op16*>(p.C) + m * p.ldc + n) = o;
         } else {
           *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n) = v;
         }
@@ -112,7 +112,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if (n + q < p.N) {
-            if (p.out_is_bf16) reinterpret_cast<bf16*>(p.C)[m * p.ldc + n + q] = f2bf(v[q]);
+            if (p.out_is_16bit) reinterpret_cast<op16*>(p.C)[m * p.ldc + n + q] = f2op(v[q]);
             else reinterpret_cast<float*>(p.C)[m * p.ldc + n + q] = v[q];
           }
       }
@@ -121,15 +121,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 }
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmParams p) {
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM, TN = BN / WN;  // per-wave tile
   constexpr int FM = TM / 32, FN = TN / 32;  // 32x32 MFMA tiles per wave
   constexpr int A_CHUNKS = BM * 4, W_CHUNKS = BN * 4;
   constexpr int A_PER = (A_CHUNKS + NT - 1) / NT, W_PER = (W_CHUNKS + NT - 1) / NT;
-  __shared__ __attribute__((aligned(16))) bf16 lds[2 * (BM + BN) * GEMM_LDS_STRIDE];
-  bf16* As = lds;
-  bf16* Ws = lds + 2 * BM * GEMM_LDS_STRIDE;
+  __shared__ __attribute__((aligned(16))) op16 lds[2 * (BM + BN) * GEMM_LDS_STRIDE];
+  op16* As = lds;
+  op16* Ws = lds + 2 * BM * GEMM_LDS_STRIDE;
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -194,17 +194,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmParams p) {
     if (kt + 1 < nk) gload(kt + 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[FM], bfr[FN];
+      op16x8 af[FM], bfr[FN];
 #pragma unroll
       for (int i = 0; i < FM; ++i)
-        af[i] = *reinterpret_cast<const bf16x8*>(As + (cur * BM + wm * TM + i * 32 + r) * GEMM_LDS_STRIDE + ks * 16 + h * 8);
+        af[i] = *reinterpret_cast<const op16x8*>(As + (cur * BM + wm * TM + i * 32 + r) * GEMM_LDS_STRIDE + ks * 16 + h * 8);
 #pragma unroll
       for (int j = 0; j < FN; ++j)
-        bfr[j] = *reinterpret_cast<const bf16x8*>(Ws + (cur * BN + wn * TN + j * 32 + r) * GEMM_LDS_STRIDE + ks * 16 + h * 8);
+        bfr[j] = *reinterpret_cast<const op16x8*>(Ws + (cur * BN + wn * TN + j * 32 + r) * GEMM_LDS_STRIDE + ks * 16 + h * 8);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < FN; ++j) acc[i][j] = MSAM2_MFMA_32x32x16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) lstore(cur ^ 1);
     __syncthreads();
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmParams p) {
 // ------------------------------------------------------------------------------------------------------------------
 // Large-shape variant: 128x128x64 tiles, operands streamed global -> LDS by LDS-DMA (global_load_lds_dwordx4, no staging
 // registers), 2-stage ring per workgroup and 2 workgroups per CU so that a tile is always in flight behind the MFMA phase.
-// LDS image per operand: [128 rows][64 k] bf16 with 128-byte rows; the 16-byte chunk c of row r sits in slot
+// LDS image per operand: [128 rows][64 k] op16 with 128-byte rows; the 16-byte chunk c of row r sits in slot
 // c ^ ((r >> 1) & 7), which makes every ds_read_b128 fragment read (16-lane groups of the 32x32x16 operand map) conflict
 // free.  The DMA writes LDS linearly (wave base + lane*16), so the swizzle is applied to the per-lane SOURCE address.
 // Requires K % 64 == 0; rows beyond M / N are clamped on load and dropped in the epilogue.
@@ -305,14 +305,14 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
     const unsigned char* sb = lds + st * STAGE_BYTES;
     // all 16 operand fragments of the tile in one burst (64 VGPRs), then 16 MFMAs with the next tile's DMA pieces issued in
     // their shadow (2 per k-substep): LDS latency is paid once per tile and the DMA issue cost hides under the matrix pipe
-    bf16x8 af[4][2], bfr[4][2];
+    op16x8 af[4][2], bfr[4][2];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int c = 2 * ks + h;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        af[ks][i] = *reinterpret_cast<const bf16x8*>(sb + offA[i] + ((c ^ swz[0][i]) << 4));
-        bfr[ks][i] = *reinterpret_cast<const bf16x8*>(sb + offB[i] + ((c ^ swz[1][i]) << 4));
+        af[ks][i] = *reinterpret_cast<const op16x8*>(sb + offA[i] + ((c ^ swz[0][i]) << 4));
+        bfr[ks][i] = *reinterpret_cast<const op16x8*>(sb + offB[i] + ((c ^ swz[1][i]) << 4));
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = MSAM2_MFMA_32x32x16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
       if (kt + 1 < nk) {
         issue_piece(kt + 1, st ^ 1, 2 * ks);
         issue_piece(kt + 1, st ^ 1, 2 * ks + 1);
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
 // per CU, ONE barrier per k-step.  The deeper ring is what hides the L2 -> LDS latency (~1.5-2k cycles under load) that the
 // 2-stage kernel above exposes every step; K only needs to be a multiple of 32, which also brings the K = 96 / 160 layers
 // of Hiera stage 1 onto the DMA path.
-// LDS image per operand: [128 rows][32 k] bf16 = 64-byte rows; chunk c (0..3) of row r sits in slot c ^ ((r >> 2) & 3):
+// LDS image per operand: [128 rows][32 k] op16 = 64-byte rows; chunk c (0..3) of row r sits in slot c ^ ((r >> 2) & 3):
 // every 16-lane ds_read_b128 group of the 32x32x16 operand map then covers 16 distinct (row mod 4, slot) positions of the
 // 256-byte bank rows it touches (conflict free).
 // ------------------------------------------------------------------------------------------------------------------
@@ -413,14 +413,14 @@ __global__ __launch_bounds__(256, 2) void gemm_glds4_kernel(GemmParams p) {
     __builtin_amdgcn_s_barrier();                        // tile kt visible to all waves; stage (kt+3)&3 no longer being read
     if (kt + 3 < nk) issue(kt + 3);
     const unsigned char* sb = lds + (kt & 3) * STAGE_BYTES;
-    bf16x8 af[2][2], bfr[2][2];
+    op16x8 af[2][2], bfr[2][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int c = 2 * ks + h;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        af[ks][i] = *reinterpret_cast<const bf16x8*>(sb + offA[i] + ((c ^ swz[0][i]) << 4));
-        bfr[ks][i] = *reinterpret_cast<const bf16x8*>(sb + offB[i] + ((c ^ swz[1][i]) << 4));
+        af[ks][i] = *reinterpret_cast<const op16x8*>(sb + offA[i] + ((c ^ swz[0][i]) << 4));
+        bfr[ks][i] = *reinterpret_cast<const op16x8*>(sb + offB[i] + ((c ^ swz[1][i]) << 4));
       }
     }
 #pragma unroll
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds4_kernel(GemmParams p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = MSAM2_MFMA_32x32x16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
   }
   __builtin_amdgcn_s_barrier();
   gemm_epilogue<2, 2>(p, acc, reinterpret_cast<float*>(lds) + wave * 32 * 68, m0 + wm * 64, n0 + wn * 64, lane);
@@ -438,12 +438,12 @@ __global__ __launch_bounds__(256, 2) void gemm_glds4_kernel(GemmParams p) {
 template <int BM, int BN, int WM, int WN>
 static void launch_gemm(const GemmParams& p, hipStream_t s) {
   dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM));
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN>), grid, dim3(WM * WN * 64), 0, s, p);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN>), grid, dim3(WM * WN * 64), 0, s, p);
 }
 
-extern "C" int msam2_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
-                               const float* colscale, const void* residual, int64_t ldr, int res_is_bf16, int64_t res_mod,
-                               void* C, int64_t ldc, int out_is_bf16, int64_t M, int64_t N, int64_t K, int act,
+extern "C" int msam2_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                               const float* colscale, const void* residual, int64_t ldr, int res_is_16bit, int64_t res_mod,
+                               void* C, int64_t ldc, int out_is_16bit, int64_t M, int64_t N, int64_t K, int act,
                                void* stream) {
   MSAM2_REQUIRE(A && W && C, "gemm: null operand");
   MSAM2_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
@@ -452,9 +452,9 @@ extern "C" int msam2_gemm_bf16(const void* A, int64_t lda, const void* W, int64_
   MSAM2_REQUIRE(M < (1ll << 31) && N < (1ll << 31), "gemm: M/N too large");
   MSAM2_REQUIRE(act >= 0 && act <= 3, "gemm: bad activation %d", act);
   GemmParams p;
-  p.A = (const bf16*)A; p.W = (const bf16*)W; p.bias = bias; p.colscale = colscale; p.res = residual; p.C = C;
+  p.A = (const op16*)A; p.W = (const op16*)W; p.bias = bias; p.colscale = colscale; p.res = residual; p.C = C;
   p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldc = ldc; p.res_mod = res_mod;
-  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act; p.res_is_bf16 = res_is_bf16; p.out_is_bf16 = out_is_bf16;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act; p.res_is_16bit = res_is_16bit; p.out_is_16bit = out_is_16bit;
   hipStream_t s = (hipStream_t)stream;
   const char* force = getenv("MSAM2_GEMM_V1");
   const char* var = getenv("MSAM2_GEMM_VARIANT");  // "4": 4-stage BK=32 DMA kernel (experiment); default: 2-stage BK=64 DMA kernel

@@ -8,7 +8,7 @@ import torch
 
 from .. import ops
 
-BF16, F32 = torch.bfloat16, torch.float32
+OP16, F32 = ops.OP16, torch.float32  # OP16: the library 16-bit MFMA operand dtype (fp16 by default)
 
 
 class WeightCache:
@@ -34,7 +34,7 @@ class WeightCache:
 
 def w_bf16(cache: WeightCache, key: str, *weights: torch.Tensor) -> torch.Tensor:
     """bf16 [sum(out_i), in] matrix from one or more nn.Linear / 1x1-conv weights stacked along the output dim."""
-    return cache.get(key, weights, lambda: torch.cat([w.detach().reshape(w.shape[0], -1) for w in weights], 0).to(BF16).contiguous())
+    return cache.get(key, weights, lambda: torch.cat([w.detach().reshape(w.shape[0], -1) for w in weights], 0).to(OP16).contiguous())
 
 
 def v_f32(cache: WeightCache, key: str, *vecs: torch.Tensor) -> torch.Tensor:
@@ -58,9 +58,9 @@ def nchw_view(tokens: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
 
 def to_bf16(x2d: torch.Tensor) -> torch.Tensor:
     """bf16 copy of a [rows, C] tensor through the add_cast kernel (no-op for bf16 input)."""
-    if x2d.dtype == BF16:
+    if x2d.dtype == OP16:
         return x2d
-    return ops.add_cast(x2d.unsqueeze(0), None, 1.0, BF16)[0]
+    return ops.add_cast(x2d.unsqueeze(0), None, 1.0, OP16)[0]
 
 
 def attn_splits(B: int, H: int, Lq: int, Lk: int) -> int:

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .common import BF16, F32, WeightCache, nchw_view, to_bf16, tokens_of, v_f32, w_bf16
+from .common import OP16, F32, WeightCache, nchw_view, to_bf16, tokens_of, v_f32, w_bf16
 from .position import PositionEmbeddingSine
 
 
@@ -29,8 +29,8 @@ class PatchEmbed(nn.Module):
 
     def _weight(self):
         def build():
-            w = torch.zeros(self.proj.weight.shape[0], 160, dtype=BF16, device=self.proj.weight.device)
-            w[:, :147] = self.proj.weight.detach().reshape(-1, 147).to(BF16)
+            w = torch.zeros(self.proj.weight.shape[0], 160, dtype=OP16, device=self.proj.weight.device)
+            w[:, :147] = self.proj.weight.detach().reshape(-1, 147).to(OP16)
             return w
         return self._wc.get("w", [self.proj.weight], build)
 
@@ -68,7 +68,7 @@ class MLP(nn.Module):
             last_act = ops.ACT_SIGMOID if self.sigmoid_output else ops.ACT_NONE
             h = ops.gemm(h, w_bf16(self._wc, f"w{i}", layer.weight), v_f32(self._wc, f"b{i}", layer.bias),
                          act=last_act if last else self._act_code, residual=residual if last else None,
-                         out_dtype=out_dtype if last else BF16)
+                         out_dtype=out_dtype if last else OP16)
         return h
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

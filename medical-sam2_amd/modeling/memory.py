@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .common import BF16, F32, WeightCache, attn_splits, nchw_view, to_bf16, tokens_of, v_f32, w_bf16
+from .common import OP16, F32, WeightCache, attn_splits, nchw_view, to_bf16, tokens_of, v_f32, w_bf16
 from .encoder import MLP  # noqa: F401  (re-export for the registry)
 
 
@@ -169,8 +169,8 @@ class MemoryAttentionLayer(nn.Module):
                 num_k_exclude_rope: int = 0) -> torch.Tensor:
         assert not self.training or self.dropout_value == 0.0, "dropout (train mode) is outside the forward hot path"
         B, L, C = tgt.shape
-        mem_k = ops.add_cast(memory, pos, 1.0, BF16)
-        mem_v = ops.add_cast(memory, None, 1.0, BF16)
+        mem_k = ops.add_cast(memory, pos, 1.0, OP16)
+        mem_v = ops.add_cast(memory, None, 1.0, OP16)
         x = ops.add_cast(tgt, None, 1.0, F32).reshape(B * L, C)
         return self.run(x, mem_k, mem_v, B, L, num_k_exclude_rope).view(B, L, C)
 
@@ -200,8 +200,8 @@ class MemoryAttention(nn.Module):
         use_pos = self.pos_enc_at_input and curr_pos is not None
         x = ops.add_cast(curr.transpose(0, 1), curr_pos.transpose(0, 1) if use_pos else None, 0.1, F32).reshape(B * L, C)
         mem_bf = memory.transpose(0, 1)
-        mem_k = ops.add_cast(mem_bf, memory_pos.transpose(0, 1), 1.0, BF16)
-        mem_v = ops.add_cast(mem_bf, None, 1.0, BF16)
+        mem_k = ops.add_cast(mem_bf, memory_pos.transpose(0, 1), 1.0, OP16)
+        mem_v = ops.add_cast(mem_bf, None, 1.0, OP16)
         for layer in self.layers:
             x = layer.run(x, mem_k, mem_v, B, L, num_obj_ptr_tokens)
         y = ops.layernorm(x, v_f32(self._wc, "nw", self.norm.weight), v_f32(self._wc, "nb", self.norm.bias), self.norm.eps,
@@ -247,8 +247,8 @@ class MaskDownSampler(nn.Module):
 
             def pack(c=conv, ld=cols.shape[1]):
                 w = c.weight.detach().permute(0, 2, 3, 1).reshape(c.weight.shape[0], -1)
-                out = torch.zeros(w.shape[0], ld, dtype=BF16, device=w.device)
-                out[:, : w.shape[1]] = w.to(BF16)
+                out = torch.zeros(w.shape[0], ld, dtype=OP16, device=w.device)
+                out[:, : w.shape[1]] = w.to(OP16)
                 return out
             g = ops.gemm(cols, wc.get(f"cw{j}", [conv.weight], pack), f(f"cb{j}", conv.bias), out_dtype=F32)
             h = ops.layernorm(g, f(f"lw{j}", ln.weight), f(f"lb{j}", ln.bias), ln.eps, act=ops.ACT_GELU)

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .common import BF16, F32, WeightCache, nchw_view, to_bf16, tokens_of, v_f32, w_bf16
+from .common import OP16, F32, WeightCache, nchw_view, to_bf16, tokens_of, v_f32, w_bf16
 from .encoder import MLP
 from .sam_heads import MaskDecoder, PromptEncoder, TwoWayTransformer
 
@@ -209,7 +209,7 @@ class SAM2Base(nn.Module):
         ious = torch.ones(B, 1, device=mf.device, dtype=F32)
         S = mf.shape[-1]
         cols = ops.space_to_depth(mf.reshape(B * S * S, 1), B, S, S, 4)
-        wm = self._wc.get("mdw", [self.mask_downsample.weight], lambda: self.mask_downsample.weight.detach().reshape(1, 16).to(BF16).contiguous())
+        wm = self._wc.get("mdw", [self.mask_downsample.weight], lambda: self.mask_downsample.weight.detach().reshape(1, 16).to(OP16).contiguous())
         md = ops.gemm(cols, wm, v_f32(self._wc, "mdb", self.mask_downsample.bias), out_dtype=F32).reshape(B, 1, S // 4, S // 4)
         _, _, _, _, _, obj_ptr, _ = self._forward_sam_heads(backbone_features=backbone_features, mask_inputs=md,
                                                             high_res_features=high_res_features)
@@ -292,7 +292,7 @@ class SAM2Base(nn.Module):
         C = self.hidden_dim
         H, W = feat_sizes[-1]
         top = current_vision_feats[-1]  # [HW, B, C]
-        pix_tokens = ops.add_cast(top.transpose(0, 1), None, 1.0, BF16).view(B * H * W, C)
+        pix_tokens = ops.add_cast(top.transpose(0, 1), None, 1.0, OP16).view(B * H * W, C)
         binarize = self.binarize_mask_from_pts_for_mem_enc and is_mask_from_pts and not self.training
         y = self.memory_encoder.run(pix_tokens, pred_masks_high_res, 2 if binarize else 1, float(self.sigmoid_scale_for_mem_enc),
                                     float(self.sigmoid_bias_for_mem_enc), B, H, W)

@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .common import BF16, F32, WeightCache, nchw_view, to_bf16, tokens_of, v_f32, w_bf16
+from .common import OP16, F32, WeightCache, nchw_view, to_bf16, tokens_of, v_f32, w_bf16
 from .encoder import MLP
 from .memory import Attention, LayerNorm2d
 from .position import PositionEmbeddingRandom
@@ -63,8 +63,8 @@ class PromptEncoder(nn.Module):
             def build():
                 w = conv.weight.detach().permute(0, 2, 3, 1).reshape(conv.weight.shape[0], -1)
                 ld = (w.shape[1] + 7) // 8 * 8
-                out = torch.zeros(w.shape[0], ld, dtype=BF16, device=w.device)
-                out[:, : w.shape[1]] = w.to(BF16)
+                out = torch.zeros(w.shape[0], ld, dtype=OP16, device=w.device)
+                out[:, : w.shape[1]] = w.to(OP16)
                 return out
             return wc.get(key, [conv.weight], build)
 
@@ -142,20 +142,20 @@ class TwoWayAttentionBlock(nn.Module):
             qb = to_bf16(queries)
             queries = sa.out(sa.core(q3(sa.proj("q", qb), T), q3(sa.proj("k", qb), T), q3(sa.proj("v", qb), T)), None)
         else:
-            qb = ops.add_cast(queries.view(1, B * T, C), query_pe.view(1, B * T, C), 1.0, BF16)[0]
+            qb = ops.add_cast(queries.view(1, B * T, C), query_pe.view(1, B * T, C), 1.0, OP16)[0]
             queries = sa.out(sa.core(q3(sa.proj("q", qb), T), q3(sa.proj("k", qb), T), q3(sa.proj("v", to_bf16(queries)), T)), queries)
         queries = self._ln("norm1", queries)
         # tokens -> image
         ca = self.cross_attn_token_to_image
-        qb = ops.add_cast(queries.view(1, B * T, C), query_pe.view(1, B * T, C), 1.0, BF16)[0]
-        kb = ops.add_cast(keys.view(B, L, C), key_pe.view(1, L, C), 1.0, BF16).view(B * L, C)
+        qb = ops.add_cast(queries.view(1, B * T, C), query_pe.view(1, B * T, C), 1.0, OP16)[0]
+        kb = ops.add_cast(keys.view(B, L, C), key_pe.view(1, L, C), 1.0, OP16).view(B * L, C)
         keys_b = to_bf16(keys)
         o = ca.core(q3(ca.proj("q", qb), T), q3(ca.proj("k", kb), L), q3(ca.proj("v", keys_b), L))
         queries = self._ln("norm2", ca.out(o, queries))
         queries = self._ln("norm3", self.mlp.run(to_bf16(queries), residual=queries, out_dtype=F32))
         # image -> tokens
         ia = self.cross_attn_image_to_token
-        qb = ops.add_cast(queries.view(1, B * T, C), query_pe.view(1, B * T, C), 1.0, BF16)[0]
+        qb = ops.add_cast(queries.view(1, B * T, C), query_pe.view(1, B * T, C), 1.0, OP16)[0]
         o = ia.core(q3(ia.proj("q", kb), L), q3(ia.proj("k", qb), T), q3(ia.proj("v", to_bf16(queries)), T))
         keys = self._ln("norm4", ia.out(o, keys))
         return queries, keys
@@ -191,8 +191,8 @@ class TwoWayTransformer(nn.Module):
         for layer in self.layers:
             queries, keys = layer.run(queries, keys, qpe, key_pe, B, T, L)
         fa = self.final_attn_token_to_image
-        qb = ops.add_cast(queries.view(1, B * T, C), qpe.view(1, B * T, C), 1.0, BF16)[0]
-        kb = ops.add_cast(keys.view(B, L, C), key_pe.view(1, L, C), 1.0, BF16).view(B * L, C)
+        qb = ops.add_cast(queries.view(1, B * T, C), qpe.view(1, B * T, C), 1.0, OP16)[0]
+        kb = ops.add_cast(keys.view(B, L, C), key_pe.view(1, L, C), 1.0, OP16).view(B * L, C)
         q3 = lambda t, n: t.view(B, n, -1)
         o = fa.core(q3(fa.proj("q", qb), T), q3(fa.proj("k", kb), L), q3(fa.proj("v", to_bf16(keys)), L))
         n = self.norm_final_attn
@@ -244,7 +244,7 @@ class MaskDecoder(nn.Module):
         self.dynamic_multimask_stability_thresh = dynamic_multimask_stability_thresh
         self._wc = WeightCache()
 
-    def conv_s(self, which: int, tokens_bf16: torch.Tensor, out_dtype=BF16) -> torch.Tensor:
+    def conv_s(self, which: int, tokens_bf16: torch.Tensor, out_dtype=OP16) -> torch.Tensor:
         """conv_s0 / conv_s1 (sam2_base.py:470-475) on token-major bf16 features."""
         c = self.conv_s0 if which == 0 else self.conv_s1
         return ops.gemm(tokens_bf16, w_bf16(self._wc, f"cs{which}w", c.weight), v_f32(self._wc, f"cs{which}b", c.bias), out_dtype=out_dtype)
@@ -265,10 +265,10 @@ class MaskDecoder(nn.Module):
         hs, keys = self.transformer.run(src_tokens, pe_tokens, tokens.view(B * T, C), B, T, h * w)
         hs = hs.view(B, T, C)
         up = self.output_upscaling
-        dc1_w = wc.get("dc1", [up[0].weight], lambda: up[0].weight.detach().permute(2, 3, 1, 0).reshape(-1, C).to(BF16).contiguous())
+        dc1_w = wc.get("dc1", [up[0].weight], lambda: up[0].weight.detach().permute(2, 3, 1, 0).reshape(-1, C).to(OP16).contiguous())
         g = ops.gemm(to_bf16(keys), dc1_w)
         u = ops.convt2x2_shuffle(g, v_f32(wc, "dc1b", up[0].bias), feat_s1, v_f32(wc, "lnw", up[1].weight), v_f32(wc, "lnb", up[1].bias), B, h, w)
-        dc2_w = wc.get("dc2", [up[3].weight], lambda: up[3].weight.detach().permute(2, 3, 1, 0).reshape(-1, C // 4).to(BF16).contiguous())
+        dc2_w = wc.get("dc2", [up[3].weight], lambda: up[3].weight.detach().permute(2, 3, 1, 0).reshape(-1, C // 4).to(OP16).contiguous())
         g = ops.gemm(u, dc2_w)
         u = ops.convt2x2_shuffle(g, v_f32(wc, "dc2b", up[3].bias), feat_s0, None, None, B, 2 * h, 2 * w)  # [B*16hw, C/8] bf16
         hyper = torch.empty(B, self.num_mask_tokens, C // 8, dtype=F32, device=u.device)

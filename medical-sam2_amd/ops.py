@@ -14,7 +14,9 @@ import torch
 
 from ._lib import check, lib
 
-BF16 = torch.bfloat16
+# 16-bit MFMA operand dtype of the loaded library: fp16 by default, bf16 when built with -DMSAM2_OPERAND_BF16
+OP16 = torch.float16 if lib().msam2_operand_is_fp16() else torch.bfloat16
+
 F32 = torch.float32
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 
@@ -28,11 +30,12 @@ def _p(t: Optional[torch.Tensor]):
 
 
 def _is_bf16(t: torch.Tensor) -> int:
-    if t.dtype == BF16:
+    """1 for the library's 16-bit operand dtype (OP16), 0 for fp32."""
+    if t.dtype == OP16:
         return 1
     if t.dtype == F32:
         return 0
-    raise TypeError(f"expected bf16 or fp32 tensor, got {t.dtype}")
+    raise TypeError(f"expected {OP16} or fp32 tensor, got {t.dtype}")
 
 
 def _req(cond: bool, msg: str):
@@ -43,10 +46,10 @@ def _req(cond: bool, msg: str):
 # ---------------------------------------------------------------------------------------------------------------------
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = ACT_NONE,
          colscale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, res_mod: int = 0,
-         out_dtype: torch.dtype = BF16, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+         out_dtype: torch.dtype = OP16, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = residual + colscale * act(a[M,K] @ w[N,K]^T + bias).  a, w bf16; bias/colscale fp32."""
     _req(a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1], f"gemm shapes {tuple(a.shape)} x {tuple(w.shape)}")
-    _req(a.dtype == BF16 and w.dtype == BF16, "gemm operands must be bf16")
+    _req(a.dtype == OP16 and w.dtype == OP16, "gemm operands must be 16-bit (ops.OP16)")
     _req(a.stride(1) == 1 and w.stride(1) == 1, "gemm operands must be K-contiguous")
     M, K = a.shape
     N = w.shape[0]
@@ -55,7 +58,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     _req(out.stride(1) == 1 and out.shape == (M, N), "gemm out must be [M,N] row-major")
     if residual is not None:
         _req(residual.dim() == 2 and residual.stride(1) == 1 and residual.shape[1] == N, "gemm residual must be [*,N]")
-    check(lib().msam2_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(colscale), _p(residual),
+    check(lib().msam2_gemm(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(colscale), _p(residual),
                                 residual.stride(0) if residual is not None else 0,
                                 _is_bf16(residual) if residual is not None else 0, res_mod, _p(out), out.stride(0),
                                 _is_bf16(out), M, N, K, act, _stream()))
@@ -63,7 +66,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
 
 
 def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float, *, act: int = ACT_NONE,
-              out_dtype: torch.dtype = BF16) -> torch.Tensor:
+              out_dtype: torch.dtype = OP16) -> torch.Tensor:
     """Row LayerNorm over the last dim of a [rows, C] tensor (C contiguous)."""
     C = x.shape[-1]
     x2 = x.reshape(-1, C)
@@ -85,9 +88,9 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, splits: int 
     B, H, Lq, D = q.shape
     Lk = k.shape[2]
     for t in (q, k, v):
-        _req(t.dtype == BF16 and t.stride(3) == 1, "attention tensors must be bf16 with contiguous head dim")
+        _req(t.dtype == OP16 and t.stride(3) == 1, "attention tensors must be 16-bit (ops.OP16) with contiguous head dim")
     if out is None:
-        out = torch.empty(B, Lq, H, D, dtype=BF16, device=q.device).permute(0, 2, 1, 3)
+        out = torch.empty(B, Lq, H, D, dtype=OP16, device=q.device).permute(0, 2, 1, 3)
     ws_bytes = lib().msam2_attention_workspace_bytes(B, H, Lq, D, splits)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=q.device) if splits > 1 else None
     check(lib().msam2_attention_fwd(_p(q), _strides3(q), _p(k), _strides3(k), _p(v), _strides3(v), _p(out), _strides3(out),
@@ -102,12 +105,12 @@ def window_attention(qkv: torch.Tensor, B: int, H: int, W: int, heads: int, ws: 
     ([B*(H/2)*(W/2), heads*D]) queries come from it with window ws/2.  Returns o [B*Hq*Wq, heads*D] bf16."""
     dim_out = qkv.shape[1] // 3
     D = dim_out // heads
-    _req(qkv.dtype == BF16 and qkv.stride(1) == 1, "qkv must be bf16 row-major")
+    _req(qkv.dtype == OP16 and qkv.stride(1) == 1, "qkv must be 16-bit (ops.OP16) row-major")
     if q_pooled is None:
         qt, q_ts, hq, wq, ws_q = qkv, qkv.stride(0), H, W, ws
     else:
         qt, q_ts, hq, wq, ws_q = q_pooled, q_pooled.stride(0), H // 2, W // 2, ws // 2
-    o = torch.empty(B * hq * wq, dim_out, dtype=BF16, device=qkv.device)
+    o = torch.empty(B * hq * wq, dim_out, dtype=OP16, device=qkv.device)
     kpad = qkv_bias[dim_out:2 * dim_out]
     vpad = qkv_bias[2 * dim_out:]
     kptr = qkv.data_ptr() + dim_out * 2
@@ -123,15 +126,15 @@ def attention_small(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: in
     Lk = k.shape[1]
     D = C // heads
     for t in (q, k, v):
-        _req(t.dtype == BF16 and t.stride(2) == 1, "attention_small tensors must be bf16, channel-contiguous")
-    o = torch.empty(B, Lq, C, dtype=BF16, device=q.device)
+        _req(t.dtype == OP16 and t.stride(2) == 1, "attention_small tensors must be 16-bit (ops.OP16), channel-contiguous")
+    o = torch.empty(B, Lq, C, dtype=OP16, device=q.device)
     check(lib().msam2_attention_small_fwd(_p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0),
                                           v.stride(1), _p(o), o.stride(0), o.stride(1), B, heads, Lq, Lk, D,
                                           1.0 / math.sqrt(D), _stream()))
     return o
 
 
-def add_cast(a: torch.Tensor, b: Optional[torch.Tensor] = None, alpha: float = 1.0, out_dtype: torch.dtype = BF16,
+def add_cast(a: torch.Tensor, b: Optional[torch.Tensor] = None, alpha: float = 1.0, out_dtype: torch.dtype = OP16,
              out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = a + alpha*b over a logical [D0, D1, C] volume (C contiguous in a and b; outer dims may be strided or, for b,
     broadcast with stride 0).  Result is contiguous (or written into the contiguous `out`)."""
@@ -198,7 +201,7 @@ def rope_table(side: int, D: int, theta: float, device) -> Tuple[torch.Tensor, t
 def rope_(x: torch.Tensor, n_rope: int, table: Tuple[torch.Tensor, torch.Tensor]) -> torch.Tensor:
     """Rotate rows l < n_rope of every batch of x [B, L, D] (bf16 view, D contiguous) in place."""
     B, L, D = x.shape
-    _req(x.dtype == BF16 and x.stride(2) == 1, "rope: bf16 with contiguous D")
+    _req(x.dtype == OP16 and x.stride(2) == 1, "rope: 16-bit with contiguous D")
     cs, sn = table
     check(lib().msam2_rope_inplace(_p(x), x.stride(0), x.stride(1), B, L, n_rope, cs.shape[0], D, _p(cs), _p(sn), _stream()))
     return x
@@ -239,7 +242,7 @@ def im2col_patch(img: torch.Tensor) -> torch.Tensor:
     """img fp32 [B,3,S,S] -> bf16 [B*(S/4)^2, 160]."""
     _req(img.dtype == F32 and img.is_contiguous() and img.shape[1] == 3 and img.shape[2] == img.shape[3], "im2col_patch: [B,3,S,S] fp32")
     B, _, S, _ = img.shape
-    out = torch.empty(B * (S // 4) ** 2, 160, dtype=BF16, device=img.device)
+    out = torch.empty(B * (S // 4) ** 2, 160, dtype=OP16, device=img.device)
     check(lib().msam2_im2col_patch7x7s4(_p(img), _p(out), B, S, _stream()))
     return out
 
@@ -247,9 +250,9 @@ def im2col_patch(img: torch.Tensor) -> torch.Tensor:
 def im2col3x3s2(x: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
     """bf16 NHWC -> [B*(H/2)*(W/2), ld] patches, columns (ky,kx,c), ld = 9*C rounded up to a multiple of 8 (zero filled)."""
     C = x.shape[-1]
-    _req(x.dtype == BF16 and x.is_contiguous(), "im2col3x3s2: bf16 contiguous NHWC")
+    _req(x.dtype == OP16 and x.is_contiguous(), "im2col3x3s2: 16-bit contiguous NHWC")
     ld = (9 * C + 7) // 8 * 8
-    out = torch.empty(B * (H // 2) * (W // 2), ld, dtype=BF16, device=x.device)
+    out = torch.empty(B * (H // 2) * (W // 2), ld, dtype=OP16, device=x.device)
     check(lib().msam2_im2col3x3s2(_p(x), _p(out), B, H, W, C, ld, _stream()))
     return out
 
@@ -257,7 +260,7 @@ def im2col3x3s2(x: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
 def conv3x3s2_ln_gelu(x: torch.Tensor, B: int, H: int, W: int, weight, bias, ln_w, ln_b, mask_mode: int = 0,
                       mask_scale: float = 0.0, mask_bias: float = 0.0) -> torch.Tensor:
     cout, cin = weight.shape[0], weight.shape[1]
-    y = torch.empty(B * (H // 2) * (W // 2), cout, dtype=BF16, device=x.device)
+    y = torch.empty(B * (H // 2) * (W // 2), cout, dtype=OP16, device=x.device)
     check(lib().msam2_conv3x3s2_ln_gelu(_p(x), _is_bf16(x), _p(weight), _p(bias), _p(ln_w), _p(ln_b), _p(y), B, H, W, cin, cout,
                                         mask_mode, mask_scale, mask_bias, _stream()))
     return y
@@ -266,15 +269,15 @@ def conv3x3s2_ln_gelu(x: torch.Tensor, B: int, H: int, W: int, weight, bias, ln_
 def dwconv7x7_ln(x: torch.Tensor, B: int, H: int, W: int, w_tap_major, bias, ln_w, ln_b) -> torch.Tensor:
     _req(x.dtype == F32 and x.is_contiguous(), "dwconv7x7_ln: fp32 contiguous NHWC")
     C = x.shape[-1]
-    y = torch.empty(B * H * W, C, dtype=BF16, device=x.device)
+    y = torch.empty(B * H * W, C, dtype=OP16, device=x.device)
     check(lib().msam2_dwconv7x7_ln(_p(x), _p(w_tap_major), _p(bias), _p(ln_w), _p(ln_b), _p(y), B, H, W, C, _stream()))
     return y
 
 
 def convt2x2_shuffle(g: torch.Tensor, bias, skip: torch.Tensor, ln_w, ln_b, B: int, h: int, w: int) -> torch.Tensor:
     C = g.shape[1] // 4
-    _req(g.dtype == BF16 and skip.dtype == BF16 and g.is_contiguous() and skip.is_contiguous(), "convt2x2_shuffle: bf16 contiguous")
-    y = torch.empty(B * 4 * h * w, C, dtype=BF16, device=g.device)
+    _req(g.dtype == OP16 and skip.dtype == OP16 and g.is_contiguous() and skip.is_contiguous(), "convt2x2_shuffle: 16-bit contiguous")
+    y = torch.empty(B * 4 * h * w, C, dtype=OP16, device=g.device)
     check(lib().msam2_convt2x2_shuffle(_p(g), _p(bias), _p(skip), _p(ln_w), _p(ln_b), _p(y), B, h, w, C, _stream()))
     return y
 
@@ -385,7 +388,7 @@ def space_to_depth(x: torch.Tensor, B: int, H: int, W: int, k: int) -> torch.Ten
     """NHWC [B*H*W, C] -> bf16 [B*(H/k)*(W/k), ld] patches with columns (ky,kx,c), ld = k*k*C rounded up to 8."""
     C = x.shape[-1]
     ld = (k * k * C + 7) // 8 * 8
-    out = torch.empty(B * (H // k) * (W // k), ld, dtype=BF16, device=x.device)
+    out = torch.empty(B * (H // k) * (W // k), ld, dtype=OP16, device=x.device)
     check(lib().msam2_space_to_depth(_p(x), _is_bf16(x), _p(out), B, H, W, C, k, ld, _stream()))
     return out
 

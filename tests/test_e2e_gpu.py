@@ -2,13 +2,18 @@
 vectors captured from the reference's own fp32 modules (tests/golden/make_golden.py) on the same seeded inputs and
 name-keyed weights.
 
-The kernels compute with bf16 MFMA operands and fp32 accumulation / residual streams, so this is the "stated bf16
-tolerance" of BASELINE.json's north_star; the reference itself, run under CPU bf16 autocast, differs from its own
-fp32 run by IoU 0.993-0.996 and max |dlogit| 0.19 on these random weights.  Tolerances below:
-  trunk / FPN features          relative L2 <= 2e-2
-  memory attention output       relative L2 <= 2e-2
-  mask logits (pred_masks)      mean |d| <= 0.08, max |d| <= 0.3   and   IoU >= 0.97 vs the reference fp32 mask
-  obj_ptr / maskmem_features    relative L2 <= 3e-2
+The kernels compute with 16-bit MFMA operands (IEEE fp16 by default: 11-bit significand) and fp32 accumulation, residual
+streams, LayerNorm, softmax statistics and logits.  Stated tolerance of that mode against the reference's fp32 run
+(measured values in parentheses, round 1, fp16 operands):
+  trunk / FPN features          relative L2 <= 3e-3      (5e-4 .. 7e-4)
+  memory attention output       relative L2 <= 3e-3      (4.5e-4)
+  mask logits (pred_masks)      mean |d| <= 0.01, max |d| <= 0.05      (0.002-0.004, 0.016)
+  mask IoU vs the reference     >= 0.99 on every slice, >= 0.999 pooled over a slice chain
+                                (1.0 on 7 of 9 slices; 0.9991 / 0.9955 on two propagated 1024^2 slices whose random-weight
+                                 masks cover ~1100 pixels: 1 and 5 pixels with |logit| < 0.016 flip)
+  obj_ptr / maskmem_features    relative L2 <= 5e-3
+With -DMSAM2_OPERAND_BF16 the same tests hold at ~10x these bounds (features 5e-3..7e-3, max |dlogit| 0.12, IoU 0.983-0.9997),
+i.e. inside the reference's own fp32-vs-bf16-autocast disagreement (IoU 0.993-0.996, max |dlogit| 0.19).
 """
 import numpy as np
 import pytest
@@ -22,6 +27,23 @@ from helpers import load_meta, load_npz, mask_iou, max_abs, rel_err, sub  # noqa
 
 DEV = "cuda"
 REPORT = {}
+
+
+def _fp16():
+    import medical_sam2_amd.ops as ops
+    return ops.OP16 == torch.float16
+
+
+# tolerances of the build's operand type (fp16 default / bf16)
+TOL_FEAT, TOL_PTR, TOL_MAX, TOL_MEAN, TOL_IOU, TOL_IOU_POOLED = 3e-3, 5e-3, 0.05, 0.01, 0.99, 0.999
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _set_tolerances():
+    global TOL_FEAT, TOL_PTR, TOL_MAX, TOL_MEAN, TOL_IOU, TOL_IOU_POOLED
+    if torch.cuda.is_available() and not _fp16():
+        TOL_FEAT, TOL_PTR, TOL_MAX, TOL_MEAN, TOL_IOU, TOL_IOU_POOLED = 2e-2, 3e-2, 0.3, 0.08, 0.97, 0.99
+    yield
 
 
 @pytest.fixture(scope="module")
@@ -53,6 +75,7 @@ def _chain(build, model, image_size, n_slices, tag, gold):
     m = build(model, image_size)
     od = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
     worst = {"iou": 1.0, "max": 0.0, "mean": 0.0}
+    inter = union = 0.0
     with torch.no_grad():
         for t in range(n_slices):
             img, pts, labels = syn.image_batch([10 + t], image_size)
@@ -61,7 +84,7 @@ def _chain(build, model, image_size, n_slices, tag, gold):
                 for lvl in range(3):
                     e = rel_err(sub(bo["backbone_fpn"][lvl].cpu()), gold[f"{tag}_fpn{lvl}_sub"])
                     REPORT[f"{tag}_fpn{lvl}"] = e
-                    assert e < 2e-2, (lvl, e)
+                    assert e < TOL_FEAT, (lvl, e)
                     assert rel_err(sub(bo["vision_pos_enc"][lvl].cpu()), gold[f"{tag}_pos{lvl}_sub"]) < 1e-4
             _, feats, pos, sizes = m._prepare_backbone_features(bo)
             pin = {"point_coords": pts.to(DEV), "point_labels": labels.to(DEV)} if t == 0 else None
@@ -73,14 +96,16 @@ def _chain(build, model, image_size, n_slices, tag, gold):
             iou, mx, mean = mask_iou(got, ref), max_abs(got, ref), _mean_abs(got, ref)
             REPORT[f"{tag}_t{t}"] = dict(iou=iou, max_abs=mx, mean_abs=mean)
             worst = {"iou": min(worst["iou"], iou), "max": max(worst["max"], mx), "mean": max(worst["mean"], mean)}
-            assert rel_err(cur["obj_ptr"].cpu(), gold[f"{tag}_t{t}_obj_ptr"]) < 3e-2
-            assert rel_err(sub(cur["maskmem_features"].cpu()), gold[f"{tag}_t{t}_maskmem_features_sub"]) < 3e-2
+            inter += float(((got > 0) & (ref > 0)).sum())
+            union += float(((got > 0) | (ref > 0)).sum())
+            assert rel_err(cur["obj_ptr"].cpu(), gold[f"{tag}_t{t}_obj_ptr"]) < TOL_PTR
+            assert rel_err(sub(cur["maskmem_features"].cpu()), gold[f"{tag}_t{t}_maskmem_features_sub"]) < TOL_PTR
             assert rel_err(sub(cur["maskmem_pos_enc"][0].cpu()), gold[f"{tag}_t{t}_maskmem_pos_sub"]) < 1e-4
             assert cur["pred_masks"].shape == ref.shape and cur["pred_masks_high_res"].shape[-1] == image_size
+    REPORT[f"{tag}_pooled_iou"] = inter / max(union, 1.0)
     _dump()
-    # measured (round 1): IoU 0.9997 on the prompted slice, 0.983-0.995 on propagated slices whose masks cover only ~2-3 % of
-    # the image (a few pixels flip where |logit| < 0.12); mean |dlogit| 0.02-0.05, max 0.12
-    assert worst["iou"] >= 0.97 and worst["max"] <= 0.3 and worst["mean"] <= 0.08, worst
+    assert worst["iou"] >= TOL_IOU and worst["max"] <= TOL_MAX and worst["mean"] <= TOL_MEAN, worst
+    assert inter / max(union, 1.0) >= TOL_IOU_POOLED, inter / max(union, 1.0)
 
 
 def test_chain_hiera_s_256(build):
@@ -117,34 +142,34 @@ def test_modules_vs_reference(build):
     with torch.no_grad():
         y = m.memory_attention(curr=[d(curr)], curr_pos=[d(curr_pos)], memory=d(memory), memory_pos=d(memory_pos), num_obj_ptr_tokens=8)
         assert y.shape == (E * E, B, 256)
-        e = rel_err(y.cpu(), g["mod256_memattn_out"]); REPORT["memattn"] = e; assert e < 2e-2, e
+        e = rel_err(y.cpu(), g["mod256_memattn_out"]); REPORT["memattn"] = e; assert e < TOL_FEAT, e
         y = m.memory_attention(curr=[d(curr)], curr_pos=[d(curr_pos)], memory=d(memory[: E * E]), memory_pos=d(memory_pos[: E * E]),
                                num_obj_ptr_tokens=0)
-        e = rel_err(y.cpu(), g["mod256_memattn_out_noptr"]); assert e < 2e-2, e
+        e = rel_err(y.cpu(), g["mod256_memattn_out_noptr"]); assert e < TOL_FEAT, e
         for mm in (True, False):
             r = m._forward_sam_heads(backbone_features=d(feat), point_inputs={"point_coords": d(pts), "point_labels": d(labs)},
                                      mask_inputs=None, high_res_features=[d(h) for h in hr], multimask_output=mm)
             k = f"mod256_heads_mm{int(mm)}"
-            assert rel_err(r[0].cpu(), g[k + "_low_multi"]) < 3e-2
-            assert rel_err(r[2].cpu(), g[k + "_ious"]) < 2e-2
-            assert rel_err(r[3].cpu(), g[k + "_low"]) < 3e-2
-            assert rel_err(r[5].cpu(), g[k + "_ptr"]) < 3e-2
-            assert rel_err(r[6].cpu(), g[k + "_obj"]) < 3e-2
-            assert rel_err(sub(r[4].cpu()), g[k + "_high_sub"]) < 3e-2
+            assert rel_err(r[0].cpu(), g[k + "_low_multi"]) < TOL_PTR
+            assert rel_err(r[2].cpu(), g[k + "_ious"]) < TOL_PTR
+            assert rel_err(r[3].cpu(), g[k + "_low"]) < TOL_PTR
+            assert rel_err(r[5].cpu(), g[k + "_ptr"]) < TOL_PTR
+            assert rel_err(r[6].cpu(), g[k + "_obj"]) < TOL_PTR
+            assert rel_err(sub(r[4].cpu()), g[k + "_high_sub"]) < TOL_PTR
         r = m._forward_sam_heads(backbone_features=d(feat), point_inputs=None, mask_inputs=None, high_res_features=[d(h) for h in hr],
                                  multimask_output=True)
-        assert rel_err(r[3].cpu(), g["mod256_heads_noprompt_low"]) < 3e-2
+        assert rel_err(r[3].cpu(), g["mod256_heads_noprompt_low"]) < TOL_PTR
         boxes = torch.tensor([[10.0, 20.0, 100.0, 120.0], [30.0, 40.0, 200.0, 220.0]])
         sp, _ = m.sam_prompt_encoder(points=None, boxes=d(boxes), masks=None)
         assert rel_err(sp.cpu(), g["mod256_pe_box_sparse"]) < 1e-4
         assert rel_err(sub(m.sam_prompt_encoder.get_dense_pe().cpu()), g["mod256_pe_dense_pe_sub"]) < 1e-4
         r = m._use_mask_as_output(d(feat), [d(h) for h in hr], d(mask_in))
         assert rel_err(sub(r[0].cpu()), g["mod256_maskout_low_sub"]) < 1e-4
-        assert rel_err(r[5].cpu(), g["mod256_maskout_ptr"]) < 3e-2
+        assert rel_err(r[5].cpu(), g["mod256_maskout_ptr"]) < TOL_PTR
         assert max_abs(r[6].cpu(), g["mod256_maskout_obj"]) == 0.0
         for flag in (True, False):
             f, p = m._encode_new_memory([d(top)], [(E, E)], d(high), is_mask_from_pts=flag)
-            e = rel_err(f.cpu(), g[f"mod256_memenc_pts{int(flag)}"]); assert e < 3e-2, e
+            e = rel_err(f.cpu(), g[f"mod256_memenc_pts{int(flag)}"]); assert e < TOL_PTR, e
         assert rel_err(sub(p[0].cpu()), g["mod256_memenc_pos_sub"]) < 1e-4
     _dump()
 
@@ -155,3 +180,53 @@ def test_state_dict_roundtrip_and_reference_yaml(build):
     spec = wts.state_dict_spec("hiera_s")
     assert list(sd.keys()) == list(spec.keys())
     assert all(tuple(sd[k].shape) == tuple(v) for k, v in spec.items())
+
+
+def test_volume_bbox_prompts_vs_oracle(build):
+    """BASELINE config 3 in miniature: 6 slices, 2 objects, bbox prompt on every 2nd slice, propagation through the rest; the
+    drop-in volume driver against the same flow run through the CPU oracle (multi-object batch, pointer tokens, several
+    conditioning memories, hole filling)."""
+    from oracle import sam2_oracle as O
+    from oracle import cc as cc_oracle
+    import medical_sam2_amd.volume as vol
+    S, T, n = 256, 6, 2
+    m = build("hiera_t", S)
+    W = wts.init_weights("hiera_t", 0)
+    cfg = O.model_config("hiera_t", S)
+    volume, boxes = syn.blob_volume(3, n_slices=T, size=S, n_objects=n)
+    def box_at(t):
+        rows = []
+        for o in range(n):
+            bb = boxes[o][t] or (S * 0.3, S * 0.3, S * 0.6, S * 0.6)
+            rows.append([float(v) for v in bb])
+        return torch.tensor(rows)
+    prompts = {t: {"boxes": box_at(t).to(DEV)} for t in range(0, T, 2)}
+    got = vol.segment_volume(m, volume.to(DEV), prompts, fill_hole_area=8)
+    # oracle flow
+    od = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
+    ref = {}
+    enc = {}
+    for t in range(T):
+        bo = O.forward_image(W, cfg, volume[t][None])
+        bo = {"backbone_fpn": [f.expand(n, -1, -1, -1) for f in bo["backbone_fpn"]],
+              "vision_pos_enc": [p.expand(n, -1, -1, -1) for p in bo["vision_pos_enc"]]}
+        enc[t] = O.prepare_backbone_features(bo)
+    for t in range(0, T, 2):
+        pin = {"point_coords": box_at(t).reshape(n, 2, 2), "point_labels": torch.tensor([[2, 3]], dtype=torch.int32).expand(n, 2)}
+        od["cond_frame_outputs"][t] = O.track_step(W, cfg, t, True, *enc[t], pin, None, {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}, T)
+        ref[t] = od["cond_frame_outputs"][t]["pred_masks"]
+    for t in range(1, T, 2):
+        col = {}
+        od["non_cond_frame_outputs"][t] = O.track_step(W, cfg, t, False, *enc[t], None, None, od, T, collect=col)
+        ref[t] = od["non_cond_frame_outputs"][t]["pred_masks"]
+        assert col["memory_shape"][0] == 256 * (3 + (t // 2)) + 4 * (t // 2 + 1 + (t // 2))  # cond memories + recent + pointer tokens
+    worst_iou, worst_max = 1.0, 0.0
+    for t in range(T):
+        r = O.fill_holes_in_mask_scores(ref[t], 8, cc_oracle.connected_components)
+        g = got[t].float().cpu()
+        # compare logits away from the hole-fill value; IoU on the final masks
+        worst_iou = min(worst_iou, mask_iou(g.numpy(), r.numpy()))
+        worst_max = max(worst_max, float((g - r)[(g != 0.1) & (r != 0.1)].abs().max()))
+    REPORT["volume"] = dict(iou=worst_iou, max_abs=worst_max)
+    _dump()
+    assert worst_iou >= (0.98 if _fp16() else 0.95) and worst_max <= TOL_MAX, (worst_iou, worst_max)

@@ -1,6 +1,6 @@
 """Kernel-level parity (GPU): every C-ABI op against the CPU oracle's primitive on the same seeded inputs.
 
-bf16 operands are rounded once on the host so both sides see identical inputs; accumulation is fp32 on the GPU and
+16-bit operands (fp16 by default) are rounded once on the host so both sides see identical inputs; accumulation is fp32 on the GPU and
 fp32/fp64 in the oracle, so tolerances only cover accumulation order and the bf16 rounding of outputs / of the
 softmax probabilities:  integer-valued GEMM data is compared bit-exactly (validates the MFMA fragment maps).
 """
@@ -28,8 +28,15 @@ def ops():
 DEV = "cuda"
 
 
+def OP16():
+    import medical_sam2_amd.ops as _o
+    return _o.OP16
+
+
 def bf(x):
-    return x.to(torch.bfloat16)
+    """round to the library's 16-bit MFMA operand dtype (fp16 by default, bf16 with -DMSAM2_OPERAND_BF16)"""
+    import medical_sam2_amd.ops as _o
+    return x.to(_o.OP16)
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -73,7 +80,7 @@ def test_gemm_epilogues(ops):
         out = ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), act=act, colscale=cs.to(DEV), residual=res.to(DEV), res_mod=50,
                        out_dtype=torch.float32)
         close(out, ref, 2e-4, 1e-5, f"gemm act={act}")
-    out = ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), residual=bf(res.repeat(4, 1)).to(DEV), out_dtype=torch.bfloat16)
+    out = ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), residual=bf(res.repeat(4, 1)).to(DEV), out_dtype=OP16())
     close(out, lin + bf(res.repeat(4, 1)).float(), 1e-3, 8e-3, "gemm bf16 out")
     # strided A (a column slice of a wider buffer) and strided output
     wide = bf(rnd(M, 3 * K, seed=6)).to(DEV)
@@ -98,7 +105,7 @@ def test_layernorm(ops, rows, C, eps, act):
         ref = O.gelu(ref)
     out = ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), eps, act=act, out_dtype=torch.float32)
     close(out, ref, 2e-5, 1e-5, "layernorm f32")
-    out = ops.layernorm(bf(x).to(DEV), w.to(DEV), b.to(DEV), eps, act=act, out_dtype=torch.bfloat16)
+    out = ops.layernorm(bf(x).to(DEV), w.to(DEV), b.to(DEV), eps, act=act, out_dtype=OP16())
     refb = O.lnorm(P, "n", bf(x).float(), eps)
     close(out, O.gelu(refb) if act else refb, 2e-3, 8e-3, "layernorm bf16")
 
@@ -190,7 +197,7 @@ def test_add_cast_strided_broadcast(ops):
     # seq-first -> batch-first move with a broadcast vector
     at = a.to(DEV).transpose(0, 1)  # [5, 6, 64] strided view
     vec = rnd(1, 1, 64, seed=3)
-    out = ops.add_cast(at, vec.to(DEV), 1.0, torch.bfloat16)
+    out = ops.add_cast(at, vec.to(DEV), 1.0, OP16())
     close(out, (a.transpose(0, 1) + vec), 1e-2, 8e-3, "add_cast bf16 strided")
     close(ops.add_cast(bf(a).to(DEV), None, 1.0, torch.float32), bf(a).float(), 0, 0, "cast")
 
@@ -218,7 +225,7 @@ def test_rope(ops):
     x = bf(rnd(B, L, D, seed=1))
     n_rope = 3 * side * side
     ref = torch.cat([O.rope_rotate(x[:, :n_rope].float(), rc.repeat(3, 1), rs.repeat(3, 1)), x[:, n_rope:].float()], dim=1)
-    wide = torch.zeros(B, L, 3 * D, dtype=torch.bfloat16, device=DEV)
+    wide = torch.zeros(B, L, 3 * D, dtype=OP16(), device=DEV)
     wide[:, :, D:2 * D] = x.to(DEV)
     ops.rope_(wide[:, :, D:2 * D], n_rope, (cs, sn))
     close(wide[:, :, D:2 * D], ref, 2e-2, 8e-3, "rope")
@@ -250,7 +257,7 @@ def test_patch_embed_via_im2col(ops):
     wb = bf(w)
     ref = F.conv2d(img, wb.float(), b, stride=4, padding=3).permute(0, 2, 3, 1).reshape(-1, E)
     cols = ops.im2col_patch(img.to(DEV))
-    wmat = torch.zeros(E, 160, dtype=torch.bfloat16)
+    wmat = torch.zeros(E, 160, dtype=OP16())
     wmat[:, :147] = wb.reshape(E, 147)
     out = ops.gemm(cols, wmat.to(DEV), b.to(DEV), out_dtype=torch.float32)
     # the im2col rounds the image to bf16: compare against the conv of the rounded image

@@ -9,18 +9,19 @@ CSRC = os.path.join(ROOT, "medical-sam2_amd", "csrc")
 
 DOC = {
     "msam2_version": "Library version (major*10000 + minor*100 + patch).",
+    "msam2_operand_is_fp16": "16-bit operand type of this build: 1 = IEEE fp16 (default), 0 = bf16 (built with -DMSAM2_OPERAND_BF16).  All\n`*_is_16bit` flags below select between that type and fp32.",
     "msam2_last_error": "Message of the last failing call on this thread.  Errors never cross the ABI as exceptions: every entry returns\n0 on success, <0 on failure (reference behaviour: AT_ASSERTM -> RuntimeError, connected_components.cu:215-228; the\nPython wrapper re-raises as RuntimeError).",
-    "msam2_gemm_bf16": "C[M,N] = residual[m % res_mod] + colscale[n] * act(A[M,K] W[N,K]^T + bias[n]); A, W bf16 (K contiguous), bias/colscale\nfp32, residual/C bf16 or fp32.  act: 0 none, 1 exact-erf GELU, 2 ReLU, 3 sigmoid.\nReplaces every nn.Linear / 1x1 Conv2d / im2col'ed conv of the path: hieradet.py:61,79,141; sam2_utils.py:127-131;\ntransformer.py:241-243,261; memory_attention.py:96; image_encoder.py:112; mask_decoder.py:240-256;\nmemory_encoder.py:103-105,171-175; sam2_base.py:470-475.",
+    "msam2_gemm": "C[M,N] = residual[m % res_mod] + colscale[n] * act(A[M,K] W[N,K]^T + bias[n]); A, W 16-bit (K contiguous), bias/colscale\nfp32, residual/C 16-bit or fp32.  act: 0 none, 1 exact-erf GELU, 2 ReLU, 3 sigmoid.\nReplaces every nn.Linear / 1x1 Conv2d / im2col'ed conv of the path: hieradet.py:61,79,141; sam2_utils.py:127-131;\ntransformer.py:241-243,261; memory_attention.py:96; image_encoder.py:112; mask_decoder.py:240-256;\nmemory_encoder.py:103-105,171-175; sam2_base.py:470-475.",
     "msam2_layernorm": "Row LayerNorm (fp32 statistics) on [rows, C], optional GELU: nn.LayerNorm at hieradet.py:138,166,\nmemory_attention.py:60,73,94,162, transformer.py:173-194,116; LayerNorm2d (sam2_utils.py:137-149) on NHWC tokens.",
     "msam2_attention_workspace_bytes": "Scratch needed by msam2_attention_fwd when splits > 1 (fp32 partial O, running max, partial sum).",
-    "msam2_attention_fwd": "softmax(Q K^T * scale) V, non-causal, bf16 in/out, fp32 softmax/accumulate; head dim 64/96/128/256; q/k/v/o given by\nelement strides {batch, head, token}.  splits > 1 = split-KV (flash-decoding) with an in-library merge.\nReplaces F.scaled_dot_product_attention at hieradet.py:72-76 (global blocks) and transformer.py:318 (RoPEAttention,\nmemory attention self/cross).",
+    "msam2_attention_fwd": "softmax(Q K^T * scale) V, non-causal, 16-bit in/out, fp32 softmax/accumulate; head dim 64/96/128/256; q/k/v/o given by\nelement strides {batch, head, token}.  splits > 1 = split-KV (flash-decoding) with an in-library merge.\nReplaces F.scaled_dot_product_attention at hieradet.py:72-76 (global blocks) and transformer.py:318 (RoPEAttention,\nmemory attention self/cross).",
     "msam2_window_attention_fwd": "Windowed Hiera attention straight from un-partitioned qkv tokens: replaces window_partition -> SDPA ->\nwindow_unpartition (backbones/utils.py:16-62 + hieradet.py:138-158,72-76).  Zero-padded window tokens are unmasked keys\nwhose K/V rows are kpad/vpad (= qkv bias), exactly what the reference computes; q may come from a 2x2 max-pooled image\n(q-pool at stage changes, hieradet.py:65-69).",
-    "msam2_attention_small_fwd": "Attention with head dim 16/32 (two-way decoder: transformer.py:239-263 via 165-196, 74-118): tokens->image,\nimage->tokens and token self-attention.  q/k/v/o: bf16 [B, L, heads*D].",
+    "msam2_attention_small_fwd": "Attention with head dim 16/32 (two-way decoder: transformer.py:239-263 via 165-196, 74-118): tokens->image,\nimage->tokens and token self-attention.  q/k/v/o: 16-bit [B, L, heads*D].",
     "msam2_add_cast": "out = a + alpha * b on a logical [D0,D1,C] volume with arbitrary outer strides (0 = broadcast) and dtype conversion:\nmemory_attention.py:139-147 (+0.1*pos, seq-first -> batch-first), 74-76 (memory + pos), transformer.py:175-190 (q + pe,\nk + pe), mask_decoder.py:231 (src + dense), sam2_base.py:642 (+ no_mem_embed), 571-580,626-635 (memory-bank assembly).",
     "msam2_maxpool2x2": "MaxPool2d(2,2) on NHWC tokens (do_pool, hieradet.py:23-34: q-pool and pooled shortcut).",
     "msam2_upsample2x_add": "FPN top-down step y += nearest2x(top) (image_encoder.py:113-124).",
     "msam2_rope_table": "cos/sin of compute_axial_cis (position_encoding.py:174-183) for a side x side grid.",
-    "msam2_rope_inplace": "apply_rotary_enc (position_encoding.py:194-216) in place on bf16 rows; rows >= n_rope of each batch are left\nuntouched (num_k_exclude_rope, transformer.py:308-315); positions wrap modulo n_pos (rope_k_repeat).",
+    "msam2_rope_inplace": "apply_rotary_enc (position_encoding.py:194-216) in place on 16-bit rows; rows >= n_rope of each batch are left\nuntouched (num_k_exclude_rope, transformer.py:308-315); positions wrap modulo n_pos (rope_k_repeat).",
     "msam2_bilinear_upsample": "F.interpolate(mode=\"bilinear\", align_corners=False) on fp32 planes (sam2_base.py:367-373).",
     "msam2_sine_pos_2d": "PositionEmbeddingSine.forward (position_encoding.py:78-112) as a token-major [h*w, C] table.",
     "msam2_fourier_pe_grid": "PromptEncoder.get_dense_pe (prompt_encoder.py:68-77; position_encoding.py:130-151) as [h*w, C].",
@@ -67,7 +68,8 @@ def main():
            ' * frees device memory and keeps no mutable global state besides lazily loaded code objects.  All work is enqueued on the',
            ' * `stream` argument (a hipStream_t passed as void*, 0 = default stream) without host synchronisation, so every entry',
            ' * is hipGraph-capturable and re-entrant.  Return value: 0 = ok, <0 = error (see msam2_last_error).',
-           ' * Tensors: "bf16" = 16-bit brain float, "fp32" = IEEE float; *_is_bf16 flags select between the two.',
+           ' * Tensors: "16-bit" = the operand type of the build (IEEE fp16 by default, bf16 with -DMSAM2_OPERAND_BF16, see',
+           ' * msam2_operand_is_fp16), "fp32" = IEEE float; *_is_16bit flags select between the two.',
            ' * file:line citations refer to the reference tree (1275468127/Medical-SAM2 @ 2024_10_08).',
            ' */',
            '#ifndef MSAM2_HIP_H', '#define MSAM2_HIP_H', '', '#include <stddef.h>', '#include <stdint.h>', '',

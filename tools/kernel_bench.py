@@ -46,10 +46,10 @@ def bench_gemm():
     tot = 0.0
     print(f"{'name':12s} {'M':>8s} {'N':>5s} {'K':>5s} {'us':>9s} {'TF/s':>8s} {'GB/s':>8s}")
     for name, M, N, K, od in gemm_shapes():
-        a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
-        w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+        a = torch.randn(M, K, generator=g).to(ops.OP16).to(DEV)
+        w = (torch.randn(N, K, generator=g) * 0.05).to(ops.OP16).to(DEV)
         bias = torch.randn(N, generator=g).to(DEV)
-        out = torch.empty(M, N, dtype=torch.float32 if od == "f32" else torch.bfloat16, device=DEV)
+        out = torch.empty(M, N, dtype=torch.float32 if od == "f32" else ops.OP16, device=DEV)
         res = torch.randn(M, N, generator=g).to(DEV) if od == "f32" else None
         t = timeit(lambda: ops.gemm(a, w, bias, act=1 if "fc1" in name else 0, residual=res, out=out))
         by = 2 * M * K + 2 * N * K + M * N * (4 if od == "f32" else 2) + (M * N * 4 if res is not None else 0)
@@ -64,20 +64,20 @@ def bench_attn():
     print(f"{'shape':40s} {'splits':>6s} {'us':>9s} {'TF/s':>8s}")
     for (B, H, Lq, Lk, D) in [(4, 1, 4096, 4096, 256), (4, 1, 4096, 16384, 256), (1, 1, 4096, 28704, 256), (4, 4, 4096, 4096, 96),
                               (1, 4, 4096, 4096, 96)]:
-        q = torch.randn(B, H, Lq, D, generator=g).to(torch.bfloat16).to(DEV)
-        k = torch.randn(B, H, Lk, D, generator=g).to(torch.bfloat16).to(DEV)
-        v = torch.randn(B, H, Lk, D, generator=g).to(torch.bfloat16).to(DEV)
+        q = torch.randn(B, H, Lq, D, generator=g).to(ops.OP16).to(DEV)
+        k = torch.randn(B, H, Lk, D, generator=g).to(ops.OP16).to(DEV)
+        v = torch.randn(B, H, Lk, D, generator=g).to(ops.OP16).to(DEV)
         for sp in sorted({1, attn_splits(B, H, Lq, Lk), 2, 4, 8}):
             t = timeit(lambda: ops.attention(q, k, v, splits=sp))
             print(f"B{B} H{H} Lq{Lq} Lk{Lk} D{D}".ljust(40) + f" {sp:6d} {t * 1e6:9.1f} {4 * B * H * Lq * Lk * D / t / 1e12:8.1f}")
     # windowed stage-3 block: 4 images, 64x64 tokens, 4 heads, ws 14
     B, Hh, heads, D = 4, 64, 4, 96
-    qkv = torch.randn(B * Hh * Hh, 3 * heads * D, generator=g).to(torch.bfloat16).to(DEV)
+    qkv = torch.randn(B * Hh * Hh, 3 * heads * D, generator=g).to(ops.OP16).to(DEV)
     bias = torch.randn(3 * heads * D, generator=g).to(DEV)
     t = timeit(lambda: ops.window_attention(qkv, B, Hh, Hh, heads, 14, bias))
     print(f"window ws14 B4 64x64 h4".ljust(40) + f" {1:6d} {t * 1e6:9.1f} {4 * B * 25 * heads * 196 * 196 * D / t / 1e12:8.1f}")
     B, Hh, heads = 4, 256, 1
-    qkv = torch.randn(B * Hh * Hh, 3 * heads * D, generator=g).to(torch.bfloat16).to(DEV)
+    qkv = torch.randn(B * Hh * Hh, 3 * heads * D, generator=g).to(ops.OP16).to(DEV)
     bias = torch.randn(3 * heads * D, generator=g).to(DEV)
     t = timeit(lambda: ops.window_attention(qkv, B, Hh, Hh, heads, 8, bias))
     print(f"window ws8 B4 256x256 h1".ljust(40) + f" {1:6d} {t * 1e6:9.1f} {4 * B * 1024 * heads * 64 * 64 * D / t / 1e12:8.1f}  ({qkv.numel() * 2 * 4 / 3 / t / 1e9:.0f} GB/s)")
