@@ -165,13 +165,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP library is the only compute path (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    dist = None
+    # rehearsal mode for a 1-GPU box: several ranks share device 0 and talk over gloo (RCCL refuses duplicate devices)
+    one_gpu = os.environ.get("MSAM2_BENCH_ONE_GPU") == "1"
+    dev_index = 0 if one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    import medical_sam2_amd.parallel as par
+    backend = os.environ.get("MSAM2_BENCH_BACKEND", "nccl")
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        par.init_distributed(backend=backend, device=device)
+    dist = torch.distributed if world > 1 else None
+    sync_dev = device if backend == "nccl" else torch.device("cpu")
 
     torch.set_grad_enabled(False)
     m = build_model(device)
@@ -196,21 +200,15 @@ def main():
     for _ in range(args.warmup):
         run()
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    par.barrier(sync_dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    par.barrier(sync_dev)
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = par.max_over_ranks(time.perf_counter() - t0, sync_dev)
 
     import medical_sam2_amd.ops as ops
     if rank == 0:
@@ -235,7 +233,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if dist is not None:
-        dist.barrier()
+        par.barrier(sync_dev)
         dist.destroy_process_group()
 
 
