@@ -703,6 +703,62 @@ __global__ void attn_small_kernel(const op16* q, const op16* k, const op16* v, o
 }
 
 // q/k/v/o: op16 [B, L, H*D] with element strides {batch, token}
+// Few-keys form (image -> tokens, Lk <= 32): one THREAD per (batch, head, query); the handful of keys/values of a (batch, head)
+// is read by every thread of it (L1 broadcast), scores and the softmax live in registers.
+template <int D>
+__global__ void attn_fewkeys_kernel(const op16* q, const op16* k, const op16* v, op16* o, int64_t q_bs, int64_t q_ts, int64_t k_bs,
+                                    int64_t k_ts, int64_t v_bs, int64_t v_ts, int64_t o_bs, int64_t o_ts, int B, int H, int Lq, int Lk,
+                                    float scale_log2) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)B * H * Lq) return;
+  // consecutive threads walk the heads of one query first: their q/o accesses tile a contiguous H*D row
+  const int head = gid % H;
+  const int qi = (gid / H) % Lq;
+  const int b = gid / ((int64_t)H * Lq);
+  float qv[D];
+  const op16* qp = q + b * q_bs + (int64_t)qi * q_ts + head * D;
+#pragma unroll
+  for (int d = 0; d < D; d += 8) {
+    const op16x8 t = *reinterpret_cast<const op16x8*>(qp + d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[d + e] = op2f(t[e]) * scale_log2;
+  }
+  float m = -INFINITY, l = 0.f, acc[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) acc[d] = 0.f;
+  for (int key = 0; key < Lk; ++key) {
+    const op16* kp = k + b * k_bs + (int64_t)key * k_ts + head * D;
+    const op16* vp = v + b * v_bs + (int64_t)key * v_ts + head * D;
+    float sc = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; d += 8) {
+      const op16x8 t = *reinterpret_cast<const op16x8*>(kp + d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sc += qv[d + e] * op2f(t[e]);
+    }
+    const float mn = fmaxf(m, sc);
+    const float al = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - mn);
+    const float pe = __builtin_amdgcn_exp2f(sc - mn);
+    l = l * al + pe;
+#pragma unroll
+    for (int d = 0; d < D; d += 8) {
+      const op16x8 u = *reinterpret_cast<const op16x8*>(vp + d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[d + e] = acc[d + e] * al + pe * op2f(u[e]);
+    }
+    m = mn;
+  }
+  const float inv = 1.f / l;
+  op16* op = o + b * o_bs + (int64_t)qi * o_ts + head * D;
+#pragma unroll
+  for (int d = 0; d < D; d += 8) {
+    op16x8 w;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[e] = f2op(acc[d + e] * inv);
+    *reinterpret_cast<op16x8*>(op + d) = w;
+  }
+}
+
 extern "C" int msam2_attention_small_fwd(const void* q, int64_t q_bs, int64_t q_ts, const void* k, int64_t k_bs, int64_t k_ts,
                                          const void* v, int64_t v_bs, int64_t v_ts, void* o, int64_t o_bs, int64_t o_ts,
                                          int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t D, float scale, void* stream) {
@@ -711,10 +767,20 @@ extern "C" int msam2_attention_small_fwd(const void* q, int64_t q_bs, int64_t q_
   MSAM2_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attention_small: empty problem");
   MSAM2_REQUIRE(q_ts % 8 == 0 && k_ts % 8 == 0 && v_ts % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 && v_bs % 8 == 0,
                 "attention_small: strides must keep 16-byte alignment");
-  const int64_t waves = B * H * Lq;
-  dim3 grid(cdiv(waves * 64, 256));
   const float sl = scale * 1.4426950408889634f;
   hipStream_t s = (hipStream_t)stream;
+  if (Lk <= 32 && Lq >= 64 && o_ts % 8 == 0 && o_bs % 8 == 0) {
+    dim3 g1(cdiv(B * H * Lq, 256));
+    if (D == 16)
+      hipLaunchKernelGGL((attn_fewkeys_kernel<16>), g1, dim3(256), 0, s, (const op16*)q, (const op16*)k, (const op16*)v, (op16*)o, q_bs,
+                         q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts, (int)B, (int)H, (int)Lq, (int)Lk, sl);
+    else
+      hipLaunchKernelGGL((attn_fewkeys_kernel<32>), g1, dim3(256), 0, s, (const op16*)q, (const op16*)k, (const op16*)v, (op16*)o, q_bs,
+                         q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts, (int)B, (int)H, (int)Lq, (int)Lk, sl);
+    return msam2_check_launch("attention_small(fewkeys)");
+  }
+  const int64_t waves = B * H * Lq;
+  dim3 grid(cdiv(waves * 64, 256));
   if (D == 16)
     hipLaunchKernelGGL((attn_small_kernel<16>), grid, dim3(256), 0, s, (const op16*)q, (const op16*)k, (const op16*)v, (op16*)o,
                        q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts, (int)B, (int)H, (int)Lq, (int)Lk, sl);

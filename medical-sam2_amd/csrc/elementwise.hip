@@ -7,9 +7,89 @@
 // 60,73,94,162; transformer.py:173-194; sam2_utils.py:137-149.  One wave per row, fp32 statistics (two-pass on
 // registers), optional exact-erf GELU on the way out.  C <= 1024.
 // ------------------------------------------------------------------------------------------------------------------
-template <typename TI, typename TO>
+template <typename T>
+struct Vec4 {};
+template <>
+struct Vec4<float> {
+  typedef f32x4 type;
+};
+template <>
+struct Vec4<op16> {
+  typedef op16x4 type;
+};
+
+// 16 lanes per row (4 rows per wave), each lane owns the 4-element chunks lane16, lane16+16, ... of its row: 16 lanes x 16 B
+// (fp32) are one 256-byte line per load instruction; statistics are reduced over the 16-lane group with 4 shuffles.
+template <typename TI, typename TO, int CHUNKS>
 __global__ void layernorm_kernel(const TI* __restrict__ x, int64_t ldx, const float* __restrict__ w, const float* __restrict__ b,
                                  TO* __restrict__ y, int64_t ldy, int64_t rows, int C, float eps, int act) {
+  typedef typename Vec4<TI>::type VI;
+  typedef typename Vec4<TO>::type VO;
+  const int64_t row = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+  const int l16 = threadIdx.x & 15;
+  const bool live = row < rows;
+  const int nch = C >> 2;
+  const TI* xr = x + (live ? row : 0) * ldx;
+  float v[CHUNKS][4];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < CHUNKS; ++j) {
+    const int ch = l16 + 16 * j;
+    if (live && ch < nch) {
+      const VI t = *reinterpret_cast<const VI*>(xr + ch * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[j][e] = (float)t[e];
+        s += v[j][e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[j][e] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / C;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < CHUNKS; ++j) {
+    const int ch = l16 + 16 * j;
+    if (ch < nch) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[j][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = 1.0f / sqrtf(q / C + eps);
+  if (!live) return;
+  TO* yr = y + row * ldy;
+#pragma unroll
+  for (int j = 0; j < CHUNKS; ++j) {
+    const int ch = l16 + 16 * j;
+    if (ch < nch) {
+      const f32x4 ww = *reinterpret_cast<const f32x4*>(w + ch * 4);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(b + ch * 4);
+      VO o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = (v[j][e] - mean) * rstd * ww[e] + bb[e];
+        if (act == 1) t = gelu_erf(t);
+        o[e] = (decltype(o[e] + o[e]))t;
+      }
+      *reinterpret_cast<VO*>(yr + ch * 4) = o;
+    }
+  }
+}
+
+// scalar fallback for C % 4 != 0 or unaligned rows: one wave per row
+template <typename TI, typename TO>
+__global__ void layernorm_scalar_kernel(const TI* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+                                        const float* __restrict__ b, TO* __restrict__ y, int64_t ldy, int64_t rows, int C,
+                                        float eps, int act) {
   const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -47,15 +127,38 @@ extern "C" int msam2_layernorm(const void* x, int in_is_16bit, int64_t ldx, cons
                                int out_is_16bit, int64_t ldy, int64_t rows, int64_t C, float eps, int act, void* stream) {
   MSAM2_REQUIRE(x && y && weight && bias, "layernorm: null tensor");
   MSAM2_REQUIRE(rows > 0 && C > 0 && C <= 1024, "layernorm: rows=%lld C=%lld unsupported (C<=1024)", (long long)rows, (long long)C);
-  dim3 grid(cdiv(rows * 64, 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
+  const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 7) == 0) &&
+                   (((uintptr_t)weight & 15) == 0) && (((uintptr_t)bias & 15) == 0);
+  if (vec) {
+    dim3 grid(cdiv(rows * 16, 256)), block(256);
+    const int chunks = (int)((C / 4 + 15) / 16);
+#define LN_V(TI, TO, CH) \
+  hipLaunchKernelGGL((layernorm_kernel<TI, TO, CH>), grid, block, 0, s, (const TI*)x, ldx, weight, bias, (TO*)y, ldy, rows, (int)C, eps, act)
+#define LN_VC(TI, TO)                                     \
+  do {                                                    \
+    if (chunks <= 2) LN_V(TI, TO, 2);                     \
+    else if (chunks <= 4) LN_V(TI, TO, 4);                \
+    else if (chunks <= 6) LN_V(TI, TO, 6);                \
+    else if (chunks <= 12) LN_V(TI, TO, 12);              \
+    else LN_V(TI, TO, 16);                                \
+  } while (0)
+    if (in_is_16bit && out_is_16bit) LN_VC(op16, op16);
+    else if (in_is_16bit) LN_VC(op16, float);
+    else if (out_is_16bit) LN_VC(float, op16);
+    else LN_VC(float, float);
+#undef LN_VC
+#undef LN_V
+  } else {
+    dim3 grid(cdiv(rows * 64, 256)), block(256);
 #define LN_LAUNCH(TI, TO) \
-  hipLaunchKernelGGL((layernorm_kernel<TI, TO>), grid, block, 0, s, (const TI*)x, ldx, weight, bias, (TO*)y, ldy, rows, (int)C, eps, act)
-  if (in_is_16bit && out_is_16bit) LN_LAUNCH(op16, op16);
-  else if (in_is_16bit) LN_LAUNCH(op16, float);
-  else if (out_is_16bit) LN_LAUNCH(float, op16);
-  else LN_LAUNCH(float, float);
+  hipLaunchKernelGGL((layernorm_scalar_kernel<TI, TO>), grid, block, 0, s, (const TI*)x, ldx, weight, bias, (TO*)y, ldy, rows, (int)C, eps, act)
+    if (in_is_16bit && out_is_16bit) LN_LAUNCH(op16, op16);
+    else if (in_is_16bit) LN_LAUNCH(op16, float);
+    else if (out_is_16bit) LN_LAUNCH(float, op16);
+    else LN_LAUNCH(float, float);
 #undef LN_LAUNCH
+  }
   return msam2_check_launch("layernorm");
 }
 
@@ -79,18 +182,68 @@ __global__ void add_cast_kernel(const TA* __restrict__ a, int64_t a_s0, int64_t 
   }
 }
 
+// vector form: C % 4 == 0 and 4-element groups aligned in a, b and out; one thread per group, 32-bit index math
+template <typename TA, typename TB, typename TO>
+__global__ void add_cast_vec_kernel(const TA* __restrict__ a, int64_t a_s0, int64_t a_s1, const TB* __restrict__ b, int64_t b_s0,
+                                    int64_t b_s1, float alpha, TO* __restrict__ out, unsigned D0, unsigned D1, unsigned C4) {
+  typedef typename Vec4<TA>::type VA;
+  typedef typename Vec4<TB>::type VB;
+  typedef typename Vec4<TO>::type VO;
+  const unsigned rows = D0 * D1;
+  const unsigned total = rows * C4;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned g = i % C4, rj = i / C4;
+    const unsigned j = rj % D1, r = rj / D1;
+    const VA va = *reinterpret_cast<const VA*>(a + r * a_s0 + j * a_s1 + g * 4);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (float)va[e];
+    if (b) {
+      const VB vb = *reinterpret_cast<const VB*>(b + r * b_s0 + j * b_s1 + g * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += alpha * (float)vb[e];
+    }
+    VO o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (decltype(o[e] + o[e]))v[e];
+    *reinterpret_cast<VO*>(out + (int64_t)i * 4) = o;
+  }
+}
+
 extern "C" int msam2_add_cast(const void* a, int a_is_16bit, int64_t a_s0, int64_t a_s1, const void* b, int b_is_16bit, int64_t b_s0,
                               int64_t b_s1, float alpha, void* out, int out_is_16bit, int64_t D0, int64_t D1, int64_t C,
                               void* stream) {
   MSAM2_REQUIRE(a && out, "add_cast: null tensor");
   MSAM2_REQUIRE(D0 > 0 && D1 > 0 && C > 0, "add_cast: empty volume");
   const int64_t total = D0 * D1 * C;
-  dim3 grid((unsigned)min((int64_t)8192, (total + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
+  const int key = (a_is_16bit ? 4 : 0) | (b_is_16bit ? 2 : 0) | (out_is_16bit ? 1 : 0);
+  const int asz = a_is_16bit ? 2 : 4, bsz = b_is_16bit ? 2 : 4, osz = out_is_16bit ? 2 : 4;
+  const bool vec = (C % 4 == 0) && total / 4 < (1ll << 31) && (a_s0 % 4 == 0) && (a_s1 % 4 == 0) && (((uintptr_t)a % (4 * asz)) == 0) &&
+                   (((uintptr_t)out % (4 * osz)) == 0) &&
+                   (!b || ((b_s0 % 4 == 0) && (b_s1 % 4 == 0) && (((uintptr_t)b % (4 * bsz)) == 0)));
+  if (vec) {
+    dim3 grid((unsigned)min((int64_t)16384, (total / 4 + 255) / 256)), block(256);
+#define ACV(TA, TB, TO)                                                                                                          \
+  hipLaunchKernelGGL((add_cast_vec_kernel<TA, TB, TO>), grid, block, 0, s, (const TA*)a, a_s0, a_s1, (const TB*)b, b_s0, b_s1, alpha, \
+                     (TO*)out, (unsigned)D0, (unsigned)D1, (unsigned)(C / 4))
+    switch (key) {
+      case 0: ACV(float, float, float); break;
+      case 1: ACV(float, float, op16); break;
+      case 2: ACV(float, op16, float); break;
+      case 3: ACV(float, op16, op16); break;
+      case 4: ACV(op16, float, float); break;
+      case 5: ACV(op16, float, op16); break;
+      case 6: ACV(op16, op16, float); break;
+      default: ACV(op16, op16, op16); break;
+    }
+#undef ACV
+    return msam2_check_launch("add_cast");
+  }
+  dim3 grid((unsigned)min((int64_t)8192, (total + 255) / 256)), block(256);
 #define AC(TA, TB, TO)                                                                                                   \
   hipLaunchKernelGGL((add_cast_kernel<TA, TB, TO>), grid, block, 0, s, (const TA*)a, a_s0, a_s1, (const TB*)b, b_s0, b_s1, \
                      alpha, (TO*)out, D0, D1, (int)C)
-  const int key = (a_is_16bit ? 4 : 0) | (b_is_16bit ? 2 : 0) | (out_is_16bit ? 1 : 0);
   switch (key) {
     case 0: AC(float, float, float); break;
     case 1: AC(float, float, op16); break;
