@@ -55,6 +55,8 @@ SIGNATURES = {
     "msam2_cc_label": (c_i, [c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_z, c_p]),
     "msam2_fill_holes_workspace_bytes": (c_z, [c_l, c_l, c_l]),
     "msam2_fill_holes": (c_i, [c_p, c_l, c_l, c_l, c_i, c_p, c_z, c_p]),
+    "msam2_fill_components": (c_i, [c_p, c_l, c_l, c_l, c_i, c_f, c_i, c_f, c_p, c_z, c_p]),
+    "msam2_image_prep": (c_i, [c_p, c_p, c_l, c_l, c_l, ctypes.POINTER(c_f), ctypes.POINTER(c_f), c_p]),
     "msam2_graph_begin": (c_i, [c_p]),
     "msam2_graph_end": (c_i, [c_p, ctypes.POINTER(c_p)]),
     "msam2_graph_launch": (c_i, [c_p, c_p]),

@@ -112,13 +112,14 @@ __global__ void cc_area_kernel(const int* __restrict__ labels_all, const int* __
 }
 
 // hole filling helpers (utils/misc.py:247-258)
-__global__ void le_zero_kernel(const float* __restrict__ m, uint8_t* __restrict__ out, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = m[i] <= 0.f;
+__global__ void threshold_kernel(const float* __restrict__ m, uint8_t* __restrict__ out, int64_t n, float thr, int above) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = above ? (m[i] > thr) : (m[i] <= thr);
 }
 __global__ void fill_kernel(float* __restrict__ m, const int* __restrict__ labels, const int* __restrict__ counts, int max_area,
-                            int64_t n) {
+                            int64_t n, float value) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    if (labels[i] > 0 && counts[i] <= max_area) m[i] = 0.1f;
+    if (labels[i] > 0 && counts[i] <= max_area) m[i] = value;
 }
 
 }  // namespace
@@ -152,21 +153,31 @@ extern "C" size_t msam2_fill_holes_workspace_bytes(int64_t N, int64_t H, int64_t
   return (size_t)(N * H * W) * (1 + 4 * sizeof(int)) + 256;
 }
 
-// mask scores fp32 [N,1,H,W] updated in place: background components (score <= 0) of area <= max_area get score 0.1
-extern "C" int msam2_fill_holes(float* mask, int64_t N, int64_t H, int64_t W, int max_area, void* workspace, size_t workspace_bytes,
-                                void* stream) {
-  MSAM2_REQUIRE(mask && workspace, "fill_holes: null pointer");
-  MSAM2_REQUIRE(max_area > 0, "fill_holes: max_area must be positive");
-  MSAM2_REQUIRE(workspace_bytes >= msam2_fill_holes_workspace_bytes(N, H, W), "fill_holes: workspace too small");
+// Small-component filling on fp32 mask scores [N,1,H,W], in place.  above = 0: components of (score <= threshold) ("holes");
+// above = 1: components of (score > threshold) ("sprinkles"); components of area <= max_area get `fill_value`.
+// Covers fill_holes_in_mask_scores (utils/misc.py:247-258: threshold 0, value 0.1) and SAM2Transforms.postprocess_masks
+// (utils/transforms.py:74-98: holes -> threshold + 10, sprinkles -> threshold - 10).
+extern "C" int msam2_fill_components(float* mask, int64_t N, int64_t H, int64_t W, int max_area, float threshold, int above,
+                                     float fill_value, void* workspace, size_t workspace_bytes, void* stream) {
+  MSAM2_REQUIRE(mask && workspace, "fill_components: null pointer");
+  MSAM2_REQUIRE(max_area > 0, "fill_components: max_area must be positive");
+  MSAM2_REQUIRE(workspace_bytes >= msam2_fill_holes_workspace_bytes(N, H, W), "fill_components: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const int64_t n = N * H * W;
   int* labels = (int*)workspace;
   int* counts = labels + n;
   int* ccws = counts + n;
   uint8_t* bin = (uint8_t*)(ccws + 2 * n);
-  hipLaunchKernelGGL(le_zero_kernel, dim3((unsigned)min((int64_t)4096, (n + 255) / 256)), dim3(256), 0, s, mask, bin, n);
+  hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)min((int64_t)4096, (n + 255) / 256)), dim3(256), 0, s, mask, bin, n, threshold, above);
   const int rc = msam2_cc_label(bin, labels, counts, N, H, W, ccws, sizeof(int) * 2 * n, stream);
   if (rc != MSAM2_OK) return rc;
-  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)min((int64_t)4096, (n + 255) / 256)), dim3(256), 0, s, mask, labels, counts, max_area, n);
-  return msam2_check_launch("fill_holes");
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)min((int64_t)4096, (n + 255) / 256)), dim3(256), 0, s, mask, labels, counts, max_area, n,
+                     fill_value);
+  return msam2_check_launch("fill_components");
+}
+
+// fill_holes_in_mask_scores (utils/misc.py:247-258): background components (score <= 0) of area <= max_area get score 0.1
+extern "C" int msam2_fill_holes(float* mask, int64_t N, int64_t H, int64_t W, int max_area, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+  return msam2_fill_components(mask, N, H, W, max_area, 0.0f, 0, 0.1f, workspace, workspace_bytes, stream);
 }

@@ -573,3 +573,35 @@ extern "C" int msam2_any_positive(const float* x, float* out, int64_t B, int64_t
   hipLaunchKernelGGL(any_positive_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, x, out, row_len);
   return msam2_check_launch("any_positive");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Image pre-processing of SAM2Transforms.__call__ (utils/transforms.py:22-37): uint8 HWC RGB -> /255 -> bilinear resize to
+// S x S (align_corners=False, no antialias: identity when the image already has the model resolution) -> (x - mean) / std,
+// written as fp32 [3, S, S].
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void image_prep_kernel(const uint8_t* __restrict__ img, float* __restrict__ out, int H, int W, int S, float m0, float m1,
+                                  float m2, float s0, float s1, float s2) {
+  const float sy = (float)H / S, sx = (float)W / S;
+  const int64_t total = (int64_t)3 * S * S;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int X = i % S;
+    const int Y = (i / S) % S;
+    const int c = i / ((int64_t)S * S);
+    const float fy = fmaxf((Y + 0.5f) * sy - 0.5f, 0.f), fx = fmaxf((X + 0.5f) * sx - 0.5f, 0.f);
+    const int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ly = fy - y0, lx = fx - x0;
+    auto px = [&](int y, int x) { return (float)img[((int64_t)y * W + x) * 3 + c] * (1.0f / 255.0f); };
+    const float v = (1.f - ly) * ((1.f - lx) * px(y0, x0) + lx * px(y0, x1)) + ly * ((1.f - lx) * px(y1, x0) + lx * px(y1, x1));
+    const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+    out[i] = (v - mean) / sd;
+  }
+}
+
+extern "C" int msam2_image_prep(const uint8_t* img_hwc, float* out_chw, int64_t H, int64_t W, int64_t S, const float* mean3,
+                                const float* std3, void* stream) {
+  MSAM2_REQUIRE(img_hwc && out_chw && mean3 && std3 && H > 0 && W > 0 && S > 0, "image_prep: bad arguments (mean3/std3 are HOST pointers)");
+  hipLaunchKernelGGL(image_prep_kernel, dim3((unsigned)min((int64_t)8192, (3 * S * S + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     img_hwc, out_chw, (int)H, (int)W, (int)S, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+  return msam2_check_launch("image_prep");
+}

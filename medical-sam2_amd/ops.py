@@ -400,3 +400,26 @@ def aa_downsample(x: torch.Tensor, factor: int, in_scale: float = 1.0, in_bias: 
     y = torch.empty(*x.shape[:-2], H // factor, W // factor, dtype=F32, device=x.device)
     check(lib().msam2_aa_downsample(_p(x), _p(y), x.numel() // (H * W), H, W, factor, in_scale, in_bias, _stream()))
     return y
+
+
+def fill_components_(mask: torch.Tensor, max_area: int, threshold: float, above: bool, fill_value: float) -> torch.Tensor:
+    """In place on fp32 [N,1,H,W]: components of (mask > threshold) if `above` else (mask <= threshold) with area <= max_area
+    are set to fill_value (SAM2Transforms.postprocess_masks, utils/transforms.py:74-98)."""
+    _req(mask.dtype == F32 and mask.is_contiguous(), "fill_components: fp32 contiguous")
+    N, _, H, W = mask.shape
+    nb = lib().msam2_fill_holes_workspace_bytes(N, H, W)
+    ws = torch.empty(nb, dtype=torch.uint8, device=mask.device)
+    check(lib().msam2_fill_components(_p(mask), N, H, W, int(max_area), float(threshold), int(above), float(fill_value), _p(ws), nb, _stream()))
+    return mask
+
+
+def image_prep(img_u8_hwc: torch.Tensor, size: int, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)) -> torch.Tensor:
+    """uint8 [H,W,3] on device -> fp32 [3,size,size], /255, bilinear resize, ImageNet normalisation."""
+    _req(img_u8_hwc.dtype == torch.uint8 and img_u8_hwc.dim() == 3 and img_u8_hwc.shape[2] == 3 and img_u8_hwc.is_contiguous(),
+         "image_prep: uint8 [H,W,3] contiguous")
+    H, W, _ = img_u8_hwc.shape
+    out = torch.empty(3, size, size, dtype=F32, device=img_u8_hwc.device)
+    m = (ctypes.c_float * 3)(*mean)
+    s = (ctypes.c_float * 3)(*std)
+    check(lib().msam2_image_prep(_p(img_u8_hwc), _p(out), H, W, size, m, s, _stream()))
+    return out

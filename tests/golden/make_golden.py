@@ -235,6 +235,37 @@ def run_modules(model: str, image_size: int, tag: str):
     return out, meta
 
 
+def run_image_predictor_case():
+    """BASELINE.json configs[0]: sam2_hiera_t, one synthetic 1024x1024 image, one positive click, through the steps of
+    SAM2ImagePredictor.set_image/_predict (sam2_image_predictor.py:66-109, 317-418) with the reference's modules; the
+    torchvision-based SAM2Transforms (not importable here) is the identity resize + ImageNet normalisation at 1024."""
+    m = build_reference("hiera_t", 1024)
+    img255, (cx, cy) = syn.blob_image(0, 1024)
+    u8 = img255.clamp(0, 255).round().to(torch.uint8).permute(1, 2, 0).contiguous()          # HWC uint8, what a user passes
+    x = syn.normalize_image(u8.permute(2, 0, 1).float())[None]
+    out = {}
+    with torch.no_grad():
+        bo = m.forward_image(x)
+        _, feats, _, _ = m._prepare_backbone_features(bo)
+        feats[-1] = feats[-1] + m.no_mem_embed
+        sizes = [(256, 256), (128, 128), (64, 64)]
+        f = [t.permute(1, 2, 0).view(1, -1, *s) for t, s in zip(feats[::-1], sizes[::-1])][::-1]
+        pts = torch.tensor([[[cx, cy]]], dtype=torch.float32)
+        labs = torch.tensor([[1]], dtype=torch.int32)
+        for mm in (True, False):
+            sp, de = m.sam_prompt_encoder(points=(pts, labs), boxes=None, masks=None)
+            low, iou, _, _ = m.sam_mask_decoder(image_embeddings=f[-1], image_pe=m.sam_prompt_encoder.get_dense_pe(),
+                                                sparse_prompt_embeddings=sp, dense_prompt_embeddings=de, multimask_output=mm,
+                                                repeat_image=False, high_res_features=f[:-1])
+            masks = F.interpolate(low.float(), (1024, 1024), mode="bilinear", align_corners=False)
+            out[f"cfg1_mm{int(mm)}_low"] = low.numpy().copy()
+            out[f"cfg1_mm{int(mm)}_iou"] = iou.numpy().copy()
+            out[f"cfg1_mm{int(mm)}_mask_bits"] = np.packbits((masks > 0).numpy())
+        out["cfg1_image_embed_sub"] = sub(f[-1])
+    out["cfg1_click"] = np.array([cx, cy], dtype=np.float32)
+    return out, {"model": "hiera_t", "image_size": 1024, "image_seed": 0}
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     spec = {m: {k: list(v.shape) for k, v in build_reference(m, 256).state_dict().items()} for m in ("hiera_t", "hiera_s")}
@@ -253,6 +284,9 @@ def main():
     o, meta = run_slice_chain("hiera_s", 1024, 3, "s1024", store_full=False)
     np.savez_compressed(os.path.join(OUT, "chain_hiera_s_1024.npz"), **o)
     allmeta["chain_hiera_s_1024"] = meta
+    o, meta = run_image_predictor_case()
+    np.savez_compressed(os.path.join(OUT, "config1_image_predictor.npz"), **o)
+    allmeta["config1_image_predictor"] = meta
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(allmeta, f, indent=1)
     for fn in sorted(os.listdir(OUT)):

@@ -230,3 +230,35 @@ def test_volume_bbox_prompts_vs_oracle(build):
     REPORT["volume"] = dict(iou=worst_iou, max_abs=worst_max)
     _dump()
     assert worst_iou >= (0.98 if _fp16() else 0.95) and worst_max <= TOL_MAX, (worst_iou, worst_max)
+
+
+def test_config1_image_predictor(build):
+    """BASELINE.json configs[0]: sam2_hiera_t, one 1024x1024 image, one click, through the drop-in SAM2ImagePredictor
+    (set_image / predict) against the reference-derived golden."""
+    from medical_sam2_amd.image_predictor import SAM2ImagePredictor
+    g = load_npz("config1_image_predictor.npz")
+    m = build("hiera_t", 1024)
+    img255, _ = syn.blob_image(0, 1024)
+    u8 = img255.clamp(0, 255).round().to(torch.uint8).permute(1, 2, 0).contiguous().numpy()
+    pred = SAM2ImagePredictor(m)
+    with pytest.raises(RuntimeError):
+        pred.predict(point_coords=g["cfg1_click"][None], point_labels=np.array([1]))
+    pred.set_image(u8)
+    assert rel_err(sub(pred.get_image_embedding().cpu()), g["cfg1_image_embed_sub"]) < TOL_FEAT
+    for mm in (True, False):
+        masks, iou, low = pred.predict(point_coords=g["cfg1_click"][None], point_labels=np.array([1]), multimask_output=mm)
+        assert masks.shape == ((3 if mm else 1), 1024, 1024) and masks.dtype == np.float32  # like the reference: bool -> .float()
+        masks = masks > 0.5
+        ref_low = g[f"cfg1_mm{int(mm)}_low"][0]
+        assert max_abs(low, np.clip(ref_low, -32, 32)) <= TOL_MAX
+        assert rel_err(iou, g[f"cfg1_mm{int(mm)}_iou"][0]) < TOL_PTR
+        ref = np.unpackbits(g[f"cfg1_mm{int(mm)}_mask_bits"]).reshape(1, -1, 1024, 1024)[0].astype(bool)
+        inter, union = (masks & ref).sum(), (masks | ref).sum()
+        REPORT[f"cfg1_mm{int(mm)}_iou"] = float(inter / max(union, 1))
+        assert inter / max(union, 1) >= TOL_IOU_POOLED
+    # hole / sprinkle post-processing path (connected components) runs and keeps shapes
+    pred2 = SAM2ImagePredictor(m, max_hole_area=8, max_sprinkle_area=8)
+    pred2.set_image(u8)
+    masks2, _, _ = pred2.predict(point_coords=g["cfg1_click"][None], point_labels=np.array([1]), multimask_output=False)
+    assert masks2.shape == (1, 1024, 1024)
+    _dump()

@@ -160,3 +160,30 @@ def test_slice_chain_hiera_t_256():
 
 def test_slice_chain_hiera_s_1024():
     _run_chain("hiera_s", 1024, 3, "s1024", load_npz("chain_hiera_s_1024.npz"), load_meta()["chain_hiera_s_1024"])
+
+
+def test_config1_image_predictor_path_hiera_t_1024():
+    """BASELINE.json configs[0] through the oracle: set_image (+no_mem_embed) -> prompt encoder -> mask decoder -> bilinear."""
+    import torch.nn.functional as F
+    g = load_npz("config1_image_predictor.npz")
+    P = wts.init_weights("hiera_t", 0)
+    cfg = O.model_config("hiera_t", 1024)
+    img255, _ = syn.blob_image(0, 1024)
+    u8 = img255.clamp(0, 255).round().to(torch.uint8)
+    x = syn.normalize_image(u8.float())[None]
+    bo = O.forward_image(P, cfg, x)
+    feats, _, sizes = O.prepare_backbone_features(bo)
+    top = feats[-1] + P["no_mem_embed"]
+    emb = top.permute(1, 2, 0).reshape(1, 256, 64, 64)
+    assert rel_err(sub(emb), g["cfg1_image_embed_sub"]) < 3e-4
+    hr = [f.permute(1, 2, 0).reshape(1, -1, *s) for f, s in zip(feats[:-1], sizes[:-1])]
+    pts = torch.tensor(g["cfg1_click"]).reshape(1, 1, 2)
+    labs = torch.ones(1, 1, dtype=torch.int32)
+    for mm in (True, False):
+        sp, de = O.prompt_encoder(P, cfg, (pts, labs), None, None)
+        low, iou, _, _ = O.mask_decoder(P, cfg, emb, O.dense_pe(P, 64, 64), sp, de, mm, hr)
+        assert rel_err(low, g[f"cfg1_mm{int(mm)}_low"]) < 3e-4
+        assert rel_err(iou, g[f"cfg1_mm{int(mm)}_iou"]) < 3e-4
+        masks = F.interpolate(low, (1024, 1024), mode="bilinear", align_corners=False) > 0
+        ref = np.unpackbits(g[f"cfg1_mm{int(mm)}_mask_bits"]).reshape(masks.shape).astype(bool)
+        assert mask_iou(masks.numpy().astype(np.float32) - 0.5, ref.astype(np.float32) - 0.5) >= 0.9999

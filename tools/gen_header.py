@@ -43,6 +43,8 @@ DOC = {
     "msam2_cc_workspace_bytes": "Scratch (union-find parents + area histogram) for msam2_cc_label.",
     "msam2_cc_label": "Drop-in for the reference's only native op, `_C.get_connected_componnets` (sam2_train/csrc/connected_components.cu:\n213-282; Python wrapper utils/misc.py:47-63): 8-connected labels (1 + smallest 2x2-block corner index of the component)\nand per-pixel component areas for uint8 masks [N,1,H,W], H and W even.  The caller allocates labels/counts/workspace.",
     "msam2_fill_holes_workspace_bytes": "Scratch for msam2_fill_holes.",
+    "msam2_fill_components": "Small-component filling on mask scores: generalisation of msam2_fill_holes used by SAM2Transforms.postprocess_masks\n(utils/transforms.py:74-98).",
+    "msam2_image_prep": "SAM2Transforms.__call__ (utils/transforms.py:22-37): uint8 HWC -> /255 -> bilinear resize -> normalise -> fp32 CHW.\nmean3/std3 are HOST pointers to 3 floats.",
     "msam2_fill_holes": "fill_holes_in_mask_scores (utils/misc.py:247-258): background components of area <= max_area get score 0.1.",
     "msam2_graph_begin": "hipGraph capture of everything enqueued on `stream` until msam2_graph_end (the per-slice forward is launch-bound in\nthe reference: ~750 dependent ATen kernels per slice, SURVEY.md section 0.9).",
     "msam2_graph_end": "Ends the capture and instantiates the executable graph.",
