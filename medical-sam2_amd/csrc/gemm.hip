@@ -342,10 +342,11 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
 // every 16-lane ds_read_b128 group of the 32x32x16 operand map then covers 16 distinct (row mod 4, slot) positions of the
 // 256-byte bank rows it touches (conflict free).
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void gemm_glds4_kernel(GemmParams p) {
+template <int NST, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_glds32_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BM = 128, BN = 128, BK = 32, NST = 4, STAGE_BYTES = (BM + BN) * BK * 2;  // 16 KiB
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE_BYTES];
+  constexpr int BM = 128, BN = 128, BK = 32, STAGE_BYTES = (BM + BN) * BK * 2;  // 16 KiB
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[(NST * STAGE_BYTES > 34816) ? NST * STAGE_BYTES : 34816];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds4_kernel(GemmParams p) {
     offsW[i] = (unsigned)(gw * p.ldw * 2 + chunk * 16);
   }
   auto issue = [&](int kt) {
-    unsigned char* base = lds + (kt & 3) * STAGE_BYTES + wave * 2048;
+    unsigned char* base = lds + (kt % NST) * STAGE_BYTES + wave * 2048;
     const unsigned so = (unsigned)kt * BK * 2;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -403,16 +404,17 @@ __global__ __launch_bounds__(256, 2) void gemm_glds4_kernel(GemmParams p) {
 
   const int nk = p.K / BK;
   issue(0);
-  if (nk > 1) issue(1);
-  if (nk > 2) issue(2);
+#pragma unroll
+  for (int i = 1; i < NST - 1; ++i)
+    if (nk > i) issue(i);
   for (int kt = 0; kt < nk; ++kt) {
-    const int ahead = min(nk - 1 - kt, 2);               // DMA groups younger than tile kt still allowed in flight
-    if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    const int ahead = min(nk - 1 - kt, NST - 2);         // DMA groups younger than tile kt still allowed in flight
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                        // tile kt visible to all waves; stage (kt+3)&3 no longer being read
-    if (kt + 3 < nk) issue(kt + 3);
-    const unsigned char* sb = lds + (kt & 3) * STAGE_BYTES;
+    __builtin_amdgcn_s_barrier();                        // tile kt visible to all waves; the stage of tile kt-1 is no longer read
+    if (kt + NST - 1 < nk) issue(kt + NST - 1);
+    const unsigned char* sb = lds + (kt % NST) * STAGE_BYTES;
     op16x8 af[2][2], bfr[2][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -457,15 +459,18 @@ extern "C" int msam2_gemm(const void* A, int64_t lda, const void* W, int64_t ldw
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act; p.res_is_16bit = res_is_16bit; p.out_is_16bit = out_is_16bit;
   hipStream_t s = (hipStream_t)stream;
   const char* force = getenv("MSAM2_GEMM_V1");
-  const char* var = getenv("MSAM2_GEMM_VARIANT");  // "4": 4-stage BK=32 DMA kernel (experiment); default: 2-stage BK=64 DMA kernel
+  // DMA kernels: long reductions (K >= 1024) run the 128x128x64 2-stage kernel (more MFMA work per barrier); shorter ones the
+  // 128x128x32 kernel at 4 workgroups per CU, whose extra co-resident workgroups hide the per-tile prologue/epilogue that
+  // dominates when there are only a few k-steps.  MSAM2_GEMM_VARIANT = 2 | 5 forces one of them (experiments).
+  const char* var = getenv("MSAM2_GEMM_VARIANT");
   const bool dma_ok = !(force && force[0] == '1') && M >= 256 && N >= 96 && (N % 128 == 0 || N >= 256 || N % 64 != 0) &&
                       M * lda * 2 < (1ll << 31) && N * ldw * 2 < (1ll << 31);
-  if (dma_ok && K % 64 == 0 && !(var && var[0] == '4')) {
-    const int tiles = cdiv(p.N, 128) * cdiv(p.M, 128);
+  const int tiles = cdiv(p.N, 128) * cdiv(p.M, 128);
+  const bool want64 = var ? (var[0] == '2') : (K >= 1024);
+  if (dma_ok && K % 64 == 0 && want64) {
     hipLaunchKernelGGL(gemm_glds_kernel, dim3(tiles), dim3(256), 0, s, p);
-  } else if (dma_ok && K % 32 == 0 && var && var[0] == '4') {
-    const int tiles = cdiv(p.N, 128) * cdiv(p.M, 128);
-    hipLaunchKernelGGL(gemm_glds4_kernel, dim3(tiles), dim3(256), 0, s, p);
+  } else if (dma_ok && K % 32 == 0) {
+    hipLaunchKernelGGL((gemm_glds32_kernel<2, 4>), dim3(tiles), dim3(256), 0, s, p);
   } else if (M <= 32) launch_gemm<32, 128, 1, 4>(p, s);
   else if (N <= 32) launch_gemm<128, 32, 4, 1>(p, s);
   else if (N <= 64 || (N % 128 != 0 && N % 64 == 0 && N < 512)) launch_gemm<128, 64, 2, 2>(p, s);
