@@ -292,10 +292,13 @@ __global__ void attn_merge_kernel(AttnParams p, int Bz) {
 //   K image [32 keys][2D B]: 16-byte chunk c of key r sits at (c & ~15) | ((c & 15) ^ (r & 15))   (ds_read_b128 rows)
 //   V image [32 keys][2D B]: chunk c of key r sits at c ^ ((r & 3) << 2)                          (ds_read_b64_tr_b16)
 // ------------------------------------------------------------------------------------------------------------------
-template <int D, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void attn_glds_kernel(AttnParams p) {
+// DP = LDS row pitch in elements (power of two >= D).  D = 96 (Hiera global blocks) runs with DP = 128: each 192-byte K/V row is
+// DMA'd into a 256-byte LDS row slot (12 of every 16 lanes carry data, the other 4 re-read the row start), so the same
+// power-of-two swizzles apply.
+template <int D, int DP, int NW, int OCC>
+__global__ __launch_bounds__(NW * 64, OCC) void attn_glds_kernel(AttnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor builtins exist only in the device pass; the host pass just needs the launch stub
-  constexpr int BK = 32, RB = D * 2, CPR = D / 8;            // row bytes, 16-byte chunks per row
+  constexpr int BK = 32, RB = DP * 2, CPR = DP / 8, GCPR = D / 8;  // LDS row bytes, chunks per LDS row, valid chunks per global row
   constexpr int TILE = BK * RB, STAGE = 2 * TILE;
   constexpr int KI = TILE / 1024;                            // DMA instructions per operand tile
   constexpr int PW = KI / NW;                                // per wave
@@ -353,8 +356,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_glds_kernel(AttnParams p) {
   for (int j = 0; j < PW; ++j) {
     const int f = (wave * PW + j) * 64 + lane;
     const int row = f / CPR, c = f % CPR;
-    koff[j] = (unsigned)(row * k_rb + (((c & ~15) | ((c & 15) ^ (row & 15))) << 4));
-    voff[j] = (unsigned)(row * v_rb + ((c ^ ((row & 3) << 2)) << 4));
+    const int kc = (c & ~15) | ((c & 15) ^ (row & 15)), vc = c ^ ((row & 3) << 2);   // global chunk held by LDS slot c of this row
+    koff[j] = (unsigned)(row * k_rb + ((kc < GCPR ? kc : 0) << 4));
+    voff[j] = (unsigned)(row * v_rb + ((vc < GCPR ? vc : 0) << 4));
   }
   auto issue = [&](int tile, int stage) {
     unsigned char* base = smem + stage * STAGE + wave * PW * 1024;
@@ -387,19 +391,40 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_glds_kernel(AttnParams p) {
     f32x16 s;
 #pragma unroll
     for (int e = 0; e < 16; ++e) s[e] = 0.f;
-    // K fragments two at a time: the scheduling fence keeps the compiler from hoisting all D/16 reads at once, which would
-    // push the kernel over its 256-register budget
+    if constexpr (D <= 128) {
+      // registers to spare: software-pipelined K fragments (the pair for step g+2 is in flight while step g's MFMAs issue)
+      auto kread = [&](int st) {
+        const int c = 2 * st + h;
+        return *reinterpret_cast<const op16x8*>(kbase + k_row + (((c & ~15) | ((c & 15) ^ k_x)) << 4));
+      };
+      op16x8 kf[2][2];
+      kf[0][0] = kread(0);
+      kf[0][1] = kread(1);
 #pragma unroll
-    for (int g2 = 0; g2 < DSTEPS; g2 += 2) {
-      op16x8 kf[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int c = 2 * (g2 + u) + h;
-        kf[u] = *reinterpret_cast<const op16x8*>(kbase + k_row + (((c & ~15) | ((c & 15) ^ k_x)) << 4));
+      for (int g2 = 0; g2 < DSTEPS; g2 += 2) {
+        const int cur = (g2 >> 1) & 1;
+        if (g2 + 2 < DSTEPS) {
+          kf[cur ^ 1][0] = kread(g2 + 2);
+          kf[cur ^ 1][1] = kread(g2 + 3);
+        }
+        s = MSAM2_MFMA_32x32x16(kf[cur][0], qf[g2], s, 0, 0, 0);
+        s = MSAM2_MFMA_32x32x16(kf[cur][1], qf[g2 + 1], s, 0, 0, 0);
       }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) s = MSAM2_MFMA_32x32x16(kf[u], qf[g2 + u], s, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+    } else {
+    // K fragments two at a time: the scheduling fence keeps the compiler from hoisting all D/16 reads at once, which would
+      // push the kernel over its 256-register budget
+  #pragma unroll
+      for (int g2 = 0; g2 < DSTEPS; g2 += 2) {
+        op16x8 kf[2];
+  #pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int c = 2 * (g2 + u) + h;
+          kf[u] = *reinterpret_cast<const op16x8*>(kbase + k_row + (((c & ~15) | ((c & 15) ^ k_x)) << 4));
+        }
+  #pragma unroll
+        for (int u = 0; u < 2; ++u) s = MSAM2_MFMA_32x32x16(kf[u], qf[g2 + u], s, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     float mx = -INFINITY;
 #pragma unroll
@@ -432,11 +457,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_glds_kernel(AttnParams p) {
       pf[e >> 3][e & 7] = f2op(pe);
     }
     l_run += psum;
-#pragma unroll
-    for (int d = 0; d < DBLK; ++d) {
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        typedef __attribute__((ext_vector_type(8))) short short8_t;
+    if constexpr (D <= 128) {
+      typedef __attribute__((ext_vector_type(8))) short short8_t;
+      auto vread = [&](int d, int st) {
         const int cch = (d * 4 + v_c0) ^ v_sw;   // swizzled 16-byte chunk; (key & 3) == q for every read below
         const unsigned char* a0 = vbase + v_row + (16 * st) * RB + (cch << 4);
         const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0));
@@ -444,9 +467,38 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_glds_kernel(AttnParams p) {
         short8_t vv8;
         vv8[0] = lo[0]; vv8[1] = lo[1]; vv8[2] = lo[2]; vv8[3] = lo[3];
         vv8[4] = hi[0]; vv8[5] = hi[1]; vv8[6] = hi[2]; vv8[7] = hi[3];
-        o[d] = MSAM2_MFMA_32x32x16(__builtin_bit_cast(op16x8, vv8), pf[st], o[d], 0, 0, 0);
+        return __builtin_bit_cast(op16x8, vv8);
+      };
+      op16x8 vf[2][2];
+      vf[0][0] = vread(0, 0);
+      vf[0][1] = vread(0, 1);
+#pragma unroll
+      for (int d = 0; d < DBLK; ++d) {
+        const int cur = d & 1;
+        if (d + 1 < DBLK) {
+          vf[cur ^ 1][0] = vread(d + 1, 0);
+          vf[cur ^ 1][1] = vread(d + 1, 1);
+        }
+        o[d] = MSAM2_MFMA_32x32x16(vf[cur][0], pf[0], o[d], 0, 0, 0);
+        o[d] = MSAM2_MFMA_32x32x16(vf[cur][1], pf[1], o[d], 0, 0, 0);
       }
-      __builtin_amdgcn_sched_barrier(0);
+    } else {
+#pragma unroll
+      for (int d = 0; d < DBLK; ++d) {
+  #pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          typedef __attribute__((ext_vector_type(8))) short short8_t;
+          const int cch = (d * 4 + v_c0) ^ v_sw;   // swizzled 16-byte chunk; (key & 3) == q for every read below
+          const unsigned char* a0 = vbase + v_row + (16 * st) * RB + (cch << 4);
+          const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0));
+          const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0 + 8 * RB));
+          short8_t vv8;
+          vv8[0] = lo[0]; vv8[1] = lo[1]; vv8[2] = lo[2]; vv8[3] = lo[3];
+          vv8[4] = hi[0]; vv8[5] = hi[1]; vv8[6] = hi[2]; vv8[7] = hi[3];
+          o[d] = MSAM2_MFMA_32x32x16(__builtin_bit_cast(op16x8, vv8), pf[st], o[d], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
 
@@ -475,8 +527,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_glds_kernel(AttnParams p) {
     for (int j = 0; j < PW; ++j) {
       const int f = (wave * PW + j) * 64 + lane;
       const int row = f / CPR, c = f % CPR, rr = min(row, last);
-      const unsigned ko = (unsigned)((key0 + rr) * k_rb + (((c & ~15) | ((c & 15) ^ (row & 15))) << 4));
-      const unsigned vo = (unsigned)((key0 + rr) * v_rb + ((c ^ ((row & 3) << 2)) << 4));
+      const int kc = (c & ~15) | ((c & 15) ^ (row & 15)), vc = c ^ ((row & 3) << 2);
+      const unsigned ko = (unsigned)((key0 + rr) * k_rb + ((kc < GCPR ? kc : 0) << 4));
+      const unsigned vo = (unsigned)((key0 + rr) * v_rb + ((vc < GCPR ? vc : 0) << 4));
       __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(base + j * 1024), 16, ko, 0, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(base + TILE + j * 1024), 16, vo, 0, 0, 0);
     }
@@ -523,7 +576,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_glds_kernel(AttnParams p) {
 template <int D>
 static int launch_attn_glds(const AttnParams& p, int Bz, hipStream_t s) {
   dim3 grid(cdiv(p.Lq, 128), p.H, Bz * p.splits);
-  hipLaunchKernelGGL((attn_glds_kernel<D, 4>), grid, dim3(256), 0, s, p);
+  if constexpr (D == 96) hipLaunchKernelGGL((attn_glds_kernel<96, 128, 4, 3>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((attn_glds_kernel<D, D, 4, 2>), grid, dim3(256), 0, s, p);
   if (p.splits > 1) {
     const int64_t rows = (int64_t)Bz * p.H * p.Lq;
     hipLaunchKernelGGL((attn_merge_kernel<D>), dim3(cdiv(rows * 64, 256)), dim3(256), 0, s, p, Bz);
@@ -592,7 +646,7 @@ extern "C" int msam2_attention_fwd(const void* q, const int64_t* q_strides, cons
   const char* force = getenv("MSAM2_ATTN_V1");
   const bool v2 = !(force && force[0] == '1') && Lq > 64;
   switch (D) {
-    case 96: return dispatch_nw<96, false>(p, (int)B, s);
+    case 96: return (v2 && k_strides[2] * 2 * 32 < (1ll << 31)) ? launch_attn_glds<96>(p, (int)B, s) : dispatch_nw<96, false>(p, (int)B, s);
     case 256: return v2 ? launch_attn_glds<256>(p, (int)B, s) : dispatch_nw<256, false>(p, (int)B, s);
     case 64: return dispatch_nw<64, false>(p, (int)B, s);
     default: return v2 ? launch_attn_glds<128>(p, (int)B, s) : dispatch_nw<128, false>(p, (int)B, s);
