@@ -12,6 +12,20 @@
 //                   B = the S^T accumulator itself converted to op16: its k-order is what the tr-read reproduces)
 //   so the query stays on the lane for both products and the O rescale needs no cross-lane traffic.
 #include "common.h"
+#ifdef MSAM2_STAMP
+// diagnostic build only (tools/attn_probe.hip): per-section cycle sums of one wave, never compiled into the product library
+__device__ unsigned long long g_stamp[16];
+#define STAMP(var)                                                                     \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");         \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+  } while (0)
+#define STAMP_DECL unsigned long long t0_ = 0, t1_ = 0, t2_ = 0, t3_ = 0, t4_ = 0, t5_ = 0, acc_[5] = {0, 0, 0, 0, 0}
+#else
+#define STAMP(var)
+#define STAMP_DECL
+#endif
 #include <stdlib.h>
 
 struct AttnParams {
@@ -377,6 +391,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_glds_kernel(AttnParams p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  STAMP_DECL;
 
   // fragment read offsets.  K: key row r, chunk 2*st + h.  V (transposed read): lane supplies key 4h + q (+16 st, +8 u),
   // elements d0 + 16*cgrp + 4p .. +3 with q = li>>2, p = li&3.
@@ -426,18 +441,18 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_glds_kernel(AttnParams p) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    STAMP(t2_);
+    // scores stay unscaled in s[]; the softmax scale (log2 domain) is folded into one fma per element: exp2(s*c - m)
     float mx = -INFINITY;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       if (masked) {
         const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        s[e] = (key < p.Lk) ? s[e] * p.scale_log2 : -INFINITY;
-      } else {
-        s[e] *= p.scale_log2;
+        if (key >= p.Lk) s[e] = -INFINITY;
       }
       mx = fmaxf(mx, s[e]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;   // scale > 0: max commutes with it
     const float m_new = fmaxf(m_run, mx);
     if (__any(m_new > m_run)) {
       const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
@@ -450,13 +465,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_glds_kernel(AttnParams p) {
     }
     float psum = 0.f;
     op16x8 pf[2];
+    const float neg_m = -m_run;                               // finite: every tile holds >= 1 valid key
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float pe = __builtin_amdgcn_exp2f(s[e] - m_run);   // m_run is finite here: every tile holds >= 1 valid key
+      const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], p.scale_log2, neg_m));
       psum += pe;
       pf[e >> 3][e & 7] = f2op(pe);
     }
     l_run += psum;
+    STAMP(t3_);
     if constexpr (D <= 128) {
       typedef __attribute__((ext_vector_type(8))) short short8_t;
       auto vread = [&](int d, int st) {
@@ -505,6 +522,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_glds_kernel(AttnParams p) {
   if (t_begin < t_full_end) issue(t_begin, 0);
   for (int tile = t_begin; tile < t_full_end; ++tile) {
     const int st_i = (tile - t_begin) & 1;
+    STAMP(t0_);
     if (tile + 1 < t_full_end) {
       issue(tile + 1, st_i ^ 1);
       if constexpr (2 * PW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -515,10 +533,22 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_glds_kernel(AttnParams p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+    STAMP(t1_);
     compute(st_i, tile * BK, false);
+    STAMP(t4_);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    STAMP(t5_);
+#ifdef MSAM2_STAMP
+    acc_[0] += t1_ - t0_; acc_[1] += t2_ - t1_; acc_[2] += t3_ - t2_; acc_[3] += t4_ - t3_; acc_[4] += t5_ - t4_;
+#endif
   }
+#ifdef MSAM2_STAMP
+  if (blockIdx.x == 3 && blockIdx.y == 0 && blockIdx.z == 1 && threadIdx.x == 64) {
+    for (int i = 0; i < 5; ++i) g_stamp[i] = acc_[i];
+    g_stamp[5] = (unsigned long long)(t_full_end - t_begin);
+  }
+#endif
   if (t_full_end < t_end) {
     // partial last tile: rows past Lk re-read the last valid key (their scores are masked to -inf)
     const int key0 = t_full_end * BK, last = p.Lk - 1 - key0;
