@@ -104,11 +104,46 @@ class MultiScaleBlock(nn.Module):
             self.proj = nn.Linear(dim, dim_out)
         self._wc = WeightCache()
 
+    def _packed_attn_weights(self):
+        """qkv / proj weights laid out for the attention kernels.  Head dims the kernels are built for (64/96/128/256) are used
+        as they are; others (56 of Hiera-B+) are zero-padded per head to the next one (a zero q/k channel adds nothing to the
+        scores, a zero v channel yields an output channel that the padded proj column ignores)."""
+        a = self.attn
+        heads, dim_out = a.num_heads, self.dim_out
+        D = dim_out // heads
+        Dp = D if D in (64, 96, 128, 256) else next(d for d in (64, 96, 128, 256) if d >= D)
+        wc = self._wc
+
+        def qkv_w():
+            w = a.qkv.weight.detach().reshape(3, heads, D, -1)
+            out = torch.zeros(3, heads, Dp, w.shape[-1], dtype=w.dtype, device=w.device)
+            out[:, :, :D] = w
+            return out.reshape(3 * heads * Dp, -1).to(OP16).contiguous()
+
+        def qkv_b():
+            b = a.qkv.bias.detach().reshape(3, heads, D)
+            out = torch.zeros(3, heads, Dp, dtype=F32, device=b.device)
+            out[:, :, :D] = b
+            return out.reshape(-1).contiguous()
+
+        def proj_w():
+            w = a.proj.weight.detach().reshape(dim_out, heads, D)
+            out = torch.zeros(dim_out, heads, Dp, dtype=w.dtype, device=w.device)
+            out[:, :, :D] = w
+            return out.reshape(dim_out, heads * Dp).to(OP16).contiguous()
+
+        if Dp == D:
+            return D, Dp, w_bf16(wc, "qkvw", a.qkv.weight), v_f32(wc, "qkvb", a.qkv.bias), w_bf16(wc, "ow", a.proj.weight)
+        return (D, Dp, wc.get("qkvw_p", [a.qkv.weight], qkv_w), wc.get("qkvb_p", [a.qkv.bias], qkv_b),
+                wc.get("ow_p", [a.proj.weight], proj_w))
+
     def run(self, t: torch.Tensor, B: int, H: int, W: int) -> Tuple[torch.Tensor, int, int]:
         """fp32 tokens [B*H*W, dim] -> (fp32 tokens [B*H'*W', dim_out], H', W')."""
         wc, a = self._wc, self.attn
         heads, dim_out = a.num_heads, self.dim_out
-        D = dim_out // heads
+        D, Dp, qkv_w, qkv_b, proj_w = self._packed_attn_weights()
+        width = heads * Dp                      # per-token width of each of q, k, v in the (possibly padded) layout
+        scale = 1.0 / (D ** 0.5)
         xn = ops.layernorm(t, v_f32(wc, "n1w", self.norm1.weight), v_f32(wc, "n1b", self.norm1.bias), 1e-6)
         pool = self.q_stride is not None
         if self.dim != dim_out:
@@ -117,18 +152,17 @@ class MultiScaleBlock(nn.Module):
                 shortcut = ops.maxpool2x2(shortcut, B, H, W)
         else:
             shortcut = t
-        qkv_b = v_f32(wc, "qkvb", a.qkv.bias)
-        qkv = ops.gemm(xn, w_bf16(wc, "qkvw", a.qkv.weight), qkv_b)  # bf16 [T, 3*dim_out]
-        qp = ops.maxpool2x2(qkv[:, :dim_out], B, H, W) if pool else None
+        qkv = ops.gemm(xn, qkv_w, qkv_b)  # 16-bit [T, 3*width]
+        qp = ops.maxpool2x2(qkv[:, :width], B, H, W) if pool else None
         Hq, Wq = (H // 2, W // 2) if pool else (H, W)
         if self.window_size > 0:
-            o = ops.window_attention(qkv, B, H, W, heads, self.window_size, qkv_b, q_pooled=qp)
+            o = ops.window_attention(qkv, B, H, W, heads, self.window_size, qkv_b, q_pooled=qp, scale=scale)
         else:
-            v5 = qkv.view(B, H * W, 3, heads, D)
-            q = (qp.view(B, Hq * Wq, heads, D) if pool else v5[:, :, 0]).permute(0, 2, 1, 3)
-            o = ops.attention(q, v5[:, :, 1].permute(0, 2, 1, 3), v5[:, :, 2].permute(0, 2, 1, 3))
-            o = o.permute(0, 2, 1, 3).reshape(B * Hq * Wq, dim_out)
-        t = ops.gemm(o, w_bf16(wc, "ow", a.proj.weight), v_f32(wc, "ob", a.proj.bias), residual=shortcut, out_dtype=F32)
+            v5 = qkv.view(B, H * W, 3, heads, Dp)
+            q = (qp.view(B, Hq * Wq, heads, Dp) if pool else v5[:, :, 0]).permute(0, 2, 1, 3)
+            o = ops.attention(q, v5[:, :, 1].permute(0, 2, 1, 3), v5[:, :, 2].permute(0, 2, 1, 3), scale=scale)
+            o = o.permute(0, 2, 1, 3).reshape(B * Hq * Wq, width)
+        t = ops.gemm(o, proj_w, v_f32(wc, "ob", a.proj.bias), residual=shortcut, out_dtype=F32)
         xn2 = ops.layernorm(t, v_f32(wc, "n2w", self.norm2.weight), v_f32(wc, "n2b", self.norm2.bias), 1e-6)
         t = self.mlp.run(xn2, residual=t, out_dtype=F32)
         return t, Hq, Wq

@@ -82,7 +82,7 @@ def _strides3(t: torch.Tensor) -> "ctypes.Array":
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, splits: int = 1,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, scale: Optional[float] = None) -> torch.Tensor:
     """softmax(q k^T / sqrt(D)) v.  q [B,H,Lq,D], k/v [B,H,Lk,D] as (possibly strided) bf16 views with D contiguous.
     Returns [B,H,Lq,D] view of a [B,Lq,H,D] buffer (heads recombined for the following out-projection)."""
     B, H, Lq, D = q.shape
@@ -94,13 +94,14 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, splits: int 
     ws_bytes = lib().msam2_attention_workspace_bytes(B, H, Lq, D, splits)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=q.device) if splits > 1 else None
     check(lib().msam2_attention_fwd(_p(q), _strides3(q), _p(k), _strides3(k), _p(v), _strides3(v), _p(out), _strides3(out),
-                                    B, H, Lq, Lk, D, 1.0 / math.sqrt(D), splits, _p(ws), ws_bytes if ws is not None else 0,
+                                    B, H, Lq, Lk, D, scale if scale is not None else 1.0 / math.sqrt(D), splits, _p(ws),
+                                    ws_bytes if ws is not None else 0,
                                     _stream()))
     return out
 
 
 def window_attention(qkv: torch.Tensor, B: int, H: int, W: int, heads: int, ws: int, qkv_bias: torch.Tensor,
-                     q_pooled: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     q_pooled: Optional[torch.Tensor] = None, scale: Optional[float] = None) -> torch.Tensor:
     """Hiera windowed MHA straight from the fused qkv tokens [B*H*W, 3*heads*D] (bf16); if q_pooled is given
     ([B*(H/2)*(W/2), heads*D]) queries come from it with window ws/2.  Returns o [B*Hq*Wq, heads*D] bf16."""
     dim_out = qkv.shape[1] // 3
@@ -116,7 +117,7 @@ def window_attention(qkv: torch.Tensor, B: int, H: int, W: int, heads: int, ws: 
     kptr = qkv.data_ptr() + dim_out * 2
     vptr = qkv.data_ptr() + 2 * dim_out * 2
     check(lib().msam2_window_attention_fwd(_p(qt), q_ts, D, hq, wq, ws_q, kptr, vptr, qkv.stride(0), D, H, W, ws, _p(kpad),
-                                           _p(vpad), _p(o), o.stride(0), D, B, heads, D, 1.0 / math.sqrt(D), _stream()))
+                                           _p(vpad), _p(o), o.stride(0), D, B, heads, D, scale if scale is not None else 1.0 / math.sqrt(D), _stream()))
     return o
 
 

@@ -268,7 +268,7 @@ def run_image_predictor_case():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    spec = {m: {k: list(v.shape) for k, v in build_reference(m, 256).state_dict().items()} for m in ("hiera_t", "hiera_s")}
+    spec = {m: {k: list(v.shape) for k, v in build_reference(m, 256).state_dict().items()} for m in ("hiera_t", "hiera_s", "hiera_b+")}
     with open(os.path.join(OUT, "state_dict_keys.json"), "w") as f:
         json.dump(spec, f)
     allmeta = {}
@@ -284,6 +284,9 @@ def main():
     o, meta = run_slice_chain("hiera_s", 1024, 3, "s1024", store_full=False)
     np.savez_compressed(os.path.join(OUT, "chain_hiera_s_1024.npz"), **o)
     allmeta["chain_hiera_s_1024"] = meta
+    o, meta = run_slice_chain("hiera_b+", 256, 2, "b256", store_full=False)
+    np.savez_compressed(os.path.join(OUT, "chain_hiera_bplus_256.npz"), **o)
+    allmeta["chain_hiera_bplus_256"] = meta
     o, meta = run_image_predictor_case()
     np.savez_compressed(os.path.join(OUT, "config1_image_predictor.npz"), **o)
     allmeta["config1_image_predictor"] = meta

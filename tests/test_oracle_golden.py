@@ -19,7 +19,7 @@ torch.set_grad_enabled(False)
 def test_state_dict_contract_matches_reference():
     with open(os.path.join(GOLDEN, "state_dict_keys.json")) as f:
         ref = json.load(f)
-    for model in ("hiera_t", "hiera_s"):
+    for model in ("hiera_t", "hiera_s", "hiera_b+"):
         spec = wts.state_dict_spec(model)
         assert list(spec.keys()) == list(ref[model].keys())
         for k, shp in spec.items():
@@ -156,6 +156,11 @@ def test_slice_chain_hiera_s_256():
 
 def test_slice_chain_hiera_t_256():
     _run_chain("hiera_t", 256, 2, "t256", load_npz("chain_hiera_t_256.npz"), load_meta()["chain_hiera_t_256"])
+
+
+def test_slice_chain_hiera_bplus_256():
+    """Hiera-B+ trunk (class defaults of hieradet.py:176-201 with the upstream embed_dim 112 / 2 heads: head dim 56)."""
+    _run_chain("hiera_b+", 256, 2, "b256", load_npz("chain_hiera_bplus_256.npz"), load_meta()["chain_hiera_bplus_256"])
 
 
 def test_slice_chain_hiera_s_1024():
