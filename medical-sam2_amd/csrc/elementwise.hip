@@ -605,3 +605,29 @@ extern "C" int msam2_image_prep(const uint8_t* img_hwc, float* out_chw, int64_t 
                      img_hwc, out_chw, (int)H, (int)W, (int)S, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
   return msam2_check_launch("image_prep");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// SAM2Base._apply_non_overlapping_constraints (sam2_base.py:812-830): per pixel keep the highest-scoring object, clamp every
+// other object's score to <= -10.  masks fp32 [n, P] (P = pixels), in -> out (may alias).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void non_overlap_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int64_t P) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+    int best = 0;
+    float bv = x[i];
+    for (int o = 1; o < n; ++o) {
+      const float v = x[(int64_t)o * P + i];
+      if (v > bv) { bv = v; best = o; }   // first maximum wins, like torch.argmax
+    }
+    for (int o = 0; o < n; ++o) {
+      const float v = x[(int64_t)o * P + i];
+      y[(int64_t)o * P + i] = (o == best) ? v : fminf(v, -10.0f);
+    }
+  }
+}
+
+extern "C" int msam2_non_overlap(const float* masks, float* out, int64_t n_obj, int64_t pixels, void* stream) {
+  MSAM2_REQUIRE(masks && out && n_obj > 0 && pixels > 0, "non_overlap: bad arguments");
+  hipLaunchKernelGGL(non_overlap_kernel, dim3((unsigned)min((int64_t)8192, (pixels + 255) / 256)), dim3(256), 0, (hipStream_t)stream, masks,
+                     out, (int)n_obj, pixels);
+  return msam2_check_launch("non_overlap");
+}

@@ -51,7 +51,7 @@ class SAM2Base(nn.Module):
         super().__init__()
         assert use_high_res_features_in_sam and use_obj_ptrs_in_encoder and pred_obj_scores and fixed_no_obj_ptr and \
             use_mlp_for_obj_ptr_proj and directly_add_no_mem_embed and not add_tpos_enc_to_obj_ptrs and not soft_no_obj_ptr and \
-            not proj_tpos_enc_in_obj_ptrs and not non_overlap_masks_for_mem_enc, \
+            not proj_tpos_enc_in_obj_ptrs, \
             "HIP path implements the model wiring of sam2_hiera_{t,s}.yaml"
         self.image_encoder = image_encoder
         self.use_high_res_features_in_sam = use_high_res_features_in_sam
@@ -291,6 +291,8 @@ class SAM2Base(nn.Module):
         B = current_vision_feats[-1].size(1)
         C = self.hidden_dim
         H, W = feat_sizes[-1]
+        if self.non_overlap_masks_for_mem_enc and not self.training:
+            pred_masks_high_res = self._apply_non_overlapping_constraints(pred_masks_high_res)
         top = current_vision_feats[-1]  # [HW, B, C]
         pix_tokens = ops.add_cast(top.transpose(0, 1), None, 1.0, OP16).view(B * H * W, C)
         binarize = self.binarize_mask_from_pts_for_mem_enc and is_mask_from_pts and not self.training
@@ -339,6 +341,12 @@ class SAM2Base(nn.Module):
             current_out["maskmem_features"] = None
             current_out["maskmem_pos_enc"] = None
         return current_out
+
+    def _apply_non_overlapping_constraints(self, pred_masks):
+        """sam2_base.py:812-830."""
+        if pred_masks.size(0) == 1:
+            return pred_masks
+        return ops.non_overlap(pred_masks)
 
     def _use_multimask(self, is_init_cond_frame, point_inputs):
         """sam2_base.py:802-810."""

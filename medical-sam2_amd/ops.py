@@ -424,3 +424,12 @@ def image_prep(img_u8_hwc: torch.Tensor, size: int, mean=(0.485, 0.456, 0.406), 
     s = (ctypes.c_float * 3)(*std)
     check(lib().msam2_image_prep(_p(img_u8_hwc), _p(out), H, W, size, m, s, _stream()))
     return out
+
+
+def non_overlap(masks: torch.Tensor) -> torch.Tensor:
+    """[n,1,H,W] fp32 -> same shape: per pixel the arg-max object keeps its score, the others are clamped to <= -10."""
+    m = masks.to(F32).contiguous()
+    n = m.shape[0]
+    out = torch.empty_like(m)
+    check(lib().msam2_non_overlap(_p(m), _p(out), n, m.numel() // n, _stream()))
+    return out
