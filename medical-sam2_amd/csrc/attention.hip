@@ -519,25 +519,20 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_glds_kernel(AttnParams p) {
     }
   };
 
+  // ONE barrier per tile: tile t's DMA pieces were issued a whole compute phase earlier (so the vmcnt wait is normally free);
+  // the barrier then says both "every wave's pieces of tile t have landed" and "every wave has finished reading tile t-1",
+  // which is what allows tile t+1 to be streamed into t-1's stage right after it, in the shadow of tile t's MFMAs.
   if (t_begin < t_full_end) issue(t_begin, 0);
   for (int tile = t_begin; tile < t_full_end; ++tile) {
     const int st_i = (tile - t_begin) & 1;
     STAMP(t0_);
-    if (tile + 1 < t_full_end) {
-      issue(tile + 1, st_i ^ 1);
-      if constexpr (2 * PW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if constexpr (2 * PW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if constexpr (2 * PW == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (tile + 1 < t_full_end) issue(tile + 1, st_i ^ 1);
     STAMP(t1_);
     compute(st_i, tile * BK, false);
     STAMP(t4_);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
     STAMP(t5_);
 #ifdef MSAM2_STAMP
     acc_[0] += t1_ - t0_; acc_[1] += t2_ - t1_; acc_[2] += t3_ - t2_; acc_[3] += t4_ - t3_; acc_[4] += t5_ - t4_;
@@ -553,6 +548,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_glds_kernel(AttnParams p) {
     // partial last tile: rows past Lk re-read the last valid key (their scores are masked to -inf)
     const int key0 = t_full_end * BK, last = p.Lk - 1 - key0;
     unsigned char* base = smem + wave * PW * 1024;
+    __builtin_amdgcn_s_barrier();                             // every wave is done with the last full tile's stage
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
       const int f = (wave * PW + j) * 64 + lane;

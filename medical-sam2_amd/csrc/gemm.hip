@@ -26,37 +26,42 @@ struct GemmParams {
   int out_is_16bit;  // output dtype
 };
 
+#ifdef MSAM2_GSTAMP
+// diagnostic build only (tools/gemm_probe.hip): per-workgroup time stamps, never compiled into the product library
+__device__ unsigned long long g_gstamp[8 * 8192];
+__device__ int g_epi_mode;   // experiment: 1 = skip global stores, 2 = skip the LDS dump, 3 = both
+#define GSTAMP(slot)                                                                                   \
+  do {                                                                                                 \
+    unsigned long long t_;                                                                             \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_gstamp[blockIdx.x * 8 + (slot)] = t_;                \
+  } while (0)
+#define GSTAMP_NW(slot)                                                                                \
+  do {                                                                                                 \
+    unsigned long long t_;                                                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                        \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_gstamp[blockIdx.x * 8 + (slot)] = t_;                \
+  } while (0)
+#else
+#define GSTAMP(slot)
+#define GSTAMP_NW(slot)
+#endif
+
 constexpr int GEMM_BK = 32;
 constexpr int GEMM_LDS_STRIDE = 40;  // op16 elements per LDS row (32 data + 8 pad = 80 B)
 
 // ---- shared epilogue.  Each wave re-lays its accumulators through a private fp32 LDS scratch ([32][TN+4], rows of the C tile
 // contiguous) so that bias / activation / layer-scale / residual and the global stores work on 16-byte row segments
 // (full 128..256-byte lines per 16 lanes) instead of one 2- or 4-byte element per lane.
+// Generic version: any alignment, any N, every mode at run time.  Deliberately a ROLLED element loop over the slab in scratch
+// (one element per lane per trip): it is only reached by odd shapes (N not a multiple of 4, unaligned views, 16-bit residuals,
+// sigmoid), and keeping it tiny keeps its registers and code out of the way of the specialised paths below.
 template <int FM, int FN>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[FM][FN], float* scr, int64_t row0, int64_t col0,
-                                              int lane) {
+__device__ __forceinline__ void gemm_epilogue_generic(const GemmParams& p, f32x16 (&acc)[FM][FN], float* scr, int64_t row0, int64_t col0,
+                                                      int lane) {
   constexpr int TN = FN * 32;
-  constexpr int SLD = TN + 4;                       // scratch row stride in floats
-  constexpr int CPR_ = TN / 4;                      // 4-float chunks per row
-  constexpr int CH_ITERS = (32 * CPR_) / 64;        // chunk iterations per lane
-  constexpr int ROWS_PER_IT = 64 / CPR_;            // rows covered by one chunk iteration of the wave
-  static_assert(64 % CPR_ == 0, "a lane keeps the same 4 columns in every chunk iteration");
+  constexpr int SLD = TN + 4;
   const int r = lane & 31, h = lane >> 5;
-  const bool vec_ok = ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
-                      (!p.res || (((p.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0)));
-  // this lane's 4 output columns are the same for every row it touches: bias / layer-scale are loaded once
-  const int col = (lane % CPR_) * 4;
-  const int64_t n = col0 + col;
-  const bool n_in = n < p.N;
-  const bool full = vec_ok && (n + 3 < p.N);
-  float bias4[4], cs4[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const bool ok = n + q < p.N;
-    bias4[q] = (p.bias && ok) ? p.bias[n + q] : 0.f;
-    cs4[q] = (p.colscale && ok) ? p.colscale[n + q] : 1.f;
-  }
-  const int row_in_it = lane / CPR_;
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -64,60 +69,215 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
       for (int e = 0; e < 16; ++e) scr[((e & 3) + 8 * (e >> 2) + 4 * h) * SLD + j * 32 + r] = acc[i][j][e];
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's scratch writes have landed (scratch is wave-private)
-#pragma unroll
-    for (int it = 0; it < CH_ITERS; ++it) {
-      const int row = it * ROWS_PER_IT + row_in_it;
-      const int64_t m = row0 + i * 32 + row;
-      if (m >= p.M || !n_in) continue;
-      f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * SLD + col);
-      float resv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.res) {
-        const int64_t rr = p.res_mod > 0 ? (int64_t)((unsigned)m % (unsigned)p.res_mod) : m;
-        if (full) {
-          if (p.res_is_16bit) {
-            const op16x4 t = *reinterpret_cast<const op16x4*>(reinterpret_cast<const op16*>(p.res) + rr * p.ldr + n);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) resv[q] = op2f(t[q]);
-          } else {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + rr * p.ldr + n);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) resv[q] = t[q];
-          }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (n + q < p.N)
-              resv[q] = p.res_is_16bit ? op2f(reinterpret_cast<const op16*>(p.res)[rr * p.ldr + n + q])
-                                      : reinterpret_cast<const float*>(p.res)[rr * p.ldr + n + q];
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float x = v[q] + bias4[q];
+#pragma unroll 1
+    for (int t = 0; t < (32 * TN) / 64; ++t) {
+      const int idx = t * 64 + lane;
+      const int row = idx / TN, col = idx % TN;
+      const int64_t m = row0 + i * 32 + row, n = col0 + col;
+      if (m < p.M && n < p.N) {
+        float x = scr[row * SLD + col] + (p.bias ? p.bias[n] : 0.f);
         if (p.act == 1) x = gelu_erf(x);
         else if (p.act == 2) x = fmaxf(x, 0.f);
         else if (p.act == 3) x = 1.f / (1.f + __expf(-x));
-        v[q] = x * cs4[q] + resv[q];
-      }
-      if (full) {
-        if (p.out_is_16bit) {
-          op16x4 o;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] = f2op(v[q]);
-          *reinterpret_cast<op16x4*>(reinterpret_cast<op16*>(p.C) + m * p.ldc + n) = o;
-        } else {
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n) = v;
+        if (p.colscale) x *= p.colscale[n];
+        if (p.res) {
+          const int64_t rr = p.res_mod > 0 ? (int64_t)((unsigned)m % (unsigned)p.res_mod) : m;
+          x += p.res_is_16bit ? op2f(reinterpret_cast<const op16*>(p.res)[rr * p.ldr + n])
+                              : reinterpret_cast<const float*>(p.res)[rr * p.ldr + n];
         }
-      } else {
+        if (p.out_is_16bit) reinterpret_cast<op16*>(p.C)[m * p.ldc + n] = f2op(x);
+        else reinterpret_cast<float*>(p.C)[m * p.ldc + n] = x;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // the slab is re-used by the next i
+  }
+}
+
+// Specialised epilogue for the combinations the hot path uses (C / residual / bias 16-byte aligned, N % 4 == 0, so every lane
+// owns whole 4-column chunks): activation, residual kind and output type are template parameters, and each 32-row slab is done
+// in three batched phases -- all scratch reads, all residual loads, then math + stores -- so LDS and memory latencies overlap
+// instead of being paid per row group.  (The generic version above tests the modes per element: ~12 scalar branches per element,
+// measured at 15k cycles per 128x128 tile, more than a 12-step K = 384 main loop; and on gfx9 vmcnt also counts stores, so a
+// per-row "wait for the residual" there waits for the previous row's store round trip as well.)
+template <int FM, int FN, int ACT, int RES /* 0 none, 1 f32 */, bool OUT16>
+__device__ __forceinline__ void gemm_epilogue_spec(const GemmParams& p, f32x16 (&acc)[FM][FN], float* scr, int64_t row0, int64_t col0,
+                                                   int lane) {
+  constexpr int TN = FN * 32;
+  constexpr int SLD = TN + 4;
+  constexpr int CPR_ = TN / 4;
+  constexpr int CH_ITERS = (32 * CPR_) / 64;
+  constexpr int ROWS_PER_IT = 64 / CPR_;
+  constexpr int BATCH = CH_ITERS < 4 ? CH_ITERS : 4;
+  const int r = lane & 31, h = lane >> 5;
+  const int col = (lane % CPR_) * 4;
+  const int64_t n = col0 + col;
+  const bool n_in = n < p.N;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, cs4 = {1.f, 1.f, 1.f, 1.f};
+  if (p.bias && n_in) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+  if (p.colscale && n_in) cs4 = *reinterpret_cast<const f32x4*>(p.colscale + n);
+  const unsigned res_mod = (unsigned)p.res_mod;
+  const int row_in_it = lane / CPR_;
+  const float* scr_rd = scr + row_in_it * SLD + col;
+  const int64_t m_lane = row0 + row_in_it;
+  const float* resp = reinterpret_cast<const float*>(p.res) + n;
+  char* cp = reinterpret_cast<char*>(p.C) + n * (OUT16 ? 2 : 4);
+  const int64_t ldc_b = p.ldc * (OUT16 ? 2 : 4);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (n + q < p.N) {
-            if (p.out_is_16bit) reinterpret_cast<op16*>(p.C)[m * p.ldc + n + q] = f2op(v[q]);
-            else reinterpret_cast<float*>(p.C)[m * p.ldc + n + q] = v[q];
+  for (int i = 0; i < FM; ++i) {
+#ifdef MSAM2_GSTAMP
+    if (!(g_epi_mode & 2))
+#endif
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) scr[((e & 3) + 8 * (e >> 2) + 4 * h) * SLD + j * 32 + r] = acc[i][j][e];
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's scratch writes have landed (scratch is wave-private)
+#pragma unroll
+    for (int b0 = 0; b0 < CH_ITERS; b0 += BATCH) {
+      f32x4 v[BATCH], rv[BATCH];
+      bool live[BATCH];
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) v[u] = *reinterpret_cast<const f32x4*>(scr_rd + (b0 + u) * ROWS_PER_IT * SLD);
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int64_t m = m_lane + i * 32 + (b0 + u) * ROWS_PER_IT;
+        live[u] = n_in && m < p.M;
+        rv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (RES == 1) {
+          if (live[u]) {
+            const int64_t rr = res_mod > 0 ? (int64_t)((unsigned)m % res_mod) : m;
+            rv[u] = *reinterpret_cast<const f32x4*>(resp + rr * p.ldr);
           }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int64_t m = m_lane + i * 32 + (b0 + u) * ROWS_PER_IT;
+        f32x4 y;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float x = v[u][q] + bias4[q];
+          if constexpr (ACT == 1) x = gelu_erf(x);
+          else if constexpr (ACT == 2) x = fmaxf(x, 0.f);
+          else if constexpr (ACT == 3) x = __builtin_amdgcn_rcpf(1.f + __expf(-x));
+          y[q] = __builtin_fmaf(x, cs4[q], rv[u][q]);
+        }
+#ifdef MSAM2_GSTAMP
+        if (g_epi_mode & 1) live[u] = live[u] && y[0] == 123.456f;
+#endif
+        if (live[u]) {
+          if constexpr (OUT16) {
+            op16x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = f2op(y[q]);
+            *reinterpret_cast<op16x4*>(cp + m * ldc_b) = o;
+          } else {
+            *reinterpret_cast<f32x4*>(cp + m * ldc_b) = y;
+          }
+        }
       }
     }
   }
+}
+
+// Direct epilogue: stores straight from the MFMA accumulator layout with buffer_store_dword -- no LDS round trip at all.
+//   fp32 out: one accumulator register is two 128-byte row segments per wave instruction (full-rate store shape).
+//   16-bit out: adjacent lanes hold adjacent columns, so each even/odd lane pair swaps one value through DPP (quad_perm
+//   [1,0,3,2]) and packs a dword: even lanes store (col r, r+1) of row(e), odd lanes (col r-1, r) of row(e+1).
+// Rows past M fall outside the buffer descriptor's num_records and are dropped by the hardware range check (the row term is in
+// the per-lane voffset because soffset is not range-checked on gfx9); columns past N are masked per lane.
+template <int FM, int FN, int ACT, int RES /* 0 none, 1 f32 */, bool OUT16>
+__device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x16 (&acc)[FM][FN], int64_t row0, int64_t col0, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int ES = OUT16 ? 2 : 4;
+  const int r = lane & 31, h = lane >> 5, odd = lane & 1;
+  const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((int64_t)p.M * p.ldc * ES), 0x00020000);
+  const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, (int)((int64_t)p.M * p.ldr * 4), 0x00020000);
+  float bias_j[FN], cs_j[FN];
+  bool colok[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int64_t n = col0 + j * 32 + r;
+    colok[j] = n < p.N;
+    bias_j[j] = (p.bias && colok[j]) ? p.bias[n] : 0.f;
+    cs_j[j] = (p.colscale && colok[j]) ? p.colscale[n] : 1.f;
+  }
+  auto fn = [&](float x, int j) {
+    x += bias_j[j];
+    if constexpr (ACT == 1) x = gelu_erf(x);
+    else if constexpr (ACT == 2) x = fmaxf(x, 0.f);
+    else if constexpr (ACT == 3) x = __builtin_amdgcn_rcpf(1.f + __expf(-x));
+    return x * cs_j[j];
+  };
+  const int ldc_b = (int)p.ldc * ES, ldr_b = (int)p.ldr * 4;
+  if constexpr (!OUT16) {
+    const int vbase = (int)((row0 + 4 * h) * p.ldc + col0 + r) * 4;
+    const int rbase = (int)((row0 + 4 * h) * p.ldr + col0 + r) * 4;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        float rv[16];
+        if constexpr (RES == 1) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int ro = i * 32 + (e & 3) + 8 * (e >> 2);
+            rv[e] = colok[j] ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, rbase + ro * ldr_b + j * 128, 0, 0)) : 0.f;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int ro = i * 32 + (e & 3) + 8 * (e >> 2);
+          float y = fn(acc[i][j][e], j);
+          if constexpr (RES == 1) y += rv[e];
+          if (colok[j]) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), c_rsrc, vbase + ro * ldc_b + j * 128, 0, 0);
+        }
+      }
+  } else {
+    static_assert(!OUT16 || RES == 0, "16-bit outputs carry no residual on the direct path");
+    const int vbase = (int)((row0 + 4 * h + odd) * p.ldc + col0 + (r & ~1)) * 2;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int e0 = 2 * k, ro = i * 32 + (e0 & 3) + 8 * (e0 >> 2);
+          const float x0 = fn(acc[i][j][e0], j), x1 = fn(acc[i][j][e0 + 1], j);
+          const float send = odd ? x0 : x1;
+          const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xf, 0xf, false));
+          const float lo = odd ? recv : x0, hi = odd ? x1 : recv;
+          op16x2 pk;
+          pk[0] = f2op(lo);
+          pk[1] = f2op(hi);
+          if (colok[j]) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk), c_rsrc, vbase + ro * ldc_b + j * 64, 0, 0);
+        }
+  }
+#endif
+}
+
+template <int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[FM][FN], float* scr, int64_t row0, int64_t col0,
+                                              int lane) {
+  const bool aligned = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                       (!p.res || (((p.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0) && !p.res_is_16bit)) &&
+                       (!p.bias || ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0)) &&
+                       (!p.colscale || ((reinterpret_cast<uintptr_t>(p.colscale) & 15) == 0));
+  // the direct path addresses C (and the residual) with 32-bit buffer offsets
+  const bool direct = aligned && p.res_mod == 0 && (int64_t)p.M * p.ldc * 4 < (1ll << 31) && (!p.res || (int64_t)p.M * p.ldr * 4 < (1ll << 31));
+  const int mode = !aligned ? -1 : (p.act * 4 + (p.res ? 2 : 0) + (p.out_is_16bit ? 1 : 0));
+  if (direct) {
+    switch (mode) {
+      case 0 * 4 + 0 + 1: gemm_epilogue_direct<FM, FN, 0, 0, true>(p, acc, row0, col0, lane); return;   // linear -> 16-bit
+      case 0 * 4 + 0 + 0: gemm_epilogue_direct<FM, FN, 0, 0, false>(p, acc, row0, col0, lane); return;  // linear -> fp32
+      case 0 * 4 + 2 + 0: gemm_epilogue_direct<FM, FN, 0, 1, false>(p, acc, row0, col0, lane); return;  // + fp32 residual -> fp32
+      case 1 * 4 + 0 + 1: gemm_epilogue_direct<FM, FN, 1, 0, true>(p, acc, row0, col0, lane); return;   // GELU -> 16-bit
+      case 2 * 4 + 0 + 1: gemm_epilogue_direct<FM, FN, 2, 0, true>(p, acc, row0, col0, lane); return;   // ReLU -> 16-bit
+      default: break;
+    }
+  }
+  if (mode == 0 * 4 + 2 + 0) gemm_epilogue_spec<FM, FN, 0, 1, false>(p, acc, scr, row0, col0, lane);   // patch embed: + pos[m % res_mod]
+  else gemm_epilogue_generic<FM, FN>(p, acc, scr, row0, col0, lane);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -347,6 +507,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds32_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = 128, BN = 128, BK = 32, STAGE_BYTES = (BM + BN) * BK * 2;  // 16 KiB
   __shared__ __attribute__((aligned(1024))) unsigned char lds[(NST * STAGE_BYTES > 34816) ? NST * STAGE_BYTES : 34816];
+  GSTAMP(0);
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
@@ -408,6 +569,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds32_kernel(GemmParams p) {
   for (int i = 1; i < NST - 1; ++i)
     if (nk > i) issue(i);
   for (int kt = 0; kt < nk; ++kt) {
+#ifdef MSAM2_GSTAMP
+    if (kt == 1) GSTAMP(1);
+#endif
     const int ahead = min(nk - 1 - kt, NST - 2);         // DMA groups younger than tile kt still allowed in flight
     if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -432,8 +596,150 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds32_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = MSAM2_MFMA_32x32x16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
   }
+  GSTAMP(2);
   __builtin_amdgcn_s_barrier();
+  GSTAMP_NW(6);
   gemm_epilogue<2, 2>(p, acc, reinterpret_cast<float*>(lds) + wave * 32 * 68, m0 + wm * 64, n0 + wn * 64, lane);
+  GSTAMP_NW(7);
+  GSTAMP(3);
+#ifdef MSAM2_GSTAMP
+  if (threadIdx.x == 0 && blockIdx.x < 8192) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_gstamp[blockIdx.x * 8 + 4] = hw; unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g_gstamp[blockIdx.x * 8 + 5] = xcc; }
+#endif
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Wide-tile DMA variant: BM x BN x 32 tiles (256x128 / 256x256 ...), 4 waves in a 2x2 grid, each owning (BM/2) x (BN/2)
+// (FM x FN 32x32 accumulators), NST-stage LDS-DMA ring with prefetch distance NST-1 and one barrier per k-step.
+// Why: what bounds the 128x128 kernels is bytes in flight -- at 64 flop per DMA byte a CU needs ~64 B/clk from L2, i.e. more
+// than 100 KiB in flight to cover the ~2k-cycle L2->LDS latency.  A 256x128 tile needs 1.33x fewer bytes per flop, twice the
+// MFMA work per barrier, and with 3 stages keeps two tiles in flight per workgroup (2 workgroups per CU: 144 KiB of LDS).
+// Same 64-byte-row image and chunk swizzle (c ^ ((r >> 2) & 3)) as gemm_glds32_kernel.
+// ------------------------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int NST, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_wide_kernel(GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BK = 32, A_BYTES = BM * BK * 2, STAGE_BYTES = (BM + BN) * BK * 2;
+  constexpr int FM = BM / 64, FN = BN / 64;         // 32x32 accumulators per wave
+  constexpr int PA = BM / 64, PWW = BN / 64;        // DMA pieces (16 rows x 64 B) per wave per tile
+  constexpr int G = PA + PWW;                       // DMA instructions per wave per k-step
+  constexpr int SCR = 4 * 32 * (FN * 32 + 4) * 4;   // epilogue scratch
+  static_assert(G * (NST - 1) <= 63, "vmcnt is a 6-bit counter");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[(NST * STAGE_BYTES > SCR) ? NST * STAGE_BYTES : SCR];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int n_tiles_n = (p.N + BN - 1) / BN, n_tiles_m = (p.M + BM - 1) / BM;
+  const int nwg = n_tiles_n * n_tiles_m;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8;
+    bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + bid / 8;
+  }
+  const int64_t m0 = (int64_t)(bid / n_tiles_n) * BM;
+  const int64_t n0 = (int64_t)(bid % n_tiles_n) * BN;
+
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+  unsigned offsA[PA], offsW[PWW];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int row = (wave * PA + i) * 16 + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    offsA[i] = (unsigned)(min(m0 + row, (int64_t)p.M - 1) * p.lda * 2 + chunk * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < PWW; ++i) {
+    const int row = (wave * PWW + i) * 16 + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    offsW[i] = (unsigned)(min(n0 + row, (int64_t)p.N - 1) * p.ldw * 2 + chunk * 16);
+  }
+  auto issue = [&](int kt) {
+    unsigned char* base = lds + (kt % NST) * STAGE_BYTES;
+    const unsigned so = (unsigned)kt * BK * 2;
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(base + (wave * PA + i) * 1024), 16,
+                                               offsA[i], so, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PWW; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave * PWW + i) * 1024),
+                                               16, offsW[i], so, 0, 0);
+  };
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment byte offsets inside a stage for k-substep 0 / 1 (chunk 2*ks + h, swizzled by the row)
+  int offA[FM][2], offB[FN][2];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int ra = wm * (BM / 2) + i * 32 + r;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) offA[i][ks] = ra * 64 + (((2 * ks + h) ^ ((ra >> 2) & 3)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int rb = wn * (BN / 2) + j * 32 + r;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) offB[j][ks] = A_BYTES + rb * 64 + (((2 * ks + h) ^ ((rb >> 2) & 3)) << 4);
+  }
+
+  const int nk = p.K / BK;
+  auto wait_groups = [&](int younger) {                   // wait until at most `younger` DMA groups of this wave are in flight
+    if (NST >= 4 && younger >= 3) wait_vmcnt<(NST >= 4 ? 3 : 0) * G>();
+    else if (NST >= 3 && younger == 2) wait_vmcnt<(NST >= 3 ? 2 : 0) * G>();
+    else if (NST >= 2 && younger == 1) wait_vmcnt<G>();
+    else wait_vmcnt<0>();
+  };
+  auto load_frags = [&](const unsigned char* sb, int ks, op16x8 (&af)[FM], op16x8 (&bfr)[FN]) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const op16x8*>(sb + offA[i][ks]);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const op16x8*>(sb + offB[j][ks]);
+  };
+  auto mma = [&](const op16x8 (&af)[FM], const op16x8 (&bfr)[FN]) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = MSAM2_MFMA_32x32x16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+  };
+  // Software pipeline across the barrier: the fragments of (tile kt+1, k-substep 0) are fetched right after the barrier that
+  // publishes tile kt+1, in the shadow of tile kt's second-substep MFMAs -- the matrix pipe never waits for an LDS round trip.
+  // The same barrier says every wave has taken its last fragments of tile kt, so tile kt+NST is streamed into kt's stage.
+#pragma unroll
+  for (int i = 0; i < NST; ++i)
+    if (nk > i) issue(i);
+  wait_groups(min(nk, NST) - 1);
+  __builtin_amdgcn_s_barrier();
+  op16x8 a0[FM], b0[FN], a1[FM], b1[FN];
+  load_frags(lds, 0, a0, b0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned char* sb = lds + (kt % NST) * STAGE_BYTES;
+    load_frags(sb, 1, a1, b1);
+    mma(a0, b0);
+    if (kt + 1 < nk) {
+      wait_groups(min(nk - 2 - kt, NST - 2));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + NST < nk) issue(kt + NST);
+      load_frags(lds + ((kt + 1) % NST) * STAGE_BYTES, 0, a0, b0);
+    }
+    mma(a1, b1);
+  }
+  __builtin_amdgcn_s_barrier();
+  gemm_epilogue<FM, FN>(p, acc, reinterpret_cast<float*>(lds) + wave * 32 * (FN * 32 + 4), m0 + wm * (BM / 2), n0 + wn * (BN / 2), lane);
 #endif
 }
 
@@ -459,15 +765,29 @@ extern "C" int msam2_gemm(const void* A, int64_t lda, const void* W, int64_t ldw
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act; p.res_is_16bit = res_is_16bit; p.out_is_16bit = out_is_16bit;
   hipStream_t s = (hipStream_t)stream;
   const char* force = getenv("MSAM2_GEMM_V1");
-  // DMA kernels: long reductions (K >= 1024) run the 128x128x64 2-stage kernel (more MFMA work per barrier); shorter ones the
-  // 128x128x32 kernel at 4 workgroups per CU, whose extra co-resident workgroups hide the per-tile prologue/epilogue that
-  // dominates when there are only a few k-steps.  MSAM2_GEMM_VARIANT = 2 | 5 forces one of them (experiments).
   const char* var = getenv("MSAM2_GEMM_VARIANT");
-  const bool dma_ok = !(force && force[0] == '1') && M >= 256 && N >= 96 && (N % 128 == 0 || N >= 256 || N % 64 != 0) &&
+  // N = 64 / 192 waste half a 128-wide tile: with a short reduction (K < 192) the register-staged 128x64 kernel is faster
+  const bool dma_ok = !(force && force[0] == '1') && M >= 256 && N >= 96 && (N % 128 == 0 || N >= 256 || N % 64 != 0 || K >= 192) &&
                       M * lda * 2 < (1ll << 31) && N * ldw * 2 < (1ll << 31);
   const int tiles = cdiv(p.N, 128) * cdiv(p.M, 128);
-  const bool want64 = var ? (var[0] == '2') : (K >= 1024);
-  if (dma_ok && K % 64 == 0 && want64) {
+  // Variant choice (measured on the benchmark step's shapes, tools/gemm_variants.py):
+  //   few tiles (<= one per CU) and a long reduction  -> 3-stage pipelined 128x128x32 (one workgroup per CU has to hide its own latency)
+  //   K % 64 == 0 and K >= 384                        -> 128x128x64 2-stage, 2 workgroups per CU (more MFMA work per barrier)
+  //   otherwise                                       -> 128x128x32 2-stage, 4 workgroups per CU (short reductions: prologue/epilogue
+  //                                                      of one workgroup overlap the main loops of the other three)
+  // MSAM2_GEMM_VARIANT = 2 | 5 | 6 | 8 | 9 | 10 | 11 forces one (experiments).
+  const int vv = var ? atoi(var) : (tiles <= 256 && K >= 1024 ? 8 : (K % 64 == 0 && K >= 384 ? 2 : 5));
+  if (dma_ok && K % 32 == 0 && vv == 6) {
+    hipLaunchKernelGGL((gemm_wide_kernel<256, 128, 3, 2>), dim3(cdiv(p.N, 128) * cdiv(p.M, 256)), dim3(256), 0, s, p);
+  } else if (dma_ok && K % 32 == 0 && vv == 8) {
+    hipLaunchKernelGGL((gemm_wide_kernel<128, 128, 3, 3>), dim3(tiles), dim3(256), 0, s, p);
+  } else if (dma_ok && K % 32 == 0 && vv == 9) {
+    hipLaunchKernelGGL((gemm_wide_kernel<256, 128, 2, 2>), dim3(cdiv(p.N, 128) * cdiv(p.M, 256)), dim3(256), 0, s, p);
+  } else if (dma_ok && K % 32 == 0 && vv == 10) {
+    hipLaunchKernelGGL((gemm_wide_kernel<128, 128, 2, 4>), dim3(tiles), dim3(256), 0, s, p);
+  } else if (dma_ok && K % 32 == 0 && vv == 11) {
+    hipLaunchKernelGGL((gemm_wide_kernel<128, 128, 4, 2>), dim3(tiles), dim3(256), 0, s, p);
+  } else if (dma_ok && K % 64 == 0 && vv == 2) {
     hipLaunchKernelGGL(gemm_glds_kernel, dim3(tiles), dim3(256), 0, s, p);
   } else if (dma_ok && K % 32 == 0) {
     hipLaunchKernelGGL((gemm_glds32_kernel<2, 4>), dim3(tiles), dim3(256), 0, s, p);
