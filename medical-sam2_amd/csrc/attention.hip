@@ -782,6 +782,92 @@ __global__ void attn_small_kernel(const op16* q, const op16* k, const op16* v, o
   }
 }
 
+// Few-queries form (tokens -> image, Lq ~ 8, Lk = 4096): one 1024-thread workgroup per (batch, head, query).  With one wave per
+// query the 4096 keys were a 64-trip chain of dependent 32-byte loads (45 us of pure latency); here every lane owns Lk/1024
+// keys whose loads are all in flight at once, followed by a wave butterfly and a 16-way merge through LDS.
+template <int D>
+__global__ __launch_bounds__(1024) void attn_fewq_kernel(const op16* q, const op16* k, const op16* v, op16* o, int64_t q_bs, int64_t q_ts,
+                                                         int64_t k_bs, int64_t k_ts, int64_t v_bs, int64_t v_ts, int64_t o_bs, int64_t o_ts,
+                                                         int B, int H, int Lq, int Lk, float scale_log2) {
+  __shared__ float part[16][D + 2];
+  const int gw = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qi = gw % Lq;
+  const int head = (gw / Lq) % H;
+  const int b = gw / (Lq * H);
+  float qv[D];
+  const op16* qp = q + b * q_bs + (int64_t)qi * q_ts + head * D;
+#pragma unroll
+  for (int d = 0; d < D; d += 8) {
+    const op16x8 t = *reinterpret_cast<const op16x8*>(qp + d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[d + e] = op2f(t[e]) * scale_log2;
+  }
+  float m = -INFINITY, l = 0.f, acc[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) acc[d] = 0.f;
+  const op16* kb = k + b * k_bs + head * D;
+  const op16* vb = v + b * v_bs + head * D;
+#pragma unroll 4
+  for (int key = threadIdx.x; key < Lk; key += 1024) {
+    const op16* kp = kb + (int64_t)key * k_ts;
+    const op16* vp = vb + (int64_t)key * v_ts;
+    float s = 0.f;
+    float vv[D];
+#pragma unroll
+    for (int d = 0; d < D; d += 8) {
+      const op16x8 t = *reinterpret_cast<const op16x8*>(kp + d);
+      const op16x8 u = *reinterpret_cast<const op16x8*>(vp + d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s += qv[d + e] * op2f(t[e]);
+        vv[d + e] = op2f(u[e]);
+      }
+    }
+    const float mn = fmaxf(m, s);
+    const float a = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - mn);
+    const float pe = __builtin_amdgcn_exp2f(s - mn);
+    l = l * a + pe;
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] = acc[d] * a + pe * vv[d];
+    m = mn;
+  }
+  auto merge = [&](int off) {
+    const float m2 = __shfl_xor(m, off, 64), l2 = __shfl_xor(l, off, 64);
+    const float mn = fmaxf(m, m2);
+    const float a1 = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - mn);
+    const float a2 = (m2 == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m2 - mn);
+    l = l * a1 + l2 * a2;
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] = acc[d] * a1 + __shfl_xor(acc[d], off, 64) * a2;
+    m = mn;
+  };
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) merge(off);
+  if (lane == 0) {
+    part[wave][0] = m;
+    part[wave][1] = l;
+#pragma unroll
+    for (int d = 0; d < D; ++d) part[wave][2 + d] = acc[d];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int w = lane & 15;
+    m = part[w][0];
+    l = part[w][1];
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] = part[w][2 + d];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) merge(off);
+    if (lane == 0) {
+      op16* op = o + b * o_bs + (int64_t)qi * o_ts + head * D;
+      const float inv = 1.f / l;
+#pragma unroll
+      for (int d = 0; d < D; ++d) op[d] = f2op(acc[d] * inv);
+    }
+  }
+}
+
 // q/k/v/o: op16 [B, L, H*D] with element strides {batch, token}
 // Few-keys form (image -> tokens, Lk <= 32): one THREAD per (batch, head, query); the handful of keys/values of a (batch, head)
 // is read by every thread of it (L1 broadcast), scores and the softmax live in registers.
@@ -858,6 +944,16 @@ extern "C" int msam2_attention_small_fwd(const void* q, int64_t q_bs, int64_t q_
       hipLaunchKernelGGL((attn_fewkeys_kernel<32>), g1, dim3(256), 0, s, (const op16*)q, (const op16*)k, (const op16*)v, (op16*)o, q_bs,
                          q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts, (int)B, (int)H, (int)Lq, (int)Lk, sl);
     return msam2_check_launch("attention_small(fewkeys)");
+  }
+  if (Lk >= 1024 && B * H * Lq <= 4096) {
+    dim3 g2((unsigned)(B * H * Lq));
+    if (D == 16)
+      hipLaunchKernelGGL((attn_fewq_kernel<16>), g2, dim3(1024), 0, s, (const op16*)q, (const op16*)k, (const op16*)v, (op16*)o, q_bs, q_ts,
+                         k_bs, k_ts, v_bs, v_ts, o_bs, o_ts, (int)B, (int)H, (int)Lq, (int)Lk, sl);
+    else
+      hipLaunchKernelGGL((attn_fewq_kernel<32>), g2, dim3(1024), 0, s, (const op16*)q, (const op16*)k, (const op16*)v, (op16*)o, q_bs, q_ts,
+                         k_bs, k_ts, v_bs, v_ts, o_bs, o_ts, (int)B, (int)H, (int)Lq, (int)Lk, sl);
+    return msam2_check_launch("attention_small(fewq)");
   }
   const int64_t waves = B * H * Lq;
   dim3 grid(cdiv(waves * 64, 256));

@@ -307,11 +307,15 @@ extern "C" int msam2_prompt_points(const float* xy, const int* labels, const flo
 // gated by the object score (<= 0 -> NO_OBJ_SCORE).  Writes low_res [n,1,h,w], sel[n] (chosen token index 0..3),
 // iou_sel[n].  masks: fp32 [n,4,h,w]; ious: [n,4]; obj: [n].
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void select_mask_kernel(const float* __restrict__ masks, const float* __restrict__ ious, const float* __restrict__ obj,
-                                   float* __restrict__ low, int* __restrict__ sel, float* __restrict__ iou_sel, int P, int multimask,
-                                   int dynamic, float delta, float thresh) {
-  __shared__ int s_sel;
-  __shared__ float red_i[256], red_u[256];
+// grid (n, SELECT_SPLIT): every workgroup of an image evaluates the stability score itself (the token-0 mask is 256 KB and
+// L2-resident; 16-byte loads, 8 in flight per lane) and then copies its 1/SELECT_SPLIT share of the chosen mask -- one launch,
+// no workspace, and the latency of a single 256-thread sweep over the image no longer bounds the step.
+constexpr int SELECT_SPLIT = 8;
+__global__ __launch_bounds__(256) void select_mask_kernel(const float* __restrict__ masks, const float* __restrict__ ious,
+                                                          const float* __restrict__ obj, float* __restrict__ low, int* __restrict__ sel,
+                                                          float* __restrict__ iou_sel, int P, int multimask, int dynamic, float delta,
+                                                          float thresh) {
+  __shared__ float red_i[4], red_u[4];
   const int b = blockIdx.x;
   const float* m = masks + (int64_t)b * 4 * P;
   int best = 1;
@@ -323,38 +327,50 @@ __global__ void select_mask_kernel(const float* __restrict__ masks, const float*
     choice = 0;
     if (dynamic) {
       float ai = 0.f, au = 0.f;
-      for (int i = threadIdx.x; i < P; i += blockDim.x) {
-        ai += m[i] > delta ? 1.f : 0.f;
-        au += m[i] > -delta ? 1.f : 0.f;
+      const int P4 = P >> 2;   // P is a multiple of 4 on this path (checked on the host)
+      const f32x4* m4 = reinterpret_cast<const f32x4*>(m);
+      for (int i0 = threadIdx.x; i0 < P4; i0 += 8 * 256) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u * 256;
+          v[u] = i < P4 ? m4[i] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            ai += v[u][q] > delta ? 1.f : 0.f;
+            au += v[u][q] > -delta ? 1.f : 0.f;
+          }
       }
-      red_i[threadIdx.x] = ai;
-      red_u[threadIdx.x] = au;
+      ai = wave_sum(ai);
+      au = wave_sum(au);
+      if ((threadIdx.x & 63) == 0) { red_i[threadIdx.x >> 6] = ai; red_u[threadIdx.x >> 6] = au; }
       __syncthreads();
-      for (int o = blockDim.x / 2; o > 0; o >>= 1) {
-        if (threadIdx.x < o) { red_i[threadIdx.x] += red_i[threadIdx.x + o]; red_u[threadIdx.x] += red_u[threadIdx.x + o]; }
-        __syncthreads();
-      }
-      const float stab = red_u[0] > 0.f ? red_i[0] / red_u[0] : 1.f;
+      const float ti = red_i[0] + red_i[1] + red_i[2] + red_i[3], tu = red_u[0] + red_u[1] + red_u[2] + red_u[3];
+      const float stab = tu > 0.f ? ti / tu : 1.f;
       if (!(stab >= thresh)) choice = best;
     }
   }
-  if (threadIdx.x == 0) {
-    s_sel = choice;
+  if (threadIdx.x == 0 && blockIdx.y == 0) {
     sel[b] = choice;
     iou_sel[b] = ious[b * 4 + choice];
   }
-  __syncthreads();
   const bool appearing = obj[b] > 0.f;
-  const float* src = m + (int64_t)s_sel * P;
-  for (int i = threadIdx.x; i < P; i += blockDim.x) low[(int64_t)b * P + i] = appearing ? src[i] : -1024.0f;
+  const float* src = m + (int64_t)choice * P;
+  const int per = (P + SELECT_SPLIT - 1) / SELECT_SPLIT;
+  const int lo = blockIdx.y * per, hi = min(P, lo + per);
+  for (int i = lo + threadIdx.x; i < hi; i += 256) low[(int64_t)b * P + i] = appearing ? src[i] : -1024.0f;
 }
 
 extern "C" int msam2_select_mask(const float* masks, const float* ious, const float* obj_scores, float* low_res, int* sel,
                                  float* iou_sel, int64_t n, int64_t P, int multimask, int dynamic_stability, float delta,
                                  float thresh, void* stream) {
   MSAM2_REQUIRE(masks && ious && obj_scores && low_res && sel && iou_sel && n > 0 && P > 0, "select_mask: bad arguments");
-  hipLaunchKernelGGL(select_mask_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, masks, ious, obj_scores, low_res, sel,
-                     iou_sel, (int)P, multimask, dynamic_stability, delta, thresh);
+  MSAM2_REQUIRE(P % 4 == 0 && ((uintptr_t)masks & 15) == 0, "select_mask: masks must be 16-byte aligned with H*W %% 4 == 0");
+  hipLaunchKernelGGL(select_mask_kernel, dim3((unsigned)n, SELECT_SPLIT), dim3(256), 0, (hipStream_t)stream, masks, ious, obj_scores,
+                     low_res, sel, iou_sel, (int)P, multimask, dynamic_stability, delta, thresh);
   return msam2_check_launch("select_mask");
 }
 

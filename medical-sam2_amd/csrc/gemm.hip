@@ -256,6 +256,17 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x16
 #endif
 }
 
+// >= 0: the epilogue of this problem runs on the direct (no LDS) path in that mode; -1: it needs the LDS scratch
+__device__ __forceinline__ int gemm_epilogue_direct_mode(const GemmParams& p) {
+  const bool aligned = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                       (!p.res || (((p.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0) && !p.res_is_16bit)) &&
+                       (!p.bias || ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0)) &&
+                       (!p.colscale || ((reinterpret_cast<uintptr_t>(p.colscale) & 15) == 0));
+  const bool direct = aligned && p.res_mod == 0 && (int64_t)p.M * p.ldc * 4 < (1ll << 31) && (!p.res || (int64_t)p.M * p.ldr * 4 < (1ll << 31));
+  const int mode = p.act * 4 + (p.res ? 2 : 0) + (p.out_is_16bit ? 1 : 0);
+  return (direct && (mode == 1 || mode == 0 || mode == 2 || mode == 5 || mode == 9)) ? mode : -1;
+}
+
 template <int FM, int FN>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[FM][FN], float* scr, int64_t row0, int64_t col0,
                                               int lane) {
@@ -743,6 +754,67 @@ __global__ __launch_bounds__(256, OCC) void gemm_wide_kernel(GemmParams p) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Skinny GEMM for M <= 32 (decoder tokens, hyper-network / IoU / object-pointer MLPs: 4..32 rows): one workgroup per 32
+// output columns, its 4 waves split K, operand fragments come straight from global memory (row r, 8 consecutive k = one
+// 16-byte load per lane per operand per MFMA, all independent => the whole reduction is in flight at once), partial 32x32
+// tiles are summed through LDS.  The tiled kernel walks K serially with one global->LDS->MFMA round trip per 32 k: at
+// K = 2048 that is 64 dependent trips (~40 us) for 0.03 GFLOP.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
+  __shared__ float part[4][32][33];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t n0 = (int64_t)blockIdx.x * 32;
+  const int ksteps = p.K / 16;                      // K % 16 == 0 (host check)
+  const int per = (ksteps + 3) / 4;
+  const int s0 = wave * per, s1 = min(ksteps, s0 + per);
+  const op16* ap = p.A + (int64_t)min(r, p.M - 1) * p.lda + h * 8;
+  const op16* wp = p.W + min(n0 + r, (int64_t)p.N - 1) * p.ldw + h * 8;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  int st = s0;
+  for (; st + 8 <= s1; st += 8) {
+    op16x8 a[8], w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a[u] = *reinterpret_cast<const op16x8*>(ap + (st + u) * 16);
+      w[u] = *reinterpret_cast<const op16x8*>(wp + (st + u) * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = MSAM2_MFMA_32x32x16(a[u], w[u], acc, 0, 0, 0);
+  }
+  for (; st < s1; ++st) {
+    const op16x8 a = *reinterpret_cast<const op16x8*>(ap + st * 16);
+    const op16x8 w = *reinterpret_cast<const op16x8*>(wp + st * 16);
+    acc = MSAM2_MFMA_32x32x16(a, w, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) part[wave][(e & 3) + 8 * (e >> 2) + 4 * h][r] = acc[e];
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int idx = t * 256 + tid;
+    const int row = idx >> 5, col = idx & 31;
+    const int64_t n = n0 + col;
+    if (row < p.M && n < p.N) {
+      float x = part[0][row][col] + part[1][row][col] + part[2][row][col] + part[3][row][col] + (p.bias ? p.bias[n] : 0.f);
+      if (p.act == 1) x = gelu_erf(x);
+      else if (p.act == 2) x = fmaxf(x, 0.f);
+      else if (p.act == 3) x = 1.f / (1.f + __expf(-x));
+      if (p.colscale) x *= p.colscale[n];
+      if (p.res) {
+        const int64_t rr = p.res_mod > 0 ? (int64_t)((unsigned)row % (unsigned)p.res_mod) : row;
+        x += p.res_is_16bit ? op2f(reinterpret_cast<const op16*>(p.res)[rr * p.ldr + n]) : reinterpret_cast<const float*>(p.res)[rr * p.ldr + n];
+      }
+      if (p.out_is_16bit) reinterpret_cast<op16*>(p.C)[(int64_t)row * p.ldc + n] = f2op(x);
+      else reinterpret_cast<float*>(p.C)[(int64_t)row * p.ldc + n] = x;
+    }
+  }
+}
+
 template <int BM, int BN, int WM, int WN>
 static void launch_gemm(const GemmParams& p, hipStream_t s) {
   dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM));
@@ -791,6 +863,8 @@ extern "C" int msam2_gemm(const void* A, int64_t lda, const void* W, int64_t ldw
     hipLaunchKernelGGL(gemm_glds_kernel, dim3(tiles), dim3(256), 0, s, p);
   } else if (dma_ok && K % 32 == 0) {
     hipLaunchKernelGGL((gemm_glds32_kernel<2, 4>), dim3(tiles), dim3(256), 0, s, p);
+  } else if (M <= 32 && K % 16 == 0) {
+    hipLaunchKernelGGL(gemm_skinny_kernel, dim3(cdiv(p.N, 32)), dim3(256), 0, s, p);
   } else if (M <= 32) launch_gemm<32, 128, 1, 4>(p, s);
   else if (N <= 32) launch_gemm<128, 32, 4, 1>(p, s);
   else if (N <= 64 || (N % 128 != 0 && N % 64 == 0 && N < 512)) launch_gemm<128, 64, 2, 2>(p, s);

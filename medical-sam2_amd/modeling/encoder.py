@@ -253,19 +253,36 @@ class FpnNeck(nn.Module):
         self.fpn_top_down_levels = list(range(len(self.convs)) if fpn_top_down_levels is None else fpn_top_down_levels)
         self._wc = WeightCache()
 
-    def forward(self, xs: List[torch.Tensor]):
+    def forward(self, xs: List[torch.Tensor], post_convs=None):
+        """post_convs (private, used by SAM2Base.forward_image): {level: 1x1 nn.Conv2d applied to that level's output}.  On a level
+        that takes no part in the top-down pathway the lateral conv and the following 1x1 conv are two linear maps in a row, so
+        they run as ONE GEMM with the composed weight W_post W_lat / bias W_post b_lat + b_post (composed in fp32): the
+        256-channel level-0 map (268 MB fp32 at 4 x 1024^2) is then never written, converted or read back."""
         out, pos = [None] * len(self.convs), [None] * len(self.convs)
         assert len(xs) == len(self.convs)
         prev = None
         n = len(self.convs) - 1
+        td = self.fpn_top_down_levels
         for i in range(n, -1, -1):
             B, C, H, W = xs[i].shape
             conv = self.convs[n - i].conv
-            lat = ops.gemm(to_bf16(tokens_of(xs[i])), w_bf16(self._wc, f"w{i}", conv.weight), v_f32(self._wc, f"b{i}", conv.bias),
-                           out_dtype=F32)
-            if i in self.fpn_top_down_levels and prev is not None:
-                ops.upsample2x_add_(lat, prev, B, H, W)
-            prev = lat
+            pc = post_convs.get(i) if post_convs else None
+            if pc is not None and i not in td and (i == 0 or (i - 1) not in td):
+                w = self._wc.get(f"cw{i}", [conv.weight, pc.weight], lambda: (
+                    pc.weight.detach().float().reshape(pc.weight.shape[0], -1) @ conv.weight.detach().float().reshape(conv.weight.shape[0], -1)
+                ).to(OP16).contiguous())
+                b = self._wc.get(f"cb{i}", [conv.bias, pc.weight, pc.bias], lambda: (
+                    pc.weight.detach().float().reshape(pc.weight.shape[0], -1) @ conv.bias.detach().float() + pc.bias.detach().float()).contiguous())
+                lat = ops.gemm(to_bf16(tokens_of(xs[i])), w, b, out_dtype=F32)
+                prev = None
+            else:
+                lat = ops.gemm(to_bf16(tokens_of(xs[i])), w_bf16(self._wc, f"w{i}", conv.weight), v_f32(self._wc, f"b{i}", conv.bias),
+                               out_dtype=F32)
+                if i in td and prev is not None:
+                    ops.upsample2x_add_(lat, prev, B, H, W)
+                prev = lat
+                if pc is not None:
+                    lat = ops.gemm(to_bf16(lat), w_bf16(self._wc, f"pw{i}", pc.weight), v_f32(self._wc, f"pb{i}", pc.bias), out_dtype=F32)
             out[i] = nchw_view(lat, B, H, W)
             pos[i] = self.position_encoding(out[i]).to(out[i].dtype)
         return out, pos
@@ -280,8 +297,8 @@ class ImageEncoder(nn.Module):
         assert self.trunk.channel_list == self.neck.backbone_channel_list, \
             f"Channel dims of trunk and neck do not match. Trunk: {self.trunk.channel_list}, neck: {self.neck.backbone_channel_list}"
 
-    def forward(self, sample: torch.Tensor):
-        features, pos = self.neck(self.trunk(sample))
+    def forward(self, sample: torch.Tensor, post_convs=None):
+        features, pos = self.neck(self.trunk(sample), post_convs) if post_convs else self.neck(self.trunk(sample))
         if self.scalp > 0:
             features, pos = features[: -self.scalp], pos[: -self.scalp]
         return {"vision_features": features[-1], "vision_pos_enc": pos, "backbone_fpn": features}

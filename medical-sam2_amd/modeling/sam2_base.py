@@ -130,12 +130,11 @@ class SAM2Base(nn.Module):
     # ---------------------------------------------------------------------------------------------------------------
     def forward_image(self, img_batch: torch.Tensor):
         """sam2_base.py:464-476."""
-        backbone_out = self.image_encoder(img_batch)
+        if not self.use_high_res_features_in_sam:
+            return self.image_encoder(img_batch)
+        # conv_s0 / conv_s1 (sam2_base.py:470-475) are folded into the neck's lateral convs of levels 0 / 1 (FpnNeck.forward)
         dec = self.sam_mask_decoder
-        for lvl in (0, 1):
-            f = backbone_out["backbone_fpn"][lvl]
-            B, _, H, W = f.shape
-            backbone_out["backbone_fpn"][lvl] = nchw_view(dec.conv_s(lvl, to_bf16(tokens_of(f)), out_dtype=F32), B, H, W)
+        backbone_out = self.image_encoder(img_batch, post_convs={0: dec.conv_s0, 1: dec.conv_s1})
         return backbone_out
 
     def _prepare_backbone_features(self, backbone_out):

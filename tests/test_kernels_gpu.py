@@ -56,7 +56,8 @@ def close(a, b, atol, rtol=0.0, what=""):
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (5, 288, 96), (300, 96, 384), (70, 32, 64), (257, 576, 160), (33, 64, 16),
                                    (1000, 2048, 256), (8, 4, 256), (4096, 768, 256), (300, 128, 64), (257, 640, 192), (4099, 1152, 384),
-                                   (513, 576, 576), (256, 1536, 3072)])
+                                   (513, 576, 576), (256, 1536, 3072), (4, 256, 256), (32, 2048, 256), (7, 256, 2048), (5, 1, 256),
+                                   (31, 33, 48), (32, 128, 24), (16384, 256, 2048), (2500, 192, 768), (700, 1536, 384)])
 def test_gemm_exact_integers(ops, M, N, K):
     g = torch.Generator().manual_seed(M * 7 + N)
     a = torch.randint(-3, 4, (M, K), generator=g).float()
@@ -88,6 +89,31 @@ def test_gemm_epilogues(ops):
     ops.gemm(wide[:, K:2 * K], w.to(DEV), out=buf[:, N:])
     close(buf[:, N:], wide[:, K:2 * K].float().cpu() @ w.float().t(), 2e-4, 1e-5, "gemm strided")
     assert buf[:, :N].abs().sum().item() == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 96), (1000, 384, 384), (8, 256, 2048), (260, 192, 192)])
+def test_gemm_epilogue_modes(ops, M, N, K):
+    """Every specialised epilogue (direct stores from the accumulator layout: linear -> 16-bit / fp32, + fp32 residual, GELU /
+    ReLU -> 16-bit), the LDS path (row-modulo residual) and the generic fallback (sigmoid, 16-bit residual, unaligned views)."""
+    a, w = bf(rnd(M, K, seed=11)), bf(rnd(N, K, seed=12, scale=0.2))
+    bias, cs, res = rnd(N, seed=13), rnd(N, seed=14), rnd(M, N, seed=15)
+    lin = a.float() @ w.float().t() + bias
+    d = lambda t: t.to(DEV)
+    close(ops.gemm(d(a), d(w), d(bias), out_dtype=OP16()), lin, 1e-3, 8e-3, "linear->16")
+    close(ops.gemm(d(a), d(w), d(bias), out_dtype=torch.float32), lin, 2e-4, 1e-5, "linear->f32")
+    close(ops.gemm(d(a), d(w), d(bias), residual=d(res), out_dtype=torch.float32), lin + res, 2e-4, 1e-5, "+res->f32")
+    close(ops.gemm(d(a), d(w), d(bias), colscale=d(cs), residual=d(res), out_dtype=torch.float32), lin * cs + res, 2e-4, 1e-5, "scale+res")
+    close(ops.gemm(d(a), d(w), d(bias), act=ops.ACT_GELU, out_dtype=OP16()), O.gelu(lin), 1e-3, 8e-3, "gelu->16")
+    close(ops.gemm(d(a), d(w), d(bias), act=ops.ACT_RELU, out_dtype=OP16()), torch.relu(lin), 1e-3, 8e-3, "relu->16")
+    close(ops.gemm(d(a), d(w), d(bias), act=ops.ACT_SIGMOID, out_dtype=torch.float32), torch.sigmoid(lin), 2e-4, 1e-5, "sigmoid")
+    close(ops.gemm(d(a), d(w), d(bias), act=ops.ACT_GELU, out_dtype=torch.float32), O.gelu(lin), 2e-4, 1e-5, "gelu->f32 (generic)")
+    close(ops.gemm(d(a), d(w), d(bias), residual=d(bf(res)), out_dtype=torch.float32), lin + bf(res).float(), 2e-4, 1e-5, "16-bit residual")
+    # unaligned output view (column offset 1 of a wider fp32 buffer) and N not a multiple of 4
+    buf = torch.zeros(M, N + 3, dtype=torch.float32, device=DEV)
+    ops.gemm(d(a), d(w), d(bias), out=buf[:, 1:N + 1])
+    close(buf[:, 1:N + 1], lin, 2e-4, 1e-5, "unaligned view")
+    assert buf[:, 0].abs().sum().item() == 0 and buf[:, N + 1:].abs().sum().item() == 0
+    close(ops.gemm(d(a), d(w[:N - 2]), d(bias[:N - 2]), out_dtype=OP16()), lin[:, :N - 2], 1e-3, 8e-3, "N % 4 != 0")
 
 
 def test_gemm_rejects_bad_shapes(ops):
@@ -181,7 +207,8 @@ def test_window_attention_vs_oracle(ops, B, Hh, Ww, heads, ws, pool):
     close(out, ref, 0.02, 0.01, "window attention")
 
 
-@pytest.mark.parametrize("B,Lq,Lk,heads,C", [(2, 8, 256, 8, 128), (2, 256, 8, 8, 128), (3, 7, 7, 8, 256), (1, 9, 4096, 8, 128)])
+@pytest.mark.parametrize("B,Lq,Lk,heads,C", [(2, 8, 256, 8, 128), (2, 256, 8, 8, 128), (3, 7, 7, 8, 256), (1, 9, 4096, 8, 128),
+                                            (2, 8, 1500, 8, 256)])
 def test_attention_small(ops, B, Lq, Lk, heads, C):
     q, k, v = bf(rnd(B, Lq, C, seed=1)), bf(rnd(B, Lk, C, seed=2)), bf(rnd(B, Lk, C, seed=3))
     D = C // heads
