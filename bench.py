@@ -81,8 +81,11 @@ def assemble_memory(m, bank_feats, sampled):
 
 
 def time_dominant_kernel(device, batch):
-    """HIP-event timing (on the launch stream) of the D=256 single-head flash attention at the cross-attention shape of this
-    workload: Lq = 4096, Lk = batch*4096 per slice.  Returns (avg seconds per launch, flops per launch, bytes per launch)."""
+    """HIP-event timing (on the launch stream) of the dominant kernel -- the D=256 single-head flash attention (split-KV pass,
+    attn_glds_kernel<256,256,4,2>) at the cross-attention shape of this workload: Lq = 4096, Lk = batch*4096 per slice.
+    The split pass is launched alone (negative split count, partials stay in a caller-owned workspace) so the figure is that
+    kernel's own average duration, comparable with rocprofv3's kernel trace; the fwd+merge pair is timed as well.
+    Returns (avg seconds per launch of the kernel, flops, algorithmic bytes, splits, avg seconds of the fwd+merge pair)."""
     import medical_sam2_amd.ops as ops
     from medical_sam2_amd._lib import lib, check
     from medical_sam2_amd.modeling.common import attn_splits
@@ -93,25 +96,52 @@ def time_dominant_kernel(device, batch):
     v = (torch.randn(B, 1, Lk, D, generator=g)).to(ops.OP16).to(device)
     splits = attn_splits(B, 1, Lq, Lk)
     out = torch.empty(B, Lq, 1, D, dtype=ops.OP16, device=device).permute(0, 2, 1, 3)
-    for _ in range(3):
-        ops.attention(q, k, v, splits=splits, out=out)
-    torch.cuda.synchronize()
+    ws = ops.attention_workspace(B, 1, Lq, D, splits, device)
     stream = torch.cuda.current_stream().cuda_stream
     e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
     check(lib().msam2_event_create(ctypes.byref(e0)))
     check(lib().msam2_event_create(ctypes.byref(e1)))
     n = 20
-    check(lib().msam2_event_record(e0, stream))
-    for _ in range(n):
-        ops.attention(q, k, v, splits=splits, out=out)
-    check(lib().msam2_event_record(e1, stream))
-    ms = ctypes.c_float()
-    check(lib().msam2_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        check(lib().msam2_event_record(e0, stream))
+        for _ in range(n):
+            fn()
+        check(lib().msam2_event_record(e1, stream))
+        ms = ctypes.c_float()
+        check(lib().msam2_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+        return ms.value / 1e3 / n
+
+    defer = splits > 1
+    t_kernel = timed(lambda: ops.attention(q, k, v, splits=splits, out=out, workspace=ws, defer_merge=defer))
+    t_pair = timed(lambda: ops.attention(q, k, v, splits=splits, out=out, workspace=ws))
     lib().msam2_event_destroy(e0)
     lib().msam2_event_destroy(e1)
     flops = 4.0 * B * Lq * Lk * D
     bytes_ = 2.0 * B * (2 * Lq * D + 2 * Lk * D)
-    return ms.value / 1e3 / n, flops, bytes_, splits
+    return t_kernel, flops, bytes_, splits, t_pair
+
+
+def pmc_traffic():
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/, collected with
+    `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on tools/one_attn.py at this exact shape): counter units of 1 KiB, FETCH_SIZE doubled on
+    gfx950 (MI355X_MICROARCH.md, HBM/rocprofv3 section).  None when the files are absent."""
+    import csv
+    here = os.path.dirname(os.path.abspath(__file__))
+    tot = 0.0
+    for name, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        path = os.path.join(here, "profiles", f"r01_attn256_pmc_{name}.csv")
+        if not os.path.exists(path):
+            return None
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+                if r.get("Counter_Name") == name and "attn_glds_kernel" in r.get("Kernel_Name", "")]
+        if not vals:
+            return None
+        tot += mult * 1024.0 * sum(vals) / len(vals)
+    return tot
 
 
 def cpu_baseline():
@@ -213,7 +243,7 @@ def main():
     import medical_sam2_amd.ops as ops
     if rank == 0:
         slices = args.batch * args.steps * world
-        k_s, k_flops, k_bytes, splits = time_dominant_kernel(device, args.batch)
+        k_s, k_flops, k_bytes, splits, pair_s = time_dominant_kernel(device, args.batch)
         achieved = k_flops / k_s / 1e12
         line = {
             "metric": "slices/sec @1024^2 (Hiera-S)", "value": slices / dt, "unit": "slices/s", "n_gpus": world,
@@ -224,9 +254,10 @@ def main():
                                    "forward_image -> memory_attention -> prompt encoder -> mask decoder -> memory encoder",
                        "slices_per_step_per_gpu": args.batch, "hip_graph": graph is not None, "weights": "random name-keyed init"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
-                         "kernel": f"attn_fwd_kernel<256,4,false> (+merge, split-KV {splits}) at B={args.batch} Lq=4096 Lk={args.batch * 4096}",
-                         "avg_launch_us": k_s * 1e6, "flops_per_launch": k_flops, "algorithmic_bytes_per_launch": k_bytes,
+                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(),
+                         "kernel": f"attn_glds_kernel<256,256,4,2> (split-KV pass, {splits} splits) at B={args.batch} Lq=4096 Lk={args.batch * 4096}",
+                         "avg_launch_us": k_s * 1e6, "with_merge_us": pair_s * 1e6, "flops_per_launch": k_flops,
+                         "algorithmic_bytes_per_launch": k_bytes,
                          "hbm_GBs_on_algorithmic_bytes": k_bytes / k_s / 1e9, "hbm_frac_of_peak": k_bytes / k_s / 1e9 / HBM_PEAK_GBS},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -39,6 +39,7 @@ struct AttnParams {
   const float *kpad, *vpad;  // [H*D] fp32 rows standing in for zero-padded tokens (the qkv bias slices)
   // split-KV
   int splits;
+  int defer_merge;  // split-KV partials stay in the workspace; msam2_attention_merge finishes (benchmark / overlap use)
   float* o_part;   // [splits][Bz][H][Lq][D] fp32, unnormalised
   float* ml_part;  // [splits][Bz][H][Lq][2]  (running max in log2 domain, partial sum)
 };
@@ -604,7 +605,7 @@ static int launch_attn_glds(const AttnParams& p, int Bz, hipStream_t s) {
   dim3 grid(cdiv(p.Lq, 128), p.H, Bz * p.splits);
   if constexpr (D == 96) hipLaunchKernelGGL((attn_glds_kernel<96, 128, 4, 3>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((attn_glds_kernel<D, D, 4, 2>), grid, dim3(256), 0, s, p);
-  if (p.splits > 1) {
+  if (p.splits > 1 && !p.defer_merge) {
     const int64_t rows = (int64_t)Bz * p.H * p.Lq;
     hipLaunchKernelGGL((attn_merge_kernel<D>), dim3(cdiv(rows * 64, 256)), dim3(256), 0, s, p, Bz);
   }
@@ -621,7 +622,7 @@ static int launch_attn(const AttnParams& p, int Bz, hipStream_t s) {
   }
   dim3 grid(cdiv(p.Lq, NW * 32), p.H, Bz * p.splits);
   hipLaunchKernelGGL((attn_fwd_kernel<D, NW, WIN>), grid, dim3(NW * 64), C::LDS_BYTES, s, p);
-  if (p.splits > 1) {
+  if (p.splits > 1 && !p.defer_merge) {
     const int64_t rows = (int64_t)Bz * p.H * p.Lq;
     hipLaunchKernelGGL((attn_merge_kernel<D>), dim3(cdiv(rows * 64, 256)), dim3(256), 0, s, p, Bz);
   }
@@ -640,7 +641,44 @@ extern "C" size_t msam2_attention_workspace_bytes(int64_t Bz, int64_t H, int64_t
   return (size_t)splits * Bz * H * Lq * (D + 2) * sizeof(float);
 }
 
+// every split must own at least one 32-key tile
+static int attn_effective_splits(int64_t Lk, int splits) {
+  const int tiles = (int)((Lk + 31) / 32);
+  if (splits > tiles) splits = tiles;
+  while (splits > 1 && (int64_t)(splits - 1) * ((tiles + splits - 1) / splits) >= tiles) --splits;
+  return splits;
+}
+
+// Second half of a split-KV call made with a negative split count: combines the partial (max, sum, O) triples of the
+// workspace into o.  Same B, H, Lq, Lk, D, |splits| and workspace as the msam2_attention_fwd call it completes.
+extern "C" int msam2_attention_merge(void* o, const int64_t* o_strides, int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t D,
+                                     int splits, void* workspace, size_t workspace_bytes, void* stream) {
+  MSAM2_REQUIRE(o && workspace && B > 0 && H > 0 && Lq > 0 && Lk > 0, "attention_merge: bad arguments");
+  MSAM2_REQUIRE(D == 96 || D == 256 || D == 64 || D == 128, "attention_merge: head dim %lld not built", (long long)D);
+  splits = attn_effective_splits(Lk, splits < 0 ? -splits : splits);
+  MSAM2_REQUIRE(splits > 1, "attention_merge: nothing to merge");
+  MSAM2_REQUIRE(workspace_bytes >= msam2_attention_workspace_bytes(B, H, Lq, D, splits), "attention_merge: workspace too small");
+  AttnParams p = {};
+  p.o = (op16*)o;
+  p.o_bs = o_strides[0]; p.o_hs = o_strides[1]; p.o_ts = o_strides[2];
+  p.B = (int)B; p.H = (int)H; p.Lq = (int)Lq; p.Lk = (int)Lk;
+  p.splits = splits;
+  p.o_part = (float*)workspace;
+  p.ml_part = p.o_part + (size_t)splits * B * H * Lq * D;
+  const int64_t rows = B * H * Lq;
+  dim3 grid(cdiv(rows * 64, 256));
+  hipStream_t s = (hipStream_t)stream;
+  switch (D) {
+    case 96: hipLaunchKernelGGL((attn_merge_kernel<96>), grid, dim3(256), 0, s, p, (int)B); break;
+    case 256: hipLaunchKernelGGL((attn_merge_kernel<256>), grid, dim3(256), 0, s, p, (int)B); break;
+    case 64: hipLaunchKernelGGL((attn_merge_kernel<64>), grid, dim3(256), 0, s, p, (int)B); break;
+    default: hipLaunchKernelGGL((attn_merge_kernel<128>), grid, dim3(256), 0, s, p, (int)B); break;
+  }
+  return msam2_check_launch("attention_merge");
+}
+
 // q,k,v,o: op16 with element strides {batch, head, token}; the head dim D is contiguous.
+// splits > 1: split-KV (flash-decoding) over `splits` key ranges + merge; splits < 0: the split pass only (see above).
 extern "C" int msam2_attention_fwd(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
                                    const void* v, const int64_t* v_strides, void* o, const int64_t* o_strides, int64_t B,
                                    int64_t H, int64_t Lq, int64_t Lk, int64_t D, float scale, int splits, void* workspace,
@@ -648,15 +686,16 @@ extern "C" int msam2_attention_fwd(const void* q, const int64_t* q_strides, cons
   MSAM2_REQUIRE(q && k && v && o, "attention: null tensor");
   MSAM2_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attention: empty problem");
   MSAM2_REQUIRE(D == 96 || D == 256 || D == 64 || D == 128, "attention: head dim %lld not built (96/256/64/128)", (long long)D);
+  // splits < 0: run the split-KV pass only and leave the partials in the workspace for msam2_attention_merge
+  const bool defer = splits < 0;
+  if (defer) splits = -splits;
   MSAM2_REQUIRE(splits >= 1 && splits <= 64, "attention: bad split count %d", splits);
   for (int i = 0; i < 3; ++i)
     MSAM2_REQUIRE(q_strides[i] % 8 == 0 && k_strides[i] % 8 == 0 && v_strides[i] % 8 == 0 && o_strides[i] % 4 == 0,
                   "attention: strides must keep 16-byte row alignment");
-  const int tiles = (int)((Lk + 31) / 32);
-  if (splits > tiles) splits = tiles;
-  // every split must own at least one tile
-  while (splits > 1 && (int64_t)(splits - 1) * ((tiles + splits - 1) / splits) >= tiles) --splits;
+  splits = attn_effective_splits(Lk, splits);
   MSAM2_REQUIRE(workspace_bytes >= msam2_attention_workspace_bytes(B, H, Lq, D, splits), "attention: workspace too small");
+  MSAM2_REQUIRE(!defer || splits > 1, "attention: a deferred merge needs an effective split count > 1");
   AttnParams p = {};
   p.q = (const op16*)q; p.k = (const op16*)k; p.v = (const op16*)v; p.o = (op16*)o;
   p.q_bs = q_strides[0]; p.q_hs = q_strides[1]; p.q_ts = q_strides[2];
@@ -666,6 +705,7 @@ extern "C" int msam2_attention_fwd(const void* q, const int64_t* q_strides, cons
   p.B = (int)B; p.H = (int)H; p.Lq = (int)Lq; p.Lk = (int)Lk;
   p.scale_log2 = scale * 1.4426950408889634f;
   p.splits = splits;
+  p.defer_merge = defer ? 1 : 0;
   p.o_part = (float*)workspace;
   p.ml_part = p.o_part ? p.o_part + (size_t)splits * B * H * Lq * D : nullptr;
   hipStream_t s = (hipStream_t)stream;

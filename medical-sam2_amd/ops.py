@@ -82,9 +82,11 @@ def _strides3(t: torch.Tensor) -> "ctypes.Array":
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, splits: int = 1,
-              out: Optional[torch.Tensor] = None, scale: Optional[float] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, scale: Optional[float] = None, workspace: Optional[torch.Tensor] = None,
+              defer_merge: bool = False) -> torch.Tensor:
     """softmax(q k^T / sqrt(D)) v.  q [B,H,Lq,D], k/v [B,H,Lk,D] as (possibly strided) bf16 views with D contiguous.
-    Returns [B,H,Lq,D] view of a [B,Lq,H,D] buffer (heads recombined for the following out-projection)."""
+    Returns [B,H,Lq,D] view of a [B,Lq,H,D] buffer (heads recombined for the following out-projection).
+    defer_merge (needs a caller-owned `workspace`): run the split-KV pass only; finish with attention_merge()."""
     B, H, Lq, D = q.shape
     Lk = k.shape[2]
     for t in (q, k, v):
@@ -92,11 +94,24 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, splits: int 
     if out is None:
         out = torch.empty(B, Lq, H, D, dtype=OP16, device=q.device).permute(0, 2, 1, 3)
     ws_bytes = lib().msam2_attention_workspace_bytes(B, H, Lq, D, splits)
-    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=q.device) if splits > 1 else None
+    ws = workspace if workspace is not None else (torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=q.device) if splits > 1 else None)
+    _req(not defer_merge or (workspace is not None and splits > 1), "defer_merge needs splits > 1 and a caller-owned workspace")
+    _req(ws is None or ws.numel() * ws.element_size() >= ws_bytes, "attention workspace too small")
     check(lib().msam2_attention_fwd(_p(q), _strides3(q), _p(k), _strides3(k), _p(v), _strides3(v), _p(out), _strides3(out),
-                                    B, H, Lq, Lk, D, scale if scale is not None else 1.0 / math.sqrt(D), splits, _p(ws),
-                                    ws_bytes if ws is not None else 0,
-                                    _stream()))
+                                    B, H, Lq, Lk, D, scale if scale is not None else 1.0 / math.sqrt(D),
+                                    -splits if defer_merge else splits, _p(ws), ws_bytes if ws is not None else 0, _stream()))
+    return out
+
+
+def attention_workspace(B: int, H: int, Lq: int, D: int, splits: int, device) -> torch.Tensor:
+    return torch.empty(max(lib().msam2_attention_workspace_bytes(B, H, Lq, D, splits), 1), dtype=torch.uint8, device=device)
+
+
+def attention_merge(out: torch.Tensor, Lk: int, splits: int, workspace: torch.Tensor) -> torch.Tensor:
+    """Finish attention(..., defer_merge=True): out is the [B,H,Lq,D] view that call returned."""
+    B, H, Lq, D = out.shape
+    check(lib().msam2_attention_merge(_p(out), _strides3(out), B, H, Lq, Lk, D, splits, _p(workspace),
+                                      workspace.numel() * workspace.element_size(), _stream()))
     return out
 
 

@@ -153,6 +153,21 @@ def test_attention_vs_oracle(ops, B, H, Lq, Lk, D, splits):
     close(out, ref, 0.02, 0.01, "attention")
 
 
+def test_attention_deferred_merge(ops):
+    """split pass alone (negative split count through the C ABI) + msam2_attention_merge == the fused call, bit for bit"""
+    B, H, Lq, Lk, D, splits = 2, 1, 200, 1000, 256, 4
+    q, k, v = (bf(rnd(B, H, L, D, seed=s)).to(DEV) for L, s in ((Lq, 1), (Lk, 2), (Lk, 3)))
+    ref = ops.attention(q, k, v, splits=splits)
+    ws = ops.attention_workspace(B, H, Lq, D, splits, DEV)
+    out = torch.zeros(B, Lq, H, D, dtype=OP16(), device=DEV).permute(0, 2, 1, 3)
+    ops.attention(q, k, v, splits=splits, out=out, workspace=ws, defer_merge=True)
+    assert out.abs().sum().item() == 0          # nothing written before the merge
+    ops.attention_merge(out, Lk, splits, ws)
+    assert torch.equal(out, ref)
+    with pytest.raises(RuntimeError):
+        ops.attention(q, k, v, splits=1, out=out, workspace=ws, defer_merge=True)
+
+
 def test_attention_packed_strided_qkv(ops):
     """q/k/v as strided views of one fused [B, L, 3, H, D] projection buffer (how the callers hold them)."""
     B, H, L, D = 2, 4, 96, 96
