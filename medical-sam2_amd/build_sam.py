@@ -114,6 +114,29 @@ def build_sam2(config_file, ckpt_path=None, device="cuda", mode="eval", hydra_ov
     return model
 
 
+def build_sam2_video_predictor(config_file, ckpt_path=None, device="cuda", mode="eval", hydra_overrides_extra=[], apply_postprocessing=True):
+    """sam2_train/build_sam.py:43-76: same config with `model._target_` re-pointed at the video predictor and, with
+    post-processing, dynamic multimask fallback + binarised click masks for the memory encoder + `fill_hole_area=8`."""
+    from .video_predictor import SAM2VideoPredictor
+    TARGETS.setdefault("sam2_train.sam2_video_predictor.SAM2VideoPredictor", SAM2VideoPredictor)
+    overrides = ["++model._target_=sam2_train.sam2_video_predictor.SAM2VideoPredictor"]
+    extra = list(hydra_overrides_extra)
+    if apply_postprocessing:
+        extra += ["++model.sam_mask_decoder_extra_args.dynamic_multimask_via_stability=true",
+                  "++model.sam_mask_decoder_extra_args.dynamic_multimask_stability_delta=0.05",
+                  "++model.sam_mask_decoder_extra_args.dynamic_multimask_stability_thresh=0.98",
+                  "++model.binarize_mask_from_pts_for_mem_enc=true",
+                  "++model.fill_hole_area=8"]
+    cfg = copy.deepcopy(_load_config(config_file))
+    apply_overrides(cfg, overrides + extra)
+    model = instantiate(cfg["model"])
+    _load_checkpoint(model, ckpt_path)
+    model = model.to(device)
+    if mode == "eval":
+        model.eval()
+    return model
+
+
 def _load_checkpoint(model, ckpt_path):
     if ckpt_path is not None:
         sd = torch.load(ckpt_path, map_location="cpu")["model"]

@@ -50,9 +50,10 @@ def image_batch(seeds: List[int], size: int = 1024):
     return torch.stack(imgs), pts, labels
 
 
-def blob_volume(seed: int, n_slices: int = 64, size: int = 1024, n_objects: int = 1):
+def blob_volume(seed: int, n_slices: int = 64, size: int = 1024, n_objects: int = 1, normalised: bool = True):
     """A [T, 3, size, size] normalised volume of 3-D Gaussian-blob "organs" and, per object, the per-slice bounding box
-    (x0, y0, x1, y1) of its iso-surface (None where the organ does not cut the slice)."""
+    (x0, y0, x1, y1) of its iso-surface (None where the organ does not cut the slice).  normalised=False returns the 0..255
+    intensities instead (what `SAM2VideoPredictor.val_init_state` expects)."""
     g = torch.Generator().manual_seed(5000 + seed)
     ys = torch.arange(size, dtype=torch.float32)[:, None]
     xs = torch.arange(size, dtype=torch.float32)[None, :]
@@ -74,5 +75,6 @@ def blob_volume(seed: int, n_slices: int = 64, size: int = 1024, n_objects: int 
             if abs(dz) < 1.0:
                 s = math.sqrt(1.0 - dz * dz)
                 boxes[o][t] = ((cx - rx * s) * size, (cy - ry * s) * size, (cx + rx * s) * size, (cy + ry * s) * size)
-        vol[t] = normalize_image(sl.clamp(0, 255)[None] * gains)
+        raw = sl.clamp(0, 255)[None] * gains
+        vol[t] = normalize_image(raw) if normalised else raw
     return vol, boxes

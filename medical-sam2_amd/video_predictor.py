@@ -1,0 +1,514 @@
+"""Drop-in for `sam2_train/sam2_video_predictor.py` (SAM2VideoPredictor): the interactive / volumetric state machine on top of the
+MI355X `SAM2Base` mirror -- same method names, arguments, `inference_state` keys and return values, so `func_3d/function.py`
+and the upstream notebooks drive it unchanged:
+
+    state = predictor.val_init_state(imgs_tensor)              | init_state(jpeg_dir)          (sam2_video_predictor.py:39-177)
+    predictor.add_new_points / add_new_bbox / add_new_mask(...)                                (293-423, 557-639)
+    for frame_idx, obj_ids, video_res_masks in predictor.propagate_in_video(state): ...        (1041-1124)
+
+What is re-designed without changing any result:
+  * the reference caches the backbone features of ONE frame (`cached_features = {frame_idx: ...}`, 1270-1281), so every prompted
+    slice is encoded twice (once when the prompt is added, once when its memory is encoded in the preflight) and every revisit
+    re-runs the image encoder.  Here the cache keeps every frame (`feature_cache_frames`, default: all of them -- 17 MB per
+    1024^2 slice in fp32, 288 GB of HBM) and `prefetch_features` encodes the not-yet-seen frames in batches, where the trunk's
+    kernels are far better filled than at batch 1;
+  * frames are normalised on the device by one kernel-free broadcast; hole filling runs the batched HIP connected-components
+    path (`ops.fill_holes_`); resizing uses the HIP bilinear kernel.
+The `train_*` entry points of the fork (179-248, 425-555, 641-722, 971-1039, 1126-1208: the same code without
+`torch.inference_mode`) are aliases of the forward path: the backward pass is outside this round's scope.
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .modeling.sam2_base import NO_OBJ_SCORE, SAM2Base
+
+F32 = torch.float32
+_IMG_MEAN = (0.485, 0.456, 0.406)
+_IMG_STD = (0.229, 0.224, 0.225)
+
+
+def concat_points(old_point_inputs, new_points, new_labels):
+    """utils/misc.py:261-269."""
+    if old_point_inputs is None:
+        points, labels = new_points, new_labels
+    else:
+        points = torch.cat([old_point_inputs["point_coords"], new_points], dim=1)
+        labels = torch.cat([old_point_inputs["point_labels"], new_labels], dim=1)
+    return {"point_coords": points, "point_labels": labels}
+
+
+def _normalise(images: torch.Tensor, device) -> torch.Tensor:
+    """(x - mean) / std per channel, fp32 (utils/misc.py:205-211, 240-244)."""
+    images = images.to(device=device, dtype=F32)
+    mean = torch.tensor(_IMG_MEAN, dtype=F32, device=device)[:, None, None]
+    std = torch.tensor(_IMG_STD, dtype=F32, device=device)[:, None, None]
+    return (images - mean) / std
+
+
+def load_video_frames_from_data(imgs_tensor: torch.Tensor, offload_video_to_cpu: bool = False, async_loading_frames: bool = False):
+    """utils/misc.py:215-244: [T,3,S,S] values in 0..255 -> normalised fp32 frames."""
+    dev = torch.device("cpu") if offload_video_to_cpu else torch.device("cuda")
+    return _normalise(imgs_tensor / 255.0, dev)
+
+
+def load_video_frames(video_path, image_size: int, offload_video_to_cpu: bool = False, async_loading_frames: bool = False):
+    """utils/misc.py:163-212: a directory of "<frame_index>.jpg" files, resized to image_size (PIL bilinear-free default resize,
+    like the reference) and normalised."""
+    from PIL import Image
+    if not (isinstance(video_path, str) and os.path.isdir(video_path)):
+        raise NotImplementedError("Only JPEG frames are supported at this moment")
+    names = [p for p in os.listdir(video_path) if os.path.splitext(p)[-1] in [".jpg", ".jpeg", ".JPG", ".JPEG"]]
+    names.sort(key=lambda p: int(os.path.splitext(p)[0]))
+    if not names:
+        raise RuntimeError(f"no images found in {video_path}")
+    images = torch.zeros(len(names), 3, image_size, image_size, dtype=F32)
+    video_height = video_width = None
+    for n, name in enumerate(names):
+        img_pil = Image.open(os.path.join(video_path, name))
+        img_np = np.array(img_pil.convert("RGB").resize((image_size, image_size)))
+        if img_np.dtype != np.uint8:
+            raise RuntimeError(f"Unknown image dtype: {img_np.dtype} on {name}")
+        images[n] = torch.from_numpy(img_np / 255.0).permute(2, 0, 1)
+        video_width, video_height = img_pil.size
+    dev = torch.device("cpu") if offload_video_to_cpu else torch.device("cuda")
+    return _normalise(images, dev), video_height, video_width
+
+
+class SAM2VideoPredictor(SAM2Base):
+    """sam2_video_predictor.py:17-1441 (see the module docstring for the mapping)."""
+
+    def __init__(self, fill_hole_area=0, non_overlap_masks=False, clear_non_cond_mem_around_input=False,
+                 clear_non_cond_mem_for_multi_obj=False, feature_cache_frames: Optional[int] = None, **kwargs):
+        super().__init__(**kwargs)
+        self.fill_hole_area = fill_hole_area
+        self.non_overlap_masks = non_overlap_masks
+        self.clear_non_cond_mem_around_input = clear_non_cond_mem_around_input
+        self.clear_non_cond_mem_for_multi_obj = clear_non_cond_mem_for_multi_obj
+        self.feature_cache_frames = feature_cache_frames     # None = keep every frame's features (reference: 1)
+
+    # ------------------------------------------------------------------------------------------------------------ state
+    def _new_state(self, images, video_height, video_width, offload_video_to_cpu, offload_state_to_cpu):
+        dev = torch.device("cuda")
+        s = {
+            "images": images, "num_frames": len(images), "offload_video_to_cpu": offload_video_to_cpu,
+            "offload_state_to_cpu": offload_state_to_cpu, "video_height": video_height, "video_width": video_width,
+            "device": dev, "storage_device": torch.device("cpu") if offload_state_to_cpu else dev,
+            "point_inputs_per_obj": {}, "mask_inputs_per_obj": {}, "cached_features": {}, "constants": {},
+            "obj_id_to_idx": OrderedDict(), "obj_idx_to_id": OrderedDict(), "obj_ids": [],
+            "output_dict": {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}},
+            "output_dict_per_obj": {}, "temp_output_dict_per_obj": {},
+            "consolidated_frame_inds": {"cond_frame_outputs": set(), "non_cond_frame_outputs": set()},
+            "tracking_has_started": False, "frames_already_tracked": {},
+        }
+        # warm up the backbone and cache frame 0, like the reference
+        self._get_image_feature(s, frame_idx=0, batch_size=1)
+        return s
+
+    @torch.no_grad()
+    def init_state(self, video_path, offload_video_to_cpu=False, offload_state_to_cpu=False, async_loading_frames=False):
+        images, h, w = load_video_frames(video_path, self.image_size, offload_video_to_cpu, async_loading_frames)
+        return self._new_state(images, h, w, offload_video_to_cpu, offload_state_to_cpu)
+
+    @torch.no_grad()
+    def val_init_state(self, imgs_tensor, video_height=None, video_width=None, offload_video_to_cpu=False,
+                       offload_state_to_cpu=False, async_loading_frames=False):
+        if video_height is None or video_width is None:
+            video_height = video_width = self.image_size
+        images = load_video_frames_from_data(imgs_tensor, offload_video_to_cpu, async_loading_frames)
+        return self._new_state(images, video_height, video_width, offload_video_to_cpu, offload_state_to_cpu)
+
+    def _obj_id_to_idx(self, inference_state, obj_id):
+        obj_idx = inference_state["obj_id_to_idx"].get(obj_id, None)
+        if obj_idx is not None:
+            return obj_idx
+        if inference_state["tracking_has_started"]:
+            raise RuntimeError(f"Cannot add new object id {obj_id} after tracking starts. "
+                               f"All existing object ids: {inference_state['obj_ids']}. "
+                               f"Please call 'reset_state' to restart from scratch.")
+        obj_idx = len(inference_state["obj_id_to_idx"])
+        inference_state["obj_id_to_idx"][obj_id] = obj_idx
+        inference_state["obj_idx_to_id"][obj_idx] = obj_id
+        inference_state["obj_ids"] = list(inference_state["obj_id_to_idx"])
+        inference_state["point_inputs_per_obj"][obj_idx] = {}
+        inference_state["mask_inputs_per_obj"][obj_idx] = {}
+        inference_state["output_dict_per_obj"][obj_idx] = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
+        inference_state["temp_output_dict_per_obj"][obj_idx] = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
+        return obj_idx
+
+    def _obj_idx_to_id(self, inference_state, obj_idx):
+        return inference_state["obj_idx_to_id"][obj_idx]
+
+    def _get_obj_num(self, inference_state):
+        return len(inference_state["obj_idx_to_id"])
+
+    # ---------------------------------------------------------------------------------------------------------- prompts
+    def _frame_role(self, inference_state, frame_idx):
+        is_init_cond_frame = frame_idx not in inference_state["frames_already_tracked"]
+        reverse = False if is_init_cond_frame else inference_state["frames_already_tracked"][frame_idx]["reverse"]
+        is_cond = is_init_cond_frame or self.add_all_frames_to_correct_as_cond
+        return is_init_cond_frame, reverse, is_cond, ("cond_frame_outputs" if is_cond else "non_cond_frame_outputs")
+
+    def _finish_interaction(self, inference_state, frame_idx, is_cond):
+        consolidated_out = self._consolidate_temp_output_across_obj(inference_state, frame_idx, is_cond=is_cond, run_mem_encoder=False,
+                                                                    consolidate_at_video_res=True)
+        _, video_res_masks = self._get_orig_video_res_output(inference_state, consolidated_out["pred_masks_video_res"])
+        return frame_idx, inference_state["obj_ids"], video_res_masks
+
+    @torch.no_grad()
+    def add_new_points(self, inference_state, frame_idx, obj_id, points, labels, clear_old_points=True, normalize_coords=True):
+        obj_idx = self._obj_id_to_idx(inference_state, obj_id)
+        point_inputs_per_frame = inference_state["point_inputs_per_obj"][obj_idx]
+        mask_inputs_per_frame = inference_state["mask_inputs_per_obj"][obj_idx]
+        if not isinstance(points, torch.Tensor):
+            points = torch.tensor(points, dtype=F32)
+        if not isinstance(labels, torch.Tensor):
+            labels = torch.tensor(labels, dtype=torch.int32)
+        if points.dim() == 2:
+            points = points.unsqueeze(0)
+        if labels.dim() == 1:
+            labels = labels.unsqueeze(0)
+        if normalize_coords:
+            scale = torch.tensor([inference_state["video_width"], inference_state["video_height"]]).to(points.device)
+            points = points / scale
+        points = (points * self.image_size).to(inference_state["device"])
+        labels = labels.to(inference_state["device"])
+        point_inputs = concat_points(None if clear_old_points else point_inputs_per_frame.get(frame_idx, None), points, labels)
+        point_inputs_per_frame[frame_idx] = point_inputs
+        mask_inputs_per_frame.pop(frame_idx, None)
+        is_init_cond_frame, reverse, is_cond, storage_key = self._frame_role(inference_state, frame_idx)
+        obj_output_dict = inference_state["output_dict_per_obj"][obj_idx]
+        obj_temp_output_dict = inference_state["temp_output_dict_per_obj"][obj_idx]
+        # previous mask logits of this object on this frame feed the SAM decoder together with the new clicks
+        prev_out = obj_temp_output_dict[storage_key].get(frame_idx)
+        if prev_out is None:
+            prev_out = obj_output_dict["cond_frame_outputs"].get(frame_idx)
+            if prev_out is None:
+                prev_out = obj_output_dict["non_cond_frame_outputs"].get(frame_idx)
+        prev_sam_mask_logits = None
+        if prev_out is not None and prev_out["pred_masks"] is not None:
+            prev_sam_mask_logits = torch.clamp(prev_out["pred_masks"].to(inference_state["device"], non_blocking=True), -32.0, 32.0)
+        current_out, _ = self._run_single_frame_inference(
+            inference_state=inference_state, output_dict=obj_output_dict, frame_idx=frame_idx, batch_size=1,
+            is_init_cond_frame=is_init_cond_frame, point_inputs=point_inputs, mask_inputs=None, reverse=reverse,
+            run_mem_encoder=False, prev_sam_mask_logits=prev_sam_mask_logits)
+        obj_temp_output_dict[storage_key][frame_idx] = current_out
+        return self._finish_interaction(inference_state, frame_idx, is_cond)
+
+    @torch.no_grad()
+    def add_new_bbox(self, inference_state, frame_idx, obj_id, bbox, clear_old_points=True, normalize_coords=True):
+        if not isinstance(bbox, torch.Tensor):
+            bbox = torch.tensor(bbox, dtype=F32)
+        return self.add_new_points(inference_state=inference_state, frame_idx=frame_idx, obj_id=obj_id, points=bbox.reshape(-1, 2, 2),
+                                   labels=torch.tensor([2, 3], dtype=torch.int), clear_old_points=clear_old_points,
+                                   normalize_coords=normalize_coords)
+
+    @torch.no_grad()
+    def add_new_mask(self, inference_state, frame_idx, obj_id, mask):
+        obj_idx = self._obj_id_to_idx(inference_state, obj_id)
+        point_inputs_per_frame = inference_state["point_inputs_per_obj"][obj_idx]
+        mask_inputs_per_frame = inference_state["mask_inputs_per_obj"][obj_idx]
+        if not isinstance(mask, torch.Tensor):
+            mask = torch.tensor(mask, dtype=torch.bool)
+        assert mask.dim() == 2
+        mask_H, mask_W = mask.shape
+        mask_inputs_orig = mask[None, None].float().to(inference_state["device"])
+        if mask_H != self.image_size or mask_W != self.image_size:
+            mask_inputs = torch.nn.functional.interpolate(mask_inputs_orig, size=(self.image_size, self.image_size), align_corners=False,
+                                                          mode="bilinear", antialias=True)
+            mask_inputs = (mask_inputs >= 0.5).float()
+        else:
+            mask_inputs = mask_inputs_orig
+        mask_inputs_per_frame[frame_idx] = mask_inputs
+        point_inputs_per_frame.pop(frame_idx, None)
+        is_init_cond_frame, reverse, is_cond, storage_key = self._frame_role(inference_state, frame_idx)
+        current_out, _ = self._run_single_frame_inference(
+            inference_state=inference_state, output_dict=inference_state["output_dict_per_obj"][obj_idx], frame_idx=frame_idx,
+            batch_size=1, is_init_cond_frame=is_init_cond_frame, point_inputs=None, mask_inputs=mask_inputs, reverse=reverse,
+            run_mem_encoder=False)
+        inference_state["temp_output_dict_per_obj"][obj_idx][storage_key][frame_idx] = current_out
+        return self._finish_interaction(inference_state, frame_idx, is_cond)
+
+    # ---------------------------------------------------------------------------------------------------- consolidation
+    def _resize(self, masks: torch.Tensor, H: int, W: int) -> torch.Tensor:
+        """F.interpolate(mode="bilinear", align_corners=False) on [n,1,h,w] fp32 (HIP kernel)."""
+        if masks.shape[-2:] == (H, W):
+            return masks
+        return ops.bilinear_upsample(masks.to(F32).contiguous(), H, W)
+
+    def _get_orig_video_res_output(self, inference_state, any_res_masks):
+        device = inference_state["device"]
+        any_res_masks = any_res_masks.to(device, non_blocking=True)
+        video_res_masks = self._resize(any_res_masks, inference_state["video_height"], inference_state["video_width"])
+        if self.non_overlap_masks:
+            video_res_masks = self._apply_non_overlapping_constraints(video_res_masks)
+        return any_res_masks, video_res_masks
+
+    def _consolidate_temp_output_across_obj(self, inference_state, frame_idx, is_cond, run_mem_encoder, consolidate_at_video_res=False):
+        batch_size = self._get_obj_num(inference_state)
+        storage_key = "cond_frame_outputs" if is_cond else "non_cond_frame_outputs"
+        if consolidate_at_video_res:
+            assert not run_mem_encoder, "memory encoder cannot run at video resolution"
+            H, W, key = inference_state["video_height"], inference_state["video_width"], "pred_masks_video_res"
+        else:
+            H = W = self.image_size // 4
+            key = "pred_masks"
+        consolidated_out = {
+            "maskmem_features": None, "maskmem_pos_enc": None,
+            key: torch.full((batch_size, 1, H, W), NO_OBJ_SCORE, dtype=F32, device=inference_state["storage_device"]),
+            "obj_ptr": torch.full((batch_size, self.hidden_dim), NO_OBJ_SCORE, dtype=F32, device=inference_state["device"]),
+        }
+        empty_mask_ptr = None
+        for obj_idx in range(batch_size):
+            out = inference_state["temp_output_dict_per_obj"][obj_idx][storage_key].get(frame_idx, None)
+            obj_output_dict = inference_state["output_dict_per_obj"][obj_idx]
+            if out is None:
+                out = obj_output_dict["cond_frame_outputs"].get(frame_idx, None)
+            if out is None:
+                out = obj_output_dict["non_cond_frame_outputs"].get(frame_idx, None)
+            if out is None:
+                # placeholder object on this frame: NO_OBJ_SCORE mask; its pointer comes from an empty mask when memory is encoded
+                if run_mem_encoder:
+                    if empty_mask_ptr is None:
+                        empty_mask_ptr = self._get_empty_mask_ptr(inference_state, frame_idx)
+                    consolidated_out["obj_ptr"][obj_idx: obj_idx + 1] = empty_mask_ptr
+                continue
+            obj_mask = out["pred_masks"]
+            dst = consolidated_out[key]
+            dst[obj_idx: obj_idx + 1] = self._resize(obj_mask.to(inference_state["device"]), H, W).to(dst.device)
+            consolidated_out["obj_ptr"][obj_idx: obj_idx + 1] = out["obj_ptr"]
+        if run_mem_encoder:
+            device = inference_state["device"]
+            high_res_masks = self._resize(consolidated_out["pred_masks"].to(device, non_blocking=True), self.image_size, self.image_size)
+            if self.non_overlap_masks_for_mem_enc:
+                high_res_masks = self._apply_non_overlapping_constraints(high_res_masks)
+            maskmem_features, maskmem_pos_enc = self._run_memory_encoder(
+                inference_state=inference_state, frame_idx=frame_idx, batch_size=batch_size, high_res_masks=high_res_masks,
+                is_mask_from_pts=True)
+            consolidated_out["maskmem_features"] = maskmem_features
+            consolidated_out["maskmem_pos_enc"] = maskmem_pos_enc
+        return consolidated_out
+
+    def _get_empty_mask_ptr(self, inference_state, frame_idx):
+        mask_inputs = torch.zeros((1, 1, self.image_size, self.image_size), dtype=F32, device=inference_state["device"])
+        _, _, feats, pos, sizes = self._get_image_feature(inference_state, frame_idx, 1)
+        current_out = self.track_step(frame_idx=frame_idx, is_init_cond_frame=True, current_vision_feats=feats,
+                                      current_vision_pos_embeds=pos, feat_sizes=sizes, point_inputs=None, mask_inputs=mask_inputs,
+                                      output_dict={}, num_frames=inference_state["num_frames"], track_in_reverse=False,
+                                      run_mem_encoder=False, prev_sam_mask_logits=None)
+        return current_out["obj_ptr"]
+
+    # -------------------------------------------------------------------------------------------------------- propagation
+    @torch.no_grad()
+    def propagate_in_video_preflight(self, inference_state):
+        inference_state["tracking_has_started"] = True
+        batch_size = self._get_obj_num(inference_state)
+        temp_output_dict_per_obj = inference_state["temp_output_dict_per_obj"]
+        output_dict = inference_state["output_dict"]
+        consolidated_frame_inds = inference_state["consolidated_frame_inds"]
+        clear_non_cond_mem = self.clear_non_cond_mem_around_input and (self.clear_non_cond_mem_for_multi_obj or batch_size <= 1)
+        for is_cond in [False, True]:
+            storage_key = "cond_frame_outputs" if is_cond else "non_cond_frame_outputs"
+            temp_frame_inds = set()
+            for obj_temp_output_dict in temp_output_dict_per_obj.values():
+                temp_frame_inds.update(obj_temp_output_dict[storage_key].keys())
+            consolidated_frame_inds[storage_key].update(temp_frame_inds)
+            for frame_idx in sorted(temp_frame_inds):
+                consolidated_out = self._consolidate_temp_output_across_obj(inference_state, frame_idx, is_cond=is_cond,
+                                                                            run_mem_encoder=True)
+                output_dict[storage_key][frame_idx] = consolidated_out
+                self._add_output_per_object(inference_state, frame_idx, consolidated_out, storage_key)
+                if clear_non_cond_mem:
+                    self._clear_non_cond_mem_around_input(inference_state, frame_idx)
+            for obj_temp_output_dict in temp_output_dict_per_obj.values():
+                obj_temp_output_dict[storage_key].clear()
+        # a frame that became a conditioning frame is no longer a non-conditioning one
+        for frame_idx in output_dict["cond_frame_outputs"]:
+            output_dict["non_cond_frame_outputs"].pop(frame_idx, None)
+        for obj_output_dict in inference_state["output_dict_per_obj"].values():
+            for frame_idx in obj_output_dict["cond_frame_outputs"]:
+                obj_output_dict["non_cond_frame_outputs"].pop(frame_idx, None)
+        for frame_idx in consolidated_frame_inds["cond_frame_outputs"]:
+            assert frame_idx in output_dict["cond_frame_outputs"]
+            consolidated_frame_inds["non_cond_frame_outputs"].discard(frame_idx)
+        all_consolidated = consolidated_frame_inds["cond_frame_outputs"] | consolidated_frame_inds["non_cond_frame_outputs"]
+        input_frames_inds = set()
+        for per_frame in inference_state["point_inputs_per_obj"].values():
+            input_frames_inds.update(per_frame.keys())
+        for per_frame in inference_state["mask_inputs_per_obj"].values():
+            input_frames_inds.update(per_frame.keys())
+        assert all_consolidated == input_frames_inds
+
+    @torch.no_grad()
+    def propagate_in_video(self, inference_state, start_frame_idx=None, max_frame_num_to_track=None, reverse=False):
+        self.propagate_in_video_preflight(inference_state)
+        output_dict = inference_state["output_dict"]
+        consolidated_frame_inds = inference_state["consolidated_frame_inds"]
+        obj_ids = inference_state["obj_ids"]
+        num_frames = inference_state["num_frames"]
+        batch_size = self._get_obj_num(inference_state)
+        if len(output_dict["cond_frame_outputs"]) == 0:
+            raise RuntimeError("No points are provided; please add points first")
+        clear_non_cond_mem = self.clear_non_cond_mem_around_input and (self.clear_non_cond_mem_for_multi_obj or batch_size <= 1)
+        if start_frame_idx is None:
+            start_frame_idx = min(output_dict["cond_frame_outputs"])
+        if max_frame_num_to_track is None:
+            max_frame_num_to_track = num_frames
+        if reverse:
+            end_frame_idx = max(start_frame_idx - max_frame_num_to_track, 0)
+            processing_order = range(start_frame_idx, end_frame_idx - 1, -1) if start_frame_idx > 0 else []
+        else:
+            end_frame_idx = min(start_frame_idx + max_frame_num_to_track, num_frames - 1)
+            processing_order = range(start_frame_idx, end_frame_idx + 1)
+        for frame_idx in processing_order:
+            if frame_idx in consolidated_frame_inds["cond_frame_outputs"]:
+                storage_key = "cond_frame_outputs"
+                current_out = output_dict[storage_key][frame_idx]
+                pred_masks = current_out["pred_masks"]
+                if clear_non_cond_mem:
+                    self._clear_non_cond_mem_around_input(inference_state, frame_idx)
+            elif frame_idx in consolidated_frame_inds["non_cond_frame_outputs"]:
+                storage_key = "non_cond_frame_outputs"
+                current_out = output_dict[storage_key][frame_idx]
+                pred_masks = current_out["pred_masks"]
+            else:
+                storage_key = "non_cond_frame_outputs"
+                current_out, pred_masks = self._run_single_frame_inference(
+                    inference_state=inference_state, output_dict=output_dict, frame_idx=frame_idx, batch_size=batch_size,
+                    is_init_cond_frame=False, point_inputs=None, mask_inputs=None, reverse=reverse, run_mem_encoder=True)
+                output_dict[storage_key][frame_idx] = current_out
+            self._add_output_per_object(inference_state, frame_idx, current_out, storage_key)
+            inference_state["frames_already_tracked"][frame_idx] = {"reverse": reverse}
+            _, video_res_masks = self._get_orig_video_res_output(inference_state, pred_masks)
+            yield frame_idx, obj_ids, video_res_masks
+
+    def _add_output_per_object(self, inference_state, frame_idx, current_out, storage_key):
+        maskmem_features = current_out["maskmem_features"]
+        assert maskmem_features is None or isinstance(maskmem_features, torch.Tensor)
+        maskmem_pos_enc = current_out["maskmem_pos_enc"]
+        assert maskmem_pos_enc is None or isinstance(maskmem_pos_enc, list)
+        for obj_idx, obj_output_dict in inference_state["output_dict_per_obj"].items():
+            sl = slice(obj_idx, obj_idx + 1)
+            obj_out = {"maskmem_features": None, "maskmem_pos_enc": None, "pred_masks": current_out["pred_masks"][sl],
+                       "obj_ptr": current_out["obj_ptr"][sl]}
+            if maskmem_features is not None:
+                obj_out["maskmem_features"] = maskmem_features[sl]
+            if maskmem_pos_enc is not None:
+                obj_out["maskmem_pos_enc"] = [x[sl] for x in maskmem_pos_enc]
+            obj_output_dict[storage_key][frame_idx] = obj_out
+
+    def reset_state(self, inference_state):
+        self._reset_tracking_results(inference_state)
+        for k in ("obj_id_to_idx", "obj_idx_to_id", "obj_ids", "point_inputs_per_obj", "mask_inputs_per_obj", "output_dict_per_obj",
+                  "temp_output_dict_per_obj"):
+            inference_state[k].clear()
+
+    def _reset_tracking_results(self, inference_state):
+        for k in ("point_inputs_per_obj", "mask_inputs_per_obj"):
+            for v in inference_state[k].values():
+                v.clear()
+        for k in ("output_dict_per_obj", "temp_output_dict_per_obj"):
+            for v in inference_state[k].values():
+                v["cond_frame_outputs"].clear()
+                v["non_cond_frame_outputs"].clear()
+        for k in ("output_dict", "consolidated_frame_inds"):
+            inference_state[k]["cond_frame_outputs"].clear()
+            inference_state[k]["non_cond_frame_outputs"].clear()
+        inference_state["tracking_has_started"] = False
+        inference_state["frames_already_tracked"].clear()
+
+    # ----------------------------------------------------------------------------------------------------- per-frame work
+    def _cache_put(self, inference_state, frame_idx, image, backbone_out):
+        cache = inference_state["cached_features"]
+        cache[frame_idx] = (image, backbone_out)
+        limit = self.feature_cache_frames
+        if limit is not None:
+            while len(cache) > max(1, limit):
+                cache.pop(next(iter(cache)))          # oldest first (dicts keep insertion order)
+
+    @torch.no_grad()
+    def prefetch_features(self, inference_state, frame_indices=None, batch: int = 8):
+        """Encode the listed (default: all) not-yet-cached frames `batch` at a time.  Results are identical to encoding them one by
+        one (every kernel is batch-invariant); the trunk just runs far better filled."""
+        todo = [t for t in (range(inference_state["num_frames"]) if frame_indices is None else frame_indices)
+                if t not in inference_state["cached_features"]]
+        dev = inference_state["device"]
+        for i in range(0, len(todo), batch):
+            ids = todo[i: i + batch]
+            imgs = torch.stack([inference_state["images"][t] for t in ids]).to(dev).float()
+            bo = self.forward_image(imgs)
+            for j, t in enumerate(ids):
+                one = {"backbone_fpn": [f[j: j + 1] for f in bo["backbone_fpn"]], "vision_pos_enc": [p[:1] for p in bo["vision_pos_enc"]]}
+                self._cache_put(inference_state, t, imgs[j: j + 1], one)
+
+    def _get_image_feature(self, inference_state, frame_idx, batch_size):
+        image, backbone_out = inference_state["cached_features"].get(frame_idx, (None, None))
+        if backbone_out is None:
+            image = inference_state["images"][frame_idx].to(inference_state["device"]).float().unsqueeze(0)
+            backbone_out = self.forward_image(image)
+            self._cache_put(inference_state, frame_idx, image, backbone_out)
+        expanded_image = image.expand(batch_size, -1, -1, -1)
+        expanded = {"backbone_fpn": [f.expand(batch_size, -1, -1, -1) for f in backbone_out["backbone_fpn"]],
+                    "vision_pos_enc": [p.expand(batch_size, -1, -1, -1) for p in backbone_out["vision_pos_enc"]]}
+        return (expanded_image,) + self._prepare_backbone_features(expanded)
+
+    def _run_single_frame_inference(self, inference_state, output_dict, frame_idx, batch_size, is_init_cond_frame, point_inputs,
+                                    mask_inputs, reverse, run_mem_encoder, prev_sam_mask_logits=None):
+        _, _, feats, pos, sizes = self._get_image_feature(inference_state, frame_idx, batch_size)
+        assert point_inputs is None or mask_inputs is None
+        current_out = self.track_step(frame_idx=frame_idx, is_init_cond_frame=is_init_cond_frame, current_vision_feats=feats,
+                                      current_vision_pos_embeds=pos, feat_sizes=sizes, point_inputs=point_inputs, mask_inputs=mask_inputs,
+                                      output_dict=output_dict, num_frames=inference_state["num_frames"], track_in_reverse=reverse,
+                                      run_mem_encoder=run_mem_encoder, prev_sam_mask_logits=prev_sam_mask_logits)
+        storage_device = inference_state["storage_device"]
+        maskmem_features = current_out["maskmem_features"]
+        if maskmem_features is not None:
+            maskmem_features = maskmem_features.to(storage_device, non_blocking=True)
+        pred_masks_gpu = current_out["pred_masks"]
+        if self.fill_hole_area > 0:
+            pred_masks_gpu = ops.fill_holes_(pred_masks_gpu.to(F32).contiguous().clone(), self.fill_hole_area)
+        pred_masks = pred_masks_gpu.to(storage_device, non_blocking=True)
+        compact_current_out = {"maskmem_features": maskmem_features, "maskmem_pos_enc": self._get_maskmem_pos_enc(inference_state, current_out),
+                               "pred_masks": pred_masks, "obj_ptr": current_out["obj_ptr"]}
+        return compact_current_out, pred_masks_gpu
+
+    def _run_memory_encoder(self, inference_state, frame_idx, batch_size, high_res_masks, is_mask_from_pts):
+        _, _, feats, _, sizes = self._get_image_feature(inference_state, frame_idx, batch_size)
+        maskmem_features, maskmem_pos_enc = self._encode_new_memory(current_vision_feats=feats, feat_sizes=sizes,
+                                                                    pred_masks_high_res=high_res_masks, is_mask_from_pts=is_mask_from_pts)
+        maskmem_features = maskmem_features.to(inference_state["storage_device"], non_blocking=True)
+        return maskmem_features, self._get_maskmem_pos_enc(inference_state, {"maskmem_pos_enc": maskmem_pos_enc})
+
+    def _get_maskmem_pos_enc(self, inference_state, current_out):
+        """`maskmem_pos_enc` is the same for every frame and object: one copy per session (1399-1422)."""
+        out_pos = current_out["maskmem_pos_enc"]
+        if out_pos is None:
+            return None
+        constants = inference_state["constants"]
+        if "maskmem_pos_enc" not in constants:
+            assert isinstance(out_pos, list)
+            constants["maskmem_pos_enc"] = [x[0:1].clone() for x in out_pos]
+        batch_size = out_pos[0].size(0)
+        return [x.expand(batch_size, -1, -1, -1) for x in constants["maskmem_pos_enc"]]
+
+    def _clear_non_cond_mem_around_input(self, inference_state, frame_idx):
+        r = self.memory_temporal_stride_for_eval
+        non_cond = inference_state["output_dict"]["non_cond_frame_outputs"]
+        for t in range(frame_idx - r * self.num_maskmem, frame_idx + r * self.num_maskmem + 1):
+            non_cond.pop(t, None)
+            for obj_output_dict in inference_state["output_dict_per_obj"].values():
+                obj_output_dict["non_cond_frame_outputs"].pop(t, None)
+
+    # the fork's gradient-enabled twins: same forward (no backward on this path yet)
+    train_init_state = val_init_state
+    train_add_new_points = add_new_points
+    train_add_new_bbox = add_new_bbox
+    train_add_new_mask = add_new_mask
+    train_propagate_in_video_preflight = propagate_in_video_preflight
+    train_propagate_in_video = propagate_in_video

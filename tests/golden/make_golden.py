@@ -77,7 +77,7 @@ def _md_forward_s3(self, image_embeddings, image_pe, sparse_prompt_embeddings, d
 ref_md.MaskDecoder.forward = _md_forward_s3
 
 
-def build_reference(model: str, image_size: int, seed: int = 0) -> SAM2Base:
+def build_reference(model: str, image_size: int, seed: int = 0, cls=None, **extra) -> SAM2Base:
     tc = wts.trunk_config(model)
     trunk = Hiera(embed_dim=tc["embed_dim"], num_heads=tc["num_heads"], stages=tc["stages"],
                   global_att_blocks=tc["global_att_blocks"], window_pos_embed_bkg_spatial_size=tc["bkg"])
@@ -101,7 +101,7 @@ def build_reference(model: str, image_size: int, seed: int = 0) -> SAM2Base:
                             mask_downsampler=MaskDownSampler(kernel_size=3, stride=2, padding=1),
                             fuser=Fuser(layer=CXBlock(dim=256, kernel_size=7, padding=3, layer_scale_init_value=1e-6,
                                                       use_dwconv=True), num_layers=2))
-    m = SAM2Base(image_encoder=enc, memory_attention=mem_attn, memory_encoder=mem_enc, num_maskmem=7, image_size=1024,
+    m = (cls or SAM2Base)(**extra, image_encoder=enc, memory_attention=mem_attn, memory_encoder=mem_enc, num_maskmem=7, image_size=1024,
                  sigmoid_scale_for_mem_enc=20.0, sigmoid_bias_for_mem_enc=-10.0, use_mask_input_as_output_without_sam=True,
                  directly_add_no_mem_embed=True, use_high_res_features_in_sam=True, multimask_output_in_sam=True,
                  iou_prediction_use_sigmoid=True, use_obj_ptrs_in_encoder=True, add_tpos_enc_to_obj_ptrs=False,
@@ -266,8 +266,74 @@ def run_image_predictor_case():
     return out, {"model": "hiera_t", "image_size": 1024, "image_seed": 0}
 
 
+def run_video_predictor_case():
+    """The reference's SAM2VideoPredictor state machine (sam2_video_predictor.py) on a 6-slice, 2-object synthetic volume at the
+    fork's shipped 256 setting: box prompts, a click on a later slice (placeholder object + empty-mask pointer path), a mask
+    prompt, propagation, then a correction click on an already tracked slice (previous-logits path) and a second propagation.
+    `sam2_train._C` (CUDA sm_89 build, not loadable) is replaced by the build's C restatement of connected_components.cu
+    (oracle/cc_oracle.c), which tests/test_cc_oracle.py pins against scipy.ndimage.label."""
+    from oracle import cc as cc_oracle
+    stand_in = types.ModuleType("sam2_train._C")
+    stand_in.get_connected_componnets = lambda x: list(cc_oracle.connected_components(x))
+    sys.modules["sam2_train._C"] = stand_in
+    pkg._C = stand_in
+    from sam2_train.sam2_video_predictor import SAM2VideoPredictor
+    S, T = 256, 6
+    m = build_reference("hiera_t", S, cls=SAM2VideoPredictor, fill_hole_area=8)
+    frames, centres = zip(*[syn.blob_image(20 + t, S) for t in range(T)])       # 0..255 slices + their brightest-blob centres
+    vol = torch.stack(frames)
+    out = {}
+
+    def rec(tag, ret):
+        frame_idx, obj_ids, masks = ret
+        out[f"{tag}_obj_ids"] = np.array(obj_ids, dtype=np.int64)
+        out[f"{tag}_bits"] = np.packbits((masks > 0).numpy())
+        out[f"{tag}_sub"] = sub(masks.float())
+        out[f"{tag}_shape"] = np.array(masks.shape, dtype=np.int64)
+
+    st = m.val_init_state(vol)
+    st["device"] = st["storage_device"] = torch.device("cpu")          # S5
+    (cx, cy), (cx3, cy3), (cx5, cy5) = centres[0], centres[3], centres[5]
+    clamp = lambda v: float(min(max(v, 2.0), S - 3.0))
+    box = [clamp(cx - 50), clamp(cy - 40), clamp(cx + 30), clamp(cy + 45)]
+    gt_box = [int(clamp(cx5 - 30)), int(clamp(cy5 - 35)), int(clamp(cx5 + 40)), int(clamp(cy5 + 25))]
+    click0, click3, click2 = [[cx, cy]], [[cx3, cy3]], [[clamp(centres[2][0] + 6.0), clamp(centres[2][1] - 4.0)]]
+    with torch.no_grad():
+        rec("a0", m.add_new_points(st, 0, 7, click0, [1]))
+        rec("a1", m.add_new_bbox(st, 0, 9, box))
+        rec("a2", m.add_new_points(st, 3, 7, click3, [1]))             # obj 9 is a placeholder on slice 3 (empty-mask pointer)
+        gt = torch.zeros(S, S, dtype=torch.bool)
+        gt[gt_box[1]:gt_box[3], gt_box[0]:gt_box[2]] = True
+        rec("a3", m.add_new_mask(st, 5, 9, gt))
+        for frame_idx, obj_ids, masks in m.propagate_in_video(st):
+            rec(f"p{frame_idx}", (frame_idx, obj_ids, masks))
+            od = st["output_dict"]
+            cur = od["cond_frame_outputs"].get(frame_idx) or od["non_cond_frame_outputs"][frame_idx]
+            out[f"p{frame_idx}_low"] = cur["pred_masks"].float().numpy().copy()
+            out[f"p{frame_idx}_obj_ptr"] = cur["obj_ptr"].float().numpy().copy()
+        out["cond_frames"] = np.array(sorted(st["output_dict"]["cond_frame_outputs"]), dtype=np.int64)
+        # correction click on an already tracked slice (previous-logits path), then track again from it
+        rec("c0", m.add_new_points(st, 2, 7, click2, [1]))
+        for frame_idx, obj_ids, masks in m.propagate_in_video(st, start_frame_idx=2):
+            rec(f"q{frame_idx}", (frame_idx, obj_ids, masks))
+        out["cond_frames_2"] = np.array(sorted(st["output_dict"]["cond_frame_outputs"]), dtype=np.int64)
+        out["non_cond_frames_2"] = np.array(sorted(st["output_dict"]["non_cond_frame_outputs"]), dtype=np.int64)
+    prompts = dict(click0=np.array(click0, dtype=np.float32), box=np.array(box, dtype=np.float32), click3=np.array(click3, dtype=np.float32),
+                   gt_box=np.array(gt_box, dtype=np.int64), click2=np.array(click2, dtype=np.float32))
+    out.update({f"prompt_{k}": v for k, v in prompts.items()})
+    return out, {"model": "hiera_t", "image_size": S, "slice_seeds": [20 + t for t in range(T)], "n_objects": 2, "fill_hole_area": 8}
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "video":
+        o, meta = run_video_predictor_case()
+        np.savez_compressed(os.path.join(OUT, "video_predictor_t256.npz"), **o)
+        allmeta = json.load(open(os.path.join(OUT, "meta.json")))
+        allmeta["video_predictor_t256"] = meta
+        json.dump(allmeta, open(os.path.join(OUT, "meta.json"), "w"), indent=1)
+        print("video_predictor_t256.npz", os.path.getsize(os.path.join(OUT, "video_predictor_t256.npz")))
+        return
     spec = {m: {k: list(v.shape) for k, v in build_reference(m, 256).state_dict().items()} for m in ("hiera_t", "hiera_s", "hiera_b+")}
     with open(os.path.join(OUT, "state_dict_keys.json"), "w") as f:
         json.dump(spec, f)
@@ -290,6 +356,9 @@ def main():
     o, meta = run_image_predictor_case()
     np.savez_compressed(os.path.join(OUT, "config1_image_predictor.npz"), **o)
     allmeta["config1_image_predictor"] = meta
+    o, meta = run_video_predictor_case()
+    np.savez_compressed(os.path.join(OUT, "video_predictor_t256.npz"), **o)
+    allmeta["video_predictor_t256"] = meta
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(allmeta, f, indent=1)
     for fn in sorted(os.listdir(OUT)):
