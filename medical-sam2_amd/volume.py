@@ -21,13 +21,31 @@ from . import ops
 from .parallel import gather_cond_memories, shard_range
 
 
-def _encode(model, frame: torch.Tensor, n_obj: int):
-    """forward_image on one slice, features expanded (views) over the objects like sam2_video_predictor.py:1284-1296."""
-    bo = model.forward_image(frame[None])
-    bo = {"backbone_fpn": [f.expand(n_obj, -1, -1, -1) for f in bo["backbone_fpn"]],
-          "vision_pos_enc": [p.expand(n_obj, -1, -1, -1) for p in bo["vision_pos_enc"]]}
-    _, feats, pos, sizes = model._prepare_backbone_features(bo)
-    return feats, pos, sizes
+class _SliceEncoder:
+    """Backbone features of the slices in the order they will be consumed, encoded `batch` slices per forward_image call (the
+    trunk's kernels are far better filled at 8 slices than at 1; every kernel is batch-invariant, so the features are the ones a
+    slice-by-slice pass produces) and dropped once consumed: at most `batch` slices (17 MB each at 1024^2) are resident."""
+
+    def __init__(self, model, volume: torch.Tensor, order: List[int], batch: int):
+        self.model, self.volume, self.order, self.batch = model, volume, list(order), max(1, int(batch))
+        self.pos = 0
+        self.cache: Dict[int, dict] = {}
+
+    def get(self, t: int, n_obj: int):
+        """features of slice t expanded (views) over the objects like sam2_video_predictor.py:1284-1296"""
+        if t not in self.cache:
+            assert self.pos < len(self.order) and self.order[self.pos] == t, "slices must be consumed in the announced order"
+            ids = self.order[self.pos: self.pos + self.batch]
+            self.pos += len(ids)
+            bo = self.model.forward_image(self.volume[ids] if len(ids) > 1 else self.volume[ids[0]][None])
+            for j, u in enumerate(ids):
+                self.cache[u] = {"backbone_fpn": [f[j: j + 1] for f in bo["backbone_fpn"]],
+                                 "vision_pos_enc": [p[:1] for p in bo["vision_pos_enc"]]}
+        one = self.cache.pop(t)
+        bo = {"backbone_fpn": [f.expand(n_obj, -1, -1, -1) for f in one["backbone_fpn"]],
+              "vision_pos_enc": [p.expand(n_obj, -1, -1, -1) for p in one["vision_pos_enc"]]}
+        _, feats, pos, sizes = self.model._prepare_backbone_features(bo)
+        return feats, pos, sizes
 
 
 def box_point_inputs(boxes: torch.Tensor) -> dict:
@@ -39,9 +57,10 @@ def box_point_inputs(boxes: torch.Tensor) -> dict:
 
 @torch.no_grad()
 def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_hole_area: int = 0, group=None,
-                   shard_objects: bool = True) -> Dict[int, torch.Tensor]:
+                   shard_objects: bool = True, encode_batch: int = 8) -> Dict[int, torch.Tensor]:
     """volume: [T,3,S,S] normalised slices on the GPU; prompts: {slice_idx: {"boxes": [n,4]} | {"point_coords", "point_labels"}}
-    for the conditioning slices (same n objects everywhere).  Returns {slice_idx: low-res mask logits [n,1,S/4,S/4]}."""
+    for the conditioning slices (same n objects everywhere).  Returns {slice_idx: low-res mask logits [n,1,S/4,S/4]}.
+    encode_batch: slices per image-encoder call (results do not depend on it)."""
     T = volume.shape[0]
     cond_ids = sorted(prompts)
     assert cond_ids, "at least one conditioning slice is needed"
@@ -55,11 +74,12 @@ def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_h
     b, e = shard_range(len(cond_ids), rank, world)
     empty = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
     local = {}
+    enc = _SliceEncoder(model, volume, [cond_ids[i] for i in range(b, e)], encode_batch)
     for i in range(b, e):
         t = cond_ids[i]
         pr = prompts[t]
         pin = box_point_inputs(pr["boxes"]) if "boxes" in pr else {"point_coords": pr["point_coords"], "point_labels": pr["point_labels"]}
-        feats, pos, sizes = _encode(model, volume[t], n_obj)
+        feats, pos, sizes = enc.get(t, n_obj)
         local[t] = model.track_step(frame_idx=t, is_init_cond_frame=True, current_vision_feats=feats, current_vision_pos_embeds=pos,
                                     feat_sizes=sizes, point_inputs=pin, mask_inputs=None, output_dict=empty, num_frames=T)
     # 2. the one exchange step
@@ -73,10 +93,11 @@ def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_h
     if (ob, oe) != (0, n_obj):
         cond = {t: _slice_objects(o, sl) for t, o in cond.items()}
     output_dict = {"cond_frame_outputs": cond, "non_cond_frame_outputs": {}}
+    enc = _SliceEncoder(model, volume, [t for t in range(T) if t not in cond], encode_batch)
     for t in range(T):
         if t in cond:
             continue
-        feats, pos, sizes = _encode(model, volume[t], oe - ob)
+        feats, pos, sizes = enc.get(t, oe - ob)
         cur = model.track_step(frame_idx=t, is_init_cond_frame=False, current_vision_feats=feats, current_vision_pos_embeds=pos,
                                feat_sizes=sizes, point_inputs=None, mask_inputs=None, output_dict=output_dict, num_frames=T)
         output_dict["non_cond_frame_outputs"][t] = cur
