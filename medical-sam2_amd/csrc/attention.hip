@@ -40,7 +40,7 @@ struct AttnParams {
   // split-KV
   int splits;
   int defer_merge;  // split-KV partials stay in the workspace; msam2_attention_merge finishes (benchmark / overlap use)
-  float* o_part;   // [splits][Bz][H][Lq][D] fp32, unnormalised
+  op16* o_part;    // [splits][Bz][H][Lq][D] 16-bit, each split's own softmax-normalised output
   float* ml_part;  // [splits][Bz][H][Lq][2]  (running max in log2 domain, partial sum)
 };
 
@@ -253,15 +253,16 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
   } else {
     const int64_t Bz = gridDim.z / p.splits;
     const int64_t row = (((int64_t)split * Bz + z) * p.H + head) * p.Lq + qi;
-    float* op = p.o_part + row * D;
+    op16* op = p.o_part + row * D;
+    const float inv = 1.f / l_tot;                            // > 0: every split owns at least one valid key
 #pragma unroll
     for (int d = 0; d < DBLK; ++d)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        f32x4 w;
+        op16x4 w;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = o[d][4 * g + e];
-        *reinterpret_cast<f32x4*>(op + d * 32 + 8 * g + 4 * h) = w;
+        for (int e = 0; e < 4; ++e) w[e] = f2op(o[d][4 * g + e] * inv);
+        *reinterpret_cast<op16x4*>(op + d * 32 + 8 * g + 4 * h) = w;
       }
     if (h == 0) {
       p.ml_part[row * 2 + 0] = m_run;
@@ -270,7 +271,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
   }
 }
 
-// merge split-KV partials: one wave per (z, head, query); lanes stride over D
+// merge split-KV partials: one wave per (z, head, query), lane = 4 consecutive channels.  Partials are each split's normalised
+// output in 16 bits (half the HBM round trip of fp32 sums) with its (max, sum) pair: out = sum_s w_s O_s / sum_s w_s,
+// w_s = l_s 2^(m_s - M).
 template <int D>
 __global__ void attn_merge_kernel(AttnParams p, int Bz) {
   const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -282,20 +285,26 @@ __global__ void attn_merge_kernel(AttnParams p, int Bz) {
   const int z = gw / ((int64_t)p.Lq * p.H);
   float M = -INFINITY;
   for (int s = 0; s < p.splits; ++s) M = fmaxf(M, p.ml_part[((int64_t)s * rows + gw) * 2]);
+  const int d0 = lane * 4;
   float L = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < p.splits; ++s) {
     const float m = p.ml_part[((int64_t)s * rows + gw) * 2], l = p.ml_part[((int64_t)s * rows + gw) * 2 + 1];
-    L += (m == -INFINITY) ? 0.f : l * __builtin_amdgcn_exp2f(m - M);
-  }
-  const float inv = 1.f / L;
-  op16* ob = p.o + (int64_t)z * p.o_bs + (int64_t)head * p.o_hs + (int64_t)qi * p.o_ts;
-  for (int d = lane; d < D; d += 64) {
-    float acc = 0.f;
-    for (int s = 0; s < p.splits; ++s) {
-      const float m = p.ml_part[((int64_t)s * rows + gw) * 2];
-      if (m != -INFINITY) acc += p.o_part[((int64_t)s * rows + gw) * D + d] * __builtin_amdgcn_exp2f(m - M);
+    if (m == -INFINITY) continue;
+    const float w = l * __builtin_amdgcn_exp2f(m - M);
+    L += w;
+    if (d0 < D) {
+      const op16x4 t = *reinterpret_cast<const op16x4*>(p.o_part + ((int64_t)s * rows + gw) * D + d0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += w * op2f(t[e]);
     }
-    ob[d] = f2op(acc * inv);
+  }
+  if (d0 < D) {
+    const float inv = 1.f / L;
+    op16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f2op(acc[e] * inv);
+    *reinterpret_cast<op16x4*>(p.o + (int64_t)z * p.o_bs + (int64_t)head * p.o_hs + (int64_t)qi * p.o_ts + d0) = o;
   }
 }
 
@@ -582,15 +591,16 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_glds_kernel(AttnParams p) {
   } else {
     const int64_t Bz = gridDim.z / p.splits;
     const int64_t row = (((int64_t)split * Bz + z) * p.H + head) * p.Lq + qi;
-    float* op = p.o_part + row * D;
+    op16* op = p.o_part + row * D;
+    const float inv = 1.f / l_tot;                            // > 0: every split owns at least one valid key
 #pragma unroll
     for (int d = 0; d < DBLK; ++d)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        f32x4 w;
+        op16x4 w;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = o[d][4 * g + e];
-        *reinterpret_cast<f32x4*>(op + d * 32 + 8 * g + 4 * h) = w;
+        for (int e = 0; e < 4; ++e) w[e] = f2op(o[d][4 * g + e] * inv);
+        *reinterpret_cast<op16x4*>(op + d * 32 + 8 * g + 4 * h) = w;
       }
     if (h == 0) {
       p.ml_part[row * 2 + 0] = m_run;
@@ -638,7 +648,7 @@ static int dispatch_nw(const AttnParams& p, int Bz, hipStream_t s) {
 
 extern "C" size_t msam2_attention_workspace_bytes(int64_t Bz, int64_t H, int64_t Lq, int64_t D, int splits) {
   if (splits <= 1) return 0;
-  return (size_t)splits * Bz * H * Lq * (D + 2) * sizeof(float);
+  return (size_t)splits * Bz * H * Lq * (D * sizeof(op16) + 2 * sizeof(float));
 }
 
 // every split must own at least one 32-key tile
@@ -663,8 +673,8 @@ extern "C" int msam2_attention_merge(void* o, const int64_t* o_strides, int64_t 
   p.o_bs = o_strides[0]; p.o_hs = o_strides[1]; p.o_ts = o_strides[2];
   p.B = (int)B; p.H = (int)H; p.Lq = (int)Lq; p.Lk = (int)Lk;
   p.splits = splits;
-  p.o_part = (float*)workspace;
-  p.ml_part = p.o_part + (size_t)splits * B * H * Lq * D;
+  p.o_part = (op16*)workspace;
+  p.ml_part = reinterpret_cast<float*>(p.o_part + (size_t)splits * B * H * Lq * D);
   const int64_t rows = B * H * Lq;
   dim3 grid(cdiv(rows * 64, 256));
   hipStream_t s = (hipStream_t)stream;
@@ -706,8 +716,8 @@ extern "C" int msam2_attention_fwd(const void* q, const int64_t* q_strides, cons
   p.scale_log2 = scale * 1.4426950408889634f;
   p.splits = splits;
   p.defer_merge = defer ? 1 : 0;
-  p.o_part = (float*)workspace;
-  p.ml_part = p.o_part ? p.o_part + (size_t)splits * B * H * Lq * D : nullptr;
+  p.o_part = (op16*)workspace;
+  p.ml_part = workspace ? reinterpret_cast<float*>(p.o_part + (size_t)splits * B * H * Lq * D) : nullptr;
   hipStream_t s = (hipStream_t)stream;
   const char* force = getenv("MSAM2_ATTN_V1");
   const bool v2 = !(force && force[0] == '1') && Lq > 64;

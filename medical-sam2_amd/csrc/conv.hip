@@ -6,29 +6,37 @@
 // PatchEmbed (backbones/utils.py:84-95): Conv2d(3,E,k7,s4,p3) as im2col -> [B*(S/4)^2, 160] op16 (147 taps + zero pad),
 // column order (c, ky, kx) to match weight.reshape(E, 147).
 // ------------------------------------------------------------------------------------------------------------------
+// one thread per 8 consecutive columns of a patch row (one 16-byte store; the 2-byte-per-thread version ran at 1.4 TB/s)
 __global__ void im2col_patch_kernel(const float* __restrict__ img, op16* __restrict__ out, int B, int S) {
   const int So = S / 4;
-  const int64_t total = (int64_t)B * So * So * 160;
+  const int64_t total = (int64_t)B * So * So * 20;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int col = i % 160;
-    int64_t t = i / 160;
+    const int g = i % 20;
+    int64_t t = i / 20;
     const int xo = t % So;
     t /= So;
     const int yo = t % So;
     const int b = t / So;
-    float v = 0.f;
-    if (col < 147) {
-      const int c = col / 49, k = col % 49, ky = k / 7, kx = k % 7;
-      const int y = yo * 4 - 3 + ky, x = xo * 4 - 3 + kx;
-      if (y >= 0 && y < S && x >= 0 && x < S) v = img[(((int64_t)b * 3 + c) * S + y) * S + x];
+    op16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int col = g * 8 + e;
+      float f = 0.f;
+      if (col < 147) {
+        const int c = col / 49, k = col % 49, ky = k / 7, kx = k % 7;
+        const int y = yo * 4 - 3 + ky, x = xo * 4 - 3 + kx;
+        if (y >= 0 && y < S && x >= 0 && x < S) f = img[(((int64_t)b * 3 + c) * S + y) * S + x];
+      }
+      v[e] = f2op(f);
     }
-    out[i] = f2op(v);
+    *reinterpret_cast<op16x8*>(out + i * 8) = v;
   }
 }
 
 extern "C" int msam2_im2col_patch7x7s4(const float* img, void* out, int64_t B, int64_t S, void* stream) {
   MSAM2_REQUIRE(img && out && B > 0 && S > 0 && S % 4 == 0, "im2col_patch: bad arguments");
-  const int64_t total = B * (S / 4) * (S / 4) * 160;
+  MSAM2_REQUIRE(((uintptr_t)out & 15) == 0, "im2col_patch: output must be 16-byte aligned");
+  const int64_t total = B * (S / 4) * (S / 4) * 20;
   hipLaunchKernelGGL(im2col_patch_kernel, dim3((unsigned)min((int64_t)16384, (total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, img, (op16*)out, (int)B, (int)S);
   return msam2_check_launch("im2col_patch7x7s4");
@@ -152,45 +160,63 @@ extern "C" int msam2_conv3x3s2_ln_gelu(const void* x, int in_is_16bit, const flo
 // fp32 -> normalised op16 (the A operand of pwconv1).  One wave per pixel, C = 256 -> 4 channels per lane.
 // weights: fp32 [49][C] (tap-major, prepared from [C,1,7,7]).
 // ------------------------------------------------------------------------------------------------------------------
+// A wave owns DW_PIX horizontally adjacent pixels: per kernel row it loads the DW_PIX + 6 input columns and the 7 taps once and
+// feeds all DW_PIX accumulators (4x fewer cache reads than one pixel per wave).
+constexpr int DW_PIX = 4;
 __global__ void dwconv7x7_ln_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                     const float* __restrict__ ln_w, const float* __restrict__ ln_b, op16* __restrict__ y, int B,
                                     int H, int W, int C) {
-  const int64_t pix = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
-  if (pix >= (int64_t)B * H * W) return;
-  const int xx = pix % W;
-  const int yy = (pix / W) % H;
-  const int b = pix / ((int64_t)W * H);
+  const int gpr = (W + DW_PIX - 1) / DW_PIX;                   // pixel groups per image row
+  if (grp >= (int64_t)B * H * gpr) return;
+  const int x0 = (grp % gpr) * DW_PIX;
+  const int yy = (grp / gpr) % H;
+  const int b = grp / ((int64_t)gpr * H);
   const int c0 = lane * 4;
-  f32x4 acc = *reinterpret_cast<const f32x4*>(bias + c0);
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c0);
+  f32x4 acc[DW_PIX];
+#pragma unroll
+  for (int p = 0; p < DW_PIX; ++p) acc[p] = bv;
   for (int ky = 0; ky < 7; ++ky) {
     const int y2 = yy - 3 + ky;
     if (y2 < 0 || y2 >= H) continue;
-    for (int kx = 0; kx < 7; ++kx) {
-      const int x2 = xx - 3 + kx;
-      if (x2 < 0 || x2 >= W) continue;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((int64_t)b * H + y2) * W + x2) * C + c0);
-      const f32x4 ww = *reinterpret_cast<const f32x4*>(w + (ky * 7 + kx) * C + c0);
-      acc += v * ww;
+    f32x4 v[DW_PIX + 6], ww[7];
+#pragma unroll
+    for (int j = 0; j < DW_PIX + 6; ++j) {
+      const int x2 = x0 - 3 + j;
+      v[j] = (x2 >= 0 && x2 < W) ? *reinterpret_cast<const f32x4*>(x + (((int64_t)b * H + y2) * W + x2) * C + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) ww[kx] = *reinterpret_cast<const f32x4*>(w + (ky * 7 + kx) * C + c0);
+    // same tap order per pixel as the single-pixel form: ky outer, kx inner
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+      for (int p = 0; p < DW_PIX; ++p) acc[p] += v[p + kx] * ww[kx];
   }
-  const float mean = wave_sum(acc[0] + acc[1] + acc[2] + acc[3]) / C;
-  float q = 0.f;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) q += (acc[e] - mean) * (acc[e] - mean);
-  const float rstd = 1.f / sqrtf(wave_sum(q) / C + 1e-6f);
-  op16x4 o;
+  for (int p = 0; p < DW_PIX; ++p) {
+    if (x0 + p >= W) break;
+    const float mean = wave_sum(acc[p][0] + acc[p][1] + acc[p][2] + acc[p][3]) / C;
+    float q = 0.f;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = f2op((acc[e] - mean) * rstd * ln_w[c0 + e] + ln_b[c0 + e]);
-  *reinterpret_cast<op16x4*>(y + pix * C + c0) = o;
+    for (int e = 0; e < 4; ++e) q += (acc[p][e] - mean) * (acc[p][e] - mean);
+    const float rstd = 1.f / sqrtf(wave_sum(q) / C + 1e-6f);
+    op16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f2op((acc[p][e] - mean) * rstd * ln_w[c0 + e] + ln_b[c0 + e]);
+    const int64_t pix = ((int64_t)b * H + yy) * W + x0 + p;
+    *reinterpret_cast<op16x4*>(y + pix * C + c0) = o;
+  }
 }
 
 extern "C" int msam2_dwconv7x7_ln(const float* x, const float* weight_tap_major, const float* bias, const float* ln_w,
                                   const float* ln_b, void* y, int64_t B, int64_t H, int64_t W, int64_t C, void* stream) {
   MSAM2_REQUIRE(x && weight_tap_major && bias && ln_w && ln_b && y, "dwconv7x7_ln: null tensor");
-  MSAM2_REQUIRE(C == 256, "dwconv7x7_ln: built for C=256 (one wave per pixel, 4 channels per lane)");
-  const int64_t pix = B * H * W;
-  hipLaunchKernelGGL(dwconv7x7_ln_kernel, dim3(cdiv(pix * 64, 256)), dim3(256), 0, (hipStream_t)stream, x, weight_tap_major, bias,
+  MSAM2_REQUIRE(C == 256, "dwconv7x7_ln: built for C=256 (one wave per pixel group, 4 channels per lane)");
+  const int64_t groups = B * H * ((W + DW_PIX - 1) / DW_PIX);
+  hipLaunchKernelGGL(dwconv7x7_ln_kernel, dim3(cdiv(groups * 64, 256)), dim3(256), 0, (hipStream_t)stream, x, weight_tap_major, bias,
                      ln_w, ln_b, (op16*)y, (int)B, (int)H, (int)W, (int)C);
   return msam2_check_launch("dwconv7x7_ln");
 }

@@ -164,7 +164,7 @@ def test_attention_deferred_merge(ops):
     assert out.abs().sum().item() == 0          # nothing written before the merge
     ops.attention_merge(out, Lk, splits, ws)
     assert torch.equal(out, ref)
-    with pytest.raises(RuntimeError):
+    with pytest.raises(ValueError):
         ops.attention(q, k, v, splits=1, out=out, workspace=ws, defer_merge=True)
 
 
