@@ -24,6 +24,12 @@ struct GemmParams {
   int act;          // 0 none, 1 gelu(erf), 2 relu, 3 sigmoid
   int res_is_16bit;  // residual dtype
   int out_is_16bit;  // output dtype
+  // optional fused axial RoPE on the 16-bit output (RoPEAttention q/k projections, transformer.py:299-315): columns
+  // n < rope_cols are rotated as adjacent pairs (2i, 2i+1) of a head of rope_D channels; row m belongs to position
+  // l = m % rope_period of its batch, rotated when l < rope_n with table row l % rope_npos (rope_k_repeat tiling)
+  const float* rope_cos;
+  const float* rope_sin;
+  int rope_cols, rope_D, rope_period, rope_n, rope_npos;
 };
 
 #ifdef MSAM2_GSTAMP
@@ -186,7 +192,7 @@ __device__ __forceinline__ void gemm_epilogue_spec(const GemmParams& p, f32x16 (
 //   [1,0,3,2]) and packs a dword: even lanes store (col r, r+1) of row(e), odd lanes (col r-1, r) of row(e+1).
 // Rows past M fall outside the buffer descriptor's num_records and are dropped by the hardware range check (the row term is in
 // the per-lane voffset because soffset is not range-checked on gfx9); columns past N are masked per lane.
-template <int FM, int FN, int ACT, int RES /* 0 none, 1 f32 */, bool OUT16>
+template <int FM, int FN, int ACT, int RES /* 0 none, 1 f32 */, bool OUT16, bool ROPE = false>
 __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x16 (&acc)[FM][FN], int64_t row0, int64_t col0, int lane) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int ES = OUT16 ? 2 : 4;
@@ -236,6 +242,14 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x16
   } else {
     static_assert(!OUT16 || RES == 0, "16-bit outputs carry no residual on the direct path");
     const int vbase = (int)((row0 + 4 * h + odd) * p.ldc + col0 + (r & ~1)) * 2;
+    // RoPE bookkeeping: this lane's first row (the one of i = 0, k = 0) as (position in its batch, table row); later rows
+    // add a compile-time offset < 128 and wrap
+    int l_base = 0, pos_base = 0, hp = 0;
+    if constexpr (ROPE) {
+      l_base = (int)((unsigned)(row0 + 4 * h + odd) % (unsigned)p.rope_period);
+      pos_base = (int)((unsigned)l_base % (unsigned)p.rope_npos);
+      hp = p.rope_D >> 1;
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -246,7 +260,21 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x16
           const float x0 = fn(acc[i][j][e0], j), x1 = fn(acc[i][j][e0 + 1], j);
           const float send = odd ? x0 : x1;
           const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xf, 0xf, false));
-          const float lo = odd ? recv : x0, hi = odd ? x1 : recv;
+          float lo = odd ? recv : x0, hi = odd ? x1 : recv;
+          if constexpr (ROPE) {
+            const int ncol = (int)col0 + j * 32 + (r & ~1);
+            int l = l_base + ro, pos = pos_base + ro;
+            // (ro < 128 <= period / npos is checked on the host: one wrap suffices)
+            if (l >= p.rope_period) { l -= p.rope_period; pos = (int)((unsigned)l % (unsigned)p.rope_npos); }
+            else if (pos >= p.rope_npos) pos -= p.rope_npos;
+            if (ncol < p.rope_cols && l < p.rope_n && colok[j]) {
+              const int pr = (ncol % p.rope_D) >> 1;
+              const float c = p.rope_cos[(int64_t)pos * hp + pr], sn = p.rope_sin[(int64_t)pos * hp + pr];
+              const float re = lo, im = hi;
+              lo = re * c - im * sn;
+              hi = re * sn + im * c;
+            }
+          }
           op16x2 pk;
           pk[0] = f2op(lo);
           pk[1] = f2op(hi);
@@ -279,7 +307,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
   const int mode = !aligned ? -1 : (p.act * 4 + (p.res ? 2 : 0) + (p.out_is_16bit ? 1 : 0));
   if (direct) {
     switch (mode) {
-      case 0 * 4 + 0 + 1: gemm_epilogue_direct<FM, FN, 0, 0, true>(p, acc, row0, col0, lane); return;   // linear -> 16-bit
+      case 0 * 4 + 0 + 1:                                                                                  // linear -> 16-bit
+        if (p.rope_cos) gemm_epilogue_direct<FM, FN, 0, 0, true, true>(p, acc, row0, col0, lane);
+        else gemm_epilogue_direct<FM, FN, 0, 0, true>(p, acc, row0, col0, lane);
+        return;
       case 0 * 4 + 0 + 0: gemm_epilogue_direct<FM, FN, 0, 0, false>(p, acc, row0, col0, lane); return;  // linear -> fp32
       case 0 * 4 + 2 + 0: gemm_epilogue_direct<FM, FN, 0, 1, false>(p, acc, row0, col0, lane); return;  // + fp32 residual -> fp32
       case 1 * 4 + 0 + 1: gemm_epilogue_direct<FM, FN, 1, 0, true>(p, acc, row0, col0, lane); return;   // GELU -> 16-bit
@@ -821,10 +852,10 @@ static void launch_gemm(const GemmParams& p, hipStream_t s) {
   hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN>), grid, dim3(WM * WN * 64), 0, s, p);
 }
 
-extern "C" int msam2_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
-                               const float* colscale, const void* residual, int64_t ldr, int res_is_16bit, int64_t res_mod,
-                               void* C, int64_t ldc, int out_is_16bit, int64_t M, int64_t N, int64_t K, int act,
-                               void* stream) {
+static int gemm_launch(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* colscale,
+                       const void* residual, int64_t ldr, int res_is_16bit, int64_t res_mod, void* C, int64_t ldc, int out_is_16bit,
+                       int64_t M, int64_t N, int64_t K, int act, void* stream, const float* rope_cos, const float* rope_sin,
+                       int rope_cols, int rope_D, int rope_period, int rope_n, int rope_npos) {
   MSAM2_REQUIRE(A && W && C, "gemm: null operand");
   MSAM2_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   MSAM2_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0, "gemm: K, lda, ldw must be multiples of 8 (16-byte rows)");
@@ -835,6 +866,8 @@ extern "C" int msam2_gemm(const void* A, int64_t lda, const void* W, int64_t ldw
   p.A = (const op16*)A; p.W = (const op16*)W; p.bias = bias; p.colscale = colscale; p.res = residual; p.C = C;
   p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldc = ldc; p.res_mod = res_mod;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act; p.res_is_16bit = res_is_16bit; p.out_is_16bit = out_is_16bit;
+  p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.rope_cols = rope_cols; p.rope_D = rope_D; p.rope_period = rope_period;
+  p.rope_n = rope_n; p.rope_npos = rope_npos;
   hipStream_t s = (hipStream_t)stream;
   const char* force = getenv("MSAM2_GEMM_V1");
   const char* var = getenv("MSAM2_GEMM_VARIANT");
@@ -869,5 +902,31 @@ extern "C" int msam2_gemm(const void* A, int64_t lda, const void* W, int64_t ldw
   else if (N <= 32) launch_gemm<128, 32, 4, 1>(p, s);
   else if (N <= 64 || (N % 128 != 0 && N % 64 == 0 && N < 512)) launch_gemm<128, 64, 2, 2>(p, s);
   else launch_gemm<128, 128, 2, 2>(p, s);
-  return msam2_check_launch("gemm_bf16");
+  return msam2_check_launch("gemm");
+}
+
+extern "C" int msam2_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* colscale,
+                          const void* residual, int64_t ldr, int res_is_16bit, int64_t res_mod, void* C, int64_t ldc, int out_is_16bit,
+                          int64_t M, int64_t N, int64_t K, int act, void* stream) {
+  return gemm_launch(A, lda, W, ldw, bias, colscale, residual, ldr, res_is_16bit, res_mod, C, ldc, out_is_16bit, M, N, K, act, stream,
+                     nullptr, nullptr, 0, 0, 1, 0, 1);
+}
+
+// Linear projection with the axial RoPE of RoPEAttention (transformer.py:299-315) fused into the store: C (16-bit) =
+// rope(A W^T + bias) on columns n < rope_cols (heads of head_dim channels, adjacent pairs), for rows whose position in their batch
+// l = m % rows_per_batch is < n_rope, using table row l % n_pos of cos/sin [n_pos, head_dim/2] (fp32).  Rotation happens on the
+// fp32 accumulator, i.e. one rounding instead of the two of a projection followed by an in-place rotation.
+extern "C" int msam2_gemm_rope(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc,
+                               int64_t M, int64_t N, int64_t K, const float* rope_cos, const float* rope_sin, int64_t rope_cols,
+                               int64_t head_dim, int64_t rows_per_batch, int64_t n_rope, int64_t n_pos, void* stream) {
+  MSAM2_REQUIRE(rope_cos && rope_sin, "gemm_rope: null table");
+  MSAM2_REQUIRE(head_dim > 0 && head_dim % 4 == 0 && rope_cols >= 0 && rope_cols <= N && rope_cols % head_dim == 0,
+                "gemm_rope: rope_cols must be whole heads of head_dim channels");
+  MSAM2_REQUIRE(rows_per_batch >= 128 && n_pos >= 128 && n_rope >= 0 && n_rope <= rows_per_batch && M % rows_per_batch == 0,
+                "gemm_rope: bad row geometry (rows_per_batch, n_pos >= 128; M a multiple of rows_per_batch)");
+  MSAM2_REQUIRE(M >= 256 && N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 && M * ldc * 4 < (1ll << 31) &&
+                    (!bias || ((uintptr_t)bias & 15) == 0),
+                "gemm_rope: needs the direct-store epilogue (M >= 256, 16-byte aligned C, N %% 4 == 0, C < 2 GiB)");
+  return gemm_launch(A, lda, W, ldw, bias, nullptr, nullptr, 0, 0, 0, C, ldc, 1, M, N, K, 0, stream, rope_cos, rope_sin, (int)rope_cols,
+                     (int)head_dim, (int)rows_per_batch, (int)n_rope, (int)n_pos);
 }

@@ -19,6 +19,10 @@ from .common import OP16, F32, WeightCache, attn_splits, nchw_view, to_bf16, tok
 from .encoder import MLP  # noqa: F401  (re-export for the registry)
 
 
+import os as _os
+_FUSED_ROPE = _os.environ.get("MSAM2_NO_FUSED_ROPE") is None   # experiment switch: rotate in a separate in-place kernel instead
+
+
 class LayerNorm2d(nn.Module):
     """sam2_utils.py:137-149 -- parameters only; the kernels normalise NHWC tokens over the channel dim."""
 
@@ -98,16 +102,30 @@ class RoPEAttention(Attention):
             self._tables[key] = ops.rope_table(side, self.internal_dim // self.num_heads, float(self.rope_theta), device)
         return self._tables[key]
 
+    def proj_rope(self, which: str, x_bf16: torch.Tensor, B: int, rows_per_batch: int, n_rope: int, tab) -> torch.Tensor:
+        """q/k projection + RoPE -> bf16 [B, rows_per_batch, internal]; the rotation rides in the GEMM's store when the problem
+        qualifies (ops.gemm_rope), otherwise it is applied in place after the projection."""
+        lin = getattr(self, which + "_proj")
+        w, b = w_bf16(self._wc, which + "w", lin.weight), v_f32(self._wc, which + "b", lin.bias)
+        M = x_bf16.shape[0]
+        if _FUSED_ROPE and M >= 256 and rows_per_batch >= 128 and tab[0].shape[0] >= 128 and n_rope > 0 and M * self.internal_dim * 4 < 2 ** 31:
+            return ops.gemm_rope(x_bf16, w, b, tab, rope_cols=self.internal_dim, head_dim=self.internal_dim // self.num_heads,
+                                 rows_per_batch=rows_per_batch, n_rope=n_rope).view(B, rows_per_batch, -1)
+        y = ops.gemm(x_bf16, w, b).view(B, rows_per_batch, -1)
+        ops.rope_(y, n_rope, tab)
+        return y
+
     def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_k_exclude_rope: int = 0) -> torch.Tensor:
         assert not (self.training and self.dropout_p > 0.0), "attention dropout (train mode) is outside the forward hot path"
         B, Lq, _ = q.shape
-        f = lambda t, n: self.proj(n, to_bf16(t.reshape(-1, t.shape[-1]).contiguous())).view(B, t.shape[1], -1)
-        qp, kp, vp = f(q, "q"), f(k, "k"), f(v, "v")
-        if qp.shape[1] != kp.shape[1]:
+        Lk = k.shape[1]
+        if Lq != Lk:
             assert self.rope_k_repeat
+        flat = lambda t: to_bf16(t.reshape(-1, t.shape[-1]).contiguous())
         tab = self.table(Lq, q.device)
-        ops.rope_(qp, Lq, tab)
-        ops.rope_(kp, kp.shape[1] - num_k_exclude_rope, tab)
+        qp = self.proj_rope("q", flat(q), B, Lq, Lq, tab)
+        kp = self.proj_rope("k", flat(k), B, Lk, Lk - num_k_exclude_rope, tab)
+        vp = self.proj("v", flat(v)).view(B, Lk, -1)
         return self.out(self.core(qp, kp, vp), None).view(B, Lq, -1)
 
 
@@ -146,18 +164,22 @@ class MemoryAttentionLayer(nn.Module):
         tab = sa.table(L, x.device)
         # self attention: fused q|k|v projection, RoPE on q and k rows in place
         t = self._ln("norm1", x)
-        qkv = ops.gemm(t, w_bf16(wc, "sqkv", sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight),
-                       v_f32(wc, "sqkvb", sa.q_proj.bias, sa.k_proj.bias, sa.v_proj.bias)).view(B, L, 3 * C)
+        w_qkv = w_bf16(wc, "sqkv", sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight)
+        b_qkv = v_f32(wc, "sqkvb", sa.q_proj.bias, sa.k_proj.bias, sa.v_proj.bias)
+        fused_rope = _FUSED_ROPE and B * L >= 256 and L >= 128 and sa.num_heads == 1 and B * L * 3 * C * 4 < 2 ** 31
+        if fused_rope:   # q | k columns rotated in the GEMM's store, v columns untouched
+            qkv = ops.gemm_rope(t, w_qkv, b_qkv, tab, rope_cols=2 * C, head_dim=C, rows_per_batch=L, n_rope=L).view(B, L, 3 * C)
+        else:
+            qkv = ops.gemm(t, w_qkv, b_qkv).view(B, L, 3 * C)
         q, k, v = qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
-        ops.rope_(q, L, tab)
-        ops.rope_(k, L, tab)
+        if not fused_rope:
+            ops.rope_(q, L, tab)
+            ops.rope_(k, L, tab)
         x = sa.out(sa.core(q, k, v), x)
         # cross attention to the memory bank (keys carry the position encoding, values do not)
         t = self._ln("norm2", x)
-        q = ca.proj("q", t).view(B, L, C)
-        ops.rope_(q, L, tab)
-        kk = ca.proj("k", mem_k.reshape(B * Nk, -1)).view(B, Nk, C)
-        ops.rope_(kk, Nk - n_ptr_tokens, tab)
+        q = ca.proj_rope("q", t, B, L, L, tab)
+        kk = ca.proj_rope("k", mem_k.reshape(B * Nk, -1), B, Nk, Nk - n_ptr_tokens, tab)
         vv = ca.proj("v", mem_v.reshape(B * Nk, -1)).view(B, Nk, C)
         x = ca.out(ca.core(q, kk, vv), x)
         # FFN

@@ -65,6 +65,24 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+def gemm_rope(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], table: Tuple[torch.Tensor, torch.Tensor], *,
+              rope_cols: int, head_dim: int, rows_per_batch: int, n_rope: int) -> torch.Tensor:
+    """16-bit out[M,N] = rope(a @ w^T + bias): columns < rope_cols (whole heads of head_dim channels) of rows whose position
+    m % rows_per_batch is < n_rope are rotated with table row (m % rows_per_batch) % n_pos -- the q/k projections of RoPEAttention
+    with the rotation applied to the fp32 accumulator in the store."""
+    _req(a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1], f"gemm_rope shapes {tuple(a.shape)} x {tuple(w.shape)}")
+    _req(a.dtype == OP16 and w.dtype == OP16 and a.stride(1) == 1 and w.stride(1) == 1, "gemm_rope operands: 16-bit, K-contiguous")
+    cs, sn = table
+    _req(cs.dtype == F32 and cs.is_contiguous() and sn.is_contiguous() and cs.shape == sn.shape and cs.shape[1] * 2 == head_dim,
+         "gemm_rope: table must be cos/sin fp32 [n_pos, head_dim/2]")
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, dtype=OP16, device=a.device)
+    check(lib().msam2_gemm_rope(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, _p(cs), _p(sn),
+                                rope_cols, head_dim, rows_per_batch, n_rope, cs.shape[0], _stream()))
+    return out
+
+
 def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float, *, act: int = ACT_NONE,
               out_dtype: torch.dtype = OP16) -> torch.Tensor:
     """Row LayerNorm over the last dim of a [rows, C] tensor (C contiguous)."""

@@ -53,6 +53,10 @@ def close(a, b, atol, rtol=0.0, what=""):
     assert not bad.any(), f"{what}: max err {err.max().item():.4g} (limit {atol}+{rtol}*|ref|), {bad.sum().item()} bad of {bad.numel()}"
 
 
+def max_abs_t(a, b):
+    return (a.float() - b.float()).abs().max().item()
+
+
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (5, 288, 96), (300, 96, 384), (70, 32, 64), (257, 576, 160), (33, 64, 16),
                                    (1000, 2048, 256), (8, 4, 256), (4096, 768, 256), (300, 128, 64), (257, 640, 192), (4099, 1152, 384),
@@ -114,6 +118,29 @@ def test_gemm_epilogue_modes(ops, M, N, K):
     close(buf[:, 1:N + 1], lin, 2e-4, 1e-5, "unaligned view")
     assert buf[:, 0].abs().sum().item() == 0 and buf[:, N + 1:].abs().sum().item() == 0
     close(ops.gemm(d(a), d(w[:N - 2]), d(bias[:N - 2]), out_dtype=OP16()), lin[:, :N - 2], 1e-3, 8e-3, "N % 4 != 0")
+
+
+@pytest.mark.parametrize("B,L,n_excl,N,cols,D,K", [(2, 256, 0, 256, 256, 256, 64), (3, 260, 4, 256, 256, 256, 64), (2, 1024, 0, 768, 512, 256, 256),
+                                                   (1, 4100, 4, 128, 128, 64, 96)])
+def test_gemm_rope_fused(ops, B, L, n_excl, N, cols, D, K):
+    """RoPE fused into the projection's store == projection (fp32) followed by the oracle's rotation; rows past n_rope of every
+    batch (object-pointer tokens) and columns past rope_cols (the v third of a fused qkv) stay unrotated; keys tile the table."""
+    side = 16
+    cos, sin = ops.rope_table(side, D, 10000.0, DEV)
+    a, w, bias = bf(rnd(B * L, K, seed=21)), bf(rnd(N, K, seed=22, scale=0.2)), rnd(N, seed=23)
+    lin = (a.float() @ w.float().t() + bias).view(B, L, N)
+    oc, osn = O.axial_rope_table(D, side, side, 10000.0)
+    assert max_abs_t(cos.cpu(), oc) < 1e-5 and max_abs_t(sin.cpu(), osn) < 1e-5
+    n_rope = L - n_excl
+    ref = lin.clone()
+    reps = -(-n_rope // (side * side))
+    c, s_ = oc.repeat(reps, 1)[:n_rope], osn.repeat(reps, 1)[:n_rope]
+    for h0 in range(0, cols, D):
+        ref[:, :n_rope, h0:h0 + D] = O.rope_rotate(lin[:, :n_rope, h0:h0 + D], c, s_)
+    out = ops.gemm_rope(a.to(DEV), w.to(DEV), bias.to(DEV), (cos, sin), rope_cols=cols, head_dim=D, rows_per_batch=L, n_rope=n_rope)
+    close(out.view(B, L, N), ref, 2e-3, 8e-3, "gemm_rope")
+    with pytest.raises(RuntimeError):
+        ops.gemm_rope(a.to(DEV), w.to(DEV), bias.to(DEV), (cos, sin), rope_cols=cols + 4, head_dim=D, rows_per_batch=L, n_rope=n_rope)
 
 
 def test_gemm_rejects_bad_shapes(ops):
