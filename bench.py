@@ -147,10 +147,24 @@ def pmc_traffic():
     return tot
 
 
+def host_cpu_share() -> int:
+    """CPUs this process may actually use: the cgroup quota when there is one (the GPU box gives 16 of its 256 hardware threads;
+    running the oracle on all 256 is 3x SLOWER than on 16: tools/cpu_threads_probe.py), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline():
     """The CPU oracle (fp32 torch restatement, "port") on ONE slice of the same workload (1 memory of the 4 -> scaled
-    honestly: the sample is one slice with its full 4-memory bank), 1 warm-up + 2 timed repetitions."""
+    honestly: the sample is one slice with its full 4-memory bank), 1 warm-up + 2 timed repetitions, on the host's CPU share."""
     from oracle import sam2_oracle as O
+    torch.set_num_threads(host_cpu_share())
     import medical_sam2_amd.synthetic as syn
     import medical_sam2_amd.weights as wts
     torch.set_grad_enabled(False)
