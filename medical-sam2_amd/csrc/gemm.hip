@@ -30,7 +30,25 @@ struct GemmParams {
   const float* rope_cos;
   const float* rope_sin;
   int rope_cols, rope_D, rope_period, rope_n, rope_npos;
+  // optional fused 2x2 max-pool of the OUTPUT over the token image (Hiera's pooled shortcut, hieradet.py:141-145): logical row
+  // m = 4 * pooled_pixel + (dy * 2 + dx) reads A row ((b*pool_H + 2*y2 + dy) * pool_W + 2*x2 + dx); the four rows of a pooled
+  // pixel are the four registers (e & 3) of one lane in the MFMA accumulator layout, so the pool is a register max and only the
+  // pooled rows [M/4, N] are ever written.  pool_W == 0: off.
+  int pool_H, pool_W;
 };
+
+// A row (in elements of lda) that logical GEMM row m reads
+__device__ __forceinline__ int64_t gemm_a_row(const GemmParams& p, int64_t m) {
+  if (p.pool_W == 0) return m;
+  const int s = (int)(m & 3);
+  const int64_t pix = m >> 2;
+  const int w2 = p.pool_W >> 1, h2 = p.pool_H >> 1;
+  const int x2 = (int)(pix % w2);
+  const int64_t t = pix / w2;
+  const int y2 = (int)(t % h2);
+  const int64_t b = t / h2;
+  return (b * p.pool_H + 2 * y2 + (s >> 1)) * p.pool_W + 2 * x2 + (s & 1);
+}
 
 #ifdef MSAM2_GSTAMP
 // diagnostic build only (tools/gemm_probe.hip): per-workgroup time stamps, never compiled into the product library
@@ -295,9 +313,39 @@ __device__ __forceinline__ int gemm_epilogue_direct_mode(const GemmParams& p) {
   return (direct && (mode == 1 || mode == 0 || mode == 2 || mode == 5 || mode == 9)) ? mode : -1;
 }
 
+// 2x2 max-pool epilogue (see GemmParams::pool_W): fp32 out [M/4, N] = max over the 4 sub-pixel rows + bias; one dword per lane,
+// two 128-byte row segments per store instruction.
+template <int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue_pool(const GemmParams& p, f32x16 (&acc)[FM][FN], int64_t row0, int64_t col0, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int r = lane & 31, h = lane >> 5;
+  const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((int64_t)p.M >> 2) * p.ldc * 4), 0x00020000);
+  const int vbase = (int)(((row0 >> 2) + h) * p.ldc + col0 + r) * 4;
+  const int ldc_b = (int)p.ldc * 4;
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int64_t n = col0 + j * 32 + r;
+    const bool ok = n < p.N;
+    const float b = (p.bias && ok) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float v = fmaxf(fmaxf(acc[i][j][4 * g], acc[i][j][4 * g + 1]), fmaxf(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3])) + b;
+        // rows 8g + 4h .. +3 of the slab -> pooled row (row0 + 32 i)/4 + 2g + h
+        if (ok) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_rsrc, vbase + (i * 8 + 2 * g) * ldc_b + j * 128, 0, 0);
+      }
+  }
+#endif
+}
+
 template <int FM, int FN>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[FM][FN], float* scr, int64_t row0, int64_t col0,
                                               int lane) {
+  if (p.pool_W) {
+    gemm_epilogue_pool<FM, FN>(p, acc, row0, col0, lane);
+    return;
+  }
   const bool aligned = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
                        (!p.res || (((p.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0) && !p.res_is_16bit)) &&
                        (!p.bias || ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0)) &&
@@ -360,7 +408,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
       const int row = c >> 2, kc = (c & 3) * 8;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (c < A_CHUNKS && m0 + row < p.M && k0 + kc < p.K)
-        v = *reinterpret_cast<const uint4*>(p.A + (m0 + row) * p.lda + k0 + kc);
+        v = *reinterpret_cast<const uint4*>(p.A + gemm_a_row(p, m0 + row) * p.lda + k0 + kc);
       ra[i] = v;
     }
 #pragma unroll
@@ -454,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
   for (int i = 0; i < 4; ++i) {
     const int row = (wave * 4 + i) * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    const int64_t ga = min(m0 + row, (int64_t)p.M - 1), gw = min(n0 + row, (int64_t)p.N - 1);
+    const int64_t ga = gemm_a_row(p, min(m0 + row, (int64_t)p.M - 1)), gw = min(n0 + row, (int64_t)p.N - 1);
     offsA[i] = (unsigned)(ga * p.lda * 2 + chunk * 16);
     offsW[i] = (unsigned)(gw * p.ldw * 2 + chunk * 16);
   }
@@ -572,7 +620,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds32_kernel(GemmParams p) {
   for (int i = 0; i < 2; ++i) {
     const int row = (wave * 2 + i) * 16 + (lane >> 2);
     const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-    const int64_t ga = min(m0 + row, (int64_t)p.M - 1), gw = min(n0 + row, (int64_t)p.N - 1);
+    const int64_t ga = gemm_a_row(p, min(m0 + row, (int64_t)p.M - 1)), gw = min(n0 + row, (int64_t)p.N - 1);
     offsA[i] = (unsigned)(ga * p.lda * 2 + chunk * 16);
     offsW[i] = (unsigned)(gw * p.ldw * 2 + chunk * 16);
   }
@@ -694,7 +742,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_wide_kernel(GemmParams p) {
   for (int i = 0; i < PA; ++i) {
     const int row = (wave * PA + i) * 16 + (lane >> 2);
     const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-    offsA[i] = (unsigned)(min(m0 + row, (int64_t)p.M - 1) * p.lda * 2 + chunk * 16);
+    offsA[i] = (unsigned)(gemm_a_row(p, min(m0 + row, (int64_t)p.M - 1)) * p.lda * 2 + chunk * 16);
   }
 #pragma unroll
   for (int i = 0; i < PWW; ++i) {
@@ -855,7 +903,7 @@ static void launch_gemm(const GemmParams& p, hipStream_t s) {
 static int gemm_launch(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* colscale,
                        const void* residual, int64_t ldr, int res_is_16bit, int64_t res_mod, void* C, int64_t ldc, int out_is_16bit,
                        int64_t M, int64_t N, int64_t K, int act, void* stream, const float* rope_cos, const float* rope_sin,
-                       int rope_cols, int rope_D, int rope_period, int rope_n, int rope_npos) {
+                       int rope_cols, int rope_D, int rope_period, int rope_n, int rope_npos, int pool_H = 0, int pool_W = 0) {
   MSAM2_REQUIRE(A && W && C, "gemm: null operand");
   MSAM2_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   MSAM2_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0, "gemm: K, lda, ldw must be multiples of 8 (16-byte rows)");
@@ -868,6 +916,7 @@ static int gemm_launch(const void* A, int64_t lda, const void* W, int64_t ldw, c
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act; p.res_is_16bit = res_is_16bit; p.out_is_16bit = out_is_16bit;
   p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.rope_cols = rope_cols; p.rope_D = rope_D; p.rope_period = rope_period;
   p.rope_n = rope_n; p.rope_npos = rope_npos;
+  p.pool_H = pool_H; p.pool_W = pool_W;
   hipStream_t s = (hipStream_t)stream;
   const char* force = getenv("MSAM2_GEMM_V1");
   const char* var = getenv("MSAM2_GEMM_VARIANT");
@@ -910,6 +959,19 @@ extern "C" int msam2_gemm(const void* A, int64_t lda, const void* W, int64_t ldw
                           int64_t M, int64_t N, int64_t K, int act, void* stream) {
   return gemm_launch(A, lda, W, ldw, bias, colscale, residual, ldr, res_is_16bit, res_mod, C, ldc, out_is_16bit, M, N, K, act, stream,
                      nullptr, nullptr, 0, 0, 1, 0, 1);
+}
+
+// Linear layer followed by a 2x2/stride-2 max-pool over the token image (Hiera's pooled shortcut: `do_pool(self.proj(x_norm), self.pool)`,
+// hieradet.py:141-145, 23-34): A is the [B*H*W, K] token image, C (fp32) = maxpool2x2(A W^T + bias) as [B*(H/2)*(W/2), N].  The
+// un-pooled [B*H*W, N] map (201 MB at stage 1 -> 2) is never written: rows are gathered so that a pooled pixel's four sources are
+// the four accumulator registers of one lane.
+extern "C" int msam2_gemm_pool2x2(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
+                                  int64_t B, int64_t H, int64_t Wimg, int64_t N, int64_t K, void* stream) {
+  MSAM2_REQUIRE(B > 0 && H > 0 && Wimg > 0 && H % 2 == 0 && Wimg % 2 == 0, "gemm_pool2x2: H and W must be even");
+  const int64_t M = B * H * Wimg;
+  MSAM2_REQUIRE(M >= 256 && (M / 4) * ldc * 4 < (1ll << 31) && M * lda * 2 < (1ll << 31), "gemm_pool2x2: problem out of the 32-bit offset range");
+  return gemm_launch(A, lda, W, ldw, bias, nullptr, nullptr, 0, 0, 0, C, ldc, 0, M, N, K, 0, stream, nullptr, nullptr, 0, 0, 1, 0, 1,
+                     (int)H, (int)Wimg);
 }
 
 // Linear projection with the axial RoPE of RoPEAttention (transformer.py:299-315) fused into the store: C (16-bit) =

@@ -17,6 +17,10 @@ from .common import OP16, F32, WeightCache, nchw_view, to_bf16, tokens_of, v_f32
 from .position import PositionEmbeddingSine
 
 
+import os as _os
+_POOL_GEMM = _os.environ.get("MSAM2_NO_POOL_GEMM") is None   # experiment switch
+
+
 class PatchEmbed(nn.Module):
     """backbones/utils.py:65-95 (Conv2d k7 s4 p3 -> NHWC)."""
 
@@ -147,9 +151,12 @@ class MultiScaleBlock(nn.Module):
         xn = ops.layernorm(t, v_f32(wc, "n1w", self.norm1.weight), v_f32(wc, "n1b", self.norm1.bias), 1e-6)
         pool = self.q_stride is not None
         if self.dim != dim_out:
-            shortcut = ops.gemm(xn, w_bf16(wc, "pw", self.proj.weight), v_f32(wc, "pb", self.proj.bias), out_dtype=F32)
-            if pool:
-                shortcut = ops.maxpool2x2(shortcut, B, H, W)
+            if _POOL_GEMM and pool and B * H * W >= 256 and H % 2 == 0 and W % 2 == 0:   # projection + 2x2 max-pool in one GEMM
+                shortcut = ops.gemm_pool2x2(xn, w_bf16(wc, "pw", self.proj.weight), v_f32(wc, "pb", self.proj.bias), B, H, W)
+            else:
+                shortcut = ops.gemm(xn, w_bf16(wc, "pw", self.proj.weight), v_f32(wc, "pb", self.proj.bias), out_dtype=F32)
+                if pool:
+                    shortcut = ops.maxpool2x2(shortcut, B, H, W)
         else:
             shortcut = t
         qkv = ops.gemm(xn, qkv_w, qkv_b)  # 16-bit [T, 3*width]

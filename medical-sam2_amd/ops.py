@@ -65,6 +65,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+def gemm_pool2x2(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], B: int, H: int, W: int) -> torch.Tensor:
+    """fp32 [B*(H/2)*(W/2), N] = maxpool2x2(a @ w^T + bias) over the [B,H,W] token image a [B*H*W, K] (16-bit, K-contiguous)."""
+    _req(a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1] and a.shape[0] == B * H * W, "gemm_pool2x2 shapes")
+    _req(a.dtype == OP16 and w.dtype == OP16 and a.stride(1) == 1 and w.stride(1) == 1, "gemm_pool2x2 operands: 16-bit, K-contiguous")
+    N, K = w.shape
+    out = torch.empty(B * (H // 2) * (W // 2), N, dtype=F32, device=a.device)
+    check(lib().msam2_gemm_pool2x2(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), B, H, W, N, K, _stream()))
+    return out
+
+
 def gemm_rope(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], table: Tuple[torch.Tensor, torch.Tensor], *,
               rope_cols: int, head_dim: int, rows_per_batch: int, n_rope: int) -> torch.Tensor:
     """16-bit out[M,N] = rope(a @ w^T + bias): columns < rope_cols (whole heads of head_dim channels) of rows whose position

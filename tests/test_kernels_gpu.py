@@ -143,6 +143,17 @@ def test_gemm_rope_fused(ops, B, L, n_excl, N, cols, D, K):
         ops.gemm_rope(a.to(DEV), w.to(DEV), bias.to(DEV), (cos, sin), rope_cols=cols + 4, head_dim=D, rows_per_batch=L, n_rope=n_rope)
 
 
+@pytest.mark.parametrize("B,H,W,N,K", [(2, 16, 16, 192, 96), (1, 32, 24, 384, 192), (3, 18, 14, 768, 384), (1, 64, 64, 200, 64)])
+def test_gemm_pool2x2_fused(ops, B, H, W, N, K):
+    """projection + 2x2 max-pool in one GEMM == max_pool2d(linear(x)) (hieradet.py:23-34, 141-145), every kernel family"""
+    a, w, bias = bf(rnd(B * H * W, K, seed=31)), bf(rnd(N, K, seed=32, scale=0.2)), rnd(N, seed=33)
+    lin = (a.float() @ w.float().t() + bias).view(B, H, W, N).permute(0, 3, 1, 2)
+    ref = F.max_pool2d(lin, 2, 2).permute(0, 2, 3, 1).reshape(-1, N)
+    out = ops.gemm_pool2x2(a.to(DEV), w.to(DEV), bias.to(DEV), B, H, W)
+    assert out.shape == ref.shape
+    close(out, ref, 2e-4, 1e-5, "gemm_pool2x2")
+
+
 def test_gemm_rejects_bad_shapes(ops):
     with pytest.raises(Exception):
         ops.gemm(bf(rnd(8, 12)).to(DEV), bf(rnd(8, 12)).to(DEV))  # K % 8 != 0
