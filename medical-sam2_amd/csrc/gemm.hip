@@ -35,6 +35,11 @@ struct GemmParams {
   // pixel are the four registers (e & 3) of one lane in the MFMA accumulator layout, so the pool is a register max and only the
   // pooled rows [M/4, N] are ever written.  pool_W == 0: off.
   int pool_H, pool_W;
+  // q-pool form (16-bit out): columns n < poolq_cols (the q third of a fused qkv) are max-pooled into Q2 [M/4, poolq_cols];
+  // the other columns (k, v) are stored to their source pixel's row of C (image order); the q columns of C are not written
+  void* Q2;
+  int64_t ldq;
+  int poolq_cols;
 };
 
 // A row (in elements of lda) that logical GEMM row m reads
@@ -339,11 +344,71 @@ __device__ __forceinline__ void gemm_epilogue_pool(const GemmParams& p, f32x16 (
 #endif
 }
 
+// q-pool epilogue (see GemmParams::poolq_cols): 16-bit outputs, adjacent lanes pack column pairs through DPP like the direct
+// epilogue.  q fragments: max over the 4 sub-pixel registers, then even lanes store pooled row 2g'+h, odd lanes pooled row 2g'+1+h...
+// k/v fragments: rows go back to image order, whose address is not affine in the accumulator index (a pooled pixel run may
+// wrap to the next image row), so each (i, g) pair of rows resolves its pixel row through gemm_a_row.
+template <int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue_qpool(const GemmParams& p, f32x16 (&acc)[FM][FN], int64_t row0, int64_t col0, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int r = lane & 31, h = lane >> 5, odd = lane & 1;
+  const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((int64_t)p.M * p.ldc * 2), 0x00020000);
+  const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.Q2, 0, (int)(((int64_t)p.M >> 2) * p.ldq * 2), 0x00020000);
+  auto swap = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)); };
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int64_t ncol = col0 + j * 32;                      // first column of this fragment (wave-uniform)
+    const int64_t n = ncol + r;
+    const bool ok = n < p.N;
+    const float b = (p.bias && ok) ? p.bias[n] : 0.f;
+    if (ncol < p.poolq_cols) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {                     // pooled rows (2 gp, 2 gp + 1) of this half-wave: g = 2 gp, 2 gp + 1
+          float x0 = fmaxf(fmaxf(acc[i][j][8 * gp], acc[i][j][8 * gp + 1]), fmaxf(acc[i][j][8 * gp + 2], acc[i][j][8 * gp + 3])) + b;
+          float x1 = fmaxf(fmaxf(acc[i][j][8 * gp + 4], acc[i][j][8 * gp + 5]), fmaxf(acc[i][j][8 * gp + 6], acc[i][j][8 * gp + 7])) + b;
+          const float recv = swap(odd ? x0 : x1);
+          const float lo = odd ? recv : x0, hi = odd ? x1 : recv;
+          op16x2 pk;
+          pk[0] = f2op(lo);
+          pk[1] = f2op(hi);
+          // even lanes: g = 2 gp -> pooled row row0/4 + 8 i + 4 gp + h; odd lanes: g = 2 gp + 1 -> + 2
+          const int64_t prow = (row0 >> 2) + i * 8 + 4 * gp + 2 * odd + h;
+          if (ok) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk), q_rsrc, (int)(prow * p.ldq + ncol + (r & ~1)) * 2, 0, 0);
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          // logical rows row0 + 32 i + 8 g + 4 h + {0,1,2,3} = sub-pixels (dy, dx) of ONE pooled pixel
+          const int64_t m = row0 + i * 32 + 8 * g + 4 * h;
+          const bool live = m < p.M;
+          const int64_t top = gemm_a_row(p, live ? m : 0);    // pixel row of (dy, dx) = (0, 0); (0,1) = +1, (1,0) = +W, (1,1) = +W+1
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy) {
+            const float x0 = acc[i][j][4 * g + 2 * dy] + b, x1 = acc[i][j][4 * g + 2 * dy + 1] + b;
+            const float recv = swap(odd ? x0 : x1);
+            const float lo = odd ? recv : x0, hi = odd ? x1 : recv;
+            op16x2 pk;
+            pk[0] = f2op(lo);
+            pk[1] = f2op(hi);
+            const int64_t prow = top + dy * p.pool_W + odd;  // even lanes store sub-pixel dx = 0, odd lanes dx = 1
+            if (ok && live) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk), c_rsrc, (int)(prow * p.ldc + ncol + (r & ~1)) * 2, 0, 0);
+          }
+        }
+    }
+  }
+#endif
+}
+
 template <int FM, int FN>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[FM][FN], float* scr, int64_t row0, int64_t col0,
                                               int lane) {
   if (p.pool_W) {
-    gemm_epilogue_pool<FM, FN>(p, acc, row0, col0, lane);
+    if (p.Q2) gemm_epilogue_qpool<FM, FN>(p, acc, row0, col0, lane);
+    else gemm_epilogue_pool<FM, FN>(p, acc, row0, col0, lane);
     return;
   }
   const bool aligned = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
@@ -903,7 +968,8 @@ static void launch_gemm(const GemmParams& p, hipStream_t s) {
 static int gemm_launch(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* colscale,
                        const void* residual, int64_t ldr, int res_is_16bit, int64_t res_mod, void* C, int64_t ldc, int out_is_16bit,
                        int64_t M, int64_t N, int64_t K, int act, void* stream, const float* rope_cos, const float* rope_sin,
-                       int rope_cols, int rope_D, int rope_period, int rope_n, int rope_npos, int pool_H = 0, int pool_W = 0) {
+                       int rope_cols, int rope_D, int rope_period, int rope_n, int rope_npos, int pool_H = 0, int pool_W = 0,
+                       void* Q2 = nullptr, int64_t ldq = 0, int poolq_cols = 0) {
   MSAM2_REQUIRE(A && W && C, "gemm: null operand");
   MSAM2_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   MSAM2_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0, "gemm: K, lda, ldw must be multiples of 8 (16-byte rows)");
@@ -917,6 +983,7 @@ static int gemm_launch(const void* A, int64_t lda, const void* W, int64_t ldw, c
   p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.rope_cols = rope_cols; p.rope_D = rope_D; p.rope_period = rope_period;
   p.rope_n = rope_n; p.rope_npos = rope_npos;
   p.pool_H = pool_H; p.pool_W = pool_W;
+  p.Q2 = Q2; p.ldq = ldq; p.poolq_cols = poolq_cols;
   hipStream_t s = (hipStream_t)stream;
   const char* force = getenv("MSAM2_GEMM_V1");
   const char* var = getenv("MSAM2_GEMM_VARIANT");
@@ -972,6 +1039,23 @@ extern "C" int msam2_gemm_pool2x2(const void* A, int64_t lda, const void* W, int
   MSAM2_REQUIRE(M >= 256 && (M / 4) * ldc * 4 < (1ll << 31) && M * lda * 2 < (1ll << 31), "gemm_pool2x2: problem out of the 32-bit offset range");
   return gemm_launch(A, lda, W, ldw, bias, nullptr, nullptr, 0, 0, 0, C, ldc, 0, M, N, K, 0, stream, nullptr, nullptr, 0, 0, 1, 0, 1,
                      (int)H, (int)Wimg);
+}
+
+// Fused qkv projection of a q-pooling Hiera block (hieradet.py:61-70): QKV (16-bit, image order) gets the k and v columns
+// (n >= q_cols) of A W^T + bias; Q2 (16-bit) [B*(H/2)*(W/2), q_cols] = maxpool2x2 of the q columns.  The q columns of QKV are
+// NOT written (the pooled q is the only q the block uses), and no separate pooling pass reads them back.
+extern "C" int msam2_gemm_qkv_pool2x2(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* QKV, int64_t ldc,
+                                      void* Q2, int64_t ldq, int64_t B, int64_t H, int64_t Wimg, int64_t N, int64_t K, int64_t q_cols,
+                                      void* stream) {
+  MSAM2_REQUIRE(QKV && Q2, "gemm_qkv_pool2x2: null output");
+  MSAM2_REQUIRE(B > 0 && H > 0 && Wimg > 0 && H % 2 == 0 && Wimg % 2 == 0, "gemm_qkv_pool2x2: H and W must be even");
+  MSAM2_REQUIRE(q_cols > 0 && q_cols % 32 == 0 && q_cols <= N && N % 2 == 0 && ldc % 2 == 0 && ldq % 2 == 0 &&
+                    ((uintptr_t)QKV & 3) == 0 && ((uintptr_t)Q2 & 3) == 0,
+                "gemm_qkv_pool2x2: q_cols must be a multiple of 32; outputs 4-byte aligned with even strides");
+  const int64_t M = B * H * Wimg;
+  MSAM2_REQUIRE(M >= 256 && M * ldc * 2 < (1ll << 31) && M * lda * 2 < (1ll << 31), "gemm_qkv_pool2x2: problem out of the 32-bit offset range");
+  return gemm_launch(A, lda, W, ldw, bias, nullptr, nullptr, 0, 0, 0, QKV, ldc, 1, M, N, K, 0, stream, nullptr, nullptr, 0, 0, 1, 0, 1,
+                     (int)H, (int)Wimg, Q2, ldq, (int)q_cols);
 }
 
 // Linear projection with the axial RoPE of RoPEAttention (transformer.py:299-315) fused into the store: C (16-bit) =

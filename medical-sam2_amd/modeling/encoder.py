@@ -18,7 +18,8 @@ from .position import PositionEmbeddingSine
 
 
 import os as _os
-_POOL_GEMM = _os.environ.get("MSAM2_NO_POOL_GEMM") is None   # experiment switch
+_POOL_GEMM = _os.environ.get("MSAM2_NO_POOL_GEMM") is None   # experiment switches
+_QPOOL_GEMM = _os.environ.get("MSAM2_NO_QPOOL_GEMM") is None
 
 
 class PatchEmbed(nn.Module):
@@ -159,8 +160,11 @@ class MultiScaleBlock(nn.Module):
                     shortcut = ops.maxpool2x2(shortcut, B, H, W)
         else:
             shortcut = t
-        qkv = ops.gemm(xn, qkv_w, qkv_b)  # 16-bit [T, 3*width]
-        qp = ops.maxpool2x2(qkv[:, :width], B, H, W) if pool else None
+        if _POOL_GEMM and _QPOOL_GEMM and pool and B * H * W >= 256 and H % 2 == 0 and W % 2 == 0 and width % 32 == 0:
+            qkv, qp = ops.gemm_qkv_pool2x2(xn, qkv_w, qkv_b, B, H, W, width)   # k | v in image order + pooled q, one GEMM
+        else:
+            qkv = ops.gemm(xn, qkv_w, qkv_b)  # 16-bit [T, 3*width]
+            qp = ops.maxpool2x2(qkv[:, :width], B, H, W) if pool else None
         Hq, Wq = (H // 2, W // 2) if pool else (H, W)
         if self.window_size > 0:
             o = ops.window_attention(qkv, B, H, W, heads, self.window_size, qkv_b, q_pooled=qp, scale=scale)

@@ -75,6 +75,19 @@ def gemm_pool2x2(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
     return out
 
 
+def gemm_qkv_pool2x2(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], B: int, H: int, W: int, q_cols: int):
+    """Fused qkv projection of a q-pooling block: returns (qkv 16-bit [B*H*W, N] whose columns >= q_cols hold k | v in image order --
+    the q columns are left unwritten --, q_pooled 16-bit [B*(H/2)*(W/2), q_cols] = maxpool2x2 of the q columns)."""
+    _req(a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1] and a.shape[0] == B * H * W, "gemm_qkv_pool2x2 shapes")
+    _req(a.dtype == OP16 and w.dtype == OP16 and a.stride(1) == 1 and w.stride(1) == 1, "gemm_qkv_pool2x2 operands: 16-bit, K-contiguous")
+    N, K = w.shape
+    qkv = torch.empty(B * H * W, N, dtype=OP16, device=a.device)
+    q2 = torch.empty(B * (H // 2) * (W // 2), q_cols, dtype=OP16, device=a.device)
+    check(lib().msam2_gemm_qkv_pool2x2(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(qkv), qkv.stride(0), _p(q2), q2.stride(0),
+                                       B, H, W, N, K, q_cols, _stream()))
+    return qkv, q2
+
+
 def gemm_rope(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], table: Tuple[torch.Tensor, torch.Tensor], *,
               rope_cols: int, head_dim: int, rows_per_batch: int, n_rope: int) -> torch.Tensor:
     """16-bit out[M,N] = rope(a @ w^T + bias): columns < rope_cols (whole heads of head_dim channels) of rows whose position

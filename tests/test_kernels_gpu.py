@@ -154,6 +154,18 @@ def test_gemm_pool2x2_fused(ops, B, H, W, N, K):
     close(out, ref, 2e-4, 1e-5, "gemm_pool2x2")
 
 
+@pytest.mark.parametrize("B,H,W,width,K", [(2, 16, 16, 192, 96), (1, 32, 24, 384, 192), (3, 18, 14, 768, 384), (1, 64, 64, 64, 64)])
+def test_gemm_qkv_pool2x2_fused(ops, B, H, W, width, K):
+    """k | v columns bit-identical to the plain projection (image order), pooled q == maxpool2x2 of the plain q columns"""
+    N = 3 * width
+    a, w, bias = bf(rnd(B * H * W, K, seed=41)), bf(rnd(N, K, seed=42, scale=0.2)), rnd(N, seed=43)
+    plain = ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV))
+    qkv, q2 = ops.gemm_qkv_pool2x2(a.to(DEV), w.to(DEV), bias.to(DEV), B, H, W, width)
+    assert torch.equal(qkv[:, width:], plain[:, width:])
+    ref_q = ops.maxpool2x2(plain[:, :width], B, H, W)
+    assert torch.equal(q2, ref_q)
+
+
 def test_gemm_rejects_bad_shapes(ops):
     with pytest.raises(Exception):
         ops.gemm(bf(rnd(8, 12)).to(DEV), bf(rnd(8, 12)).to(DEV))  # K % 8 != 0
