@@ -281,6 +281,18 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x16
         for (int k = 0; k < 8; ++k) {
           const int e0 = 2 * k, ro = i * 32 + (e0 & 3) + 8 * (e0 >> 2);
           const float x0 = fn(acc[i][j][e0], j), x1 = fn(acc[i][j][e0 + 1], j);
+          if constexpr (!ROPE) {
+            // convert first, then trade 16-bit halves: P = (x0 | x1 << 16), N = the neighbour lane's P;
+            // even lanes keep (P.lo, N.lo) = row(e0) cols (r, r+1), odd lanes (N.hi, P.hi) = row(e0+1) cols (r-1, r)
+            op16x2 own;
+            own[0] = f2op(x0);
+            own[1] = f2op(x1);
+            const unsigned P = __builtin_bit_cast(unsigned, own);
+            const unsigned N = (unsigned)__builtin_amdgcn_update_dpp(0, (int)P, 0xB1, 0xf, 0xf, false);
+            const unsigned outw = __builtin_amdgcn_perm(N, P, odd ? 0x03020706u : 0x05040100u);
+            if (colok[j]) __builtin_amdgcn_raw_buffer_store_b32(outw, c_rsrc, vbase + ro * ldc_b + j * 64, 0, 0);
+            continue;
+          }
           const float send = odd ? x0 : x1;
           const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xf, 0xf, false));
           float lo = odd ? recv : x0, hi = odd ? x1 : recv;
