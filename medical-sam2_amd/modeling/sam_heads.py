@@ -271,12 +271,45 @@ class MaskDecoder(nn.Module):
         dc2_w = wc.get("dc2", [up[3].weight], lambda: up[3].weight.detach().permute(2, 3, 1, 0).reshape(-1, C // 4).to(OP16).contiguous())
         g = ops.gemm(u, dc2_w)
         u = ops.convt2x2_shuffle(g, v_f32(wc, "dc2b", up[3].bias), feat_s0, None, None, B, 2 * h, 2 * w)  # [B*16hw, C/8] bf16
-        hyper = torch.empty(B, self.num_mask_tokens, C // 8, dtype=F32, device=u.device)
-        for i, m in enumerate(self.output_hypernetworks_mlps):
-            hyper[:, i] = m.run(to_bf16(hs[:, 2 + i].contiguous()))
+        heads = list(self.output_hypernetworks_mlps) + [self.iou_prediction_head, self.pred_obj_score_head]
+        fusable = C == 256 and self.pred_obj_scores and all(
+            m.num_layers == 3 and m._act_code == ops.ACT_RELU and m.layers[0].in_features == C and m.layers[0].out_features == C
+            and m.layers[1].out_features == C and m.layers[2].out_features <= C for m in heads)
+        if fusable:
+            # the 4 hyper-network MLPs, the IoU head and the object-score head: one launch (ops.token_mlp3)
+            G = len(heads)
+            params = [t for m in heads for l in m.layers for t in (l.weight, l.bias)]
+
+            def pack():
+                dev = hs.device
+                w1 = torch.stack([m.layers[0].weight.detach() for m in heads]).to(OP16).contiguous()
+                w2 = torch.stack([m.layers[1].weight.detach() for m in heads]).to(OP16).contiguous()
+                w3 = torch.zeros(G, C, C, dtype=OP16, device=dev)
+                b3 = torch.zeros(G, C, dtype=F32, device=dev)
+                for gi, m in enumerate(heads):
+                    n = m.layers[2].out_features
+                    w3[gi, :n] = m.layers[2].weight.detach().to(OP16)
+                    b3[gi, :n] = m.layers[2].bias.detach().float()
+                b1 = torch.stack([m.layers[0].bias.detach() for m in heads]).float().contiguous()
+                b2 = torch.stack([m.layers[1].bias.detach() for m in heads]).float().contiguous()
+                nm = self.num_mask_tokens
+                tok = torch.tensor([2 + i for i in range(nm)] + [1, 0], dtype=torch.int32, device=dev)
+                od = torch.tensor([m.layers[2].out_features for m in heads], dtype=torch.int32, device=dev)
+                sg = torch.tensor([int(m.sigmoid_output) for m in heads], dtype=torch.int32, device=dev)
+                return tok, w1, b1, w2, b2, w3, b3, od, sg
+            tok, w1, b1, w2, b2, w3, b3, od, sg = wc.get("heads", params, pack)
+            y = ops.token_mlp3(hs, tok, w1, b1, w2, b2, w3, b3, od, sg)          # [B, G, 256]
+            nm = self.num_mask_tokens
+            hyper = y[:, :nm, : C // 8].contiguous()
+            iou = y[:, nm, : heads[nm].layers[2].out_features].contiguous()
+            obj = y[:, nm + 1, : heads[nm + 1].layers[2].out_features].contiguous()
+        else:
+            hyper = torch.empty(B, self.num_mask_tokens, C // 8, dtype=F32, device=u.device)
+            for i, m in enumerate(self.output_hypernetworks_mlps):
+                hyper[:, i] = m.run(to_bf16(hs[:, 2 + i].contiguous()))
+            iou = self.iou_prediction_head.run(to_bf16(hs[:, 1].contiguous()))
+            obj = self.pred_obj_score_head.run(to_bf16(hs[:, 0].contiguous()))
         masks = ops.hyper_masks(hyper, u, B, 16 * h * w).view(B, self.num_mask_tokens, 4 * h, 4 * w)
-        iou = self.iou_prediction_head.run(to_bf16(hs[:, 1].contiguous()))
-        obj = self.pred_obj_score_head.run(to_bf16(hs[:, 0].contiguous()))
         return masks, iou, hs[:, 2:2 + self.num_mask_tokens], obj
 
     def predict_masks(self, image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings, repeat_image,

@@ -489,3 +489,15 @@ def non_overlap(masks: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(m)
     check(lib().msam2_non_overlap(_p(m), _p(out), n, m.numel() // n, _stream()))
     return out
+
+
+def token_mlp3(hs: torch.Tensor, tok: torch.Tensor, w1, b1, w2, b2, w3, b3, out_dim: torch.Tensor, sigmoid: torch.Tensor) -> torch.Tensor:
+    """G three-layer ReLU MLPs of width 256 on tokens tok[g] of hs fp32 [B, T, 256] -> fp32 [B, G, 256] (first out_dim[g] valid)."""
+    B, T, C = hs.shape
+    G = tok.shape[0]
+    _req(hs.dtype == F32 and hs.stride(2) == 1 and C == 256, "token_mlp3: hs must be fp32 [B,T,256] with contiguous channels")
+    _req(w1.dtype == OP16 and w1.shape == (G, C, C) and w1.is_contiguous() and w2.shape == (G, C, C) and w3.shape == (G, C, C), "token_mlp3 weights")
+    out = torch.empty(B, G, C, dtype=F32, device=hs.device)
+    check(lib().msam2_token_mlp3(_p(hs), hs.stride(0), hs.stride(1), _p(tok), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3),
+                                 _p(out_dim), _p(sigmoid), _p(out), G, B, C, _stream()))
+    return out

@@ -489,6 +489,31 @@ def test_fill_holes(ops):
     assert (ref != m).any()
 
 
+def test_token_mlp3(ops):
+    """six 3-layer ReLU MLPs of width 256 in one launch == the per-head fp32 MLPs (16-bit weights, fp32 activations)"""
+    G, B, T, C = 6, 3, 9, 256
+    hs = rnd(B, T, C, seed=51)
+    tok = torch.tensor([2, 3, 4, 5, 1, 0], dtype=torch.int32)
+    od = torch.tensor([32, 32, 32, 32, 4, 1], dtype=torch.int32)
+    sg = torch.tensor([0, 0, 0, 0, 1, 0], dtype=torch.int32)
+    w1, w2 = bf(rnd(G, C, C, seed=52, scale=0.08)), bf(rnd(G, C, C, seed=53, scale=0.08))
+    w3 = bf(rnd(G, C, C, seed=54, scale=0.08))
+    b1, b2, b3 = rnd(G, C, seed=55), rnd(G, C, seed=56), rnd(G, C, seed=57)
+    for g in range(G):
+        w3[g, od[g]:] = 0
+        b3[g, od[g]:] = 0
+    y = ops.token_mlp3(hs.to(DEV), tok.to(DEV), w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV), w3.to(DEV), b3.to(DEV), od.to(DEV), sg.to(DEV))
+    assert y.shape == (B, G, C)
+    for g in range(G):
+        x = hs[:, tok[g]]
+        h = torch.relu(x @ w1[g].float().t() + b1[g])
+        h = torch.relu(h @ w2[g].float().t() + b2[g])
+        o = (h @ w3[g].float().t() + b3[g])[:, : od[g]]
+        if sg[g]:
+            o = torch.sigmoid(o)
+        close(y[:, g, : od[g]], o, 2e-4, 2e-4, f"token_mlp3 head {g}")
+
+
 def test_hip_graph_replay(ops):
     a, w = bf(rnd(256, 128, seed=1)).to(DEV), bf(rnd(64, 128, seed=2)).to(DEV)
     out = torch.zeros(256, 64, dtype=torch.float32, device=DEV)

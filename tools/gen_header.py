@@ -39,6 +39,7 @@ DOC = {
     "msam2_conv3x3s2_ln_gelu": "One MaskDownSampler stage: Conv2d(k3,s2,p1) + LayerNorm2d + GELU (memory_encoder.py:37-54), with the scaled\nsigmoid / binarisation of the mask logits (sam2_base.py:686-696) fused into the first stage.",
     "msam2_dwconv7x7_ln": "CXBlock head: depth-wise 7x7 conv + LayerNorm2d (memory_encoder.py:99-101).",
     "msam2_convt2x2_shuffle": "ConvTranspose2d(k2,s2) tail of the mask decoder up-scaling: pixel shuffle of the GEMM output + bias + high-res\nskip feature, then LayerNorm2d + GELU or GELU (mask_decoder.py:244-247).",
+    "msam2_token_mlp3": "The mask decoder's token heads in one launch (mask_decoder.py:249-266; MLP = sam2_utils.py:108-132): G independent\n3-layer ReLU MLPs of width 256 (4 hyper-networks, IoU head with sigmoid, object-score head), each on one token of every batch element.",
     "msam2_hyper_masks": "masks = hyper_in @ upscaled_embedding (mask_decoder.py:249-256).",
     "msam2_prompt_points": "Point / box-corner prompt embeddings (prompt_encoder.py:79-114; position_encoding.py:153-158).",
     "msam2_select_mask": "Mask selection without a host round trip: best-IoU multimask or dynamic multimask via stability\n(mask_decoder.py:147-168,269-317) and object-score gating (sam2_base.py:354-385).",
