@@ -76,6 +76,28 @@ class MLP(nn.Module):
                          out_dtype=out_dtype if last else OP16)
         return h
 
+    def run_tokens(self, x: torch.Tensor) -> torch.Tensor:
+        """fp32 [rows, in] (a few rows: decoder tokens) -> fp32 [rows, out].  A 3-layer ReLU MLP of width 256 runs as ONE launch
+        (ops.token_mlp3, fp32 activations); anything else goes through the GEMM path."""
+        L = self.layers
+        if (self.num_layers == 3 and self._act_code == ops.ACT_RELU and x.shape[0] <= 4096 and L[0].in_features == 256
+                and L[0].out_features == 256 and L[1].out_features == 256 and L[2].out_features <= 256):
+            def pack():
+                dev = x.device
+                n = L[2].out_features
+                w3 = torch.zeros(1, 256, 256, dtype=OP16, device=dev)
+                b3 = torch.zeros(1, 256, dtype=F32, device=dev)
+                w3[0, :n] = L[2].weight.detach().to(OP16)
+                b3[0, :n] = L[2].bias.detach().float()
+                return (torch.zeros(1, dtype=torch.int32, device=dev), L[0].weight.detach().to(OP16)[None].contiguous(),
+                        L[0].bias.detach().float()[None].contiguous(), L[1].weight.detach().to(OP16)[None].contiguous(),
+                        L[1].bias.detach().float()[None].contiguous(), w3, b3, torch.tensor([n], dtype=torch.int32, device=dev),
+                        torch.tensor([int(self.sigmoid_output)], dtype=torch.int32, device=dev))
+            tok, w1, b1, w2, b2, w3, b3, od, sg = self._wc.get("tok3", [t for l in L for t in (l.weight, l.bias)], pack)
+            y = ops.token_mlp3(x.to(F32).contiguous().view(x.shape[0], 1, 256), tok, w1, b1, w2, b2, w3, b3, od, sg)
+            return y[:, 0, : L[2].out_features].contiguous()
+        return self.run(to_bf16(x.contiguous()))
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         shp = x.shape
         return self.run(to_bf16(x.reshape(-1, shp[-1]).contiguous())).reshape(*shp[:-1], -1)

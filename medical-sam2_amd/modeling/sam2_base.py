@@ -194,7 +194,7 @@ class SAM2Base(nn.Module):
             sam_output_token = ops.gather_rows(mask_tokens.contiguous(), sel)
         else:
             sam_output_token = ops.gather_rows(mask_tokens.contiguous(), None)
-        obj_ptr = self.obj_ptr_proj.run(to_bf16(sam_output_token))
+        obj_ptr = self.obj_ptr_proj.run_tokens(sam_output_token)
         ops.obj_ptr_mix_(obj_ptr, obj.reshape(B).contiguous(), v_f32(self._wc, "nop", self.no_obj_ptr))
         return low_res_multimasks, high_res_multimasks, ious_out, low_res_masks, high_res_masks, obj_ptr, obj
 
