@@ -475,22 +475,22 @@ extern "C" int msam2_space_to_depth(const void* x, int in_is_16bit, void* out, i
 // (sam2_utils.py:108-132: Linear-ReLU-Linear-ReLU-Linear, optional sigmoid) of width C = 256, each applied to one token of
 // every batch element -- the 4 hyper-network MLPs (tokens 2..5 -> 32 channels), the IoU head (token 1 -> 4, sigmoid) and the
 // object-score head (token 0 -> 1).  As separate GEMM calls these are ~40 launches of a few microseconds each.
-// grid (G, B), 256 threads: a wave owns 64 output rows of a layer; each row is one coalesced 512-byte read (lane = 4 k's)
+// grid (G, B), 1024 threads: a wave owns 16 output rows of a layer (8 row loads in flight: the kernel is pure load latency); each row is one coalesced 512-byte read (lane = 4 k's)
 // followed by a wave reduction; activations stay in LDS in fp32.
 //   hs fp32 [B, T, C]; tok[g] = token index; w1/w2 16-bit [G, C, C]; w3 16-bit [G, C(out rows, zero padded), C]; b* fp32 [G, C];
 //   out fp32 [B, G, C] (first out_dim[g] entries of each row valid).
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void token_mlp3_kernel(const float* __restrict__ hs, int64_t hs_bs, int64_t hs_ts,
-                                                         const int* __restrict__ tok, const op16* __restrict__ w1,
-                                                         const float* __restrict__ b1, const op16* __restrict__ w2,
-                                                         const float* __restrict__ b2, const op16* __restrict__ w3,
-                                                         const float* __restrict__ b3, const int* __restrict__ out_dim,
-                                                         const int* __restrict__ sigmoid, float* __restrict__ out, int B) {
-  constexpr int C = 256;
+__global__ __launch_bounds__(1024) void token_mlp3_kernel(const float* __restrict__ hs, int64_t hs_bs, int64_t hs_ts,
+                                                          const int* __restrict__ tok, const op16* __restrict__ w1,
+                                                          const float* __restrict__ b1, const op16* __restrict__ w2,
+                                                          const float* __restrict__ b2, const op16* __restrict__ w3,
+                                                          const float* __restrict__ b3, const int* __restrict__ out_dim,
+                                                          const int* __restrict__ sigmoid, float* __restrict__ out, int B) {
+  constexpr int C = 256, RPW = 16;                            // 16 waves x 16 rows per layer, 8 rows (8 loads) in flight per wave
   __shared__ float act[2][C];
   const int g = blockIdx.x, b = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  act[0][threadIdx.x] = hs[(int64_t)b * hs_bs + (int64_t)tok[g] * hs_ts + threadIdx.x];
+  if (threadIdx.x < C) act[0][threadIdx.x] = hs[(int64_t)b * hs_bs + (int64_t)tok[g] * hs_ts + threadIdx.x];
   __syncthreads();
   const op16* ws[3] = {w1 + (int64_t)g * C * C, w2 + (int64_t)g * C * C, w3 + (int64_t)g * C * C};
   const float* bs[3] = {b1 + g * C, b2 + g * C, b3 + g * C};
@@ -500,13 +500,14 @@ __global__ __launch_bounds__(256) void token_mlp3_kernel(const float* __restrict
     const float* xin = act[layer & 1];
     const f32x4 xv = *reinterpret_cast<const f32x4*>(xin + lane * 4);
     const int rows = layer == 2 ? n_out : C;
-    for (int o0 = wave * 64; o0 < wave * 64 + 64; o0 += 4) {
+#pragma unroll
+    for (int o0 = wave * RPW; o0 < wave * RPW + RPW; o0 += 8) {
       if (o0 >= rows) break;
-      op16x4 wv[4];
+      op16x4 wv[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) wv[u] = *reinterpret_cast<const op16x4*>(ws[layer] + (int64_t)(o0 + u) * C + lane * 4);
+      for (int u = 0; u < 8; ++u) wv[u] = *reinterpret_cast<const op16x4*>(ws[layer] + (int64_t)(o0 + u) * C + lane * 4);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         float s = op2f(wv[u][0]) * xv[0] + op2f(wv[u][1]) * xv[1] + op2f(wv[u][2]) * xv[2] + op2f(wv[u][3]) * xv[3];
         s = wave_sum(s) + bs[layer][o0 + u];
         if (lane == 0) {
@@ -524,7 +525,7 @@ extern "C" int msam2_token_mlp3(const float* hs, int64_t hs_batch_stride, int64_
                                 const int* out_dim, const int* sigmoid_flag, float* out, int64_t G, int64_t B, int64_t C, void* stream) {
   MSAM2_REQUIRE(hs && token_index && w1 && b1 && w2 && b2 && w3 && b3 && out_dim && sigmoid_flag && out, "token_mlp3: null tensor");
   MSAM2_REQUIRE(C == 256 && G > 0 && B > 0 && G < 65536 && B < 65536, "token_mlp3: built for width 256");
-  hipLaunchKernelGGL(token_mlp3_kernel, dim3((unsigned)G, (unsigned)B), dim3(256), 0, (hipStream_t)stream, hs, hs_batch_stride,
+  hipLaunchKernelGGL(token_mlp3_kernel, dim3((unsigned)G, (unsigned)B), dim3(1024), 0, (hipStream_t)stream, hs, hs_batch_stride,
                      hs_token_stride, token_index, (const op16*)w1, b1, (const op16*)w2, b2, (const op16*)w3, b3, out_dim, sigmoid_flag,
                      out, (int)B);
   return msam2_check_launch("token_mlp3");
