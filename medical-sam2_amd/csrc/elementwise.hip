@@ -631,3 +631,54 @@ extern "C" int msam2_non_overlap(const float* masks, float* out, int64_t n_obj, 
                      out, (int)n_obj, pixels);
   return msam2_check_launch("non_overlap");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Segmentation-metric counts for eval_seg (func_3d/utils.py:139-214, func_2d/utils.py:505-580): for every threshold t, batch
+// element b and class c, the integer counts  I = |pred > t  and  gt > t|,  P = |pred > t|,  G = |gt > t|  over the H*W pixels, in
+// ONE pass over pred / gt (the reference thresholds, moves the maps to the CPU and reduces once per threshold).  IoU and Dice follow
+// from the counts on the host (U = P + G - I).  counts: int32 [T, B*C, 3], zeroed by the caller.  T <= 8 thresholds per launch.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void seg_counts_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                         const float* __restrict__ thr, int T, int64_t P, int* __restrict__ counts,
+                                                         int planes) {
+  const int plane = blockIdx.y;
+  float th[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) th[t] = t < T ? thr[t] : INFINITY;
+  int ci[8], cp[8], cg[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) ci[t] = cp[t] = cg[t] = 0;
+  const float* pp = pred + (int64_t)plane * P;
+  const float* gp = gt + (int64_t)plane * P;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+    const float a = pp[i], g = gp[i];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int pa = a > th[t], pg = g > th[t];
+      cp[t] += pa;
+      cg[t] += pg;
+      ci[t] += pa & pg;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t >= T) break;
+    const int si = (int)wave_sum((float)ci[t]), sp = (int)wave_sum((float)cp[t]), sg = (int)wave_sum((float)cg[t]);  // < 2^24: exact
+    if ((threadIdx.x & 63) == 0) {
+      int* c = counts + ((int64_t)t * planes + plane) * 3;
+      if (si) atomicAdd(c + 0, si);
+      if (sp) atomicAdd(c + 1, sp);
+      if (sg) atomicAdd(c + 2, sg);
+    }
+  }
+}
+
+extern "C" int msam2_seg_counts(const float* pred, const float* gt, const float* thresholds, int64_t n_thresholds, int64_t planes,
+                                int64_t pixels, int* counts, void* stream) {
+  MSAM2_REQUIRE(pred && gt && thresholds && counts, "seg_counts: null tensor");
+  MSAM2_REQUIRE(n_thresholds >= 1 && n_thresholds <= 8 && planes > 0 && planes < 65536 && pixels > 0, "seg_counts: 1..8 thresholds per launch");
+  const unsigned gx = (unsigned)min((int64_t)64, (pixels + 255) / 256);
+  hipLaunchKernelGGL(seg_counts_kernel, dim3(gx, (unsigned)planes), dim3(256), 0, (hipStream_t)stream, pred, gt, thresholds,
+                     (int)n_thresholds, pixels, counts, (int)planes);
+  return msam2_check_launch("seg_counts");
+}

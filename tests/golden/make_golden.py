@@ -324,8 +324,40 @@ def run_video_predictor_case():
     return out, {"model": "hiera_t", "image_size": S, "slice_seeds": [20 + t for t in range(T)], "n_objects": 2, "fill_hole_area": 8}
 
 
+def run_eval_seg_case():
+    """The reference's own eval_seg (func_3d/utils.py:139-203) on seeded random prediction / ground-truth maps for 1, 2 and 3
+    classes.  func_3d/utils.py parses the command line at import (cfg.parse_args()), so it is imported with an empty argv."""
+    argv, sys.argv = sys.argv, [sys.argv[0]]
+    sys.path.insert(0, "/root/reference")
+    try:
+        from func_3d.utils import eval_seg
+    finally:
+        sys.argv = argv
+    out = {}
+    th = (0.1, 0.3, 0.5, 0.7, 0.9)
+    for c in (1, 2, 3):
+        g = torch.Generator().manual_seed(700 + c)
+        pred = torch.rand(3, c, 40, 48, generator=g)
+        mask = (torch.rand(3, c, 40, 48, generator=g) > 0.6).float() * torch.rand(3, c, 40, 48, generator=g).clamp(min=0.2)
+        mask[0, 0] = 0.0                      # an empty ground truth plane (IoU/Dice smoothing terms)
+        # the reference's c > 2 branch rebinds `pred` to a numpy array inside the threshold loop (func_3d/utils.py:181), so it only
+        # survives ONE threshold there; 1 and 2 classes take the 5 thresholds func_3d/function.py uses
+        use = th if c <= 2 else (0.5,)
+        out[f"c{c}_result"] = np.array(eval_seg(pred, mask, use), dtype=np.float64)
+        out[f"c{c}_thresholds"] = np.array(use, dtype=np.float64)
+    return out, {"seeds": [701, 702, 703], "shape": [3, "c", 40, 48]}
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "evalseg":
+        o, meta = run_eval_seg_case()
+        np.savez_compressed(os.path.join(OUT, "eval_seg.npz"), **o)
+        allmeta = json.load(open(os.path.join(OUT, "meta.json")))
+        allmeta["eval_seg"] = meta
+        json.dump(allmeta, open(os.path.join(OUT, "meta.json"), "w"), indent=1)
+        print({k: v.tolist() for k, v in o.items()})
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "video":
         o, meta = run_video_predictor_case()
         np.savez_compressed(os.path.join(OUT, "video_predictor_t256.npz"), **o)
@@ -359,6 +391,9 @@ def main():
     o, meta = run_video_predictor_case()
     np.savez_compressed(os.path.join(OUT, "video_predictor_t256.npz"), **o)
     allmeta["video_predictor_t256"] = meta
+    o, meta = run_eval_seg_case()
+    np.savez_compressed(os.path.join(OUT, "eval_seg.npz"), **o)
+    allmeta["eval_seg"] = meta
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(allmeta, f, indent=1)
     for fn in sorted(os.listdir(OUT)):

@@ -31,6 +31,7 @@ DOC = {
     "msam2_fourier_pe_grid": "PromptEncoder.get_dense_pe (prompt_encoder.py:68-77; position_encoding.py:130-151) as [h*w, C].",
     "msam2_hiera_pos_embed": "Hiera._get_pos_embed (hieradet.py:269-277): bicubic resize of pos_embed + tiled pos_embed_window.",
     "msam2_aa_downsample": "F.interpolate(mode=\"bilinear\", antialias=True) by an integer factor (sam2_base.py:321-327, 421-427).",
+    "msam2_seg_counts": "Counts behind eval_seg (func_3d/utils.py:139-214, func_2d/utils.py:505-580): per threshold, batch element and class the\ninteger |pred>t & gt>t|, |pred>t|, |gt>t| in one pass; IoU / Dice follow on the host.",
     "msam2_non_overlap": "SAM2Base._apply_non_overlapping_constraints (sam2_base.py:812-830): keep the arg-max object per pixel, clamp the\nothers to <= -10.",
     "msam2_gate_rows": "masks[b] = value where object score <= 0 (NO_OBJ_SCORE fill, sam2_base.py:354-363).",
     "msam2_any_positive": "is_obj_appearing = any(mask > 0) per object (sam2_base.py:445-447).",
