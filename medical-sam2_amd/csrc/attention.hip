@@ -61,7 +61,7 @@ __device__ __forceinline__ int64_t win_token_offset(int t, int ws, int wy, int w
 }
 
 template <int D, int NW, bool WIN>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(NW * 64, (WIN && NW == 4) ? 3 : 1) void attn_fwd_kernel(AttnParams p) {
   using C = AttnCfg<D>;
   constexpr int NT = NW * 64;
   constexpr int DSTEPS = D / 16;   // k-steps of the QK^T product
