@@ -228,10 +228,14 @@ extern "C" int msam2_dwconv7x7_ln(const float* x, const float* weight_tap_major,
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void pixel_shuffle_kernel(const op16* __restrict__ g, const float* __restrict__ bias, const op16* __restrict__ skip,
                                      const float* __restrict__ ln_w, const float* __restrict__ ln_b, op16* __restrict__ y, int B,
-                                     int h, int w, int C) {
-  const int64_t pix = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+                                     int h, int w, int C, int ppw) {
+  // ppw output pixels per wave: 1 when LayerNorm needs the whole wave for one pixel's channels, 64 / C otherwise (C = 32 -> 2)
+  const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   const int H = 2 * h, W = 2 * w;
+  const int sub_px = ppw > 1 ? lane / C : 0;
+  const int ch = ppw > 1 ? lane % C : lane;
+  const int64_t pix = wv * ppw + sub_px;
   if (pix >= (int64_t)B * H * W) return;
   const int X = pix % W;
   const int Y = (pix / W) % H;
@@ -239,14 +243,14 @@ __global__ void pixel_shuffle_kernel(const op16* __restrict__ g, const float* __
   const int64_t tok = ((int64_t)b * h + Y / 2) * w + X / 2;
   const int sub = (Y & 1) * 2 + (X & 1);
   float v = 0.f;
-  if (lane < C) v = op2f(g[tok * 4 * C + sub * C + lane]) + bias[lane] + op2f(skip[pix * C + lane]);
+  if (ch < C) v = op2f(g[tok * 4 * C + sub * C + ch]) + bias[ch] + op2f(skip[pix * C + ch]);
   if (ln_w) {
-    const float mean = wave_sum(lane < C ? v : 0.f) / C;
-    const float d = lane < C ? v - mean : 0.f;
+    const float mean = wave_sum(ch < C ? v : 0.f) / C;
+    const float d = ch < C ? v - mean : 0.f;
     const float rstd = 1.f / sqrtf(wave_sum(d * d) / C + 1e-6f);
-    v = d * rstd * (lane < C ? ln_w[lane] : 0.f) + (lane < C ? ln_b[lane] : 0.f);
+    v = d * rstd * (ch < C ? ln_w[ch] : 0.f) + (ch < C ? ln_b[ch] : 0.f);
   }
-  if (lane < C) y[pix * C + lane] = f2op(gelu_erf(v));
+  if (ch < C) y[pix * C + ch] = f2op(gelu_erf(v));
 }
 
 extern "C" int msam2_convt2x2_shuffle(const void* gemm_out, const float* bias, const void* skip, const float* ln_w,
@@ -254,8 +258,9 @@ extern "C" int msam2_convt2x2_shuffle(const void* gemm_out, const float* bias, c
   MSAM2_REQUIRE(gemm_out && bias && skip && y, "convt2x2_shuffle: null tensor");
   MSAM2_REQUIRE(C > 0 && C <= 64, "convt2x2_shuffle: C must be <= 64");
   const int64_t pix = B * 4 * h * w;
-  hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(cdiv(pix * 64, 256)), dim3(256), 0, (hipStream_t)stream, (const op16*)gemm_out,
-                     bias, (const op16*)skip, ln_w, ln_b, (op16*)y, (int)B, (int)h, (int)w, (int)C);
+  const int ppw = (!ln_w && C <= 32 && 64 % C == 0) ? (int)(64 / C) : 1;
+  hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(cdiv(cdiv(pix, ppw) * 64, 256)), dim3(256), 0, (hipStream_t)stream, (const op16*)gemm_out,
+                     bias, (const op16*)skip, ln_w, ln_b, (op16*)y, (int)B, (int)h, (int)w, (int)C, ppw);
   return msam2_check_launch("convt2x2_shuffle");
 }
 
