@@ -23,6 +23,7 @@ SIGNATURES = {
     "msam2_gemm": (c_i, [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_l, c_p, c_l, c_i, c_l, c_l, c_l, c_i, c_p]),
     "msam2_gemm_pool2x2": (c_i, [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_l, c_p]),
     "msam2_gemm_qkv_pool2x2": (c_i, [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_l, c_l, c_l, c_l, c_l, c_l, c_p]),
+    "msam2_gemm_tokens": (c_i, [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_i, c_l, c_l, c_l, c_i, c_p]),
     "msam2_gemm_rope": (c_i, [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_l, c_l, c_l, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_p]),
     "msam2_layernorm": (c_i, [c_p, c_i, c_l, c_p, c_p, c_p, c_i, c_l, c_l, c_l, c_f, c_i, c_p]),
     "msam2_attention_workspace_bytes": (c_z, [c_l, c_l, c_l, c_l, c_i]),

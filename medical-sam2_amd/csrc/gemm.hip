@@ -40,6 +40,11 @@ struct GemmParams {
   void* Q2;
   int64_t ldq;
   int poolq_cols;
+  // token form (skinny kernel only): A is fp32 [M, K] (row stride lda in floats) and columns n < add_cols use A + A2 instead
+  // (decoder tokens: queries + query_pe for the q | k thirds of a fused projection, queries alone for v)
+  const float* A32;
+  const float* A2;
+  int add_cols;
 };
 
 // A row (in elements of lda) that logical GEMM row m reads
@@ -917,6 +922,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_wide_kernel(GemmParams p) {
 // tiles are summed through LDS.  The tiled kernel walks K serially with one global->LDS->MFMA round trip per 32 k: at
 // K = 2048 that is 64 dependent trips (~40 us) for 0.03 GFLOP.
 // ------------------------------------------------------------------------------------------------------------------
+template <bool F32A>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
   __shared__ float part[4][32][33];
   const int tid = threadIdx.x;
@@ -926,8 +932,29 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
   const int ksteps = p.K / 16;                      // K % 16 == 0 (host check)
   const int per = (ksteps + 3) / 4;
   const int s0 = wave * per, s1 = min(ksteps, s0 + per);
-  const op16* ap = p.A + (int64_t)min(r, p.M - 1) * p.lda + h * 8;
+  const int64_t arow = (int64_t)min(r, p.M - 1) * p.lda + h * 8;
+  const op16* ap = p.A + arow;
+  const float* ap32 = p.A32 + arow;
+  const float* ap2 = (F32A && p.A2 && n0 < p.add_cols) ? p.A2 + arow : nullptr;   // workgroup-uniform: add_cols is a multiple of 32
   const op16* wp = p.W + min(n0 + r, (int64_t)p.N - 1) * p.ldw + h * 8;
+  auto load_a = [&](int step) -> op16x8 {
+    if constexpr (!F32A) {
+      return *reinterpret_cast<const op16x8*>(ap + step * 16);
+    } else {
+      f32x4 lo = *reinterpret_cast<const f32x4*>(ap32 + step * 16), hi = *reinterpret_cast<const f32x4*>(ap32 + step * 16 + 4);
+      if (ap2) {
+        lo += *reinterpret_cast<const f32x4*>(ap2 + step * 16);
+        hi += *reinterpret_cast<const f32x4*>(ap2 + step * 16 + 4);
+      }
+      op16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = f2op(lo[e]);
+        o[4 + e] = f2op(hi[e]);
+      }
+      return o;
+    }
+  };
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -936,14 +963,14 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
     op16x8 a[8], w[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      a[u] = *reinterpret_cast<const op16x8*>(ap + (st + u) * 16);
+      a[u] = load_a(st + u);
       w[u] = *reinterpret_cast<const op16x8*>(wp + (st + u) * 16);
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc = MSAM2_MFMA_32x32x16(a[u], w[u], acc, 0, 0, 0);
   }
   for (; st < s1; ++st) {
-    const op16x8 a = *reinterpret_cast<const op16x8*>(ap + st * 16);
+    const op16x8 a = load_a(st);
     const op16x8 w = *reinterpret_cast<const op16x8*>(wp + st * 16);
     acc = MSAM2_MFMA_32x32x16(a, w, acc, 0, 0, 0);
   }
@@ -996,6 +1023,7 @@ static int gemm_launch(const void* A, int64_t lda, const void* W, int64_t ldw, c
   p.rope_n = rope_n; p.rope_npos = rope_npos;
   p.pool_H = pool_H; p.pool_W = pool_W;
   p.Q2 = Q2; p.ldq = ldq; p.poolq_cols = poolq_cols;
+  p.A32 = nullptr; p.A2 = nullptr; p.add_cols = 0;
   hipStream_t s = (hipStream_t)stream;
   const char* force = getenv("MSAM2_GEMM_V1");
   const char* var = getenv("MSAM2_GEMM_VARIANT");
@@ -1025,7 +1053,7 @@ static int gemm_launch(const void* A, int64_t lda, const void* W, int64_t ldw, c
   } else if (dma_ok && K % 32 == 0) {
     hipLaunchKernelGGL((gemm_glds32_kernel<2, 4>), dim3(tiles), dim3(256), 0, s, p);
   } else if (M <= 32 && K % 16 == 0) {
-    hipLaunchKernelGGL(gemm_skinny_kernel, dim3(cdiv(p.N, 32)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((gemm_skinny_kernel<false>), dim3(cdiv(p.N, 32)), dim3(256), 0, s, p);
   } else if (M <= 32) launch_gemm<32, 128, 1, 4>(p, s);
   else if (N <= 32) launch_gemm<128, 32, 4, 1>(p, s);
   else if (N <= 64 || (N % 128 != 0 && N % 64 == 0 && N < 512)) launch_gemm<128, 64, 2, 2>(p, s);
@@ -1038,6 +1066,27 @@ extern "C" int msam2_gemm(const void* A, int64_t lda, const void* W, int64_t ldw
                           int64_t M, int64_t N, int64_t K, int act, void* stream) {
   return gemm_launch(A, lda, W, ldw, bias, colscale, residual, ldr, res_is_16bit, res_mod, C, ldc, out_is_16bit, M, N, K, act, stream,
                      nullptr, nullptr, 0, 0, 1, 0, 1);
+}
+
+// Token-side linear layer of the two-way decoder (transformer.py:165-196, 239-263): M <= 32 rows (batch x tokens), A in fp32 straight
+// from the residual stream; columns n < add_cols are computed from A + A2 (e.g. queries + query_pe for the q | k thirds of a fused
+// projection, queries alone for the v third), the sum and the 16-bit conversion happen in the operand load.  One launch replaces
+// the add, the cast and up to three projections.
+extern "C" int msam2_gemm_tokens(const float* A, int64_t lda, const float* A2, int64_t add_cols, const void* W, int64_t ldw,
+                                 const float* bias, const float* residual, int64_t ldr, void* C, int64_t ldc, int out_is_16bit,
+                                 int64_t M, int64_t N, int64_t K, int act, void* stream) {
+  MSAM2_REQUIRE(A && W && C, "gemm_tokens: null operand");
+  MSAM2_REQUIRE(M > 0 && M <= 32 && N > 0 && K > 0 && K % 16 == 0, "gemm_tokens: needs 1 <= M <= 32 rows and K %% 16 == 0");
+  MSAM2_REQUIRE(lda % 4 == 0 && ((uintptr_t)A & 15) == 0 && (!A2 || ((uintptr_t)A2 & 15) == 0) && ldw % 8 == 0 && ((uintptr_t)W & 15) == 0,
+                "gemm_tokens: 16-byte aligned rows");
+  MSAM2_REQUIRE(add_cols >= 0 && (add_cols % 32 == 0 || add_cols >= N) && act >= 0 && act <= 3,
+                "gemm_tokens: add_cols must be a multiple of 32 (or >= N: every column)");
+  GemmParams p = {};
+  p.A32 = A; p.A2 = A2; p.add_cols = (int)(add_cols > N ? N + 31 : add_cols); p.lda = lda;
+  p.W = (const op16*)W; p.ldw = ldw; p.bias = bias; p.res = residual; p.ldr = ldr; p.C = C; p.ldc = ldc;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act; p.out_is_16bit = out_is_16bit;
+  hipLaunchKernelGGL((gemm_skinny_kernel<true>), dim3(cdiv(p.N, 32)), dim3(256), 0, (hipStream_t)stream, p);
+  return msam2_check_launch("gemm_tokens");
 }
 
 // Linear layer followed by a 2x2/stride-2 max-pool over the token image (Hiera's pooled shortcut: `do_pool(self.proj(x_norm), self.pool)`,

@@ -137,8 +137,18 @@ class TwoWayAttentionBlock(nn.Module):
         """queries/query_pe fp32 [B*T, C]; keys fp32 [B*L, C]; key_pe fp32 [L, C] (shared over the batch)."""
         C = queries.shape[1]
         q3 = lambda t, n: t.view(B, n, -1)
-        sa = self.self_attn
-        if self.skip_first_layer_pe:
+        sa, ca, ia, wc = self.self_attn, self.cross_attn_token_to_image, self.cross_attn_image_to_token, self._wc
+        # token-side projections read the fp32 residual stream directly (ops.gemm_tokens: "+ query_pe" and the 16-bit conversion
+        # happen in the operand load; q | k | v of one attention are one launch)
+        fused = B * T <= 32 and C % 32 == 0 and sa.internal_dim % 32 == 0 and ia.internal_dim % 32 == 0
+        if fused:
+            Ci = sa.internal_dim
+            qkv = ops.gemm_tokens(queries, w_bf16(wc, "sqkv", sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight),
+                                  v_f32(wc, "sqkvb", sa.q_proj.bias, sa.k_proj.bias, sa.v_proj.bias),
+                                  addend=None if self.skip_first_layer_pe else query_pe, add_cols=2 * Ci).view(B, T, 3 * Ci)
+            o = sa.core(qkv[:, :, :Ci], qkv[:, :, Ci:2 * Ci], qkv[:, :, 2 * Ci:])
+            queries = sa.out(o, None if self.skip_first_layer_pe else queries)
+        elif self.skip_first_layer_pe:
             qb = to_bf16(queries)
             queries = sa.out(sa.core(q3(sa.proj("q", qb), T), q3(sa.proj("k", qb), T), q3(sa.proj("v", qb), T)), None)
         else:
@@ -146,17 +156,30 @@ class TwoWayAttentionBlock(nn.Module):
             queries = sa.out(sa.core(q3(sa.proj("q", qb), T), q3(sa.proj("k", qb), T), q3(sa.proj("v", to_bf16(queries)), T)), queries)
         queries = self._ln("norm1", queries)
         # tokens -> image
-        ca = self.cross_attn_token_to_image
-        qb = ops.add_cast(queries.view(1, B * T, C), query_pe.view(1, B * T, C), 1.0, OP16)[0]
         kb = ops.add_cast(keys.view(B, L, C), key_pe.view(1, L, C), 1.0, OP16).view(B * L, C)
         keys_b = to_bf16(keys)
-        o = ca.core(q3(ca.proj("q", qb), T), q3(ca.proj("k", kb), L), q3(ca.proj("v", keys_b), L))
+        if fused:
+            qp = ops.gemm_tokens(queries, w_bf16(wc, "cqw", ca.q_proj.weight), v_f32(wc, "cqb", ca.q_proj.bias), addend=query_pe,
+                                 add_cols=ca.internal_dim)
+        else:
+            qp = ca.proj("q", ops.add_cast(queries.view(1, B * T, C), query_pe.view(1, B * T, C), 1.0, OP16)[0])
+        o = ca.core(q3(qp, T), q3(ca.proj("k", kb), L), q3(ca.proj("v", keys_b), L))
         queries = self._ln("norm2", ca.out(o, queries))
-        queries = self._ln("norm3", self.mlp.run(to_bf16(queries), residual=queries, out_dtype=F32))
+        if fused and self.mlp.num_layers == 2:
+            l1, l2 = self.mlp.layers
+            hmid = ops.gemm_tokens(queries, w_bf16(wc, "m1w", l1.weight), v_f32(wc, "m1b", l1.bias), act=self.mlp._act_code)
+            queries = self._ln("norm3", ops.gemm(hmid, w_bf16(wc, "m2w", l2.weight), v_f32(wc, "m2b", l2.bias), residual=queries, out_dtype=F32))
+        else:
+            queries = self._ln("norm3", self.mlp.run(to_bf16(queries), residual=queries, out_dtype=F32))
         # image -> tokens
-        ia = self.cross_attn_image_to_token
-        qb = ops.add_cast(queries.view(1, B * T, C), query_pe.view(1, B * T, C), 1.0, OP16)[0]
-        o = ia.core(q3(ia.proj("q", kb), L), q3(ia.proj("k", qb), T), q3(ia.proj("v", to_bf16(queries)), T))
+        if fused:
+            Cd = ia.internal_dim
+            kv = ops.gemm_tokens(queries, w_bf16(wc, "ikv", ia.k_proj.weight, ia.v_proj.weight), v_f32(wc, "ikvb", ia.k_proj.bias, ia.v_proj.bias),
+                                 addend=query_pe, add_cols=Cd).view(B, T, 2 * Cd)
+            o = ia.core(q3(ia.proj("q", kb), L), kv[:, :, :Cd], kv[:, :, Cd:])
+        else:
+            qb = ops.add_cast(queries.view(1, B * T, C), query_pe.view(1, B * T, C), 1.0, OP16)[0]
+            o = ia.core(q3(ia.proj("q", kb), L), q3(ia.proj("k", qb), T), q3(ia.proj("v", to_bf16(queries)), T))
         keys = self._ln("norm4", ia.out(o, keys))
         return queries, keys
 
@@ -191,10 +214,14 @@ class TwoWayTransformer(nn.Module):
         for layer in self.layers:
             queries, keys = layer.run(queries, keys, qpe, key_pe, B, T, L)
         fa = self.final_attn_token_to_image
-        qb = ops.add_cast(queries.view(1, B * T, C), qpe.view(1, B * T, C), 1.0, OP16)[0]
         kb = ops.add_cast(keys.view(B, L, C), key_pe.view(1, L, C), 1.0, OP16).view(B * L, C)
         q3 = lambda t, n: t.view(B, n, -1)
-        o = fa.core(q3(fa.proj("q", qb), T), q3(fa.proj("k", kb), L), q3(fa.proj("v", to_bf16(keys)), L))
+        if B * T <= 32 and fa.internal_dim % 32 == 0:
+            qp = ops.gemm_tokens(queries, w_bf16(self._wc, "fqw", fa.q_proj.weight), v_f32(self._wc, "fqb", fa.q_proj.bias), addend=qpe,
+                                 add_cols=fa.internal_dim)
+        else:
+            qp = fa.proj("q", ops.add_cast(queries.view(1, B * T, C), qpe.view(1, B * T, C), 1.0, OP16)[0])
+        o = fa.core(q3(qp, T), q3(fa.proj("k", kb), L), q3(fa.proj("v", to_bf16(keys)), L))
         n = self.norm_final_attn
         queries = ops.layernorm(fa.out(o, queries), v_f32(self._wc, "nw", n.weight), v_f32(self._wc, "nb", n.bias), n.eps, out_dtype=F32)
         return queries, keys

@@ -65,6 +65,26 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+def gemm_tokens(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, addend: Optional[torch.Tensor] = None,
+                add_cols: int = 0, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None, out_dtype: torch.dtype = OP16) -> torch.Tensor:
+    """out[M,N] = residual + act((a [+ addend on columns < add_cols]) @ w^T + bias) for M <= 32 fp32 token rows (a, addend fp32
+    [M,K] row-major, w 16-bit [N,K]); add_cols must be a multiple of 32 (or >= N for all columns)."""
+    _req(a.dim() == 2 and a.dtype == F32 and a.stride(1) == 1 and a.shape[0] <= 32, "gemm_tokens: a must be fp32 [M<=32, K]")
+    _req(w.dtype == OP16 and w.stride(1) == 1 and w.shape[1] == a.shape[1], "gemm_tokens: w must be 16-bit [N, K]")
+    if addend is not None:
+        _req(addend.dtype == F32 and addend.shape == a.shape and addend.stride(1) == 1 and addend.stride(0) == a.stride(0),
+             "gemm_tokens: addend must match a")
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    if residual is not None:
+        _req(residual.dtype == F32 and residual.shape == (M, N) and residual.stride(1) == 1, "gemm_tokens: residual must be fp32 [M,N]")
+    check(lib().msam2_gemm_tokens(_p(a), a.stride(0), _p(addend), add_cols if addend is not None else 0, _p(w), w.stride(0), _p(bias),
+                                  _p(residual), residual.stride(0) if residual is not None else 0, _p(out), out.stride(0), _is_bf16(out),
+                                  M, N, K, act, _stream()))
+    return out
+
+
 def gemm_pool2x2(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], B: int, H: int, W: int) -> torch.Tensor:
     """fp32 [B*(H/2)*(W/2), N] = maxpool2x2(a @ w^T + bias) over the [B,H,W] token image a [B*H*W, K] (16-bit, K-contiguous)."""
     _req(a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1] and a.shape[0] == B * H * W, "gemm_pool2x2 shapes")

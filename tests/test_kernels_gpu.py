@@ -489,6 +489,27 @@ def test_fill_holes(ops):
     assert (ref != m).any()
 
 
+@pytest.mark.parametrize("M,N,K,add_cols", [(32, 768, 256, 512), (9, 128, 256, 128), (4, 2048, 256, 0), (28, 256, 2048, 0), (1, 96, 64, 64)])
+def test_gemm_tokens(ops, M, N, K, add_cols):
+    """fp32 token rows + optional addend on the leading columns, converted in the operand load (two-way decoder projections)"""
+    a, a2 = rnd(M, K, seed=61), rnd(M, K, seed=62)
+    w, bias, res = bf(rnd(N, K, seed=63, scale=0.1)), rnd(N, seed=64), rnd(M, N, seed=65)
+    wf = w.float()
+    ref = torch.empty(M, N)
+    ref[:, :add_cols] = bf(a + a2).float() @ wf[:add_cols].t()
+    ref[:, add_cols:] = bf(a).float() @ wf[add_cols:].t()
+    ref = ref + bias
+    d = lambda t: t.to(DEV)
+    out = ops.gemm_tokens(d(a), d(w), d(bias), addend=d(a2) if add_cols else None, add_cols=add_cols, out_dtype=torch.float32)
+    close(out, ref, 3e-4, 1e-5, "gemm_tokens f32")
+    out = ops.gemm_tokens(d(a), d(w), d(bias), addend=d(a2) if add_cols else None, add_cols=add_cols, act=ops.ACT_RELU)
+    close(out, torch.relu(ref), 2e-3, 8e-3, "gemm_tokens relu->16")
+    out = ops.gemm_tokens(d(a), d(w), d(bias), addend=d(a2), add_cols=N + 5, residual=d(res), out_dtype=torch.float32)
+    close(out, bf(a + a2).float() @ wf.t() + bias + res, 3e-4, 1e-5, "gemm_tokens all columns + residual")
+    with pytest.raises(RuntimeError):
+        ops.gemm_tokens(d(a), d(w), d(bias), addend=d(a2), add_cols=8)
+
+
 def test_token_mlp3(ops):
     """six 3-layer ReLU MLPs of width 256 in one launch == the per-head fp32 MLPs (16-bit weights, fp32 activations)"""
     G, B, T, C = 6, 3, 9, 256

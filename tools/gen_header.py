@@ -13,6 +13,7 @@ DOC = {
     "msam2_last_error": "Message of the last failing call on this thread.  Errors never cross the ABI as exceptions: every entry returns\n0 on success, <0 on failure (reference behaviour: AT_ASSERTM -> RuntimeError, connected_components.cu:215-228; the\nPython wrapper re-raises as RuntimeError).",
     "msam2_gemm_pool2x2": "Hiera's pooled shortcut `do_pool(self.proj(x_norm), self.pool)` (hieradet.py:141-145, 23-34) as one GEMM: C (fp32)\n[B*(H/2)*(W/2), N] = maxpool2x2(A W^T + bias) over the [B,H,W] token image A; the un-pooled map is never written.",
     "msam2_gemm_qkv_pool2x2": "Fused qkv projection of a q-pooling Hiera block (hieradet.py:61-70 with do_pool, 23-34): k/v columns to QKV in image order,\nQ2 = maxpool2x2 of the q columns; the un-pooled q is neither written nor read back.",
+    "msam2_gemm_tokens": "Token-side linear layers of the two-way decoder (transformer.py:165-196, 239-263): M <= 32 rows, A in fp32 from the residual\nstream, columns < add_cols computed from A + A2 (queries + query_pe), add and 16-bit conversion fused into the operand load.",
     "msam2_gemm_rope": "Linear projection with the axial RoPE of RoPEAttention fused into the store (transformer.py:241-243 + 299-315,\nposition_encoding.py:200-216): C (16-bit) = rope(A W^T + bias) on columns < rope_cols (whole heads, adjacent channel pairs) of rows\nwhose position l = m % rows_per_batch is < n_rope, with table row l % n_pos of cos/sin [n_pos, head_dim/2] (rope_k_repeat).",
     "msam2_gemm": "C[M,N] = residual[m % res_mod] + colscale[n] * act(A[M,K] W[N,K]^T + bias[n]); A, W 16-bit (K contiguous), bias/colscale\nfp32, residual/C 16-bit or fp32.  act: 0 none, 1 exact-erf GELU, 2 ReLU, 3 sigmoid.\nReplaces every nn.Linear / 1x1 Conv2d / im2col'ed conv of the path: hieradet.py:61,79,141; sam2_utils.py:127-131;\ntransformer.py:241-243,261; memory_attention.py:96; image_encoder.py:112; mask_decoder.py:240-256;\nmemory_encoder.py:103-105,171-175; sam2_base.py:470-475.",
     "msam2_layernorm": "Row LayerNorm (fp32 statistics) on [rows, C], optional GELU: nn.LayerNorm at hieradet.py:138,166,\nmemory_attention.py:60,73,94,162, transformer.py:173-194,116; LayerNorm2d (sam2_utils.py:137-149) on NHWC tokens.",
