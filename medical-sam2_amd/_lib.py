@@ -7,7 +7,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmsam2_hip.so")
+LIB_PATH = os.environ.get("MSAM2_LIB_PATH") or os.path.join(_HERE, "libmsam2_hip.so")   # override: experiments with alternative builds
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
