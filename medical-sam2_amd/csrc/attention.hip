@@ -473,16 +473,22 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_glds_kernel(AttnParams p) {
         for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
       m_run = m_new;
     }
-    float psum = 0.f;
     op16x8 pf[2];
-    const float neg_m = -m_run;                               // finite: every tile holds >= 1 valid key
+    // two elements per VALU slot where the ISA has packed fp32 ops (v_pk_fma_f32 for the exponent argument, v_pk_add_f32 for the
+    // running sum): the softmax is issue-bound, and for D = 96 it is longer than the tile's MFMAs
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t sc2 = {p.scale_log2, p.scale_log2}, nm2 = {-m_run, -m_run};   // -m_run finite: every tile holds >= 1 valid key
+    f32x2_t psum2 = {0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], p.scale_log2, neg_m));
-      psum += pe;
-      pf[e >> 3][e & 7] = f2op(pe);
+    for (int e = 0; e < 16; e += 2) {
+      const f32x2_t sv = {s[e], s[e + 1]};
+      const f32x2_t t = __builtin_elementwise_fma(sv, sc2, nm2);
+      const f32x2_t pe = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+      psum2 += pe;
+      pf[e >> 3][e & 7] = f2op(pe[0]);
+      pf[e >> 3][(e & 7) + 1] = f2op(pe[1]);
     }
-    l_run += psum;
+    l_run += psum2[0] + psum2[1];
     STAMP(t3_);
     if constexpr (D <= 128) {
       typedef __attribute__((ext_vector_type(8))) short short8_t;
