@@ -51,6 +51,10 @@ SIGNATURES = {
     "msam2_aa_downsample": (c_i, [c_p, c_p, c_l, c_l, c_l, c_l, c_f, c_f, c_p]),
     "msam2_gate_rows": (c_i, [c_p, c_p, c_f, c_l, c_l, c_p]),
     "msam2_any_positive": (c_i, [c_p, c_p, c_l, c_l, c_p]),
+    "msam2_transpose16": (c_i, [c_p, c_l, c_p, c_l, c_l, c_l, c_p]),
+    "msam2_colsum": (c_i, [c_p, c_i, c_l, c_p, c_l, c_l, c_p]),
+    "msam2_act_bwd": (c_i, [c_p, c_i, c_p, c_i, c_p, c_l, c_i, c_p]),
+    "msam2_layernorm_bwd": (c_i, [c_p, c_l, c_p, c_i, c_l, c_p, c_p, c_l, c_p, c_p, c_l, c_l, c_f, c_p]),
     "msam2_seg_counts": (c_i, [c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_p]),
     "msam2_non_overlap": (c_i, [c_p, c_p, c_l, c_l, c_p]),
     "msam2_token_mlp3": (c_i, [c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_p]),

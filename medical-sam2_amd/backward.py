@@ -1,0 +1,82 @@
+"""First slice of the backward pass ("fused LN/MLP backward"): gradients of nn.LayerNorm, nn.Linear and
+the Linear-act-Linear MLP (sam2_utils.py:108-132; hieradet.py:96-106,160-166; memory_attention.py:43-47,96) on the HIP path.  The
+gradient GEMMs are the forward GEMM kernel on transposed operands (`ops.gemm(dy, W^T)` / `ops.gemm(dy^T, x^T)`), the rest are the
+kernels of csrc/backward.hip.  Attention backward (flash-style dQ/dK/dV) is not built yet, so there is no end-to-end training step.
+
+Operands are 16-bit (ops.OP16) like the forward: with the default fp16 build callers must keep gradients in fp16 range (loss scaling);
+the bf16 build has fp32's range.  Parity: tests/test_backward_gpu.py against torch.autograd on the fp32 oracle primitives.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import ops
+from ._lib import check, lib
+from .ops import F32, OP16, _is_bf16, _p, _req, _stream
+
+
+def transpose16(x: torch.Tensor, pad_rows_to: int = 1) -> torch.Tensor:
+    """16-bit [R, C] (row-major, possibly strided rows) -> contiguous [C, R'] with R' = R rounded up to a multiple of `pad_rows_to`
+    (extra columns zero: as a GEMM operand they add nothing to the reduction, and the row length stays 16-byte aligned)."""
+    _req(x.dim() == 2 and x.dtype == OP16 and x.stride(1) == 1, "transpose16: 16-bit row-major matrix")
+    R, C = x.shape
+    Rp = -(-R // pad_rows_to) * pad_rows_to
+    out = torch.empty(C, Rp, dtype=OP16, device=x.device) if Rp == R else torch.zeros(C, Rp, dtype=OP16, device=x.device)
+    check(lib().msam2_transpose16(_p(x), x.stride(0), _p(out), out.stride(0), R, C, _stream()))
+    return out
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [C] = column sums of a [R, C] matrix (16-bit or fp32)."""
+    _req(x.dim() == 2 and x.stride(1) == 1, "colsum: row-major matrix")
+    out = torch.zeros(x.shape[1], dtype=F32, device=x.device)
+    check(lib().msam2_colsum(_p(x), _is_bf16(x), x.stride(0), _p(out), x.shape[0], x.shape[1], _stream()))
+    return out
+
+
+def act_backward(pre: torch.Tensor, dy: torch.Tensor, act: int) -> torch.Tensor:
+    """16-bit dy * act'(pre); act = ops.ACT_GELU | ops.ACT_RELU."""
+    _req(pre.shape == dy.shape and pre.is_contiguous() and dy.is_contiguous(), "act_backward: contiguous tensors of one shape")
+    out = torch.empty(pre.shape, dtype=OP16, device=pre.device)
+    check(lib().msam2_act_bwd(_p(pre), _is_bf16(pre), _p(dy), _is_bf16(dy), _p(out), pre.numel(), act, _stream()))
+    return out
+
+
+def layernorm_backward(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, eps: float) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """x fp32 [rows, C] (the LayerNorm input), dy [rows, C] (16-bit or fp32) -> (dx fp32, dgamma fp32 [C], dbeta fp32 [C])."""
+    _req(x.dim() == 2 and x.dtype == F32 and x.stride(1) == 1 and dy.shape == x.shape and dy.stride(1) == 1, "layernorm_backward shapes")
+    rows, C = x.shape
+    dx = torch.empty(rows, C, dtype=F32, device=x.device)
+    dg = torch.zeros(C, dtype=F32, device=x.device)
+    db = torch.zeros(C, dtype=F32, device=x.device)
+    check(lib().msam2_layernorm_bwd(_p(x), x.stride(0), _p(dy), _is_bf16(dy), dy.stride(0), _p(gamma), _p(dx), dx.stride(0), _p(dg), _p(db),
+                                    rows, C, eps, _stream()))
+    return dx, dg, db
+
+
+def _op16(t: torch.Tensor) -> torch.Tensor:
+    return t if t.dtype == OP16 else ops.add_cast(t.reshape(1, t.shape[0], t.shape[1]), None, 1.0, OP16)[0]
+
+
+def linear_backward(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, need_dx: bool = True, dx_dtype: torch.dtype = F32):
+    """y = x W^T + b with x 16-bit [M, K], W 16-bit [N, K]; dy [M, N] (any float type).  Returns (dx [M, K] or None, dW fp32 [N, K],
+    db fp32 [N])."""
+    dy16 = _op16(dy)
+    _req(w.shape[0] % 8 == 0, "linear_backward: out_features must be a multiple of 8 (GEMM reduction length of dX)")
+    dx = ops.gemm(dy16, transpose16(w), out_dtype=dx_dtype) if need_dx else None          # [M,N] @ (W^T [K,N])^T
+    dw = ops.gemm(transpose16(dy16, 8), transpose16(x, 8), out_dtype=F32)                  # [N,M'] @ (x^T [K,M'])^T, M' = M padded to 8
+    return dx, dw, colsum(dy16)
+
+
+def mlp_backward(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: Optional[torch.Tensor], dy: torch.Tensor,
+                 act: int):
+    """y = W2 act(W1 x + b1) + b2 (two-layer MLP of hieradet / memory attention / two-way blocks).  The hidden activations are
+    recomputed (one extra forward GEMM pair) instead of being saved by the forward.  Returns (dx fp32, dW1, db1, dW2, db2)."""
+    pre = ops.gemm(x, w1, b1, out_dtype=F32)
+    h = ops.gemm(x, w1, b1, act=act)
+    dh, dw2, db2 = linear_backward(h, w2, dy, dx_dtype=F32)
+    dpre = act_backward(pre, dh, act)
+    dx, dw1, db1 = linear_backward(x, w1, dpre)
+    return dx, dw1, db1, dw2, db2

@@ -1,0 +1,101 @@
+"""Backward building blocks (medical_sam2_amd.backward) against torch.autograd on the fp32 oracle primitives.
+Tolerances: 16-bit operands on both GEMM inputs (activations/weights and gradients), fp32 accumulation."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import sam2_oracle as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def mods():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import medical_sam2_amd.backward as B
+    import medical_sam2_amd.ops as ops
+    return B, ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+@pytest.mark.parametrize("R,C", [(64, 64), (100, 37), (16384, 384), (5, 1000)])
+def test_transpose_and_colsum(mods, R, C):
+    B, ops = mods
+    x = rnd(R, C, seed=1).to(ops.OP16)
+    assert torch.equal(B.transpose16(x.to(DEV)).cpu(), x.t().contiguous())
+    wide = rnd(R, C + 8, seed=2).to(ops.OP16).to(DEV)
+    assert torch.equal(B.transpose16(wide[:, 3:C + 3]).cpu(), wide[:, 3:C + 3].cpu().t().contiguous())
+    xi = torch.randint(-4, 5, (R, C), generator=torch.Generator().manual_seed(3)).float()
+    assert torch.equal(B.colsum(xi.to(DEV)).cpu(), xi.sum(0))                       # integer-valued: exact in any order
+    assert torch.equal(B.colsum(xi.to(ops.OP16).to(DEV)).cpu(), xi.sum(0))
+
+
+@pytest.mark.parametrize("rows,C,eps", [(300, 96, 1e-6), (1000, 384, 1e-6), (64, 256, 1e-5), (7, 768, 1e-6)])
+def test_layernorm_backward(mods, rows, C, eps):
+    B, ops = mods
+    x = (rnd(rows, C, seed=4) * 2 + 0.5).requires_grad_(True)
+    g = (rnd(C, seed=5) * 0.3 + 1).requires_grad_(True)
+    b = rnd(C, seed=6).requires_grad_(True)
+    dy = rnd(rows, C, seed=7)
+    F.layer_norm(x, (C,), g, b, eps).backward(dy)
+    dx, dg, db = B.layernorm_backward(x.detach().to(DEV), g.detach().to(DEV), dy.to(DEV), eps)
+    assert rel(dx, x.grad) < 1e-5 and rel(dg, g.grad) < 1e-5 and rel(db, b.grad) < 1e-5
+    dx2, _, _ = B.layernorm_backward(x.detach().to(DEV), g.detach().to(DEV), dy.to(ops.OP16).to(DEV), eps)
+    assert rel(dx2, x.grad) < 2e-3                                               # 16-bit upstream gradient
+
+
+@pytest.mark.parametrize("act", [1, 2])
+def test_act_backward(mods, act):
+    B, ops = mods
+    pre = rnd(513, 96, seed=8, scale=2.0).requires_grad_(True)
+    dy = rnd(513, 96, seed=9)
+    (O.gelu(pre) if act == 1 else torch.relu(pre)).backward(dy)
+    out = B.act_backward(pre.detach().to(DEV), dy.to(DEV), act)
+    assert (out.float().cpu() - pre.grad).abs().max().item() < 4e-3             # 16-bit output rounding
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 384, 96), (4096, 96, 384), (1000, 256, 2048), (64, 32, 64)])
+def test_linear_backward(mods, M, N, K):
+    B, ops = mods
+    q = lambda t: t.to(ops.OP16).float()
+    x = q(rnd(M, K, seed=10)).requires_grad_(True)
+    w = q(rnd(N, K, seed=11, scale=0.1)).requires_grad_(True)
+    b = rnd(N, seed=12).requires_grad_(True)
+    dy = q(rnd(M, N, seed=13))
+    F.linear(x, w, b).backward(dy)
+    dx, dw, db = B.linear_backward(x.detach().to(ops.OP16).to(DEV), w.detach().to(ops.OP16).to(DEV), dy.to(DEV))
+    assert rel(dx, x.grad) < 1e-5 and rel(dw, w.grad) < 1e-5 and rel(db, b.grad) < 1e-5     # inputs exact in 16 bits, fp32 accumulate
+    assert dx.shape == x.shape and dw.shape == w.shape
+
+
+@pytest.mark.parametrize("M,C,Hd,act", [(1024, 96, 384, 1), (512, 384, 1536, 1), (256, 256, 2048, 2)])
+def test_mlp_backward(mods, M, C, Hd, act):
+    """fc1 -> GELU/ReLU -> fc2 of a Hiera block / memory-attention layer (sam2_utils.py:108-132) against autograd"""
+    B, ops = mods
+    q = lambda t: t.to(ops.OP16).float()
+    x = q(rnd(M, C, seed=14)).requires_grad_(True)
+    w1, w2 = q(rnd(Hd, C, seed=15, scale=C ** -0.5)).requires_grad_(True), q(rnd(C, Hd, seed=16, scale=Hd ** -0.5)).requires_grad_(True)
+    b1, b2 = rnd(Hd, seed=17, scale=0.1).requires_grad_(True), rnd(C, seed=18, scale=0.1).requires_grad_(True)
+    dy = q(rnd(M, C, seed=19))
+    h = F.linear(x, w1, b1)
+    h = O.gelu(h) if act == 1 else torch.relu(h)
+    F.linear(h, w2, b2).backward(dy)
+    d = lambda t: t.detach().to(DEV)
+    dx, dw1, db1, dw2, db2 = B.mlp_backward(d(x).to(ops.OP16), d(w1).to(ops.OP16), d(b1), d(w2).to(ops.OP16), d(b2), d(dy), act)
+    tol = 4e-3                                                                   # hidden activations and dh are rounded to 16 bits
+    assert rel(dx, x.grad) < tol and rel(dw1, w1.grad) < tol and rel(db1, b1.grad) < tol
+    assert rel(dw2, w2.grad) < tol and rel(db2, b2.grad) < 1e-5

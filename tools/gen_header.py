@@ -32,6 +32,10 @@ DOC = {
     "msam2_fourier_pe_grid": "PromptEncoder.get_dense_pe (prompt_encoder.py:68-77; position_encoding.py:130-151) as [h*w, C].",
     "msam2_hiera_pos_embed": "Hiera._get_pos_embed (hieradet.py:269-277): bicubic resize of pos_embed + tiled pos_embed_window.",
     "msam2_aa_downsample": "F.interpolate(mode=\"bilinear\", antialias=True) by an integer factor (sam2_base.py:321-327, 421-427).",
+    "msam2_transpose16": "16-bit matrix transpose (backward GEMMs: dX = dY W needs W^T rows, dW = dY^T X needs dY^T and X^T as K-contiguous operands\nof msam2_gemm).",
+    "msam2_colsum": "Column sums into a zeroed fp32 vector: the bias gradient of nn.Linear (sam2_utils.py:127-131 under torch.autograd).",
+    "msam2_act_bwd": "dpre = dy * act'(pre) as a 16-bit GEMM operand; act 1 = exact-erf GELU (hieradet.py:96, memory_encoder.py:95), 2 = ReLU\n(memory_attention.py:96, transformer.py MLP blocks).",
+    "msam2_layernorm_bwd": "nn.LayerNorm backward (hieradet.py:101-102, memory_attention.py:43-45): dx, and dgamma / dbeta accumulated into zeroed fp32\nvectors; statistics are recomputed from x, the forward saves nothing.",
     "msam2_seg_counts": "Counts behind eval_seg (func_3d/utils.py:139-214, func_2d/utils.py:505-580): per threshold, batch element and class the\ninteger |pred>t & gt>t|, |pred>t|, |gt>t| in one pass; IoU / Dice follow on the host.",
     "msam2_non_overlap": "SAM2Base._apply_non_overlapping_constraints (sam2_base.py:812-830): keep the arg-max object per pixel, clamp the\nothers to <= -10.",
     "msam2_gate_rows": "masks[b] = value where object score <= 0 (NO_OBJ_SCORE fill, sam2_base.py:354-363).",
@@ -65,7 +69,7 @@ DOC = {
 
 def main():
     decls = []
-    for f in ["api.hip", "gemm.hip", "attention.hip", "elementwise.hip", "conv.hip", "cc.hip"]:
+    for f in ["api.hip", "gemm.hip", "attention.hip", "elementwise.hip", "conv.hip", "cc.hip", "backward.hip"]:
         s = open(os.path.join(CSRC, f)).read()
         for m in re.finditer(r'extern "C" ([^{;]+?)\s*\{', s, re.S):
             decls.append(" ".join(m.group(1).split()))
