@@ -80,3 +80,33 @@ def mlp_backward(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.
     dpre = act_backward(pre, dh, act)
     dx, dw1, db1 = linear_backward(x, w1, dpre)
     return dx, dw1, db1, dw2, db2
+
+
+def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: torch.Tensor, scale: Optional[float] = None):
+    """Gradients of o = softmax(q k^T * scale) v for 16-bit q [B,H,Lq,D], k/v [B,H,Lk,D], upstream do [B,H,Lq,D] (any float type).
+    MATERIALISED form: per (batch, head) the [Lq, Lk] scores live in HBM (fp32 S, 16-bit P / dS: 0.5 GB at 4096 x 16384), which
+    288 GB affords; the five products (S = q k^T, dV = P^T dO, dP = dO V^T, dQ = dS K, dK = dS^T Q) run on the forward GEMM kernel and
+    the softmax and its Jacobian on two row kernels.  A flash-style (recomputing, O(L) memory) backward is the next step.
+    Needs Lq, Lk and D to be multiples of 8.  Returns (dq, dk, dv) in fp32, shaped like q / k / v."""
+    B, H, Lq, D = q.shape
+    Lk = k.shape[2]
+    _req(q.dtype == OP16 and k.dtype == OP16 and v.dtype == OP16, "attention_backward: 16-bit q, k, v")
+    _req(Lq % 8 == 0 and Lk % 8 == 0 and D % 8 == 0, "attention_backward: Lq, Lk and D must be multiples of 8")
+    scale = scale if scale is not None else D ** -0.5
+    dq = torch.empty(B, H, Lq, D, dtype=F32, device=q.device)
+    dk = torch.empty(B, H, Lk, D, dtype=F32, device=q.device)
+    dv = torch.empty(B, H, Lk, D, dtype=F32, device=q.device)
+    P = torch.empty(Lq, Lk, dtype=OP16, device=q.device)
+    dS = torch.empty(Lq, Lk, dtype=OP16, device=q.device)
+    for b in range(B):
+        for h in range(H):
+            qm, km, vm = (t[b, h] if t[b, h].stride(1) == 1 and t[b, h].stride(0) % 8 == 0 else t[b, h].contiguous() for t in (q, k, v))
+            dom = _op16(do[b, h].contiguous())
+            S = ops.gemm(qm, km, out_dtype=F32)                                   # [Lq, Lk]
+            check(lib().msam2_softmax_rows(_p(S), S.stride(0), _p(P), P.stride(0), Lq, Lk, scale, _stream()))
+            ops.gemm(transpose16(P), transpose16(dom), out=dv[b, h])             # dV = P^T dO
+            dP = ops.gemm(dom, vm, out_dtype=F32)                                 # dO V^T
+            check(lib().msam2_softmax_bwd_rows(_p(P), P.stride(0), _p(dP), dP.stride(0), _p(dS), dS.stride(0), Lq, Lk, scale, _stream()))
+            ops.gemm(dS, transpose16(km), out=dq[b, h])                          # dQ = dS K
+            ops.gemm(transpose16(dS), transpose16(qm), out=dk[b, h])             # dK = dS^T Q
+    return dq, dk, dv

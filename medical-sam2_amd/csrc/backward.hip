@@ -163,3 +163,58 @@ extern "C" int msam2_layernorm_bwd(const float* x, int64_t ldx, const void* dy, 
                        ldo, dgamma, dbeta, rows, (int)C, eps);
   return msam2_check_launch("layernorm_bwd");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Row softmax pieces of the MATERIALISED attention backward (backward.attention_backward): with 288 GB of HBM the [Lq, Lk] score
+// matrix of one (batch, head) fits (268 MB fp32 at 4096 x 16384), so the five gradient products run on the forward GEMM kernel and
+// only these two row kernels are specific.  One wave per row, any Lk.
+//   softmax_rows:      P (16-bit) = softmax(scale * S) row-wise, S fp32
+//   softmax_bwd_rows:  dS (16-bit) = scale * P * (dP - sum_k P dP) row-wise, P 16-bit, dP fp32
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, int64_t lds_, op16* __restrict__ p, int64_t ldp,
+                                                           int64_t rows, int64_t cols, float scale_log2) {
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* sr = s + row * lds_;
+  float m = -INFINITY;
+  for (int64_t c = lane; c < cols; c += 64) m = fmaxf(m, sr[c]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  m *= scale_log2;
+  float l = 0.f;
+  for (int64_t c = lane; c < cols; c += 64) l += __builtin_amdgcn_exp2f(sr[c] * scale_log2 - m);
+  l = wave_sum(l);
+  const float inv = 1.f / l;
+  op16* pr = p + row * ldp;
+  for (int64_t c = lane; c < cols; c += 64) pr[c] = f2op(__builtin_amdgcn_exp2f(sr[c] * scale_log2 - m) * inv);
+}
+
+extern "C" int msam2_softmax_rows(const float* s, int64_t ld_s, void* p, int64_t ld_p, int64_t rows, int64_t cols, float scale, void* stream) {
+  MSAM2_REQUIRE(s && p && rows > 0 && cols > 0 && scale > 0.f, "softmax_rows: bad arguments");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows * 64, 256)), dim3(256), 0, (hipStream_t)stream, s, ld_s, (op16*)p, ld_p, rows, cols,
+                     scale * 1.4426950408889634f);
+  return msam2_check_launch("softmax_rows");
+}
+
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const op16* __restrict__ p, int64_t ldp, const float* __restrict__ dp, int64_t ldd,
+                                                               op16* __restrict__ ds, int64_t ldo, int64_t rows, int64_t cols, float scale) {
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const op16* pr = p + row * ldp;
+  const float* dr = dp + row * ldd;
+  float acc = 0.f;
+  for (int64_t c = lane; c < cols; c += 64) acc += op2f(pr[c]) * dr[c];
+  acc = wave_sum(acc);
+  op16* o = ds + row * ldo;
+  for (int64_t c = lane; c < cols; c += 64) o[c] = f2op(scale * op2f(pr[c]) * (dr[c] - acc));
+}
+
+extern "C" int msam2_softmax_bwd_rows(const void* p, int64_t ld_p, const float* dp, int64_t ld_dp, void* ds, int64_t ld_ds, int64_t rows,
+                                      int64_t cols, float scale, void* stream) {
+  MSAM2_REQUIRE(p && dp && ds && rows > 0 && cols > 0, "softmax_bwd_rows: bad arguments");
+  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3(cdiv(rows * 64, 256)), dim3(256), 0, (hipStream_t)stream, (const op16*)p, ld_p, dp, ld_dp,
+                     (op16*)ds, ld_ds, rows, cols, scale);
+  return msam2_check_launch("softmax_bwd_rows");
+}

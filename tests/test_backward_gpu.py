@@ -99,3 +99,19 @@ def test_mlp_backward(mods, M, C, Hd, act):
     tol = 4e-3                                                                   # hidden activations and dh are rounded to 16 bits
     assert rel(dx, x.grad) < tol and rel(dw1, w1.grad) < tol and rel(db1, b1.grad) < tol
     assert rel(dw2, w2.grad) < tol and rel(db2, b2.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,D", [(1, 1, 256, 1024, 256), (2, 2, 128, 128, 96), (1, 1, 4096, 4104, 256), (1, 4, 64, 200, 64)])
+def test_attention_backward(mods, B, H, Lq, Lk, D):
+    """materialised attention backward (memory-attention / Hiera-global shapes incl. object-pointer tokens) against autograd"""
+    B_, ops = mods
+    q16 = lambda t: t.to(ops.OP16)
+    q = q16(rnd(B, H, Lq, D, seed=20)).float().requires_grad_(True)
+    k = q16(rnd(B, H, Lk, D, seed=21)).float().requires_grad_(True)
+    v = q16(rnd(B, H, Lk, D, seed=22)).float().requires_grad_(True)
+    do = q16(rnd(B, H, Lq, D, seed=23)).float()
+    O.softmax_attention(q, k, v).backward(do)
+    d = lambda t: t.detach().to(ops.OP16).to(DEV)
+    dq, dk, dv = B_.attention_backward(d(q), d(k), d(v), do.to(DEV))
+    assert dq.shape == q.shape and dk.shape == k.shape and dv.shape == v.shape
+    assert rel(dv, v.grad) < 3e-3 and rel(dq, q.grad) < 6e-3 and rel(dk, k.grad) < 6e-3, (rel(dq, q.grad), rel(dk, k.grad), rel(dv, v.grad))

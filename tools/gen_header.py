@@ -36,6 +36,8 @@ DOC = {
     "msam2_colsum": "Column sums into a zeroed fp32 vector: the bias gradient of nn.Linear (sam2_utils.py:127-131 under torch.autograd).",
     "msam2_act_bwd": "dpre = dy * act'(pre) as a 16-bit GEMM operand; act 1 = exact-erf GELU (hieradet.py:96, memory_encoder.py:95), 2 = ReLU\n(memory_attention.py:96, transformer.py MLP blocks).",
     "msam2_layernorm_bwd": "nn.LayerNorm backward (hieradet.py:101-102, memory_attention.py:43-45): dx, and dgamma / dbeta accumulated into zeroed fp32\nvectors; statistics are recomputed from x, the forward saves nothing.",
+    "msam2_softmax_rows": "P (16-bit) = softmax(scale * S) row-wise from materialised fp32 scores: forward half of the materialised attention backward\n(F.scaled_dot_product_attention under autograd, transformer.py:318, hieradet.py:72-76).",
+    "msam2_softmax_bwd_rows": "dS (16-bit) = scale * P * (dP - sum_k P dP) row-wise: the softmax Jacobian of the attention backward.",
     "msam2_seg_counts": "Counts behind eval_seg (func_3d/utils.py:139-214, func_2d/utils.py:505-580): per threshold, batch element and class the\ninteger |pred>t & gt>t|, |pred>t|, |gt>t| in one pass; IoU / Dice follow on the host.",
     "msam2_non_overlap": "SAM2Base._apply_non_overlapping_constraints (sam2_base.py:812-830): keep the arg-max object per pixel, clamp the\nothers to <= -10.",
     "msam2_gate_rows": "masks[b] = value where object score <= 0 (NO_OBJ_SCORE fill, sam2_base.py:354-363).",
