@@ -87,26 +87,104 @@ def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: to
     MATERIALISED form: per (batch, head) the [Lq, Lk] scores live in HBM (fp32 S, 16-bit P / dS: 0.5 GB at 4096 x 16384), which
     288 GB affords; the five products (S = q k^T, dV = P^T dO, dP = dO V^T, dQ = dS K, dK = dS^T Q) run on the forward GEMM kernel and
     the softmax and its Jacobian on two row kernels.  A flash-style (recomputing, O(L) memory) backward is the next step.
-    Needs Lq, Lk and D to be multiples of 8.  Returns (dq, dk, dv) in fp32, shaped like q / k / v."""
+    Any Lq / Lk (reduction dims are zero-padded to multiples of 8); D % 8 == 0.  Returns (dq, dk, dv) in fp32, shaped like q / k / v."""
     B, H, Lq, D = q.shape
     Lk = k.shape[2]
     _req(q.dtype == OP16 and k.dtype == OP16 and v.dtype == OP16, "attention_backward: 16-bit q, k, v")
-    _req(Lq % 8 == 0 and Lk % 8 == 0 and D % 8 == 0, "attention_backward: Lq, Lk and D must be multiples of 8")
+    _req(D % 8 == 0, "attention_backward: head dim must be a multiple of 8")
     scale = scale if scale is not None else D ** -0.5
     dq = torch.empty(B, H, Lq, D, dtype=F32, device=q.device)
     dk = torch.empty(B, H, Lk, D, dtype=F32, device=q.device)
     dv = torch.empty(B, H, Lk, D, dtype=F32, device=q.device)
-    P = torch.empty(Lq, Lk, dtype=OP16, device=q.device)
-    dS = torch.empty(Lq, Lk, dtype=OP16, device=q.device)
+    # P / dS are GEMM operands with the keys as reduction dim: rows padded to a multiple of 8 keys with zeros (memory banks hold
+    # 4 tokens per object pointer, so Lk is only a multiple of 4)
+    Lkp = -(-Lk // 8) * 8
+    Pbuf = torch.zeros(Lq, Lkp, dtype=OP16, device=q.device)
+    dSbuf = torch.zeros(Lq, Lkp, dtype=OP16, device=q.device)
+    P, dS = Pbuf[:, :Lk], dSbuf[:, :Lk]
     for b in range(B):
         for h in range(H):
             qm, km, vm = (t[b, h] if t[b, h].stride(1) == 1 and t[b, h].stride(0) % 8 == 0 else t[b, h].contiguous() for t in (q, k, v))
             dom = _op16(do[b, h].contiguous())
             S = ops.gemm(qm, km, out_dtype=F32)                                   # [Lq, Lk]
             check(lib().msam2_softmax_rows(_p(S), S.stride(0), _p(P), P.stride(0), Lq, Lk, scale, _stream()))
-            ops.gemm(transpose16(P), transpose16(dom), out=dv[b, h])             # dV = P^T dO
+            ops.gemm(transpose16(P, 8), transpose16(dom, 8), out=dv[b, h])       # dV = P^T dO        (reduction over Lq, padded)
             dP = ops.gemm(dom, vm, out_dtype=F32)                                 # dO V^T
             check(lib().msam2_softmax_bwd_rows(_p(P), P.stride(0), _p(dP), dP.stride(0), _p(dS), dS.stride(0), Lq, Lk, scale, _stream()))
-            ops.gemm(dS, transpose16(km), out=dq[b, h])                          # dQ = dS K
-            ops.gemm(transpose16(dS), transpose16(qm), out=dk[b, h])             # dK = dS^T Q
+            ops.gemm(dSbuf, transpose16(km, 8), out=dq[b, h])                    # dQ = dS K          (reduction over Lk, padded)
+            ops.gemm(transpose16(dS, 8), transpose16(qm, 8), out=dk[b, h])       # dK = dS^T Q        (reduction over Lq, padded)
     return dq, dk, dv
+
+
+def _rope_adjoint_(t: torch.Tensor, n_rope: int, table) -> torch.Tensor:
+    """adjoint of the axial RoPE rotation (a rotation by the negative angle), in place on a 16-bit [B, N, D] gradient"""
+    cs, sn = table
+    return ops.rope_(t, n_rope, (cs, -sn))
+
+
+def memory_attention_layer_backward(layer, x: torch.Tensor, mem_k: torch.Tensor, mem_v: torch.Tensor, B: int, L: int, n_ptr_tokens: int,
+                                    dy: torch.Tensor):
+    """Backward of `MemoryAttentionLayer.run` (memory_attention.py:17-99 in eval mode: pre-LN RoPE self-attention, RoPE cross-attention
+    to the memory bank, ReLU FFN, three residuals).  The forward is recomputed here with its intermediates kept (the inference forward
+    saves nothing).  x fp32 [B*L, C]; mem_k / mem_v 16-bit [B, Nk, 64]; dy fp32 [B*L, C].
+    Returns (dx fp32 [B*L, C], dmem_k fp32 [B, Nk, 64], dmem_v fp32 [B, Nk, 64], {parameter name: fp32 gradient})."""
+    from .modeling.common import v_f32, w_bf16
+    sa, ca, wc = layer.self_attn, layer.cross_attn_image, layer._wc
+    C, Nk = layer.d_model, mem_k.shape[1]
+    assert sa.num_heads == 1 and ca.num_heads == 1, "memory attention runs single-head (sam2_hiera_*.yaml)"
+    tab = sa.table(L, x.device)
+    ln = lambda name, t: ops.layernorm(t, v_f32(wc, name + "w", getattr(layer, name).weight), v_f32(wc, name + "b", getattr(layer, name).bias),
+                                       getattr(layer, name).eps)
+    W = lambda key, *ws: w_bf16(wc, key, *ws)
+    Bv = lambda key, *bs: v_f32(wc, key, *bs)
+    # ---- forward with intermediates
+    t1 = ln("norm1", x)
+    w_qkv, b_qkv = W("sqkv", sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight), Bv("sqkvb", sa.q_proj.bias, sa.k_proj.bias, sa.v_proj.bias)
+    qkv = ops.gemm(t1, w_qkv, b_qkv).view(B, L, 3 * C)
+    q1, k1, v1 = qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
+    ops.rope_(q1, L, tab)
+    ops.rope_(k1, L, tab)
+    a1 = sa.core(q1, k1, v1)                                                     # 16-bit [B*L, C]
+    x1 = sa.out(a1, x)
+    t2 = ln("norm2", x1)
+    wq, wk, wv = W("qw", ca.q_proj.weight), W("kw", ca.k_proj.weight), W("vw", ca.v_proj.weight)
+    q2 = ops.gemm(t2, wq, Bv("qb", ca.q_proj.bias)).view(B, L, C)
+    ops.rope_(q2, L, tab)
+    mk2, mv2 = mem_k.reshape(B * Nk, -1), mem_v.reshape(B * Nk, -1)
+    kk = ops.gemm(mk2, wk, Bv("kb", ca.k_proj.bias)).view(B, Nk, C)
+    ops.rope_(kk, Nk - n_ptr_tokens, tab)
+    vv = ops.gemm(mv2, wv, Bv("vb", ca.v_proj.bias)).view(B, Nk, C)
+    a2 = ca.core(q2, kk, vv)
+    x2 = ca.out(a2, x1)
+    t3 = ln("norm3", x2)
+    w1, w2 = W("f1", layer.linear1.weight), W("f2", layer.linear2.weight)
+    # ---- backward
+    g = {}
+    dt3, g["linear1.weight"], g["linear1.bias"], g["linear2.weight"], g["linear2.bias"] = mlp_backward(
+        t3, w1, Bv("f1b", layer.linear1.bias), w2, Bv("f2b", layer.linear2.bias), dy, ops.ACT_RELU)
+    d, g["norm3.weight"], g["norm3.bias"] = layernorm_backward(x2, layer.norm3.weight.detach().float(), dt3, layer.norm3.eps)
+    dx2 = dy + d                                                                  # residual branch + LayerNorm branch
+    # cross attention
+    da2, g["cross_attn_image.out_proj.weight"], g["cross_attn_image.out_proj.bias"] = linear_backward(a2, W("ow", ca.out_proj.weight), dx2)
+    u4 = lambda t: t.unsqueeze(1)                                                 # [B, N, C] -> [B, 1, N, C]
+    dq2, dkk, dvv = attention_backward(u4(q2), u4(kk), u4(vv), u4(da2.view(B, L, C)))
+    dq2, dkk = _op16(dq2.view(B * L, C)).view(B, L, C), _op16(dkk.view(B * Nk, C)).view(B, Nk, C)
+    _rope_adjoint_(dq2, L, tab)
+    _rope_adjoint_(dkk, Nk - n_ptr_tokens, tab)
+    dt2, g["cross_attn_image.q_proj.weight"], g["cross_attn_image.q_proj.bias"] = linear_backward(t2, wq, dq2.view(B * L, C))
+    dmk, g["cross_attn_image.k_proj.weight"], g["cross_attn_image.k_proj.bias"] = linear_backward(mk2, wk, dkk.view(B * Nk, C))
+    dmv, g["cross_attn_image.v_proj.weight"], g["cross_attn_image.v_proj.bias"] = linear_backward(mv2, wv, dvv.view(B * Nk, C))
+    d, g["norm2.weight"], g["norm2.bias"] = layernorm_backward(x1, layer.norm2.weight.detach().float(), dt2, layer.norm2.eps)
+    dx1 = dx2 + d
+    # self attention
+    da1, g["self_attn.out_proj.weight"], g["self_attn.out_proj.bias"] = linear_backward(a1, W("ow_s", sa.out_proj.weight), dx1)
+    dq1, dk1, dv1 = attention_backward(u4(q1), u4(k1), u4(v1), u4(da1.view(B, L, C)))
+    dq16, dk16, dv16 = (_op16(t.view(B * L, C)).view(B, L, C) for t in (dq1, dk1, dv1))
+    _rope_adjoint_(dq16, L, tab)
+    _rope_adjoint_(dk16, L, tab)
+    dqkv = torch.cat([dq16, dk16, dv16], dim=2)                                  # data movement only: the fused projection's gradient rows
+    dt1, dw_qkv, db_qkv = linear_backward(t1, w_qkv, dqkv.view(B * L, 3 * C))
+    for i, nm in enumerate(("q", "k", "v")):
+        g[f"self_attn.{nm}_proj.weight"], g[f"self_attn.{nm}_proj.bias"] = dw_qkv[i * C:(i + 1) * C], db_qkv[i * C:(i + 1) * C]
+    d, g["norm1.weight"], g["norm1.bias"] = layernorm_backward(x, layer.norm1.weight.detach().float(), dt1, layer.norm1.eps)
+    return dx1 + d, dmk.view(B, Nk, -1), dmv.view(B, Nk, -1), g

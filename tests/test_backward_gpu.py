@@ -101,7 +101,7 @@ def test_mlp_backward(mods, M, C, Hd, act):
     assert rel(dw2, w2.grad) < tol and rel(db2, b2.grad) < 1e-5
 
 
-@pytest.mark.parametrize("B,H,Lq,Lk,D", [(1, 1, 256, 1024, 256), (2, 2, 128, 128, 96), (1, 1, 4096, 4104, 256), (1, 4, 64, 200, 64)])
+@pytest.mark.parametrize("B,H,Lq,Lk,D", [(1, 1, 256, 1024, 256), (2, 2, 128, 128, 96), (1, 1, 4096, 4104, 256), (1, 4, 64, 200, 64), (2, 1, 256, 516, 256), (1, 2, 100, 77, 32)])
 def test_attention_backward(mods, B, H, Lq, Lk, D):
     """materialised attention backward (memory-attention / Hiera-global shapes incl. object-pointer tokens) against autograd"""
     B_, ops = mods
@@ -115,3 +115,54 @@ def test_attention_backward(mods, B, H, Lq, Lk, D):
     dq, dk, dv = B_.attention_backward(d(q), d(k), d(v), do.to(DEV))
     assert dq.shape == q.shape and dk.shape == k.shape and dv.shape == v.shape
     assert rel(dv, v.grad) < 3e-3 and rel(dq, q.grad) < 6e-3 and rel(dk, k.grad) < 6e-3, (rel(dq, q.grad), rel(dk, k.grad), rel(dv, v.grad))
+
+
+def test_memory_attention_layer_backward(mods):
+    """One MemoryAttentionLayer (memory_attention.py:17-99): gradients w.r.t. the input tokens, the memory (key / value sides) and all 26
+    parameter tensors against torch.autograd through the fp32 oracle primitives."""
+    B_, ops = mods
+    import medical_sam2_amd.build_sam as bs
+    import medical_sam2_amd.weights as wts
+    m = bs.build_sam2("sam2_hiera_t", device="cpu", hydra_overrides_extra=["++model.image_size=256"])
+    sd = wts.init_weights("hiera_t", 0)
+    m.load_state_dict(sd, strict=True)
+    layer = m.memory_attention.layers[0].to(DEV).eval()
+    pre = "memory_attention.layers.0"
+    P = {k: v.clone().float().requires_grad_(k.startswith(pre)) for k, v in sd.items()}
+    B, L, C, n_ptr = 2, 256, 256, 4
+    Nk = 2 * L + n_ptr
+    q16 = lambda t: t.to(ops.OP16).float()
+    x = rnd(B, L, C, seed=30).requires_grad_(True)
+    mem_k = q16(rnd(B, Nk, 64, seed=31)).requires_grad_(True)
+    mem_v = q16(rnd(B, Nk, 64, seed=32)).requires_grad_(True)
+    dy = rnd(B, L, C, seed=33)
+    theta = 10000.0
+
+    def rope_attn(pfx, q, k, v, excl):
+        # RoPEAttention.forward with separately given key / value inputs (transformer.py:288-331)
+        qq, kk, vv = O.lin(P, pfx + ".q_proj", q), O.lin(P, pfx + ".k_proj", k), O.lin(P, pfx + ".v_proj", v)
+        cos, sin = O.axial_rope_table(C, 16, 16, theta)
+        qq = O.rope_rotate(qq, cos, sin)
+        n = kk.shape[1] - excl
+        r = n // L
+        kk = torch.cat([O.rope_rotate(kk[:, :n], cos.repeat(r, 1), sin.repeat(r, 1)), kk[:, n:]], dim=1)
+        return O.lin(P, pfx + ".out_proj", O.softmax_attention(qq, kk, vv))
+
+    t = O.lnorm(P, pre + ".norm1", x, 1e-5)
+    r = x + rope_attn(pre + ".self_attn", t, t, t, 0)
+    t = O.lnorm(P, pre + ".norm2", r, 1e-5)
+    r = r + rope_attn(pre + ".cross_attn_image", t, mem_k, mem_v, n_ptr)
+    t = O.lnorm(P, pre + ".norm3", r, 1e-5)
+    y = r + O.lin(P, pre + ".linear2", torch.relu(O.lin(P, pre + ".linear1", t)))
+    y.backward(dy)
+
+    d = lambda tns: tns.detach().to(DEV)
+    dx, dmk, dmv, grads = B_.memory_attention_layer_backward(layer, d(x).reshape(B * L, C).contiguous(), d(mem_k).to(ops.OP16), d(mem_v).to(ops.OP16),
+                                                             B, L, n_ptr, d(dy).reshape(B * L, C).contiguous())
+    tol = 2e-2
+    report = {"dx": rel(dx.view(B, L, C), x.grad), "dmem_k": rel(dmk, mem_k.grad), "dmem_v": rel(dmv, mem_v.grad)}
+    for name, gten in grads.items():
+        ref = P[f"{pre}.{name}"].grad
+        assert ref is not None and gten.shape == ref.shape, name
+        report[name] = rel(gten, ref)
+    assert len(grads) == 26 and max(report.values()) < tol, report
