@@ -188,3 +188,31 @@ def memory_attention_layer_backward(layer, x: torch.Tensor, mem_k: torch.Tensor,
         g[f"self_attn.{nm}_proj.weight"], g[f"self_attn.{nm}_proj.bias"] = dw_qkv[i * C:(i + 1) * C], db_qkv[i * C:(i + 1) * C]
     d, g["norm1.weight"], g["norm1.bias"] = layernorm_backward(x, layer.norm1.weight.detach().float(), dt1, layer.norm1.eps)
     return dx1 + d, dmk.view(B, Nk, -1), dmv.view(B, Nk, -1), g
+
+
+def memory_attention_backward(module, curr: torch.Tensor, curr_pos: torch.Tensor, memory: torch.Tensor, memory_pos: torch.Tensor,
+                              num_obj_ptr_tokens: int, dy: torch.Tensor):
+    """Backward of `MemoryAttention.forward` (memory_attention.py:119-169; seq-first [L, B, C] tensors like the forward): x = curr +
+    0.1 curr_pos, the layers of `memory_attention_layer_backward` over keys memory + memory_pos / values memory, final LayerNorm.
+    Returns (dcurr [L,B,C], dmemory [Nk,B,64], dmemory_pos [Nk,B,64], {"layers.i.<param>" | "norm.weight|bias": fp32 gradient})."""
+    from .modeling.common import v_f32
+    L, B, C = curr.shape
+    x = ops.add_cast(curr.transpose(0, 1), curr_pos.transpose(0, 1), 0.1, F32).reshape(B * L, C)
+    mem_bf = memory.transpose(0, 1)
+    mem_k = ops.add_cast(mem_bf, memory_pos.transpose(0, 1), 1.0, OP16)
+    mem_v = ops.add_cast(mem_bf, None, 1.0, OP16)
+    xs = []
+    for layer in module.layers:                                                   # forward, keeping every layer's input
+        xs.append(x)
+        x = layer.run(x, mem_k, mem_v, B, L, num_obj_ptr_tokens)
+    grads = {}
+    d = ops.add_cast(dy.transpose(0, 1), None, 1.0, F32).reshape(B * L, C)
+    d, grads["norm.weight"], grads["norm.bias"] = layernorm_backward(x, module.norm.weight.detach().float(), d, module.norm.eps)
+    dmk = dmv = None
+    for i in range(len(module.layers) - 1, -1, -1):
+        d, gk, gv, g = memory_attention_layer_backward(module.layers[i], xs[i], mem_k, mem_v, B, L, num_obj_ptr_tokens, d)
+        dmk = gk if dmk is None else dmk + gk                                     # (tensor adds on small gradient slabs: plumbing)
+        dmv = gv if dmv is None else dmv + gv
+        grads.update({f"layers.{i}.{k}": v for k, v in g.items()})
+    dcurr = d.view(B, L, C).transpose(0, 1)
+    return dcurr, (dmk + dmv).transpose(0, 1), dmk.transpose(0, 1), grads

@@ -166,3 +166,36 @@ def test_memory_attention_layer_backward(mods):
         assert ref is not None and gten.shape == ref.shape, name
         report[name] = rel(gten, ref)
     assert len(grads) == 26 and max(report.values()) < tol, report
+
+
+def test_memory_attention_module_backward(mods):
+    """MemoryAttention.forward (4 layers + final norm, memory_attention.py:119-169) end to end: d/d(curr), d/d(memory),
+    d/d(memory_pos) and all 106 parameter gradients against autograd through oracle.memory_attention."""
+    B_, ops = mods
+    import medical_sam2_amd.build_sam as bs
+    import medical_sam2_amd.weights as wts
+    m = bs.build_sam2("sam2_hiera_t", device="cpu", hydra_overrides_extra=["++model.image_size=256"])
+    sd = wts.init_weights("hiera_t", 0)
+    m.load_state_dict(sd, strict=True)
+    mod = m.memory_attention.to(DEV).eval()
+    cfg = O.model_config("hiera_t", 256)
+    P = {k: v.clone().float().requires_grad_(k.startswith("memory_attention.")) for k, v in sd.items()}
+    B, L, C, n_ptr = 2, 256, 256, 4
+    Nk = L + n_ptr
+    curr = rnd(L, B, C, seed=40).requires_grad_(True)
+    curr_pos = rnd(L, B, C, seed=41)
+    memory = rnd(Nk, B, 64, seed=42).requires_grad_(True)
+    memory_pos = rnd(Nk, B, 64, seed=43).requires_grad_(True)
+    dy = rnd(L, B, C, seed=44)
+    O.memory_attention(P, cfg, curr, memory, curr_pos, memory_pos, n_ptr).backward(dy)
+    d = lambda t: t.detach().to(DEV)
+    dcurr, dmem, dmpos, grads = B_.memory_attention_backward(mod, d(curr), d(curr_pos), d(memory), d(memory_pos), n_ptr, d(dy))
+    report = {"dcurr": rel(dcurr, curr.grad), "dmemory": rel(dmem, memory.grad), "dmemory_pos": rel(dmpos, memory_pos.grad)}
+    for name, g in grads.items():
+        ref = P["memory_attention." + name].grad
+        assert ref is not None and g.shape == ref.shape, name
+        report[name] = rel(g, ref)
+    n_params = sum(1 for k in sd if k.startswith("memory_attention."))
+    assert len(grads) == n_params == 106, (len(grads), n_params)
+    worst = sorted(report.items(), key=lambda kv: -kv[1])[:5]
+    assert worst[0][1] < 3e-2, worst
