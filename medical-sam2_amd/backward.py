@@ -216,3 +216,136 @@ def memory_attention_backward(module, curr: torch.Tensor, curr_pos: torch.Tensor
         grads.update({f"layers.{i}.{k}": v for k, v in g.items()})
     dcurr = d.view(B, L, C).transpose(0, 1)
     return dcurr, (dmk + dmv).transpose(0, 1), dmk.transpose(0, 1), grads
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Two-way transformer of the mask decoder (sam/transformer.py:28-263): recomputing forward + backward
+# ---------------------------------------------------------------------------------------------------------------------
+def _add16(a: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """16-bit (a + b) for fp32 [rows, C] a and b ([rows, C] or [L, C] broadcast over the leading batch of a)"""
+    rows, C = a.shape
+    if b is None:
+        return ops.add_cast(a.view(1, rows, C), None, 1.0, OP16)[0]
+    if b.shape[0] == rows:
+        return ops.add_cast(a.view(1, rows, C), b.view(1, rows, C), 1.0, OP16)[0]
+    L = b.shape[0]
+    return ops.add_cast(a.view(rows // L, L, C), b.view(1, L, C), 1.0, OP16).view(rows, C)
+
+
+def _attn_fwd(att, q_in16, k_in16, v_in16, B):
+    """Attention.forward pieces (transformer.py:239-263) on 16-bit token-major inputs; returns (projected q, k, v, attention output)"""
+    from .modeling.common import v_f32, w_bf16
+    wc = att._wc
+    qp = ops.gemm(q_in16, w_bf16(wc, "qw", att.q_proj.weight), v_f32(wc, "qb", att.q_proj.bias))
+    kp = ops.gemm(k_in16, w_bf16(wc, "kw", att.k_proj.weight), v_f32(wc, "kb", att.k_proj.bias))
+    vp = ops.gemm(v_in16, w_bf16(wc, "vw", att.v_proj.weight), v_f32(wc, "vb", att.v_proj.bias))
+    a = att.core(qp.view(B, -1, qp.shape[1]), kp.view(B, -1, kp.shape[1]), vp.view(B, -1, vp.shape[1]))   # 16-bit [B*Lq, Ci]
+    return qp, kp, vp, a
+
+
+def attention_module_backward(att, q_in16, k_in16, v_in16, B: int, d_out: torch.Tensor, prefix: str, grads: dict):
+    """Backward of `Attention.forward` (q/k/v projections, H heads, output projection).  q_in16 [B*Lq, C], k_in16 / v_in16 [B*Lk, Ck]
+    16-bit; d_out fp32 [B*Lq, C].  Adds the 8 parameter gradients under `prefix` to `grads`; returns (dq_in, dk_in, dv_in) fp32."""
+    from .modeling.common import w_bf16
+    wc, H = att._wc, att.num_heads
+    qp, kp, vp, a = _attn_fwd(att, q_in16, k_in16, v_in16, B)
+    Ci = qp.shape[1]
+    D = Ci // H
+    da, grads[prefix + ".out_proj.weight"], grads[prefix + ".out_proj.bias"] = linear_backward(a, w_bf16(wc, "ow", att.out_proj.weight), d_out)
+    heads = lambda t: t.view(B, -1, H, D).permute(0, 2, 1, 3)                     # [B, H, L, D] views of the token-major rows
+    dq, dk, dv = attention_backward(heads(qp), heads(kp), heads(vp), heads(da))
+    rows = lambda t: t.permute(0, 2, 1, 3).reshape(-1, Ci)                        # back to token-major (data movement)
+    outs = []
+    for nm, x16, g in (("q", q_in16, dq), ("k", k_in16, dk), ("v", v_in16, dv)):
+        dx, grads[f"{prefix}.{nm}_proj.weight"], grads[f"{prefix}.{nm}_proj.bias"] = linear_backward(
+            x16, w_bf16(wc, nm + "w", getattr(att, nm + "_proj").weight), rows(g))
+        outs.append(dx)
+    return outs
+
+
+def two_way_transformer_backward(tw, keys: torch.Tensor, key_pe: torch.Tensor, tokens: torch.Tensor, B: int, T: int, L: int,
+                                 d_queries: torch.Tensor, d_keys: torch.Tensor):
+    """Backward of `TwoWayTransformer.run` (transformer.py:74-118 with its TwoWayAttentionBlocks 165-196): keys fp32 [B*L, C] (image
+    embedding + dense prompt), key_pe fp32 [L, C] (constant), tokens fp32 [B*T, C] (output tokens + prompt embeddings; also the
+    query position encoding), upstream gradients d_queries [B*T, C], d_keys [B*L, C].
+    Returns (d_keys_in fp32 [B*L, C], d_tokens fp32 [B*T, C], {"layers.i.<...>" | "final_attn_token_to_image.<...>" |
+    "norm_final_attn.<...>": gradient})."""
+    from .modeling.common import v_f32, w_bf16
+    grads: dict = {}
+    qpe = tokens
+
+    def ln_fwd(mod, x):
+        return ops.layernorm(x, mod.weight.detach().float(), mod.bias.detach().float(), mod.eps, out_dtype=F32)
+
+    def ln_bwd(mod, x, dy, name):
+        dx, grads[name + ".weight"], grads[name + ".bias"] = layernorm_backward(x, mod.weight.detach().float(), dy, mod.eps)
+        return dx
+
+    # ---- forward, keeping the inputs of every LayerNorm and attention
+    saved = []
+    Q, K = tokens, keys
+    for i, blk in enumerate(tw.layers):
+        s = {"Q0": Q, "K0": K}
+        sa, ca, ia = blk.self_attn, blk.cross_attn_token_to_image, blk.cross_attn_image_to_token
+        if blk.skip_first_layer_pe:
+            s["sa_in"] = (_add16(Q, None),) * 3
+            s["Q0p"] = sa.out(_attn_fwd(sa, *s["sa_in"], B)[3], None)
+        else:
+            qk = _add16(Q, qpe)
+            s["sa_in"] = (qk, qk, _add16(Q, None))
+            s["Q0p"] = sa.out(_attn_fwd(sa, *s["sa_in"], B)[3], Q)
+        s["Q1"] = ln_fwd(blk.norm1, s["Q0p"])
+        s["ca_in"] = (_add16(s["Q1"], qpe), _add16(K, key_pe), _add16(K, None))
+        s["Q1p"] = ca.out(_attn_fwd(ca, *s["ca_in"], B)[3], s["Q1"])
+        s["Q2"] = ln_fwd(blk.norm2, s["Q1p"])
+        s["Q2_16"] = _add16(s["Q2"], None)
+        s["Q2p"] = blk.mlp.run(s["Q2_16"], residual=s["Q2"], out_dtype=F32)
+        s["Q3"] = ln_fwd(blk.norm3, s["Q2p"])
+        s["ia_in"] = (s["ca_in"][1], _add16(s["Q3"], qpe), _add16(s["Q3"], None))
+        s["K1"] = ia.out(_attn_fwd(ia, *s["ia_in"], B)[3], K)
+        Q, K = s["Q3"], ln_fwd(blk.norm4, s["K1"])
+        saved.append(s)
+    fa = tw.final_attn_token_to_image
+    fa_in = (_add16(Q, qpe), _add16(K, key_pe), _add16(K, None))
+    Qf = fa.out(_attn_fwd(fa, *fa_in, B)[3], Q)
+    # ---- backward
+    d_tok = torch.zeros_like(tokens)                                              # accumulates every use of the query position encoding
+    dQf = ln_bwd(tw.norm_final_attn, Qf, d_queries, "norm_final_attn")
+    dq_in, dk_in, dv_in = attention_module_backward(fa, *fa_in, B, dQf, "final_attn_token_to_image", grads)
+    dQ = dQf + dq_in
+    d_tok += dq_in
+    dK = d_keys + dk_in + dv_in
+    for i in range(len(tw.layers) - 1, -1, -1):
+        blk, s, pre = tw.layers[i], saved[i], f"layers.{i}"
+        sa, ca, ia = blk.self_attn, blk.cross_attn_token_to_image, blk.cross_attn_image_to_token
+        # keys: K_out = LN4(K1), K1 = K0 + ia(K0 + kpe, Q3 + qpe, Q3)
+        dK1 = ln_bwd(blk.norm4, s["K1"], dK, pre + ".norm4")
+        dq_in, dk_in, dv_in = attention_module_backward(ia, *s["ia_in"], B, dK1, pre + ".cross_attn_image_to_token", grads)
+        dK0 = dK1 + dq_in
+        dQ3 = dQ + dk_in + dv_in
+        d_tok += dk_in
+        # Q3 = LN3(Q2 + MLP(Q2))
+        dQ2p = ln_bwd(blk.norm3, s["Q2p"], dQ3, pre + ".norm3")
+        l1, l2 = blk.mlp.layers
+        res = mlp_backward(s["Q2_16"], w_bf16(blk.mlp._wc, "w0", l1.weight), v_f32(blk.mlp._wc, "b0", l1.bias),
+                           w_bf16(blk.mlp._wc, "w1", l2.weight), v_f32(blk.mlp._wc, "b1", l2.bias), dQ2p, blk.mlp._act_code)
+        dx = res[0]
+        for nm, gten in zip(("mlp.layers.0.weight", "mlp.layers.0.bias", "mlp.layers.1.weight", "mlp.layers.1.bias"), res[1:]):
+            grads[f"{pre}.{nm}"] = gten
+        dQ2 = dQ2p + dx
+        # Q2 = LN2(Q1 + ca(Q1 + qpe, K0 + kpe, K0))
+        dQ1p = ln_bwd(blk.norm2, s["Q1p"], dQ2, pre + ".norm2")
+        dq_in, dk_in, dv_in = attention_module_backward(ca, *s["ca_in"], B, dQ1p, pre + ".cross_attn_token_to_image", grads)
+        dQ1 = dQ1p + dq_in
+        d_tok += dq_in
+        dK0 = dK0 + dk_in + dv_in
+        # Q1 = LN1(Q0p), Q0p = sa(...) [+ Q0]
+        dQ0p = ln_bwd(blk.norm1, s["Q0p"], dQ1, pre + ".norm1")
+        dq_in, dk_in, dv_in = attention_module_backward(sa, *s["sa_in"], B, dQ0p, pre + ".self_attn", grads)
+        if blk.skip_first_layer_pe:
+            dQ = dq_in + dk_in + dv_in
+        else:
+            dQ = dQ0p + dq_in + dk_in + dv_in
+            d_tok += dq_in + dk_in
+        dK = dK0
+    return dK, d_tok + dQ, grads

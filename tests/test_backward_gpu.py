@@ -199,3 +199,45 @@ def test_memory_attention_module_backward(mods):
     assert len(grads) == n_params == 106, (len(grads), n_params)
     worst = sorted(report.items(), key=lambda kv: -kv[1])[:5]
     assert worst[0][1] < 3e-2, worst
+
+
+def test_two_way_transformer_backward(mods):
+    """TwoWayTransformer.run (transformer.py:74-118, 165-196, 239-263; 8 heads of 32 / 16 channels): d/d(image tokens),
+    d/d(point / output tokens, which are also the query position encoding) and every parameter gradient against autograd."""
+    B_, ops = mods
+    import medical_sam2_amd.build_sam as bs
+    import medical_sam2_amd.weights as wts
+    m = bs.build_sam2("sam2_hiera_t", device="cpu", hydra_overrides_extra=["++model.image_size=256"])
+    sd = wts.init_weights("hiera_t", 0)
+    m.load_state_dict(sd, strict=True)
+    tw = m.sam_mask_decoder.transformer.to(DEV).eval()
+    pre = "sam_mask_decoder.transformer"
+    P = {k: v.clone().float().requires_grad_(k.startswith(pre)) for k, v in sd.items()}
+    B, T, E, C = 2, 7, 16, 256
+    L = E * E
+    src = rnd(B, C, E, E, seed=50).requires_grad_(True)
+    pos = rnd(1, C, E, E, seed=51)
+    tok = rnd(B, T, C, seed=52).requires_grad_(True)
+    dq, dk = rnd(B, T, C, seed=53), rnd(B, L, C, seed=54)
+    q_ref, k_ref = O.two_way_transformer(P, pre, src, pos.expand(B, -1, -1, -1), tok)
+    ((q_ref * dq).sum() + (k_ref * dk).sum()).backward()
+    d = lambda t: t.detach().to(DEV)
+    keys = d(src).flatten(2).permute(0, 2, 1).reshape(B * L, C).contiguous()
+    kpe = d(pos).flatten(2).permute(0, 2, 1).reshape(L, C).contiguous()
+    dK, dT, grads = B_.two_way_transformer_backward(tw, keys, kpe, d(tok).reshape(B * T, C).contiguous(), B, T, L,
+                                                    d(dq).reshape(B * T, C).contiguous(), d(dk).reshape(B * L, C).contiguous())
+    report = {"d_src": rel(dK.view(B, L, C), src.grad.flatten(2).permute(0, 2, 1)), "d_tokens": rel(dT.view(B, T, C), tok.grad)}
+    for name, g in grads.items():
+        ref = P[f"{pre}.{name}"].grad
+        assert ref is not None and g.shape == ref.shape, name
+        if name.endswith("k_proj.bias"):
+            # a key bias shifts every score of a query equally: its true gradient is exactly 0 (softmax shift invariance) and autograd
+            # returns rounding noise -> compare on the scale of the matching query-bias gradient instead of relatively
+            scale = P[f"{pre}.{name.replace('k_proj', 'q_proj')}"].grad.norm().item()
+            report[name] = (g.cpu() - ref).norm().item() / scale
+        else:
+            report[name] = rel(g, ref)
+    n_params = sum(1 for k in sd if k.startswith(pre + "."))
+    assert len(grads) == n_params, (len(grads), n_params)
+    worst = sorted(report.items(), key=lambda kv: -kv[1])[:6]
+    assert worst[0][1] < 3e-2, worst
