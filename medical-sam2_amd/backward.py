@@ -349,3 +349,106 @@ def two_way_transformer_backward(tw, keys: torch.Tensor, key_pe: torch.Tensor, t
             d_tok += dq_in + dk_in
         dK = dK0
     return dK, d_tok + dQ, grads
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Mask decoder (sam/mask_decoder.py:170-267): recomputing forward + backward of the mask logits w.r.t. every parameter
+# ---------------------------------------------------------------------------------------------------------------------
+def mlp_layers_backward(mlp, x16: torch.Tensor, dy: torch.Tensor, prefix: str, grads: dict) -> torch.Tensor:
+    """Backward of an n-layer `MLP` (sam2_utils.py:108-132, no output sigmoid) by recomputation: x16 16-bit [M, in], dy [M, out].
+    Adds `prefix.layers.i.weight|bias` to grads, returns dx fp32."""
+    from .modeling.common import v_f32, w_bf16
+    assert not mlp.sigmoid_output, "sigmoid-output heads (IoU) are not differentiated here"
+    wc, n = mlp._wc, mlp.num_layers
+    Ws = [w_bf16(wc, f"w{i}", l.weight) for i, l in enumerate(mlp.layers)]
+    Bs = [v_f32(wc, f"b{i}", l.bias) for i, l in enumerate(mlp.layers)]
+    hs, pres = [x16], []
+    for i in range(n - 1):
+        pres.append(ops.gemm(hs[-1], Ws[i], Bs[i], out_dtype=F32))
+        hs.append(ops.gemm(hs[-1], Ws[i], Bs[i], act=mlp._act_code))
+    d = dy
+    for i in range(n - 1, -1, -1):
+        d, grads[f"{prefix}.layers.{i}.weight"], grads[f"{prefix}.layers.{i}.bias"] = linear_backward(hs[i], Ws[i], d)
+        if i > 0:
+            d = act_backward(pres[i - 1], d, mlp._act_code)
+    return d
+
+
+def _convt_gather(g, bias, skip, B, h, w):
+    C = g.shape[1] // 4
+    z = torch.empty(B * 4 * h * w, C, dtype=F32, device=g.device)
+    check(lib().msam2_convt2x2_gather(_p(g), _p(bias), _p(skip), _p(z), B, h, w, C, _stream()))
+    return z
+
+
+def _convt_scatter_grad(dz, B, h, w):
+    C = dz.shape[1]
+    dg = torch.empty(B * h * w, 4 * C, dtype=OP16, device=dz.device)
+    check(lib().msam2_convt2x2_scatter_grad(_p(dz), _is_bf16(dz), _p(dg), B, h, w, C, _stream()))
+    return dg
+
+
+def mask_decoder_backward(dec, src_tokens: torch.Tensor, pe_tokens: torch.Tensor, sparse: torch.Tensor, feat_s0: torch.Tensor,
+                          feat_s1: torch.Tensor, B: int, h: int, w: int, d_masks: torch.Tensor):
+    """Backward of `MaskDecoder.predict_masks_tokens` for a loss on the 4 mask logit maps: src_tokens fp32 [B*h*w, C] (image embedding +
+    dense prompt), pe_tokens fp32 [h*w, C], sparse fp32 [B, P, C] prompt embeddings, feat_s0 / feat_s1 16-bit token-major high-res
+    features, d_masks fp32 [B, 4, 4h, 4w].  The IoU and object-score heads do not see the mask loss and get no gradient.
+    Returns (d_src_tokens fp32 [B*h*w, C], d_sparse fp32 [B, P, C], {parameter name relative to the decoder: gradient})."""
+    from .modeling.common import to_bf16, v_f32
+    wc, C, L = dec._wc, dec.transformer_dim, h * w
+    nm = dec.num_mask_tokens
+    out_tok = torch.cat([dec.obj_score_token.weight, dec.iou_token.weight, dec.mask_tokens.weight], 0).detach().float()
+    n_out = out_tok.shape[0]
+    T = n_out + sparse.shape[1]
+    tokens = torch.empty(B, T, C, dtype=F32, device=src_tokens.device)
+    tokens[:, :n_out] = out_tok
+    tokens[:, n_out:] = sparse
+    tokens = tokens.view(B * T, C)
+    # ---- forward with intermediates
+    hs, keys = dec.transformer.run(src_tokens, pe_tokens, tokens, B, T, L)
+    hs = hs.view(B, T, C)
+    up = dec.output_upscaling
+    dc1_w = wc.get("dc1", [up[0].weight], lambda: up[0].weight.detach().permute(2, 3, 1, 0).reshape(-1, C).to(OP16).contiguous())
+    dc2_w = wc.get("dc2", [up[3].weight], lambda: up[3].weight.detach().permute(2, 3, 1, 0).reshape(-1, C // 4).to(OP16).contiguous())
+    b1, b2 = v_f32(wc, "dc1b", up[0].bias), v_f32(wc, "dc2b", up[3].bias)
+    lnw, lnb = v_f32(wc, "lnw", up[1].weight), v_f32(wc, "lnb", up[1].bias)
+    keys16 = to_bf16(keys)
+    g1 = ops.gemm(keys16, dc1_w)
+    z1 = _convt_gather(g1, b1, feat_s1, B, h, w)                                  # [B*4L, C/4] pre-LayerNorm
+    y1 = ops.layernorm(z1, lnw, lnb, 1e-6, out_dtype=F32)                         # pre-GELU
+    u1 = ops.layernorm(z1, lnw, lnb, 1e-6, act=ops.ACT_GELU)                      # 16-bit
+    g2 = ops.gemm(u1, dc2_w)
+    z2 = _convt_gather(g2, b2, feat_s0, B, 2 * h, 2 * w)                          # [B*16L, C/8] pre-GELU
+    u2 = ops.convt2x2_shuffle(g2, b2, feat_s0, None, None, B, 2 * h, 2 * w)       # 16-bit GELU(z2)
+    Pn, Cu = 16 * L, C // 8
+    hyper16 = torch.empty(B, nm, Cu, dtype=OP16, device=u2.device)
+    tok16 = [to_bf16(hs[:, 2 + i].contiguous()) for i in range(nm)]
+    for i, m in enumerate(dec.output_hypernetworks_mlps):
+        hyper16[:, i] = m.run(tok16[i], out_dtype=OP16)
+    # ---- backward
+    grads: dict = {}
+    dm16 = _op16(d_masks.reshape(B * nm, Pn)).view(B, nm, Pn)
+    d_hyper = torch.empty(B, nm, Cu, dtype=F32, device=u2.device)
+    d_u2 = torch.empty(B * Pn, Cu, dtype=F32, device=u2.device)
+    for b in range(B):
+        u2b = u2[b * Pn:(b + 1) * Pn]
+        ops.gemm(dm16[b], transpose16(u2b), out=d_hyper[b])                      # [nm, P] @ [P, Cu]
+        ops.gemm(transpose16(dm16[b], 8), transpose16(hyper16[b], 8), out=d_u2[b * Pn:(b + 1) * Pn])   # [P, nm] @ [nm, Cu]
+    dz2 = act_backward(z2, d_u2, ops.ACT_GELU)
+    grads["output_upscaling.3.bias"] = colsum(dz2)
+    d_u1, dw2, _ = linear_backward(u1, dc2_w, _convt_scatter_grad(dz2, B, 2 * h, 2 * w))
+    grads["output_upscaling.3.weight"] = dw2.view(2, 2, C // 8, C // 4).permute(3, 2, 0, 1).contiguous()
+    dy1 = act_backward(y1, d_u1, ops.ACT_GELU)
+    dz1, grads["output_upscaling.1.weight"], grads["output_upscaling.1.bias"] = layernorm_backward(z1, lnw, dy1, 1e-6)
+    grads["output_upscaling.0.bias"] = colsum(dz1)
+    d_keys, dw1, _ = linear_backward(keys16, dc1_w, _convt_scatter_grad(dz1, B, h, w))
+    grads["output_upscaling.0.weight"] = dw1.view(2, 2, C // 4, C).permute(3, 2, 0, 1).contiguous()
+    d_hs = torch.zeros(B, T, C, dtype=F32, device=u2.device)
+    for i, m in enumerate(dec.output_hypernetworks_mlps):
+        d_hs[:, 2 + i] = mlp_layers_backward(m, tok16[i], d_hyper[:, i].contiguous(), f"output_hypernetworks_mlps.{i}", grads)
+    d_src, d_tok, g_tw = two_way_transformer_backward(dec.transformer, src_tokens, pe_tokens, tokens, B, T, L, d_hs.view(B * T, C), d_keys)
+    grads.update({"transformer." + k: v for k, v in g_tw.items()})
+    d_tok = d_tok.view(B, T, C)
+    d_out_tok = colsum(d_tok[:, :n_out].reshape(B, n_out * C).contiguous()).view(n_out, C)    # the learned output tokens are shared over the batch
+    grads["obj_score_token.weight"], grads["iou_token.weight"], grads["mask_tokens.weight"] = d_out_tok[0:1], d_out_tok[1:2], d_out_tok[2:]
+    return d_src, d_tok[:, n_out:], grads

@@ -218,3 +218,57 @@ extern "C" int msam2_softmax_bwd_rows(const void* p, int64_t ld_p, const float* 
                      (op16*)ds, ld_ds, rows, cols, scale);
   return msam2_check_launch("softmax_bwd_rows");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// ConvTranspose2d(k2, s2) tail without the fused norm / activation (training forward + its adjoint; the inference kernel is
+// pixel_shuffle_kernel in conv.hip):  z[pix, c] = g[tok(pix), sub(pix) * C + c] + bias[c] + skip[pix, c]   (fp32 out), and
+// dg[tok, sub * C + c] = dz[pix(tok, sub), c]   (16-bit GEMM operand).  pix = (b, Y, X) on the 2h x 2w grid, tok = (b, Y/2, X/2),
+// sub = (Y & 1) * 2 + (X & 1).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void convt2x2_gather_kernel(const op16* __restrict__ g, const float* __restrict__ bias, const op16* __restrict__ skip,
+                                       float* __restrict__ z, int B, int h, int w, int C) {
+  const int H = 2 * h, W = 2 * w;
+  const int64_t total = (int64_t)B * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    const int64_t pix = i / C;
+    const int X = pix % W, Y = (pix / W) % H;
+    const int64_t b = pix / ((int64_t)W * H);
+    const int64_t tok = (b * h + Y / 2) * w + X / 2;
+    const int sub = (Y & 1) * 2 + (X & 1);
+    z[i] = op2f(g[tok * 4 * C + sub * C + c]) + bias[c] + (skip ? op2f(skip[i]) : 0.f);
+  }
+}
+
+extern "C" int msam2_convt2x2_gather(const void* gemm_out, const float* bias, const void* skip, float* z, int64_t B, int64_t h, int64_t w,
+                                     int64_t C, void* stream) {
+  MSAM2_REQUIRE(gemm_out && bias && z && B > 0 && h > 0 && w > 0 && C > 0, "convt2x2_gather: bad arguments");
+  const int64_t total = B * 4 * h * w * C;
+  hipLaunchKernelGGL(convt2x2_gather_kernel, dim3((unsigned)min((int64_t)16384, cdiv(total, 256))), dim3(256), 0, (hipStream_t)stream,
+                     (const op16*)gemm_out, bias, (const op16*)skip, z, (int)B, (int)h, (int)w, (int)C);
+  return msam2_check_launch("convt2x2_gather");
+}
+
+template <typename T>
+__global__ void convt2x2_scatter_grad_kernel(const T* __restrict__ dz, op16* __restrict__ dg, int B, int h, int w, int C) {
+  const int H = 2 * h, W = 2 * w;
+  const int64_t total = (int64_t)B * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    const int64_t pix = i / C;
+    const int X = pix % W, Y = (pix / W) % H;
+    const int64_t b = pix / ((int64_t)W * H);
+    const int64_t tok = (b * h + Y / 2) * w + X / 2;
+    const int sub = (Y & 1) * 2 + (X & 1);
+    dg[tok * 4 * C + sub * C + c] = f2op((float)dz[i]);
+  }
+}
+
+extern "C" int msam2_convt2x2_scatter_grad(const void* dz, int dz_is_16bit, void* dg, int64_t B, int64_t h, int64_t w, int64_t C, void* stream) {
+  MSAM2_REQUIRE(dz && dg && B > 0 && h > 0 && w > 0 && C > 0, "convt2x2_scatter_grad: bad arguments");
+  const int64_t total = B * 4 * h * w * C;
+  dim3 grid((unsigned)min((int64_t)16384, cdiv(total, 256))), block(256);
+  if (dz_is_16bit) hipLaunchKernelGGL((convt2x2_scatter_grad_kernel<op16>), grid, block, 0, (hipStream_t)stream, (const op16*)dz, (op16*)dg, (int)B, (int)h, (int)w, (int)C);
+  else hipLaunchKernelGGL((convt2x2_scatter_grad_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)dz, (op16*)dg, (int)B, (int)h, (int)w, (int)C);
+  return msam2_check_launch("convt2x2_scatter_grad");
+}

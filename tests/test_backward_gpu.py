@@ -241,3 +241,45 @@ def test_two_way_transformer_backward(mods):
     assert len(grads) == n_params, (len(grads), n_params)
     worst = sorted(report.items(), key=lambda kv: -kv[1])[:6]
     assert worst[0][1] < 3e-2, worst
+
+
+def test_mask_decoder_backward(mods):
+    """MaskDecoder.predict_masks (mask_decoder.py:170-267): gradients of a loss on the 4 mask logit maps w.r.t. the image embedding,
+    the prompt embeddings and every decoder parameter the masks depend on (two-way transformer, both ConvTranspose stages + LayerNorm2d,
+    the 4 hyper-network MLPs, the learned output tokens) against autograd through oracle.mask_decoder_predict."""
+    B_, ops = mods
+    import medical_sam2_amd.build_sam as bs
+    import medical_sam2_amd.weights as wts
+    m = bs.build_sam2("sam2_hiera_t", device="cpu", hydra_overrides_extra=["++model.image_size=256"])
+    sd = wts.init_weights("hiera_t", 0)
+    m.load_state_dict(sd, strict=True)
+    dec = m.sam_mask_decoder.to(DEV).eval()
+    pre = "sam_mask_decoder"
+    P = {k: v.clone().float().requires_grad_(k.startswith(pre)) for k, v in sd.items()}
+    B, E, C, Pp = 2, 16, 256, 2
+    L = E * E
+    q16 = lambda t: t.to(ops.OP16).float()
+    emb = rnd(B, C, E, E, seed=60).requires_grad_(True)
+    pe = rnd(1, C, E, E, seed=61)
+    sparse = rnd(B, Pp, C, seed=62).requires_grad_(True)
+    f0, f1 = q16(rnd(B, 32, 4 * E, 4 * E, seed=63)), q16(rnd(B, 64, 2 * E, 2 * E, seed=64))
+    dmask = rnd(B, 4, 4 * E, 4 * E, seed=65, scale=0.1)
+    masks, _, _, _ = O.mask_decoder_predict(P, emb, pe, sparse, torch.zeros_like(emb), [f0, f1])
+    (masks * dmask).sum().backward()
+    d = lambda t: t.detach().to(DEV)
+    tm = lambda t: d(t).permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()       # NCHW -> token-major
+    d_src, d_sparse, grads = B_.mask_decoder_backward(dec, tm(emb), tm(pe), d(sparse), tm(f0).to(ops.OP16), tm(f1).to(ops.OP16), B, E, E, d(dmask))
+    report = {"d_emb": rel(d_src.view(B, L, C), emb.grad.flatten(2).permute(0, 2, 1)), "d_sparse": rel(d_sparse, sparse.grad)}
+    for name, g in grads.items():
+        ref = P[f"{pre}.{name}"].grad
+        assert ref is not None and g.shape == ref.shape, (name, g.shape, None if ref is None else ref.shape)
+        if name.endswith("k_proj.bias"):
+            scale = P[f"{pre}.{name.replace('k_proj', 'q_proj')}"].grad.norm().item()
+            report[name] = (g.cpu() - ref).norm().item() / scale
+        else:
+            report[name] = rel(g, ref)
+    # every decoder parameter that the masks depend on is covered (IoU / object-score heads and conv_s0/s1 do not see this loss)
+    expect = {k[len(pre) + 1:] for k, v in P.items() if k.startswith(pre + ".") and v.grad is not None and v.grad.abs().sum() > 0}
+    assert expect <= set(grads), sorted(expect - set(grads))
+    worst = sorted(report.items(), key=lambda kv: -kv[1])[:6]
+    assert worst[0][1] < 4e-2, worst
