@@ -272,3 +272,55 @@ extern "C" int msam2_convt2x2_scatter_grad(const void* dz, int dz_is_16bit, void
   else hipLaunchKernelGGL((convt2x2_scatter_grad_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)dz, (op16*)dg, (int)B, (int)h, (int)w, (int)C);
   return msam2_check_launch("convt2x2_scatter_grad");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Loss and optimiser pieces of a decoder fine-tuning step (func_3d/function.py:69 `criterion_G = BCEWithLogitsLoss(pos_weight)`,
+// train_3d.py:50 `optim.Adam(sam_layers, lr=1e-4, betas=(0.9, 0.999), eps=1e-8)`):
+//   bce_logits:  loss = mean( pos_weight * y * softplus(-x) + (1 - y) * softplus(x) ),  dx = (pos_weight * y * (s - 1) + (1 - y) * s) / n,
+//                s = sigmoid(x); the loss is accumulated into a zeroed fp32 scalar.
+//   adam_step:   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr * (m / (1 - b1^t)) / (sqrt(v / (1 - b2^t)) + eps)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ dx,
+                                                         float* __restrict__ loss, int64_t n, float pos_weight) {
+  float acc = 0.f;
+  const float inv_n = 1.f / (float)n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = x[i], t = y[i];
+    const float sp_pos = fmaxf(v, 0.f) + log1pf(__expf(-fabsf(v)));   // softplus(v)
+    const float sp_neg = sp_pos - v;                                   // softplus(-v)
+    acc += pos_weight * t * sp_neg + (1.f - t) * sp_pos;
+    const float s = 1.f / (1.f + __expf(-v));
+    dx[i] = (pos_weight * t * (s - 1.f) + (1.f - t) * s) * inv_n;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) atomicAdd(loss, acc * inv_n);
+}
+
+extern "C" int msam2_bce_logits(const float* logits, const float* target, float* dlogits, float* loss, int64_t n, float pos_weight,
+                                void* stream) {
+  MSAM2_REQUIRE(logits && target && dlogits && loss && n > 0, "bce_logits: bad arguments");
+  hipLaunchKernelGGL(bce_logits_kernel, dim3((unsigned)min((int64_t)1024, cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream, logits, target,
+                     dlogits, loss, n, pos_weight);
+  return msam2_check_launch("bce_logits");
+}
+
+__global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                 float lr, float b1, float b2, float eps, float bc1, float bc2) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+  }
+}
+
+extern "C" int msam2_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                               float eps, int64_t step, void* stream) {
+  MSAM2_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adam_step: bad arguments");
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)min((int64_t)4096, cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, n, lr, beta1, beta2, eps, bc1, bc2);
+  return msam2_check_launch("adam_step");
+}

@@ -1,0 +1,64 @@
+"""Decoder fine-tuning step on the HIP path (the `sam_layers` group of train_3d.py:34-50: every parameter of `sam_mask_decoder`, Adam at
+lr 1e-4, with the image encoder, memory and prompt encoder frozen): forward of the mask decoder, BCE-with-logits loss on its mask logits
+(func_3d/function.py:69, `criterion_G`), `backward.mask_decoder_backward`, Adam update -- all kernels from libmsam2_hip.so.
+
+Scope (partial): the loss is taken on the decoder's low-resolution logits of all `num_mask_tokens` masks
+against one target per mask token; the reference additionally up-samples to the video resolution and selects one mask per object, and it
+back-propagates through the memory bank for its second parameter group (lr 1e-8) -- neither is built.  The IoU / object-score heads do not
+receive a gradient from this loss.  Pinned by tests/test_backward_gpu.py::test_decoder_finetune_step against oracle + autograd + torch.optim.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from . import backward as bwd
+from . import ops
+from ._lib import check, lib
+from .ops import F32, _p, _stream
+
+
+def bce_with_logits(logits: torch.Tensor, target: torch.Tensor, pos_weight: float = 1.0):
+    """(loss fp32 scalar tensor, dloss/dlogits fp32) for mean-reduced BCEWithLogitsLoss(pos_weight)."""
+    x, y = logits.to(F32).contiguous(), target.to(F32).contiguous()
+    assert x.shape == y.shape
+    dx = torch.empty_like(x)
+    loss = torch.zeros(1, dtype=F32, device=x.device)
+    check(lib().msam2_bce_logits(_p(x), _p(y), _p(dx), _p(loss), x.numel(), float(pos_weight), _stream()))
+    return loss, dx
+
+
+class DecoderAdam:
+    """torch.optim.Adam(params, lr, betas, eps) semantics for the mask decoder's parameters, state kept as flat fp32 tensors."""
+
+    def __init__(self, decoder, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8):
+        self.decoder, self.lr, self.betas, self.eps, self.t = decoder, lr, betas, eps, 0
+        self.state: Dict[str, tuple] = {}
+
+    @torch.no_grad()
+    def step(self, grads: Dict[str, torch.Tensor]):
+        self.t += 1
+        params = dict(self.decoder.named_parameters())
+        for name, g in grads.items():
+            p = params[name]
+            assert p.dtype == F32 and p.is_contiguous() and g.shape == p.shape, name
+            if name not in self.state:
+                self.state[name] = (torch.zeros_like(p), torch.zeros_like(p))
+            m, v = self.state[name]
+            gc = g.to(F32).contiguous()
+            check(lib().msam2_adam_step(_p(p), _p(gc), _p(m), _p(v), p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.t,
+                                        _stream()))
+            p.add_(0)   # the update went through the raw pointer: bump the tensor version so cached kernel-ready weights are rebuilt
+
+
+@torch.no_grad()
+def decoder_finetune_step(decoder, optimizer: DecoderAdam, src_tokens, pe_tokens, sparse, feat_s0, feat_s1, B: int, h: int, w: int,
+                          target_masks: torch.Tensor, pos_weight: float = 1.0) -> float:
+    """One optimisation step of the mask decoder.  Inputs as for `MaskDecoder.predict_masks_tokens`; target_masks [B, nm, 4h, 4w] in
+    {0, 1}.  Returns the loss value before the update."""
+    masks, _, _, _ = decoder.predict_masks_tokens(src_tokens, pe_tokens, sparse, feat_s0, feat_s1, B, h, w)
+    loss, d_masks = bce_with_logits(masks, target_masks, pos_weight)
+    _, _, grads = bwd.mask_decoder_backward(decoder, src_tokens, pe_tokens, sparse, feat_s0, feat_s1, B, h, w, d_masks)
+    optimizer.step(grads)
+    return float(loss.item())

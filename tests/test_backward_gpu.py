@@ -283,3 +283,80 @@ def test_mask_decoder_backward(mods):
     assert expect <= set(grads), sorted(expect - set(grads))
     worst = sorted(report.items(), key=lambda kv: -kv[1])[:6]
     assert worst[0][1] < 4e-2, worst
+
+
+def test_bce_and_adam_kernels(mods):
+    B_, ops = mods
+    import medical_sam2_amd.training as T
+    x = rnd(3, 4, 64, 64, seed=70, scale=3.0).requires_grad_(True)
+    y = (rnd(3, 4, 64, 64, seed=71) > 0.3).float()
+    ref = F.binary_cross_entropy_with_logits(x, y, pos_weight=torch.tensor(2.0))
+    ref.backward()
+    loss, dx = T.bce_with_logits(x.detach().to(DEV), y.to(DEV), 2.0)
+    assert abs(loss.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item())) and rel(dx, x.grad) < 1e-5
+    p = torch.nn.Parameter(rnd(1000, seed=72))
+    opt = torch.optim.Adam([p], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    pd = p.detach().clone().to(DEV)
+    m, v = torch.zeros_like(pd), torch.zeros_like(pd)
+    from medical_sam2_amd._lib import lib, check
+    for step in range(1, 4):
+        g = rnd(1000, seed=80 + step)
+        p.grad = g.clone()
+        opt.step()
+        check(lib().msam2_adam_step(ops._p(pd), ops._p(g.to(DEV)), ops._p(m), ops._p(v), 1000, 1e-3, 0.9, 0.999, 1e-8, step, ops._stream()))
+    assert (pd.cpu() - p.detach()).abs().max().item() < 1e-6
+
+
+def test_decoder_finetune_step(mods):
+    """One Adam step of the mask decoder on a BCE-with-logits mask loss: loss value and parameter updates against the oracle forward +
+    torch.autograd + torch.optim.Adam (train_3d.py:50, func_3d/function.py:69)."""
+    B_, ops = mods
+    import medical_sam2_amd.build_sam as bs
+    import medical_sam2_amd.training as T
+    import medical_sam2_amd.weights as wts
+    m = bs.build_sam2("sam2_hiera_t", device="cpu", hydra_overrides_extra=["++model.image_size=256"])
+    sd = wts.init_weights("hiera_t", 0)
+    m.load_state_dict(sd, strict=True)
+    dec = m.sam_mask_decoder.to(DEV).eval()
+    pre = "sam_mask_decoder."
+    names = [k for k in sd if k.startswith(pre)]
+    P = {k: (torch.nn.Parameter(v.clone().float()) if k.startswith(pre) else v.clone().float()) for k, v in sd.items()}
+    B, E, C = 2, 16, 256
+    q16 = lambda t: t.to(ops.OP16).float()
+    emb, pe, sparse = rnd(B, C, E, E, seed=90), rnd(1, C, E, E, seed=91), rnd(B, 2, C, seed=92)
+    f0, f1 = q16(rnd(B, 32, 4 * E, 4 * E, seed=93)), q16(rnd(B, 64, 2 * E, 2 * E, seed=94))
+    target = (rnd(B, 4, 4 * E, 4 * E, seed=95) > 0.5).float()
+    lr = 1e-4
+    opt = torch.optim.Adam([P[k] for k in names], lr=lr, betas=(0.9, 0.999), eps=1e-8)
+    masks, _, _, _ = O.mask_decoder_predict(P, emb, pe, sparse, torch.zeros_like(emb), [f0, f1])
+    ref_loss = F.binary_cross_entropy_with_logits(masks, target)
+    ref_loss.backward()
+    opt.step()
+    d = lambda t: t.detach().to(DEV)
+    tm = lambda t: d(t).permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()
+    before = {k: v.detach().clone() for k, v in dec.named_parameters()}
+    optim = T.DecoderAdam(dec, lr=lr)
+    loss = T.decoder_finetune_step(dec, optim, tm(emb), tm(pe), d(sparse), tm(f0).to(ops.OP16), tm(f1).to(ops.OP16), B, E, E, d(target))
+    assert abs(loss - ref_loss.item()) < 2e-3 * abs(ref_loss.item()), (loss, ref_loss.item())
+    touched, cos_min = 0, 1.0
+    for k, v in dec.named_parameters():
+        ref_delta = P[pre + k].detach() - sd[pre + k].float()
+        delta = (v.detach() - before[k]).cpu()
+        if ref_delta.abs().max() == 0:
+            assert delta.abs().max().item() == 0, k          # heads the mask loss does not reach stay untouched
+            continue
+        touched += 1
+        assert delta.abs().max().item() <= lr * 1.001, k     # an Adam step never exceeds lr per element
+        if k.endswith("k_proj.bias"):
+            continue   # true gradient is exactly 0 (softmax shift invariance): both sides step on rounding noise (Adam normalises it to +-lr)
+        # first Adam step = lr * g / (|g| + eps): compare where the reference gradient is not within rounding of zero
+        g = P[pre + k].grad
+        sig = g.abs() > 1e-3 * g.abs().max()
+        cos = F.cosine_similarity(delta[sig].flatten(), ref_delta[sig].flatten(), dim=0).item()
+        cos_min = min(cos_min, cos)
+    # (the first Adam step is lr * g / (|g| + eps), i.e. nearly sign(g): an element whose gradient is small against the 1-4 % gradient
+    # error can flip, so the bar is on the direction of each parameter's update, not on its elements)
+    assert touched >= 60 and cos_min > 0.9, (touched, cos_min)
+    # second step runs on the updated weights (kernel-ready weight caches are invalidated by the update)
+    loss2 = T.decoder_finetune_step(dec, optim, tm(emb), tm(pe), d(sparse), tm(f0).to(ops.OP16), tm(f1).to(ops.OP16), B, E, E, d(target))
+    assert loss2 < loss

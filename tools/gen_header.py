@@ -40,6 +40,8 @@ DOC = {
     "msam2_softmax_bwd_rows": "dS (16-bit) = scale * P * (dP - sum_k P dP) row-wise: the softmax Jacobian of the attention backward.",
     "msam2_convt2x2_gather": "Training-forward tail of ConvTranspose2d(k2,s2) (mask_decoder.py:244-247) without the fused norm / activation: z = shuffle(gemm) + bias\n+ skip in fp32 (the inference path's msam2_convt2x2_shuffle fuses LayerNorm2d + GELU and keeps nothing).",
     "msam2_convt2x2_scatter_grad": "Adjoint of the 2x2 pixel shuffle: the gradient of the ConvTranspose GEMM output as a 16-bit operand.",
+    "msam2_bce_logits": "BCEWithLogitsLoss(pos_weight) value (accumulated into a zeroed scalar) and its gradient w.r.t. the logits, mean reduction\n(func_3d/function.py:69 criterion_G).",
+    "msam2_adam_step": "One torch.optim.Adam step (no weight decay / amsgrad) on a flat fp32 parameter (train_3d.py:50).",
     "msam2_seg_counts": "Counts behind eval_seg (func_3d/utils.py:139-214, func_2d/utils.py:505-580): per threshold, batch element and class the\ninteger |pred>t & gt>t|, |pred>t|, |gt>t| in one pass; IoU / Dice follow on the host.",
     "msam2_non_overlap": "SAM2Base._apply_non_overlapping_constraints (sam2_base.py:812-830): keep the arg-max object per pixel, clamp the\nothers to <= -10.",
     "msam2_gate_rows": "masks[b] = value where object score <= 0 (NO_OBJ_SCORE fill, sam2_base.py:354-363).",
