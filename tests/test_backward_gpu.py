@@ -23,6 +23,12 @@ def mods():
     return B, ops
 
 
+@pytest.fixture(autouse=True)
+def _grad_on():
+    with torch.enable_grad():    # the autograd references need it whatever another module left behind
+        yield
+
+
 def rnd(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
 

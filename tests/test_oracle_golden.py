@@ -13,7 +13,12 @@ import medical_sam2_amd.weights as wts
 from oracle import sam2_oracle as O
 from helpers import GOLDEN, load_meta, load_npz, mask_iou, max_abs, rel_err, sub
 
-torch.set_grad_enabled(False)
+
+@pytest.fixture(autouse=True)
+def _no_grad():
+    with torch.no_grad():        # (not a module-level torch.set_grad_enabled(False): that would leak into every other test module)
+        yield
+
 
 
 def test_state_dict_contract_matches_reference():
