@@ -89,11 +89,15 @@ class MLP(nn.Module):
                 b3 = torch.zeros(1, 256, dtype=F32, device=dev)
                 w3[0, :n] = L[2].weight.detach().to(OP16)
                 b3[0, :n] = L[2].bias.detach().float()
-                return (torch.zeros(1, dtype=torch.int32, device=dev), L[0].weight.detach().to(OP16)[None].contiguous(),
-                        L[0].bias.detach().float()[None].contiguous(), L[1].weight.detach().to(OP16)[None].contiguous(),
-                        L[1].bias.detach().float()[None].contiguous(), w3, b3, torch.tensor([n], dtype=torch.int32, device=dev),
+                return (L[0].weight.detach().to(OP16)[None].contiguous(), L[0].bias.detach().float()[None].contiguous(),
+                        L[1].weight.detach().to(OP16)[None].contiguous(), L[1].bias.detach().float()[None].contiguous(), w3, b3)
+
+            def consts():   # built once: host -> device copies are not capturable, the weight pack may re-run inside a capture
+                dev = x.device
+                return (torch.zeros(1, dtype=torch.int32, device=dev), torch.tensor([L[2].out_features], dtype=torch.int32, device=dev),
                         torch.tensor([int(self.sigmoid_output)], dtype=torch.int32, device=dev))
-            tok, w1, b1, w2, b2, w3, b3, od, sg = self._wc.get("tok3", [t for l in L for t in (l.weight, l.bias)], pack)
+            tok, od, sg = self._wc.get("tok3_const", [], consts)
+            w1, b1, w2, b2, w3, b3 = self._wc.get("tok3", [t for l in L for t in (l.weight, l.bias)], pack)
             y = ops.token_mlp3(x.to(F32).contiguous().view(x.shape[0], 1, 256), tok, w1, b1, w2, b2, w3, b3, od, sg)
             return y[:, 0, : L[2].out_features].contiguous()
         return self.run(to_bf16(x.contiguous()))

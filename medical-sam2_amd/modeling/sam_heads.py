@@ -319,12 +319,16 @@ class MaskDecoder(nn.Module):
                     b3[gi, :n] = m.layers[2].bias.detach().float()
                 b1 = torch.stack([m.layers[0].bias.detach() for m in heads]).float().contiguous()
                 b2 = torch.stack([m.layers[1].bias.detach() for m in heads]).float().contiguous()
-                nm = self.num_mask_tokens
-                tok = torch.tensor([2 + i for i in range(nm)] + [1, 0], dtype=torch.int32, device=dev)
-                od = torch.tensor([m.layers[2].out_features for m in heads], dtype=torch.int32, device=dev)
-                sg = torch.tensor([int(m.sigmoid_output) for m in heads], dtype=torch.int32, device=dev)
-                return tok, w1, b1, w2, b2, w3, b3, od, sg
-            tok, w1, b1, w2, b2, w3, b3, od, sg = wc.get("heads", params, pack)
+                return w1, b1, w2, b2, w3, b3
+
+            def consts():   # shape-only index tensors: built once (host -> device copies are not allowed inside a hipGraph capture,
+                dev = hs.device   # and the weight pack above re-runs whenever an optimiser step has touched the weights)
+                nm_ = self.num_mask_tokens
+                return (torch.tensor([2 + i for i in range(nm_)] + [1, 0], dtype=torch.int32, device=dev),
+                        torch.tensor([m.layers[2].out_features for m in heads], dtype=torch.int32, device=dev),
+                        torch.tensor([int(m.sigmoid_output) for m in heads], dtype=torch.int32, device=dev))
+            tok, od, sg = wc.get("heads_const", [], consts)
+            w1, b1, w2, b2, w3, b3 = wc.get("heads", params, pack)
             y = ops.token_mlp3(hs, tok, w1, b1, w2, b2, w3, b3, od, sg)          # [B, G, 256]
             nm = self.num_mask_tokens
             hyper = y[:, :nm, : C // 8].contiguous()

@@ -38,6 +38,8 @@ class DecoderAdam:
 
     @torch.no_grad()
     def step(self, grads: Dict[str, torch.Tensor]):
+        """(The bias corrections 1 - beta^t are host scalars baked into the launch: a captured graph replays the step count it was
+        captured with -- exact for t -> infinity, i.e. use eager steps while t is small if the warm-up matters.)"""
         self.t += 1
         params = dict(self.decoder.named_parameters())
         for name, g in grads.items():
@@ -54,11 +56,12 @@ class DecoderAdam:
 
 @torch.no_grad()
 def decoder_finetune_step(decoder, optimizer: DecoderAdam, src_tokens, pe_tokens, sparse, feat_s0, feat_s1, B: int, h: int, w: int,
-                          target_masks: torch.Tensor, pos_weight: float = 1.0) -> float:
+                          target_masks: torch.Tensor, pos_weight: float = 1.0, sync: bool = True):
     """One optimisation step of the mask decoder.  Inputs as for `MaskDecoder.predict_masks_tokens`; target_masks [B, nm, 4h, 4w] in
-    {0, 1}.  Returns the loss value before the update."""
+    {0, 1}.  Returns the loss value before the update (a Python float; with sync=False the 1-element device tensor, so that the whole
+    step -- ~3000 small launches -- can be captured in a hipGraph and replayed without host work)."""
     masks, _, _, _ = decoder.predict_masks_tokens(src_tokens, pe_tokens, sparse, feat_s0, feat_s1, B, h, w)
     loss, d_masks = bce_with_logits(masks, target_masks, pos_weight)
     _, _, grads = bwd.mask_decoder_backward(decoder, src_tokens, pe_tokens, sparse, feat_s0, feat_s1, B, h, w, d_masks)
     optimizer.step(grads)
-    return float(loss.item())
+    return float(loss.item()) if sync else loss
