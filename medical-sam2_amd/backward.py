@@ -252,9 +252,21 @@ def attention_module_backward(att, q_in16, k_in16, v_in16, B: int, d_out: torch.
     Ci = qp.shape[1]
     D = Ci // H
     da, grads[prefix + ".out_proj.weight"], grads[prefix + ".out_proj.bias"] = linear_backward(a, w_bf16(wc, "ow", att.out_proj.weight), d_out)
-    heads = lambda t: t.view(B, -1, H, D).permute(0, 2, 1, 3)                     # [B, H, L, D] views of the token-major rows
-    dq, dk, dv = attention_backward(heads(qp), heads(kp), heads(vp), heads(da))
-    rows = lambda t: t.permute(0, 2, 1, 3).reshape(-1, Ci)                        # back to token-major (data movement)
+    Lq, Lk = qp.shape[0] // B, kp.shape[0] // B
+    if D in (16, 32) and min(Lq, Lk) <= 32:
+        # decoder attention: one side is a handful of tokens -> one fused kernel for all (batch, head) pairs, token-major in and out
+        dq = torch.empty(B * Lq, Ci, dtype=F32, device=qp.device)
+        dk = torch.empty(B * Lk, Ci, dtype=F32, device=qp.device)
+        dv = torch.empty(B * Lk, Ci, dtype=F32, device=qp.device)
+        dac = da.contiguous()
+        check(lib().msam2_attention_small_bwd(_p(qp), Lq * qp.stride(0), qp.stride(0), _p(kp), Lk * kp.stride(0), kp.stride(0), _p(vp),
+                                              Lk * vp.stride(0), vp.stride(0), _p(dac), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, D,
+                                              D ** -0.5, _stream()))
+        rows = lambda t: t
+    else:
+        heads = lambda t: t.view(B, -1, H, D).permute(0, 2, 1, 3)                 # [B, H, L, D] views of the token-major rows
+        dq, dk, dv = attention_backward(heads(qp), heads(kp), heads(vp), heads(da))
+        rows = lambda t: t.permute(0, 2, 1, 3).reshape(-1, Ci)                    # back to token-major (data movement)
     outs = []
     for nm, x16, g in (("q", q_in16, dq), ("k", k_in16, dk), ("v", v_in16, dv)):
         dx, grads[f"{prefix}.{nm}_proj.weight"], grads[f"{prefix}.{nm}_proj.bias"] = linear_backward(

@@ -324,3 +324,232 @@ extern "C" int msam2_adam_step(float* param, const float* grad, float* exp_avg, 
                      exp_avg_sq, n, lr, beta1, beta2, eps, bc1, bc2);
   return msam2_check_launch("adam_step");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward of the two-way decoder's small-head attention (transformer.py:239-263; 8 heads of 16 / 32 channels) where ONE side is a
+// handful of tokens (T <= 32) and the other the 4096 image tokens.  One workgroup per (batch, head); the long side is spread over
+// the 256 threads, the T x T-free quantities of the short side live in LDS, and the short side's gradients are wave-reduced sums
+// over the long side.  q/k/v 16-bit token-major [B, L, H*D] (element strides given), dO / dq / dk / dv fp32 token-major contiguous.
+//   SMALL_Q: few queries, many keys  (tokens -> image);   !SMALL_Q: many queries, few keys  (image -> tokens)
+// ------------------------------------------------------------------------------------------------------------------
+template <int D, bool SMALL_Q>
+__global__ __launch_bounds__(256) void attn_small_bwd_kernel(const op16* __restrict__ q, int64_t q_bs, int64_t q_ts, const op16* __restrict__ k,
+                                                             int64_t k_bs, int64_t k_ts, const op16* __restrict__ v, int64_t v_bs, int64_t v_ts,
+                                                             const float* __restrict__ d_o, float* __restrict__ dq, float* __restrict__ dk,
+                                                             float* __restrict__ dv, int H, int Lq, int Lk, float scale) {
+  constexpr int TMAX = 32;
+  __shared__ float s_a[TMAX][D + 1];     // short side operand 1: SMALL_Q ? q (pre-scaled) : k
+  __shared__ float s_b[TMAX][D + 1];     // short side operand 2: SMALL_Q ? dO          : v
+  __shared__ float s_g1[TMAX][D + 1];    // short side gradient 1: SMALL_Q ? dq : dk
+  __shared__ float s_g2[TMAX][D + 1];    // short side gradient 2: SMALL_Q ? -  : dv
+  __shared__ float s_m[4][TMAX], s_l[4][TMAX], s_d[4][TMAX];
+  const int b = blockIdx.x / H, head = blockIdx.x % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = H * D;
+  const int T = SMALL_Q ? Lq : Lk, L = SMALL_Q ? Lk : Lq;
+  const float sl2 = scale * 1.4426950408889634f;
+  for (int i = tid; i < T * D; i += 256) {
+    const int t = i / D, d = i % D;
+    if (SMALL_Q) {
+      s_a[t][d] = op2f(q[b * q_bs + (int64_t)t * q_ts + head * D + d]);
+      s_b[t][d] = d_o[((int64_t)b * Lq + t) * C + head * D + d];
+    } else {
+      s_a[t][d] = op2f(k[b * k_bs + (int64_t)t * k_ts + head * D + d]);
+      s_b[t][d] = op2f(v[b * v_bs + (int64_t)t * v_ts + head * D + d]);
+    }
+    s_g1[t][d] = 0.f;
+    s_g2[t][d] = 0.f;
+  }
+  __syncthreads();
+  if constexpr (SMALL_Q) {
+    // ---- pass 1: per-query softmax statistics over the keys (online per thread, merged over the workgroup)
+    float m[TMAX], l[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) { m[t] = -INFINITY; l[t] = 0.f; }
+    for (int j = tid; j < L; j += 256) {
+      float kv[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) kv[d] = op2f(k[b * k_bs + (int64_t)j * k_ts + head * D + d]);
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) {
+        if (t >= T) break;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) s += s_a[t][d] * kv[d];
+        s *= sl2;
+        const float mn = fmaxf(m[t], s);
+        l[t] = l[t] * __builtin_amdgcn_exp2f(m[t] - mn) + __builtin_amdgcn_exp2f(s - mn);
+        m[t] = mn;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {                       // (unrolled with an early exit: m[] / l[] stay in registers)
+      if (t >= T) break;
+      float mm = m[t], ll = l[t];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(mm, o, 64), l2 = __shfl_xor(ll, o, 64);
+        const float mn = fmaxf(mm, m2);
+        ll = (mm == -INFINITY ? 0.f : ll * __builtin_amdgcn_exp2f(mm - mn)) + (m2 == -INFINITY ? 0.f : l2 * __builtin_amdgcn_exp2f(m2 - mn));
+        mm = mn;
+      }
+      if (lane == 0) { s_m[wave][t] = mm; s_l[wave][t] = ll; }
+    }
+    __syncthreads();
+    if (tid < T) {                                         // final (max, 1 / sum) of query tid -> row 0 of the stat arrays
+      float mm = -INFINITY;
+      for (int w = 0; w < 4; ++w) mm = fmaxf(mm, s_m[w][tid]);
+      float ll = 0.f;
+      for (int w = 0; w < 4; ++w) ll += s_m[w][tid] == -INFINITY ? 0.f : s_l[w][tid] * __builtin_amdgcn_exp2f(s_m[w][tid] - mm);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      s_m[0][tid] = mm;
+      s_l[0][tid] = 1.f / ll;
+    }
+    __syncthreads();
+    // ---- pass 2: delta_t = sum_j p_tj (dO_t . v_j)
+    float dl[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) dl[t] = 0.f;
+    for (int j = tid; j < L; j += 256) {
+      float kv[D], vv[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        kv[d] = op2f(k[b * k_bs + (int64_t)j * k_ts + head * D + d]);
+        vv[d] = op2f(v[b * v_bs + (int64_t)j * v_ts + head * D + d]);
+      }
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) {
+        if (t >= T) break;
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { s += s_a[t][d] * kv[d]; dp += s_b[t][d] * vv[d]; }
+        dl[t] += __builtin_amdgcn_exp2f(s * sl2 - s_m[0][t]) * s_l[0][t] * dp;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+      if (t >= T) break;
+      const float r = wave_sum(dl[t]);
+      if (lane == 0) s_d[wave][t] = r;
+    }
+    __syncthreads();
+    if (tid < T) {
+      const float r = s_d[0][tid] + s_d[1][tid] + s_d[2][tid] + s_d[3][tid];
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      s_d[0][tid] = r;
+    }
+    __syncthreads();
+    // ---- pass 3: dV_j, dK_j per key (thread-local), dQ_t reduced over the keys
+    for (int j0 = 0; j0 < L; j0 += 256) {
+      const int j = j0 + tid;
+      const bool live = j < L;
+      float kv[D], vv[D], gk[D], gv[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        kv[d] = live ? op2f(k[b * k_bs + (int64_t)j * k_ts + head * D + d]) : 0.f;
+        vv[d] = live ? op2f(v[b * v_bs + (int64_t)j * v_ts + head * D + d]) : 0.f;
+        gk[d] = gv[d] = 0.f;
+      }
+      for (int t = 0; t < T; ++t) {
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { s += s_a[t][d] * kv[d]; dp += s_b[t][d] * vv[d]; }
+        const float p = live ? __builtin_amdgcn_exp2f(s * sl2 - s_m[0][t]) * s_l[0][t] : 0.f;
+        const float ds = scale * p * (dp - s_d[0][t]);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          gv[d] += p * s_b[t][d];
+          gk[d] += ds * s_a[t][d];
+          const float c = wave_sum(ds * kv[d]);
+          if (lane == 0) atomicAdd(&s_g1[t][d], c);
+        }
+      }
+      if (live) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          dk[((int64_t)b * Lk + j) * C + head * D + d] = gk[d];
+          dv[((int64_t)b * Lk + j) * C + head * D + d] = gv[d];
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < T * D; i += 256) dq[((int64_t)b * Lq + i / D) * C + head * D + i % D] = s_g1[i / D][i % D];
+  } else {
+    // few keys: everything about a query is thread-local; dK_t / dV_t are sums over the queries
+    for (int i0 = 0; i0 < L; i0 += 256) {
+      const int i = i0 + tid;
+      const bool live = i < L;
+      float qv[D], dov[D], gq[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        qv[d] = live ? op2f(q[b * q_bs + (int64_t)i * q_ts + head * D + d]) : 0.f;
+        dov[d] = live ? d_o[((int64_t)b * Lq + i) * C + head * D + d] : 0.f;
+        gq[d] = 0.f;
+      }
+      float s[TMAX], dp[TMAX], mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) {
+        if (t >= T) break;
+        float a = 0.f, c = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { a += qv[d] * s_a[t][d]; c += dov[d] * s_b[t][d]; }
+        s[t] = a * sl2;
+        dp[t] = c;
+        mx = fmaxf(mx, s[t]);
+      }
+      float lsum = 0.f, delta = 0.f;
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) {
+        if (t >= T) break;
+        s[t] = __builtin_amdgcn_exp2f(s[t] - mx);
+        lsum += s[t];
+      }
+      const float inv = 1.f / lsum;
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) {
+        if (t >= T) break;
+        s[t] *= inv;                       // p_it
+        delta += s[t] * dp[t];
+      }
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) {
+        if (t >= T) break;
+        const float p = live ? s[t] : 0.f;
+        const float ds = scale * p * (dp[t] - delta);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          gq[d] += ds * s_a[t][d];
+          const float c1 = wave_sum(ds * qv[d]), c2 = wave_sum(p * dov[d]);
+          if (lane == 0) { atomicAdd(&s_g1[t][d], c1); atomicAdd(&s_g2[t][d], c2); }
+        }
+      }
+      if (live) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) dq[((int64_t)b * Lq + i) * C + head * D + d] = gq[d];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < T * D; i += 256) {
+      dk[((int64_t)b * Lk + i / D) * C + head * D + i % D] = s_g1[i / D][i % D];
+      dv[((int64_t)b * Lk + i / D) * C + head * D + i % D] = s_g2[i / D][i % D];
+    }
+  }
+}
+
+extern "C" int msam2_attention_small_bwd(const void* q, int64_t q_bs, int64_t q_ts, const void* k, int64_t k_bs, int64_t k_ts, const void* v,
+                                         int64_t v_bs, int64_t v_ts, const float* d_o, float* dq, float* dk, float* dv, int64_t B, int64_t H,
+                                         int64_t Lq, int64_t Lk, int64_t D, float scale, void* stream) {
+  MSAM2_REQUIRE(q && k && v && d_o && dq && dk && dv && B > 0 && H > 0 && Lq > 0 && Lk > 0, "attention_small_bwd: bad arguments");
+  MSAM2_REQUIRE(D == 16 || D == 32, "attention_small_bwd: head dim 16 / 32");
+  MSAM2_REQUIRE(Lq <= 32 || Lk <= 32, "attention_small_bwd: one side must have at most 32 tokens");
+  dim3 grid((unsigned)(B * H)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define ASB(DD, SQ)                                                                                                                      \
+  hipLaunchKernelGGL((attn_small_bwd_kernel<DD, SQ>), grid, block, 0, s, (const op16*)q, q_bs, q_ts, (const op16*)k, k_bs, k_ts, (const op16*)v, \
+                     v_bs, v_ts, d_o, dq, dk, dv, (int)H, (int)Lq, (int)Lk, scale)
+  const bool small_q = Lq <= 32 && Lq <= Lk;
+  if (D == 16) { if (small_q) ASB(16, true); else ASB(16, false); }
+  else { if (small_q) ASB(32, true); else ASB(32, false); }
+#undef ASB
+  return msam2_check_launch("attention_small_bwd");
+}

@@ -366,3 +366,26 @@ def test_decoder_finetune_step(mods):
     # second step runs on the updated weights (kernel-ready weight caches are invalidated by the update)
     loss2 = T.decoder_finetune_step(dec, optim, tm(emb), tm(pe), d(sparse), tm(f0).to(ops.OP16), tm(f1).to(ops.OP16), B, E, E, d(target))
     assert loss2 < loss
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,D", [(2, 8, 8, 4096, 16), (2, 8, 4096, 8, 16), (3, 8, 7, 7, 32), (1, 8, 9, 1000, 32), (2, 4, 300, 32, 32),
+                                         (1, 2, 32, 33, 16)])
+def test_attention_small_backward(mods, B, H, Lq, Lk, D):
+    """fused small-head attention backward (two-way decoder shapes, both orientations) against autograd"""
+    B_, ops = mods
+    from medical_sam2_amd._lib import lib, check
+    C = H * D
+    q16 = lambda t: t.to(ops.OP16)
+    q = q16(rnd(B, Lq, C, seed=100)).float().requires_grad_(True)
+    k = q16(rnd(B, Lk, C, seed=101)).float().requires_grad_(True)
+    v = q16(rnd(B, Lk, C, seed=102)).float().requires_grad_(True)
+    do = rnd(B, Lq, C, seed=103)
+    sp = lambda t: t.reshape(B, t.shape[1], H, D).transpose(1, 2)
+    O.softmax_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(B, Lq, C).backward(do)
+    d = lambda t: t.detach().to(ops.OP16).to(DEV)
+    qd, kd, vd, dod = d(q), d(k), d(v), do.to(DEV)
+    dq = torch.empty(B, Lq, C, device=DEV)
+    dk, dv = torch.empty(B, Lk, C, device=DEV), torch.empty(B, Lk, C, device=DEV)
+    check(lib().msam2_attention_small_bwd(ops._p(qd), qd.stride(0), qd.stride(1), ops._p(kd), kd.stride(0), kd.stride(1), ops._p(vd), vd.stride(0),
+                                          vd.stride(1), ops._p(dod), ops._p(dq), ops._p(dk), ops._p(dv), B, H, Lq, Lk, D, D ** -0.5, ops._stream()))
+    assert rel(dv, v.grad) < 1e-4 and rel(dq, q.grad) < 1e-4 and rel(dk, k.grad) < 1e-4, (rel(dq, q.grad), rel(dk, k.grad), rel(dv, v.grad))
