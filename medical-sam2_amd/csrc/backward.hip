@@ -325,10 +325,60 @@ extern "C" int msam2_adam_step(float* param, const float* grad, float* exp_avg, 
   return msam2_check_launch("adam_step");
 }
 
+// Multi-tensor form: up to ADAM_CHUNK parameters per launch, their pointers passed by value in the kernel argument block (so the
+// launch is capturable and needs no device-side table); blockIdx.y = parameter, blockIdx.x strides over its elements.
+constexpr int ADAM_CHUNK = 24;
+struct AdamTable {
+  float* p[ADAM_CHUNK];
+  const float* g[ADAM_CHUNK];
+  float* m[ADAM_CHUNK];
+  float* v[ADAM_CHUNK];
+  int64_t n[ADAM_CHUNK];
+};
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable tb, float lr, float b1, float b2, float eps, float bc1, float bc2) {
+  const int t = blockIdx.y;
+  float* __restrict__ p = tb.p[t];
+  const float* __restrict__ g = tb.g[t];
+  float* __restrict__ m = tb.m[t];
+  float* __restrict__ v = tb.v[t];
+  const int64_t n = tb.n[t];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+  }
+}
+
+extern "C" int msam2_adam_step_multi(void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                                     const int64_t* numel, int64_t count, float lr, float beta1, float beta2, float eps, int64_t step,
+                                     void* stream) {
+  MSAM2_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel && count > 0 && step >= 1, "adam_step_multi: bad arguments");
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  for (int64_t c0 = 0; c0 < count; c0 += ADAM_CHUNK) {
+    const int nt = (int)min((int64_t)ADAM_CHUNK, count - c0);
+    AdamTable tb;
+    int64_t nmax = 0;
+    for (int i = 0; i < ADAM_CHUNK; ++i) {
+      const int64_t j = c0 + min(i, nt - 1);
+      MSAM2_REQUIRE(params[j] && grads[j] && exp_avg[j] && exp_avg_sq[j] && numel[j] > 0, "adam_step_multi: null / empty entry %lld", (long long)j);
+      tb.p[i] = (float*)params[j]; tb.g[i] = (const float*)grads[j]; tb.m[i] = (float*)exp_avg[j]; tb.v[i] = (float*)exp_avg_sq[j];
+      tb.n[i] = numel[j];
+      nmax = max(nmax, numel[j]);
+    }
+    dim3 grid((unsigned)min((int64_t)128, cdiv(nmax, 256)), (unsigned)nt);
+    hipLaunchKernelGGL(adam_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, tb, lr, beta1, beta2, eps, bc1, bc2);
+  }
+  return msam2_check_launch("adam_step_multi");
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Backward of the two-way decoder's small-head attention (transformer.py:239-263; 8 heads of 16 / 32 channels) where ONE side is a
-// handful of tokens (T <= 32) and the other the 4096 image tokens.  One workgroup per (batch, head); the long side is spread over
-// the 256 threads, the T x T-free quantities of the short side live in LDS, and the short side's gradients are wave-reduced sums
+// handful of tokens (T <= 32) and the other the 4096 image tokens.  gridDim.y workgroups per (batch, head); the long side is spread over
+// their threads, the T x T-free quantities of the short side live in LDS, and the short side's gradients are wave-reduced sums
 // over the long side.  q/k/v 16-bit token-major [B, L, H*D] (element strides given), dO / dq / dk / dv fp32 token-major contiguous.
 //   SMALL_Q: few queries, many keys  (tokens -> image);   !SMALL_Q: many queries, few keys  (image -> tokens)
 // ------------------------------------------------------------------------------------------------------------------
@@ -362,54 +412,12 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const op16* __restr
   }
   __syncthreads();
   if constexpr (SMALL_Q) {
-    // ---- pass 1: per-query softmax statistics over the keys (online per thread, merged over the workgroup)
-    float m[TMAX], l[TMAX];
+    // ---- pass 1: per-query softmax statistics AND delta_t = sum_j p_tj (dO_t . v_j) over all keys, online per thread (running
+    //      max m, sum l, weighted sum a), merged over the workgroup.  Every workgroup of a (batch, head) repeats it (k / v of one
+    //      head are 256 KB: L2 traffic), the expensive pass 2 below is split over gridDim.y.
+    float m[TMAX], l[TMAX], a[TMAX];
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) { m[t] = -INFINITY; l[t] = 0.f; }
-    for (int j = tid; j < L; j += 256) {
-      float kv[D];
-#pragma unroll
-      for (int d = 0; d < D; ++d) kv[d] = op2f(k[b * k_bs + (int64_t)j * k_ts + head * D + d]);
-#pragma unroll
-      for (int t = 0; t < TMAX; ++t) {
-        if (t >= T) break;
-        float s = 0.f;
-#pragma unroll
-        for (int d = 0; d < D; ++d) s += s_a[t][d] * kv[d];
-        s *= sl2;
-        const float mn = fmaxf(m[t], s);
-        l[t] = l[t] * __builtin_amdgcn_exp2f(m[t] - mn) + __builtin_amdgcn_exp2f(s - mn);
-        m[t] = mn;
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < TMAX; ++t) {                       // (unrolled with an early exit: m[] / l[] stay in registers)
-      if (t >= T) break;
-      float mm = m[t], ll = l[t];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const float m2 = __shfl_xor(mm, o, 64), l2 = __shfl_xor(ll, o, 64);
-        const float mn = fmaxf(mm, m2);
-        ll = (mm == -INFINITY ? 0.f : ll * __builtin_amdgcn_exp2f(mm - mn)) + (m2 == -INFINITY ? 0.f : l2 * __builtin_amdgcn_exp2f(m2 - mn));
-        mm = mn;
-      }
-      if (lane == 0) { s_m[wave][t] = mm; s_l[wave][t] = ll; }
-    }
-    __syncthreads();
-    if (tid < T) {                                         // final (max, 1 / sum) of query tid -> row 0 of the stat arrays
-      float mm = -INFINITY;
-      for (int w = 0; w < 4; ++w) mm = fmaxf(mm, s_m[w][tid]);
-      float ll = 0.f;
-      for (int w = 0; w < 4; ++w) ll += s_m[w][tid] == -INFINITY ? 0.f : s_l[w][tid] * __builtin_amdgcn_exp2f(s_m[w][tid] - mm);
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      s_m[0][tid] = mm;
-      s_l[0][tid] = 1.f / ll;
-    }
-    __syncthreads();
-    // ---- pass 2: delta_t = sum_j p_tj (dO_t . v_j)
-    float dl[TMAX];
-#pragma unroll
-    for (int t = 0; t < TMAX; ++t) dl[t] = 0.f;
+    for (int t = 0; t < TMAX; ++t) { m[t] = -INFINITY; l[t] = 0.f; a[t] = 0.f; }
     for (int j = tid; j < L; j += 256) {
       float kv[D], vv[D];
 #pragma unroll
@@ -420,27 +428,50 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const op16* __restr
 #pragma unroll
       for (int t = 0; t < TMAX; ++t) {
         if (t >= T) break;
-        float s = 0.f, dp = 0.f;
+        float sc = 0.f, dp = 0.f;
 #pragma unroll
-        for (int d = 0; d < D; ++d) { s += s_a[t][d] * kv[d]; dp += s_b[t][d] * vv[d]; }
-        dl[t] += __builtin_amdgcn_exp2f(s * sl2 - s_m[0][t]) * s_l[0][t] * dp;
+        for (int d = 0; d < D; ++d) { sc += s_a[t][d] * kv[d]; dp += s_b[t][d] * vv[d]; }
+        sc *= sl2;
+        const float mn = fmaxf(m[t], sc);
+        const float c0 = __builtin_amdgcn_exp2f(m[t] - mn), c1 = __builtin_amdgcn_exp2f(sc - mn);
+        l[t] = l[t] * c0 + c1;
+        a[t] = a[t] * c0 + c1 * dp;
+        m[t] = mn;
       }
     }
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) {
+    for (int t = 0; t < TMAX; ++t) {                       // (unrolled with an early exit: m[] / l[] / a[] stay in registers)
       if (t >= T) break;
-      const float r = wave_sum(dl[t]);
-      if (lane == 0) s_d[wave][t] = r;
+      float mm = m[t], ll = l[t], aa = a[t];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(mm, o, 64), l2 = __shfl_xor(ll, o, 64), a2 = __shfl_xor(aa, o, 64);
+        const float mn = fmaxf(mm, m2);
+        const float c0 = mm == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mm - mn), c1 = m2 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m2 - mn);
+        ll = ll * c0 + l2 * c1;
+        aa = aa * c0 + a2 * c1;
+        mm = mn;
+      }
+      if (lane == 0) { s_m[wave][t] = mm; s_l[wave][t] = ll; s_d[wave][t] = aa; }
     }
     __syncthreads();
-    if (tid < T) {
-      const float r = s_d[0][tid] + s_d[1][tid] + s_d[2][tid] + s_d[3][tid];
+    if (tid < T) {                                         // final (max, 1 / sum, delta) of query tid -> row 0 of the stat arrays
+      float mm = -INFINITY;
+      for (int w = 0; w < 4; ++w) mm = fmaxf(mm, s_m[w][tid]);
+      float ll = 0.f, aa = 0.f;
+      for (int w = 0; w < 4; ++w) {
+        const float c = s_m[w][tid] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(s_m[w][tid] - mm);
+        ll += s_l[w][tid] * c;
+        aa += s_d[w][tid] * c;
+      }
       __builtin_amdgcn_s_waitcnt(0xc07f);
-      s_d[0][tid] = r;
+      s_m[0][tid] = mm;
+      s_l[0][tid] = 1.f / ll;
+      s_d[0][tid] = aa / ll;
     }
     __syncthreads();
-    // ---- pass 3: dV_j, dK_j per key (thread-local), dQ_t reduced over the keys
-    for (int j0 = 0; j0 < L; j0 += 256) {
+    // ---- pass 2: dV_j, dK_j per key (thread-local), dQ_t reduced over this workgroup's keys and added to the zeroed output
+    for (int j0 = blockIdx.y * 256; j0 < L; j0 += gridDim.y * 256) {
       const int j = j0 + tid;
       const bool live = j < L;
       float kv[D], vv[D], gk[D], gv[D];
@@ -473,10 +504,11 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const op16* __restr
       }
     }
     __syncthreads();
-    for (int i = tid; i < T * D; i += 256) dq[((int64_t)b * Lq + i / D) * C + head * D + i % D] = s_g1[i / D][i % D];
+    for (int i = tid; i < T * D; i += 256) atomicAdd(dq + ((int64_t)b * Lq + i / D) * C + head * D + i % D, s_g1[i / D][i % D]);
   } else {
-    // few keys: everything about a query is thread-local; dK_t / dV_t are sums over the queries
-    for (int i0 = 0; i0 < L; i0 += 256) {
+    // few keys: everything about a query is thread-local; dK_t / dV_t are sums over the queries (workgroup partials added to
+    // the zeroed outputs)
+    for (int i0 = blockIdx.y * 256; i0 < L; i0 += gridDim.y * 256) {
       const int i = i0 + tid;
       const bool live = i < L;
       float qv[D], dov[D], gq[D];
@@ -530,9 +562,16 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const op16* __restr
     }
     __syncthreads();
     for (int i = tid; i < T * D; i += 256) {
-      dk[((int64_t)b * Lk + i / D) * C + head * D + i % D] = s_g1[i / D][i % D];
-      dv[((int64_t)b * Lk + i / D) * C + head * D + i % D] = s_g2[i / D][i % D];
+      atomicAdd(dk + ((int64_t)b * Lk + i / D) * C + head * D + i % D, s_g1[i / D][i % D]);
+      atomicAdd(dv + ((int64_t)b * Lk + i / D) * C + head * D + i % D, s_g2[i / D][i % D]);
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void zero2_kernel(float* __restrict__ a, float* __restrict__ b, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    a[i] = 0.f;
+    if (b) b[i] = 0.f;
   }
 }
 
@@ -542,12 +581,21 @@ extern "C" int msam2_attention_small_bwd(const void* q, int64_t q_bs, int64_t q_
   MSAM2_REQUIRE(q && k && v && d_o && dq && dk && dv && B > 0 && H > 0 && Lq > 0 && Lk > 0, "attention_small_bwd: bad arguments");
   MSAM2_REQUIRE(D == 16 || D == 32, "attention_small_bwd: head dim 16 / 32");
   MSAM2_REQUIRE(Lq <= 32 || Lk <= 32, "attention_small_bwd: one side must have at most 32 tokens");
-  dim3 grid((unsigned)(B * H)), block(256);
+  const bool small_q = Lq <= 32 && Lq <= Lk;
+  const int64_t L = small_q ? Lk : Lq;
+  // the long side is split over gridDim.y workgroups (~2 per CU over the launch); the short side's gradients are accumulated with
+  // atomics into zeroed outputs
+  const int64_t gy = max((int64_t)1, min(cdiv(L, 256), cdiv(512, B * H)));
+  dim3 grid((unsigned)(B * H), (unsigned)gy), block(256);
   hipStream_t s = (hipStream_t)stream;
+  // (zero fill by kernel, not hipMemsetAsync: see gemm_zero_kernel in gemm.hip)
+  const int64_t short_n = B * (small_q ? Lq : Lk) * H * D;
+  const dim3 zgrid((unsigned)min((int64_t)1024, cdiv(short_n, (int64_t)256)));
+  if (small_q) hipLaunchKernelGGL(zero2_kernel, zgrid, dim3(256), 0, s, dq, (float*)nullptr, short_n);
+  else hipLaunchKernelGGL(zero2_kernel, zgrid, dim3(256), 0, s, dk, dv, short_n);
 #define ASB(DD, SQ)                                                                                                                      \
   hipLaunchKernelGGL((attn_small_bwd_kernel<DD, SQ>), grid, block, 0, s, (const op16*)q, q_bs, q_ts, (const op16*)k, k_bs, k_ts, (const op16*)v, \
                      v_bs, v_ts, d_o, dq, dk, dv, (int)H, (int)Lq, (int)Lk, scale)
-  const bool small_q = Lq <= 32 && Lq <= Lk;
   if (D == 16) { if (small_q) ASB(16, true); else ASB(16, false); }
   else { if (small_q) ASB(32, true); else ASB(32, false); }
 #undef ASB

@@ -122,6 +122,11 @@ __global__ void fill_kernel(float* __restrict__ m, const int* __restrict__ label
     if (labels[i] > 0 && counts[i] <= max_area) m[i] = value;
 }
 
+// (a kernel, not hipMemsetAsync: memset nodes of a captured graph did not order reliably against neighbouring kernel nodes)
+__global__ void cc_zero_kernel(int* __restrict__ x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = 0;
+}
+
 }  // namespace
 
 extern "C" size_t msam2_cc_workspace_bytes(int64_t N, int64_t H, int64_t W) { return (size_t)(2 * N * H * W) * sizeof(int); }
@@ -137,7 +142,7 @@ extern "C" int msam2_cc_label(const uint8_t* img, int32_t* labels, int32_t* coun
   hipStream_t s = (hipStream_t)stream;
   int* parent = (int*)workspace;
   int* hist = parent + N * H * W;
-  hipMemsetAsync(hist, 0, sizeof(int) * N * H * W, s);
+  hipLaunchKernelGGL(cc_zero_kernel, dim3((unsigned)min((int64_t)2048, cdiv(N * H * W, (int64_t)256))), dim3(256), 0, s, hist, N * H * W);
   dim3 blk(32, 8), grid(cdiv(W / 2, 32), cdiv(H / 2, 8), (unsigned)N);
   hipLaunchKernelGGL(cc_init_kernel, grid, blk, 0, s, parent, (int)W, (int)H);
   hipLaunchKernelGGL(cc_merge_kernel, grid, blk, 0, s, img, parent, (int)W, (int)H);

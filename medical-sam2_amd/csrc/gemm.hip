@@ -49,6 +49,10 @@ struct GemmParams {
   // Hiera stage 2's first block, while outputs that fit are 15-20 % SLOWER with nt (they are absorbed by the cache and read back
   // from it by the next kernel)
   int store_nt;
+  // split-K (register-staged kernel only): blockIdx.z owns the k-tiles [z * ksplit_tiles, (z+1) * ksplit_tiles) and adds its partial
+  // product into the zeroed fp32 output with atomics (bias / residual contributed by z == 0).  For the weight-gradient GEMMs of the
+  // backward pass: a [256 x 256] output reduced over 16k..64k tokens is 4 tiles, i.e. 4 workgroups walking K serially otherwise.
+  int ksplit_tiles;
 };
 
 // A row (in elements of lda) that logical GEMM row m reads
@@ -493,7 +497,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   uint4 ra[A_PER], rw[W_PER];
-  const int nk = (p.K + GEMM_BK - 1) / GEMM_BK;
+  const int nk_all = (p.K + GEMM_BK - 1) / GEMM_BK;
+  const int kt0 = p.ksplit_tiles > 0 ? (int)blockIdx.z * p.ksplit_tiles : 0;
+  const int nk = p.ksplit_tiles > 0 ? min(nk_all, kt0 + p.ksplit_tiles) : nk_all;
+  if (kt0 >= nk) return;
 
   auto gload = [&](int kt) {
     const int k0 = kt * GEMM_BK;
@@ -531,11 +538,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
     }
   };
 
-  gload(0);
+  gload(kt0);
   lstore(0);
   __syncthreads();
   int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = kt0; kt < nk; ++kt) {
     if (kt + 1 < nk) gload(kt + 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -559,6 +566,29 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
   // ---- epilogue through wave-private LDS scratch (the operand LDS is free after the barrier)
   __syncthreads();
   static_assert(WM * WN * 32 * (TN + 4) * 4 <= 2 * (BM + BN) * GEMM_LDS_STRIDE * 2, "epilogue scratch must fit the operand LDS");
+  if (p.ksplit_tiles > 0) {
+    // split-K: fp32 atomics straight from the accumulator layout (lane = column, register = row)
+    float* C = reinterpret_cast<float*>(p.C);
+    const bool first = blockIdx.z == 0;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int64_t n = n0 + wn * TN + j * 32 + r;
+      if (n >= p.N) continue;
+      const float bv = (first && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int64_t m = m0 + wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (m < p.M) {
+            float val = acc[i][j][e] + bv;
+            if (first && p.res) val += reinterpret_cast<const float*>(p.res)[m * p.ldr + n];
+            atomicAdd(C + m * p.ldc + n, val);
+          }
+        }
+    }
+    return;
+  }
   gemm_epilogue<FM, FN>(p, acc, reinterpret_cast<float*>(lds) + wave * 32 * (TN + 4), m0 + wm * TM, n0 + wn * TN, lane);
 }
 
@@ -1017,6 +1047,14 @@ static void launch_gemm(const GemmParams& p, hipStream_t s) {
   hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN>), grid, dim3(WM * WN * 64), 0, s, p);
 }
 
+// zero fill of a strided fp32 [M, N] view (split-K accumulates into it).  A kernel rather than hipMemset2DAsync: as a captured
+// graph node the memset did not order reliably against the neighbouring kernel nodes (observed: replays of a captured training step
+// accumulated into stale data).
+__global__ __launch_bounds__(256) void gemm_zero_kernel(float* __restrict__ C, int64_t ldc, int M, int N) {
+  const int64_t total = (int64_t)M * N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) C[(i / N) * ldc + i % N] = 0.f;
+}
+
 static int gemm_launch(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* colscale,
                        const void* residual, int64_t ldr, int res_is_16bit, int64_t res_mod, void* C, int64_t ldc, int out_is_16bit,
                        int64_t M, int64_t N, int64_t K, int act, void* stream, const float* rope_cos, const float* rope_sin,
@@ -1037,6 +1075,7 @@ static int gemm_launch(const void* A, int64_t lda, const void* W, int64_t ldw, c
   p.pool_H = pool_H; p.pool_W = pool_W;
   p.Q2 = Q2; p.ldq = ldq; p.poolq_cols = poolq_cols;
   p.A32 = nullptr; p.A2 = nullptr; p.add_cols = 0;
+  p.ksplit_tiles = 0;
   {
     const char* e = getenv("MSAM2_NT_BYTES");
     const long long thr = e ? atoll(e) : (30ll << 20);
@@ -1057,6 +1096,23 @@ static int gemm_launch(const void* A, int64_t lda, const void* W, int64_t ldw, c
   //   otherwise                                       -> 128x128x32 2-stage, 4 workgroups per CU (short reductions: prologue/epilogue
   //                                                      of one workgroup overlap the main loops of the other three)
   // MSAM2_GEMM_VARIANT = 2 | 5 | 6 | 8 | 9 | 10 | 11 forces one (experiments).
+  // split-K for small outputs with a very long reduction (the weight-gradient GEMMs of the backward pass, K = tokens): fp32 output,
+  // no activation / column scale / residual.  No GEMM of the forward pass matches (their K <= 3072), so the forward stays
+  // bit-reproducible; the atomics make the gradient sums order-dependent at fp32 round-off.
+  if (!out_is_16bit && act == 0 && !colscale && !residual && !rope_cos && pool_W == 0 &&
+      (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) <= 32 && K >= 4096 && !getenv("MSAM2_NO_SPLITK")) {
+    const int nk_all = cdiv(p.K, GEMM_BK);
+    int splits = (int)min((int64_t)64, (int64_t)(512 / (cdiv(p.M, 128) * cdiv(p.N, 128))));
+    splits = max(1, min(splits, nk_all / 8));
+    if (splits > 1) {
+      p.ksplit_tiles = cdiv(nk_all, splits);
+      hipLaunchKernelGGL(gemm_zero_kernel, dim3((unsigned)min((int64_t)1024, cdiv((int64_t)M * N, (int64_t)256))), dim3(256), 0, s, (float*)C, ldc,
+                         (int)M, (int)N);
+      dim3 grid(cdiv(p.N, 128), cdiv(p.M, 128), cdiv(nk_all, p.ksplit_tiles));
+      hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, p);
+      return msam2_check_launch("gemm(split-K)");
+    }
+  }
   const int vv = var ? atoi(var) : (tiles <= 256 && K >= 1024 ? 8 : (K % 64 == 0 && K >= 384 ? 2 : 5));
   if (dma_ok && K % 32 == 0 && vv == 6) {
     hipLaunchKernelGGL((gemm_wide_kernel<256, 128, 3, 2>), dim3(cdiv(p.N, 128) * cdiv(p.M, 256)), dim3(256), 0, s, p);

@@ -40,18 +40,31 @@ class DecoderAdam:
     def step(self, grads: Dict[str, torch.Tensor]):
         """(The bias corrections 1 - beta^t are host scalars baked into the launch: a captured graph replays the step count it was
         captured with -- exact for t -> infinity, i.e. use eager steps while t is small if the warm-up matters.)"""
+        import ctypes
         self.t += 1
         params = dict(self.decoder.named_parameters())
-        for name, g in grads.items():
-            p = params[name]
+        names = list(grads.keys())
+        keep = []                                      # fp32 contiguous gradient copies stay alive until the launches are queued
+        tabs = [[], [], [], []]
+        numel = []
+        for name in names:
+            p, g = params[name], grads[name]
             assert p.dtype == F32 and p.is_contiguous() and g.shape == p.shape, name
             if name not in self.state:
                 self.state[name] = (torch.zeros_like(p), torch.zeros_like(p))
             m, v = self.state[name]
             gc = g.to(F32).contiguous()
-            check(lib().msam2_adam_step(_p(p), _p(gc), _p(m), _p(v), p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.t,
-                                        _stream()))
-            p.add_(0)   # the update went through the raw pointer: bump the tensor version so cached kernel-ready weights are rebuilt
+            keep.append(gc)
+            for tab, t in zip(tabs, (p, gc, m, v)):
+                tab.append(t.data_ptr())
+            numel.append(p.numel())
+        n = len(names)
+        arr = [(ctypes.c_void_p * n)(*tab) for tab in tabs]
+        check(lib().msam2_adam_step_multi(arr[0], arr[1], arr[2], arr[3], (ctypes.c_int64 * n)(*numel), n, self.lr, self.betas[0],
+                                          self.betas[1], self.eps, self.t, _stream()))
+        # the update went through raw pointers: bump the tensor versions (no kernel) so cached kernel-ready weights are rebuilt
+        ps = tuple(params[name] for name in names)
+        torch._C._autograd._unsafe_set_version_counter(ps, tuple(p._version + 1 for p in ps))
 
 
 @torch.no_grad()

@@ -95,6 +95,25 @@ def test_gemm_epilogues(ops):
     assert buf[:, :N].abs().sum().item() == 0
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 16384), (128, 64, 65536), (300, 200, 4104), (37, 256, 8192)])
+def test_gemm_split_k(ops, M, N, K):
+    """Weight-gradient shapes (small output, K = tokens): the split-K path (fp32 atomics into the zeroed output).  Integer operands
+    make every partial sum exact, so the result must not depend on the order of the atomics; strided output untouched outside."""
+    g = torch.Generator().manual_seed(K + M)
+    a = torch.randint(-2, 3, (M, K), generator=g).float()
+    w = torch.randint(-2, 3, (N, K), generator=g).float()
+    a[:, 0] += torch.arange(M).float() % 5
+    w[:, -1] += torch.arange(N).float() % 3
+    bias = torch.randint(-4, 5, (N,), generator=g).float()
+    ref = a.double() @ w.double().t() + bias.double()
+    buf = torch.full((M, N + 8), 7.0, dtype=torch.float32, device=DEV)
+    ops.gemm(bf(a).to(DEV), bf(w).to(DEV), bias.to(DEV), out=buf[:, 4:N + 4])
+    assert torch.equal(buf[:, 4:N + 4].cpu().double(), ref), (buf[:, 4:N + 4].cpu().double() - ref).abs().max()
+    assert (buf[:, :4] == 7).all() and (buf[:, N + 4:] == 7).all()
+    out = ops.gemm(bf(a).to(DEV), bf(w).to(DEV), out_dtype=torch.float32)
+    assert torch.equal(out.cpu().double(), ref - bias.double())
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 256, 96), (1000, 384, 384), (8, 256, 2048), (260, 192, 192)])
 def test_gemm_epilogue_modes(ops, M, N, K):
     """Every specialised epilogue (direct stores from the accumulator layout: linear -> 16-bit / fp32, + fp32 residual, GELU /
