@@ -325,7 +325,8 @@ extern "C" int msam2_adam_step(float* param, const float* grad, float* exp_avg, 
   return msam2_check_launch("adam_step");
 }
 
-// Multi-tensor form: up to ADAM_CHUNK parameters per launch, their pointers passed by value in the kernel argument block (so the
+// Multi-tensor form (gradients are multiplied by grad_scale first: the inverse of the loss scale that keeps 16-bit backward operands in
+// range): up to ADAM_CHUNK parameters per launch, their pointers passed by value in the kernel argument block (so the
 // launch is capturable and needs no device-side table); blockIdx.y = parameter, blockIdx.x strides over its elements.
 constexpr int ADAM_CHUNK = 24;
 struct AdamTable {
@@ -336,7 +337,8 @@ struct AdamTable {
   int64_t n[ADAM_CHUNK];
 };
 
-__global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable tb, float lr, float b1, float b2, float eps, float bc1, float bc2) {
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable tb, float lr, float b1, float b2, float eps, float bc1, float bc2,
+                                                         float gscale) {
   const int t = blockIdx.y;
   float* __restrict__ p = tb.p[t];
   const float* __restrict__ g = tb.g[t];
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable tb, float lr,
   float* __restrict__ v = tb.v[t];
   const int64_t n = tb.n[t];
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float gi = g[i];
+    const float gi = g[i] * gscale;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi;
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable tb, float lr,
 
 extern "C" int msam2_adam_step_multi(void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
                                      const int64_t* numel, int64_t count, float lr, float beta1, float beta2, float eps, int64_t step,
-                                     void* stream) {
+                                     float grad_scale, void* stream) {
   MSAM2_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel && count > 0 && step >= 1, "adam_step_multi: bad arguments");
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   for (int64_t c0 = 0; c0 < count; c0 += ADAM_CHUNK) {
@@ -370,7 +372,7 @@ extern "C" int msam2_adam_step_multi(void* const* params, const void* const* gra
       nmax = max(nmax, numel[j]);
     }
     dim3 grid((unsigned)min((int64_t)128, cdiv(nmax, 256)), (unsigned)nt);
-    hipLaunchKernelGGL(adam_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, tb, lr, beta1, beta2, eps, bc1, bc2);
+    hipLaunchKernelGGL(adam_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, tb, lr, beta1, beta2, eps, bc1, bc2, grad_scale);
   }
   return msam2_check_launch("adam_step_multi");
 }

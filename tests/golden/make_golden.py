@@ -348,8 +348,83 @@ def run_eval_seg_case():
     return out, {"seeds": [701, 702, 703], "shape": [3, "c", 40, 48]}
 
 
+def run_grads_case():
+    """Gradient fixtures: `.grad` of every `memory_attention` and `sam_mask_decoder` parameter (and of
+    the inputs) of the reference under torch.autograd on a 2-slice toy problem (hiera_t at 256^2: 16x16 embedding), eval mode so that
+    dropout is the identity.  Memory attention: upstream gradient dy on its output (memory_attention.py:119-169).  Mask decoder: the
+    training criterion BCEWithLogitsLoss on the mask logits of predict_masks (mask_decoder.py:170-267; func_3d/function.py:69).
+    Inputs are regenerated by seed in the tests (torch.randn with Generator(seed) -- same call order as here); gradients are stored
+    as the deterministic strided subsample `sub(g, 256)` plus their full fp64 sum / abs-sum."""
+    m = build_reference("hiera_t", 256)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    rnd = lambda *shape, seed=0, scale=1.0: torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+    out, meta = {}, {"model": "hiera_t", "image_size": 256, "grad_stats": {}}
+
+    def keep(name, g):
+        out[name] = sub(g, 256)
+        meta["grad_stats"][name] = stats(g)
+
+    # ---- memory attention
+    ma = m.memory_attention
+    for p in ma.parameters():
+        p.requires_grad_(True)
+    B, L, C, n_ptr = 2, 256, 256, 4
+    Nk = L + n_ptr
+    curr = rnd(L, B, C, seed=140).requires_grad_(True)
+    curr_pos = rnd(L, B, C, seed=141)
+    memory = rnd(Nk, B, 64, seed=142).requires_grad_(True)
+    memory_pos = rnd(Nk, B, 64, seed=143).requires_grad_(True)
+    dy = rnd(L, B, C, seed=144)
+    y = ma(curr=[curr], curr_pos=[curr_pos], memory=memory, memory_pos=memory_pos, num_obj_ptr_tokens=n_ptr)
+    y.backward(dy)
+    out["memattn_out_sub"] = sub(y, 1024)
+    keep("memattn_d_curr", curr.grad)
+    keep("memattn_d_memory", memory.grad)
+    keep("memattn_d_memory_pos", memory_pos.grad)
+    for k, p in ma.named_parameters():
+        keep("memattn_param." + k, p.grad)
+        p.requires_grad_(False)
+        p.grad = None
+    meta["memattn"] = {"B": B, "L": L, "n_ptr": n_ptr, "seeds": [140, 141, 142, 143, 144], "n_params": len(list(ma.named_parameters()))}
+    # ---- mask decoder under the training criterion
+    dec = m.sam_mask_decoder
+    for p in dec.parameters():
+        p.requires_grad_(True)
+    E, Pp = 16, 2
+    emb = rnd(B, C, E, E, seed=160).requires_grad_(True)
+    pe = rnd(1, C, E, E, seed=161)
+    sparse = rnd(B, Pp, C, seed=162).requires_grad_(True)
+    f0, f1 = rnd(B, 32, 4 * E, 4 * E, seed=163), rnd(B, 64, 2 * E, 2 * E, seed=164)
+    target = (rnd(B, 4, 4 * E, 4 * E, seed=165) > 0.3).float()
+    masks, iou, tok, obj = dec.predict_masks(image_embeddings=emb, image_pe=pe, sparse_prompt_embeddings=sparse,
+                                             dense_prompt_embeddings=torch.zeros_like(emb), repeat_image=False, cell_nums=None,
+                                             high_res_features=[f0, f1])
+    pos_weight = 2.0
+    loss = torch.nn.BCEWithLogitsLoss(pos_weight=torch.ones([1]) * pos_weight)(masks, target)
+    loss.backward()
+    out["dec_masks_sub"], out["dec_loss"] = sub(masks, 1024), np.array([loss.item()])
+    keep("dec_d_emb", emb.grad)
+    keep("dec_d_sparse", sparse.grad)
+    n_with_grad = 0
+    for k, p in dec.named_parameters():
+        if p.grad is not None and p.grad.abs().sum() > 0:
+            keep("dec_param." + k, p.grad)
+            n_with_grad += 1
+    meta["dec"] = {"B": B, "E": E, "P": Pp, "pos_weight": pos_weight, "seeds": [160, 161, 162, 163, 164, 165], "n_params_with_grad": n_with_grad}
+    return out, meta
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "grads":
+        o, meta = run_grads_case()
+        np.savez_compressed(os.path.join(OUT, "grads_t256.npz"), **o)
+        allmeta = json.load(open(os.path.join(OUT, "meta.json")))
+        allmeta["grads_t256"] = meta
+        json.dump(allmeta, open(os.path.join(OUT, "meta.json"), "w"), indent=1)
+        print("grads_t256.npz", os.path.getsize(os.path.join(OUT, "grads_t256.npz")), len(o), "arrays")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "evalseg":
         o, meta = run_eval_seg_case()
         np.savez_compressed(os.path.join(OUT, "eval_seg.npz"), **o)
@@ -394,6 +469,9 @@ def main():
     o, meta = run_eval_seg_case()
     np.savez_compressed(os.path.join(OUT, "eval_seg.npz"), **o)
     allmeta["eval_seg"] = meta
+    o, meta = run_grads_case()
+    np.savez_compressed(os.path.join(OUT, "grads_t256.npz"), **o)
+    allmeta["grads_t256"] = meta
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(allmeta, f, indent=1)
     for fn in sorted(os.listdir(OUT)):

@@ -1,0 +1,171 @@
+"""Gradient fixtures of the REFERENCE (tests/golden/grads_t256.npz, made by `make_golden.py grads`: `.grad` of every `memory_attention`
+and `sam_mask_decoder` parameter and of the inputs under torch.autograd, 2-slice toy problem, eval-mode dropout -- SURVEY.md 8(f) rank 2).
+
+  * CPU: autograd through the oracle reproduces them at fp32 round-off (pins the oracle as the gradient checker of test_backward_gpu.py);
+  * GPU: the HIP backward (`medical_sam2_amd.backward`, `training.bce_with_logits`) reproduces them within the 16-bit-operand tolerance.
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import sam2_oracle as O  # noqa: E402
+
+import medical_sam2_amd.weights as wts  # noqa: E402
+from helpers import load_meta, load_npz, sub  # noqa: E402
+
+DEV = "cuda"
+SUBN = 256
+
+
+@pytest.fixture(autouse=True)
+def _grad_on():
+    with torch.enable_grad():
+        yield
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def rel_sub(g, ref_sub):
+    a, b = torch.from_numpy(sub(g.detach().cpu(), SUBN)).double(), torch.from_numpy(np.asarray(ref_sub)).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def memattn_inputs(meta):
+    B, L, n_ptr = meta["B"], meta["L"], meta["n_ptr"]
+    s = meta["seeds"]
+    return (rnd(L, B, 256, seed=s[0]), rnd(L, B, 256, seed=s[1]), rnd(L + n_ptr, B, 64, seed=s[2]), rnd(L + n_ptr, B, 64, seed=s[3]),
+            rnd(L, B, 256, seed=s[4]), n_ptr)
+
+
+def dec_inputs(meta):
+    B, E, Pp = meta["B"], meta["E"], meta["P"]
+    s = meta["seeds"]
+    return (rnd(B, 256, E, E, seed=s[0]), rnd(1, 256, E, E, seed=s[1]), rnd(B, Pp, 256, seed=s[2]), rnd(B, 32, 4 * E, 4 * E, seed=s[3]),
+            rnd(B, 64, 2 * E, 2 * E, seed=s[4]), (rnd(B, 4, 4 * E, 4 * E, seed=s[5]) > 0.3).float())
+
+
+def test_oracle_autograd_matches_reference_gradients():
+    G, meta = load_npz("grads_t256.npz"), load_meta()["grads_t256"]
+    sd = wts.init_weights("hiera_t", 0)
+    cfg = O.model_config("hiera_t", 256)
+    # ---- memory attention
+    P = {k: v.clone().float().requires_grad_(k.startswith("memory_attention.")) for k, v in sd.items()}
+    curr, curr_pos, memory, memory_pos, dy, n_ptr = memattn_inputs(meta["memattn"])
+    curr.requires_grad_(True), memory.requires_grad_(True), memory_pos.requires_grad_(True)
+    y = O.memory_attention(P, cfg, curr, memory, curr_pos, memory_pos, n_ptr)
+    assert np.allclose(sub(y, 1024), G["memattn_out_sub"], rtol=1e-4, atol=1e-4)
+    y.backward(dy)
+    rep = {"d_curr": rel_sub(curr.grad, G["memattn_d_curr"]), "d_memory": rel_sub(memory.grad, G["memattn_d_memory"]),
+           "d_memory_pos": rel_sub(memory_pos.grad, G["memattn_d_memory_pos"])}
+    n = 0
+    for k in G:
+        if k.startswith("memattn_param."):
+            name = k[len("memattn_param."):]
+            g = P["memory_attention." + name].grad
+            st = meta["grad_stats"][k]
+            assert list(g.shape) == st["shape"], name
+            if st["abs_sum"] < 1e-3 * g.numel() ** 0.5 * 1e-3:        # identically-zero gradients (softmax key bias): absolute check
+                assert g.abs().sum().item() < 1e-2, name
+            else:
+                rep[name] = rel_sub(g, G[k])
+                assert abs(g.double().sum().item() - st["sum"]) <= 2e-3 * st["abs_sum"] + 1e-6, name
+            n += 1
+    assert n == meta["memattn"]["n_params"] == 106
+    worst = sorted(rep.items(), key=lambda kv: -kv[1])[:5]
+    assert worst[0][1] < 2e-3, worst
+    # ---- mask decoder under BCEWithLogitsLoss(pos_weight)
+    P = {k: v.clone().float().requires_grad_(k.startswith("sam_mask_decoder.")) for k, v in sd.items()}
+    emb, pe, sparse, f0, f1, target = dec_inputs(meta["dec"])
+    emb.requires_grad_(True), sparse.requires_grad_(True)
+    masks, _, _, _ = O.mask_decoder_predict(P, emb, pe, sparse, torch.zeros_like(emb), [f0, f1])
+    assert np.allclose(sub(masks, 1024), G["dec_masks_sub"], rtol=1e-4, atol=1e-4)
+    loss = torch.nn.BCEWithLogitsLoss(pos_weight=torch.ones([1]) * meta["dec"]["pos_weight"])(masks, target)
+    assert abs(loss.item() - float(G["dec_loss"][0])) < 1e-5
+    loss.backward()
+    rep = {"d_emb": rel_sub(emb.grad, G["dec_d_emb"]), "d_sparse": rel_sub(sparse.grad, G["dec_d_sparse"])}
+    n = 0
+    for k in G:
+        if k.startswith("dec_param."):
+            name = k[len("dec_param."):]
+            g = P["sam_mask_decoder." + name].grad
+            assert g is not None and list(g.shape) == meta["grad_stats"][k]["shape"], name
+            if not name.endswith("k_proj.bias"):                       # zero up to round-off: compared on the q-bias scale below
+                rep[name] = rel_sub(g, G[k])
+            else:
+                qn = "dec_param." + name.replace("k_proj", "q_proj")
+                assert np.abs(sub(g, SUBN) - G[k]).max() <= 1e-3 * np.abs(G[qn]).max() + 1e-9, name
+            n += 1
+    assert n == meta["dec"]["n_params_with_grad"]
+    worst = sorted(rep.items(), key=lambda kv: -kv[1])[:5]
+    assert worst[0][1] < 2e-3, worst
+
+
+@pytest.mark.gpu
+def test_hip_backward_matches_reference_gradients():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import medical_sam2_amd.backward as bwd
+    import medical_sam2_amd.build_sam as bs
+    import medical_sam2_amd.ops as ops
+    import medical_sam2_amd.training as tr
+    G, meta = load_npz("grads_t256.npz"), load_meta()["grads_t256"]
+    m = bs.build_sam2("sam2_hiera_t", device="cpu", hydra_overrides_extra=["++model.image_size=256"])
+    m.load_state_dict(wts.init_weights("hiera_t", 0), strict=True)
+    d = lambda t: t.detach().to(DEV)
+    with torch.no_grad():
+        # ---- memory attention
+        mod = m.memory_attention.to(DEV).eval()
+        curr, curr_pos, memory, memory_pos, dy, n_ptr = memattn_inputs(meta["memattn"])
+        dcurr, dmem, dmpos, grads = bwd.memory_attention_backward(mod, d(curr), d(curr_pos), d(memory), d(memory_pos), n_ptr, d(dy))
+        rep = {"d_curr": rel_sub(dcurr, G["memattn_d_curr"]), "d_memory": rel_sub(dmem, G["memattn_d_memory"]),
+               "d_memory_pos": rel_sub(dmpos, G["memattn_d_memory_pos"])}
+        assert len(grads) == 106
+        for name, g in grads.items():
+            k = "memattn_param." + name
+            st = meta["grad_stats"][k]
+            assert list(g.shape) == st["shape"], name
+            if st["abs_sum"] < 1e-6:
+                continue                                                # identically-zero reference gradient (softmax key bias)
+            rep[name] = rel_sub(g, G[k])
+        worst = sorted(rep.items(), key=lambda kv: -kv[1])[:5]
+        assert worst[0][1] < 4e-2, worst
+        # ---- mask decoder, loss = BCEWithLogitsLoss(pos_weight) from the HIP loss kernel
+        dec = m.sam_mask_decoder.to(DEV).eval()
+        emb, pe, sparse, f0, f1, target = dec_inputs(meta["dec"])
+        B, E = meta["dec"]["B"], meta["dec"]["E"]
+        tm = lambda t: d(t).permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()       # NCHW -> token-major
+        f0t, f1t = tm(f0).to(ops.OP16), tm(f1).to(ops.OP16)
+        masks, _, _, _ = dec.predict_masks_tokens(tm(emb), tm(pe), d(sparse), f0t, f1t, B, E, E)
+        loss, d_masks = tr.bce_with_logits(masks, d(target), meta["dec"]["pos_weight"])
+        assert abs(loss.item() - float(G["dec_loss"][0])) < 2e-3
+        want = {k[len("dec_param."):] for k in G if k.startswith("dec_param.")}
+
+        def report(d_src, d_sparse, grads, inv):
+            rep = {"d_emb": rel_sub(d_src.view(B, E * E, 256).permute(0, 2, 1).reshape(B, 256, E, E) * inv, G["dec_d_emb"]),
+                   "d_sparse": rel_sub(d_sparse * inv, G["dec_d_sparse"])}
+            assert want <= set(grads), sorted(want - set(grads))
+            for name in want:
+                k = "dec_param." + name
+                if name.endswith("k_proj.bias"):
+                    qn = "dec_param." + name.replace("k_proj", "q_proj")
+                    assert np.abs(sub(grads[name].cpu() * inv, SUBN) - G[k]).max() <= 5e-2 * np.abs(G[qn]).max() + 1e-9, name
+                else:
+                    rep[name] = rel_sub(grads[name] * inv, G[k])
+            return sorted(rep.items(), key=lambda kv: -kv[1])[:6]
+
+        plain = report(*bwd.mask_decoder_backward(dec, tm(emb), tm(pe), d(sparse), f0t, f1t, B, E, E, d_masks), 1.0)
+        # with the loss scale of training.decoder_finetune_step (the mean-reduced BCE gradient is ~1e-5 here, ~1e-6 at 1024^2: below
+        # fp16's normal range as a 16-bit GEMM operand)
+        scale = 2.0 ** (math.floor(math.log2(masks.numel() / meta["dec"]["pos_weight"])) - 4)
+        scaled = report(*bwd.mask_decoder_backward(dec, tm(emb), tm(pe), d(sparse), f0t, f1t, B, E, E, d_masks * scale), 1.0 / scale)
+        print("worst relative gradient errors, unscaled:", plain[:3], " loss-scaled:", scaled[:3])
+        assert plain[0][1] < 5e-2, plain
+        assert scaled[0][1] < 4e-2, scaled

@@ -42,7 +42,7 @@ DOC = {
     "msam2_convt2x2_scatter_grad": "Adjoint of the 2x2 pixel shuffle: the gradient of the ConvTranspose GEMM output as a 16-bit operand.",
     "msam2_bce_logits": "BCEWithLogitsLoss(pos_weight) value (accumulated into a zeroed scalar) and its gradient w.r.t. the logits, mean reduction\n(func_3d/function.py:69 criterion_G).",
     "msam2_adam_step": "One torch.optim.Adam step (no weight decay / amsgrad) on a flat fp32 parameter (train_3d.py:50).",
-    "msam2_adam_step_multi": "The same Adam step over `count` parameters (host arrays of device pointers and element counts), 24 per launch.",
+    "msam2_adam_step_multi": "The same Adam step over `count` parameters (host arrays of device pointers and element counts), 24 per launch;\ngradients are multiplied by grad_scale first (1 / loss scale).",
     "msam2_attention_small_bwd": "Backward of the two-way decoder's attention (transformer.py:239-263 under autograd; 8 heads of 16 / 32 channels) when one side has\n<= 32 tokens: dq / dk / dv (fp32, token-major) from 16-bit q / k / v and the fp32 upstream gradient, one workgroup per (batch, head).",
     "msam2_seg_counts": "Counts behind eval_seg (func_3d/utils.py:139-214, func_2d/utils.py:505-580): per threshold, batch element and class the\ninteger |pred>t & gt>t|, |pred>t|, |gt>t| in one pass; IoU / Dice follow on the host.",
     "msam2_non_overlap": "SAM2Base._apply_non_overlapping_constraints (sam2_base.py:812-830): keep the arg-max object per pixel, clamp the\nothers to <= -10.",
