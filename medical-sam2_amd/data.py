@@ -5,6 +5,14 @@ drop-in `SAM2VideoPredictor` and the device-side `eval_seg`.
     <root>/{Training,Test}/image/<case>/<i>.jpg        RGB slices, i = 0 .. T-1
     <root>/{Training,Test}/mask/<case>/<i>.npy         integer label maps (0 = background, k = object k), same indices
 
+The 2-D contract (`func_2d/dataset.py:16-100`, REFUGE optic-cup images with 7 raters):
+
+    <root>/{Training,Test}-400/<name>/<name>_cropped.jpg                     RGB fundus crop
+    <root>/{Training,Test}-400/<name>/<name>_seg_cup_<r>_cropped.jpg         rater r = 1 .. 7, grey level >= 0.5 = cup
+
+`REFUGEImages[i]` returns the reference's dictionary (`image` [3,S,S] in 0..1, `multi_rater` [7,1,S,S], `p_label`, `pt` (row, col) as
+`func_2d/utils.py:572-577` returns it, `mask` [1,out,out] majority vote resized, `mask_ori` [1,S,S], `image_meta_dict`).
+
 `BTCVVolumes[i]` returns the same dictionary the reference's `BTCV.__getitem__` does (`image` [T,3,S,S] in 0..255, `label`
 {frame: {obj: [1,S,S] int mask}}, `bbox` {frame: {obj: [4]}} or `pt` / `p_label`, `image_meta_dict`): leading / trailing slices
 without any label are cropped, the volume is cut to `video_length` slices (default: a quarter of the labelled range, like the
@@ -106,6 +114,69 @@ class BTCVVolumes:
         else:
             out["pt"], out["p_label"] = pt_dict, plabel_dict
         return out
+
+
+def random_click_2d(mask: np.ndarray, point_label: int = 1, rng: Optional[np.random.RandomState] = None):
+    """func_2d/utils.py:572-577: a random position of the maximum value of a (soft) mask as (label, [row, col]); label 0 when the
+    mask is empty."""
+    max_label = mask.max() if mask.size else 0
+    if round(float(max_label)) == 0:
+        point_label = round(float(max_label))
+    indices = np.argwhere(mask == max_label)
+    r = (rng or np.random).randint(len(indices))
+    return point_label, indices[r]
+
+
+class REFUGEImages:
+    """`func_2d/dataset.py:16-100` with the transform of train_2d.py:59-67 (Resize((S, S)) + ToTensor) built in."""
+    N_RATERS = 7
+
+    def __init__(self, data_path: str, image_size: int = 1024, out_size: int = 1024, mode: str = "Training", prompt: str = "click",
+                 seed: Optional[int] = None):
+        self.data_path, self.mode, self.prompt, self.img_size, self.mask_size = data_path, mode, prompt, image_size, out_size
+        self.rng = np.random.RandomState(seed) if seed is not None else None
+        base = os.path.join(data_path, mode + "-400")
+        self.subfolders = sorted(os.path.join(base, f) for f in os.listdir(base) if os.path.isdir(os.path.join(base, f)))
+
+    def __len__(self):
+        return len(self.subfolders)
+
+    def __getitem__(self, index: int) -> Dict:
+        from PIL import Image
+        sub = self.subfolders[index]
+        name = os.path.basename(sub)
+        S = self.img_size
+        to_tensor = lambda im: torch.from_numpy(np.asarray(im.resize((S, S), Image.BILINEAR), dtype=np.float32) / 255.0)
+        img = to_tensor(Image.open(os.path.join(sub, name + "_cropped.jpg")).convert("RGB")).permute(2, 0, 1).contiguous()
+        raters = [(to_tensor(Image.open(os.path.join(sub, f"{name}_seg_cup_{r}_cropped.jpg")).convert("L")) >= 0.5).float()[None]
+                  for r in range(1, self.N_RATERS + 1)]
+        multi = torch.stack(raters, dim=0)                                      # [7, 1, S, S]
+        out = {"image": img, "multi_rater": multi, "image_meta_dict": {"filename_or_obj": name}}
+        if self.prompt == "click":
+            mean = multi.mean(dim=0)                                             # [1, S, S] agreement in 0..1
+            out["p_label"], out["pt"] = random_click_2d(mean.squeeze(0).numpy(), 1, self.rng)
+            ori = (mean >= 0.5).float()
+            small = torch.nn.functional.interpolate(ori.unsqueeze(0), size=(self.mask_size, self.mask_size), mode="bilinear",
+                                                    align_corners=False).mean(dim=0)
+            out["mask"], out["mask_ori"] = (small >= 0.5).float(), ori
+        return out
+
+
+def write_synthetic_refuge_case(root: str, name: str, size: int = 128, seed: int = 0, mode: str = "Training"):
+    """One case in the REFUGE layout: a blob image and 7 rater masks that disagree at the rim (discs of slightly different radius)."""
+    from PIL import Image
+    from . import synthetic as syn
+    rng = np.random.RandomState(seed)
+    img, (cx, cy) = syn.blob_image(seed, size)                                # 0..255, centre of the brightest blob
+    d = os.path.join(root, mode + "-400", name)
+    os.makedirs(d, exist_ok=True)
+    Image.fromarray(img.clamp(0, 255).permute(1, 2, 0).numpy().astype(np.uint8)).save(os.path.join(d, name + "_cropped.jpg"), quality=95)
+    ys, xs = np.mgrid[0:size, 0:size]
+    r0 = size / 8.0
+    for r in range(1, REFUGEImages.N_RATERS + 1):
+        rad = r0 * (0.85 + 0.3 * rng.rand())
+        m = (((xs - cx) ** 2 + (ys - cy) ** 2) <= rad ** 2).astype(np.uint8) * 255
+        Image.fromarray(m).save(os.path.join(d, f"{name}_seg_cup_{r}_cropped.jpg"), quality=95)
 
 
 def write_synthetic_case(root: str, case: str, n_slices: int = 8, size: int = 128, n_objects: int = 2, seed: int = 0, mode: str = "Test"):

@@ -52,6 +52,32 @@ def test_btcv_layout_roundtrip(tmp_path):
         D.BTCVVolumes(root, prompt="scribble")
 
 
+def test_refuge_layout_roundtrip(tmp_path):
+    """func_2d/dataset.py:16-100: keys, shapes and value ranges of a REFUGE sample; the click lies where all raters agree; the
+    majority-vote masks at both sizes."""
+    root = str(tmp_path)
+    for i in range(3):
+        D.write_synthetic_refuge_case(root, f"g{i:04d}", size=96, seed=i)
+    ds = D.REFUGEImages(root, image_size=64, out_size=32, mode="Training", prompt="click", seed=5)
+    assert len(ds) == 3
+    s = ds[1]
+    assert set(s) == {"image", "multi_rater", "p_label", "pt", "mask", "mask_ori", "image_meta_dict"}
+    assert s["image"].shape == (3, 64, 64) and 0.0 <= s["image"].min() and s["image"].max() <= 1.0
+    assert s["multi_rater"].shape == (7, 1, 64, 64) and set(s["multi_rater"].unique().tolist()) <= {0.0, 1.0}
+    assert s["mask_ori"].shape == (1, 64, 64) and s["mask"].shape == (1, 32, 32)
+    assert s["image_meta_dict"]["filename_or_obj"] == "g0001" and s["p_label"] == 1
+    mean = s["multi_rater"].mean(dim=0)[0]
+    r, c = int(s["pt"][0]), int(s["pt"][1])                            # (row, col), func_2d/utils.py:572-577
+    assert mean[r, c] == mean.max() and s["mask_ori"][0, r, c] == 1
+    assert torch.equal(s["mask_ori"], (s["multi_rater"].mean(dim=0) >= 0.5).float())
+    # raters disagree at the rim only: the vote is strictly between "all" and "any"
+    any_, all_ = (mean > 0).sum().item(), (mean == 1).sum().item()
+    assert all_ < s["mask_ori"].sum().item() < any_
+    assert 0 < s["mask"].sum().item() < 32 * 32
+    lab, _ = D.random_click_2d(np.zeros((4, 4), dtype=np.float32))
+    assert lab == 0
+
+
 @pytest.mark.gpu
 def test_validation_flow_on_synthetic_case(tmp_path):
     if not torch.cuda.is_available():
