@@ -1,12 +1,14 @@
 """First slice of the backward pass ("fused LN/MLP backward"): gradients of nn.LayerNorm, nn.Linear and
 the Linear-act-Linear MLP (sam2_utils.py:108-132; hieradet.py:96-106,160-166; memory_attention.py:43-47,96) on the HIP path.  The
 gradient GEMMs are the forward GEMM kernel on transposed operands (`ops.gemm(dy, W^T)` / `ops.gemm(dy^T, x^T)`), the rest are the
-kernels of csrc/backward.hip.  Attention backward (flash-style dQ/dK/dV) is not built yet, so there is no end-to-end training step.
+kernels of csrc/backward.hip.  The attention backward is flash-style for head dims 64-256 (csrc/attention_bwd.hip), fused for the decoder's small heads, materialised otherwise.
 
 Operands are 16-bit (ops.OP16) like the forward: with the default fp16 build callers must keep gradients in fp16 range (loss scaling);
 the bf16 build has fp32's range.  Parity: tests/test_backward_gpu.py against torch.autograd on the fp32 oracle primitives.
 """
 from __future__ import annotations
+
+import os
 
 from typing import Optional, Tuple
 
@@ -84,10 +86,12 @@ def mlp_backward(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.
 
 def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: torch.Tensor, scale: Optional[float] = None):
     """Gradients of o = softmax(q k^T * scale) v for 16-bit q [B,H,Lq,D], k/v [B,H,Lk,D], upstream do [B,H,Lq,D] (any float type).
-    MATERIALISED form: per (batch, head) the [Lq, Lk] scores live in HBM (fp32 S, 16-bit P / dS: 0.5 GB at 4096 x 16384), which
-    288 GB affords; the five products (S = q k^T, dV = P^T dO, dP = dO V^T, dQ = dS K, dK = dS^T Q) run on the forward GEMM kernel and
-    the softmax and its Jacobian on two row kernels.  A flash-style (recomputing, O(L) memory) backward is the next step.
-    Any Lq / Lk (reduction dims are zero-padded to multiples of 8); D % 8 == 0.  Returns (dq, dk, dv) in fp32, shaped like q / k / v."""
+    Returns (dq, dk, dv) in fp32, shaped like q / k / v.
+    Head dims 64 / 96 / 128 / 256: FLASH-STYLE (`msam2_attention_bwd`, csrc/attention_bwd.hip) -- the forward is re-run for O, then
+    three recomputing passes (dQ + log-sum-exp, dK, dV) keep every score tile in registers; O(L) memory.
+    Other head dims (D % 8 == 0), or MSAM2_MATERIALISED_BWD=1: MATERIALISED form -- per (batch, head) the [Lq, Lk] scores live in
+    HBM (fp32 S, 16-bit P / dS), the five products run on the forward GEMM kernel and the softmax and its Jacobian on two row
+    kernels (reduction dims zero-padded to multiples of 8)."""
     B, H, Lq, D = q.shape
     Lk = k.shape[2]
     _req(q.dtype == OP16 and k.dtype == OP16 and v.dtype == OP16, "attention_backward: 16-bit q, k, v")
@@ -96,6 +100,18 @@ def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: to
     dq = torch.empty(B, H, Lq, D, dtype=F32, device=q.device)
     dk = torch.empty(B, H, Lk, D, dtype=F32, device=q.device)
     dv = torch.empty(B, H, Lk, D, dtype=F32, device=q.device)
+    if D in (64, 96, 128, 256) and not os.environ.get("MSAM2_MATERIALISED_BWD"):
+        from .modeling.common import attn_splits
+        q, k, v = (t if t.stride(3) == 1 and all(st % 8 == 0 for st in t.stride()[:3]) else t.contiguous() for t in (q, k, v))
+        o = ops.attention(q, k, v, scale=scale, splits=attn_splits(B, H, Lq, Lk))
+        g = do.to(F32)
+        g = g if g.stride(3) == 1 and all(st % 4 == 0 for st in g.stride()[:3]) else g.contiguous()
+        nbytes = lib().msam2_attention_bwd_workspace_bytes(B, H, Lq, D)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+        check(lib().msam2_attention_bwd(_p(q), ops._strides3(q), _p(k), ops._strides3(k), _p(v), ops._strides3(v), _p(o), ops._strides3(o),
+                                        _p(g), ops._strides3(g), _p(dq), ops._strides3(dq), _p(dk), ops._strides3(dk), _p(dv),
+                                        ops._strides3(dv), _p(ws), nbytes, B, H, Lq, Lk, D, float(scale), _stream()))
+        return dq, dk, dv
     # P / dS are GEMM operands with the keys as reduction dim: rows padded to a multiple of 8 keys with zeros (memory banks hold
     # 4 tokens per object pointer, so Lk is only a multiple of 4)
     Lkp = -(-Lk // 8) * 8

@@ -1,0 +1,373 @@
+// Flash-style (O(L) memory) attention backward for gfx950: dQ, dK, dV of softmax(Q K^T * scale) V without materialising the
+// [Lq, Lk] scores.  Replaces torch.autograd of F.scaled_dot_product_attention at transformer.py:318 (RoPEAttention of the memory
+// attention, D = 256) and hieradet.py:72-76 (global Hiera attention, D = 64 / 96 / 128) in the training loops
+// (func_3d/function.py:182-191, func_2d/function.py:246-259).
+//
+// One kernel structure, three roles.  As in the forward kernel (attention.hip) a lane OWNS one column of the score tile: its row
+// of the owner tensor is held in registers as the MFMA B operand, the other tensor is streamed through LDS in 32-row tiles, and
+// the accumulator of the first product is fed straight back as the B operand of the second one (A = transposed tile fragments
+// via ds_read_b64_tr_b16), so no score ever leaves the registers:
+//
+//   role   owner (regs)   streamed (LDS)   first products                      second product             statistics
+//   DQ     q, dO          k, v             S^T = K Q^T,  dP^T = V dO^T         dQ^T += K^T  w             online softmax per lane;
+//                                                                                                         w = 2^(s-m) (dP - delta)
+//   DK     k, v           q, dO            S   = Q K^T,  dP   = dO V^T         dK^T += Q^T  dS            lse / delta per streamed row
+//   DV     k              q, dO            S   = Q K^T                         dV^T += dO^T P             lse per streamed row
+//
+// delta = rowsum(dO o O) comes from a pre-pass that also converts dO to the 16-bit operand type; the DQ pass runs first and
+// writes the log-sum-exp of every query row for the other two (the forward kernels do not keep it).  No atomics: every output row
+// has exactly one owner.  Cost: 8 score-tile products against the minimum of 5 -- the price of three simple passes.
+#include "common.h"
+
+namespace {
+
+struct AttnBwdParams {
+  const op16 *q, *k, *v, *do16;                       // do16: [B, H, Lq, D] contiguous 16-bit copy of dO (workspace)
+  int64_t q_bs, q_hs, q_ts, k_bs, k_hs, k_ts, v_bs, v_hs, v_ts;
+  const float* delta;                                 // [B, H, Lq]
+  float* lse;                                         // [B, H, Lq], log2 domain
+  float *dq, *dk, *dv;
+  int64_t dq_bs, dq_hs, dq_ts, dk_bs, dk_hs, dk_ts, dv_bs, dv_hs, dv_ts;
+  int B, H, Lq, Lk;
+  float scale_log2, scale;
+};
+
+constexpr int ROLE_DQ = 0, ROLE_DK = 1, ROLE_DV = 2;
+
+template <int D>
+struct BwdCfg {
+  static constexpr int BK = 32;
+  static constexpr int KS = D * 2 + 16;                                  // slot-1 tile row stride (bytes)
+  static constexpr int VS = D * 2 + (((D * 2) % 128 == 64) ? 0 : 64);    // slot-2 tile row stride: VS % 128 == 64
+  static constexpr int STAGE = BK * (KS + VS);
+  static constexpr int STATS = 2 * 2 * BK * 4;                           // (lse, delta) of the streamed rows, double buffered
+  static constexpr int LDS_BYTES = 2 * STAGE + STATS;
+};
+
+// delta[row] = sum_d dO[row][d] * O[row][d];  do16[row] = (op16) dO[row].  One wave per row.
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const float* __restrict__ d_o, int64_t do_bs, int64_t do_hs, int64_t do_ts,
+                                                            const op16* __restrict__ o, int64_t o_bs, int64_t o_hs, int64_t o_ts,
+                                                            op16* __restrict__ do16, float* __restrict__ delta, int H, int Lq, int64_t rows) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t t = row % Lq, bh = row / Lq;
+  const int64_t b = bh / H, h = bh % H;
+  float acc = 0.f;
+  if (lane * 4 < D) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(d_o + b * do_bs + h * do_hs + t * do_ts + lane * 4);
+    const op16x4 ov = *reinterpret_cast<const op16x4*>(o + b * o_bs + h * o_hs + t * o_ts + lane * 4);
+    op16x4 g16;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc += g[e] * op2f(ov[e]);
+      g16[e] = f2op(g[e]);
+    }
+    *reinterpret_cast<op16x4*>(do16 + row * D + lane * 4) = g16;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) delta[row] = acc;
+}
+
+template <int D, int NW, int ROLE>
+__global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
+  using C = BwdCfg<D>;
+  constexpr int NT = NW * 64;
+  constexpr int DSTEPS = D / 16;   // k-steps of the first products
+  constexpr int DBLK = D / 32;     // 32-row blocks of the transposed output
+  constexpr int CPR = D / 8;       // 16-byte chunks per tile row
+  constexpr int CHUNKS = C::BK * CPR;
+  constexpr int PER = (CHUNKS + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* stats = reinterpret_cast<float*>(smem + 2 * C::STAGE);          // [2 buffers][lse 32 | delta 32]
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int64_t bh = (int64_t)b * p.H + head;
+
+  // ---- roles: owner rows (registers) and streamed rows (LDS slots 1 / 2)
+  const int n_own = ROLE == ROLE_DQ ? p.Lq : p.Lk;
+  const int n_str = ROLE == ROLE_DQ ? p.Lk : p.Lq;
+  const op16* qb = p.q + b * p.q_bs + head * p.q_hs;
+  const op16* kb = p.k + b * p.k_bs + head * p.k_hs;
+  const op16* vb = p.v + b * p.v_bs + head * p.v_hs;
+  const op16* gb = p.do16 + bh * p.Lq * D;
+  const op16* own1 = ROLE == ROLE_DQ ? qb : kb;
+  const int64_t own1_ts = ROLE == ROLE_DQ ? p.q_ts : p.k_ts;
+  const op16* own2 = ROLE == ROLE_DQ ? gb : vb;
+  const int64_t own2_ts = ROLE == ROLE_DQ ? (int64_t)D : p.v_ts;
+  const op16* str1 = ROLE == ROLE_DQ ? kb : qb;
+  const int64_t str1_ts = ROLE == ROLE_DQ ? p.k_ts : p.q_ts;
+  const op16* str2 = ROLE == ROLE_DQ ? vb : gb;
+  const int64_t str2_ts = ROLE == ROLE_DQ ? p.v_ts : (int64_t)D;
+
+  // ---- this lane's owner row -> B-operand fragments kept in registers
+  const int oi = blockIdx.x * (NW * 32) + wave * 32 + r;
+  const bool ovalid = oi < n_own;
+  op16x8 f1[DSTEPS], f2[ROLE == ROLE_DV ? 1 : DSTEPS];
+#pragma unroll
+  for (int s = 0; s < DSTEPS; ++s) {
+    uint4 a = make_uint4(0, 0, 0, 0), c = make_uint4(0, 0, 0, 0);
+    if (ovalid) {
+      a = *reinterpret_cast<const uint4*>(own1 + (int64_t)oi * own1_ts + s * 16 + h * 8);
+      if constexpr (ROLE != ROLE_DV) c = *reinterpret_cast<const uint4*>(own2 + (int64_t)oi * own2_ts + s * 16 + h * 8);
+    }
+    f1[s] = __builtin_bit_cast(op16x8, a);
+    if constexpr (ROLE != ROLE_DV) f2[s] = __builtin_bit_cast(op16x8, c);
+  }
+  const float delta_own = (ROLE == ROLE_DQ && ovalid) ? p.delta[bh * p.Lq + oi] : 0.f;
+
+  const int tiles = (n_str + C::BK - 1) / C::BK;
+  uint4 r1[PER], r2[PER];
+  float rs_lse = 0.f, rs_del = 0.f;
+  auto gload = [&](int tile) {
+    const int row0 = tile * C::BK;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid + i * NT;
+      uint4 a = make_uint4(0, 0, 0, 0), g = make_uint4(0, 0, 0, 0);
+      if (c < CHUNKS) {
+        const int row = row0 + c / CPR, dc = (c % CPR) * 8;
+        if (row < n_str) {
+          a = *reinterpret_cast<const uint4*>(str1 + (int64_t)row * str1_ts + dc);
+          g = *reinterpret_cast<const uint4*>(str2 + (int64_t)row * str2_ts + dc);
+        }
+      }
+      r1[i] = a;
+      r2[i] = g;
+    }
+    if (ROLE != ROLE_DQ && tid < C::BK) {
+      const int row = row0 + tid;
+      rs_lse = row < n_str ? p.lse[bh * p.Lq + row] : INFINITY;           // 2^(s - inf) = 0: rows past the end contribute nothing
+      rs_del = row < n_str ? p.delta[bh * p.Lq + row] : 0.f;
+    }
+  };
+  auto lstore = [&](int buf) {
+    unsigned char* base = smem + buf * C::STAGE;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid + i * NT;
+      if (c < CHUNKS) {
+        const int row = c / CPR, dc = (c % CPR) * 16;
+        *reinterpret_cast<uint4*>(base + row * C::KS + dc) = r1[i];
+        *reinterpret_cast<uint4*>(base + C::BK * C::KS + row * C::VS + dc) = r2[i];
+      }
+    }
+    if (ROLE != ROLE_DQ && tid < C::BK) {
+      stats[buf * 2 * C::BK + tid] = rs_lse;
+      stats[buf * 2 * C::BK + C::BK + tid] = rs_del;
+    }
+  };
+
+  f32x16 acc[DBLK];
+#pragma unroll
+  for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // per-lane LDS byte offsets: row reads (A operand of the first products) and transposed reads (A operand of the second)
+  const int row1_off = r * C::KS + h * 16;                               // + st*32 per k-step
+  const int row2_off = r * C::VS + h * 16;
+  const int li = lane & 15;
+  const int tr_row = 4 * h + (li >> 2), tr_col = (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
+  constexpr int TRS = ROLE == ROLE_DV ? C::VS : C::KS;                   // stride of the slot the second product transposes
+  const int tr_off = tr_row * TRS + tr_col;                              // + (16 st) rows + dblk*64 B; second half + 8 rows
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  int cur = 0;
+  for (int tile = 0; tile < tiles; ++tile) {
+    if (tile + 1 < tiles) gload(tile + 1);
+    const unsigned char* base1 = smem + cur * C::STAGE;
+    const unsigned char* base2 = base1 + C::BK * C::KS;
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+    for (int st = 0; st < DSTEPS; ++st) {
+      const op16x8 a = *reinterpret_cast<const op16x8*>(base1 + row1_off + st * 32);
+      s = MSAM2_MFMA_32x32x16(a, f1[st], s, 0, 0, 0);
+    }
+    if constexpr (ROLE != ROLE_DV) {
+#pragma unroll
+      for (int st = 0; st < DSTEPS; ++st) {
+        const op16x8 a = *reinterpret_cast<const op16x8*>(base2 + row2_off + st * 32);
+        dp = MSAM2_MFMA_32x32x16(a, f2[st], dp, 0, 0, 0);
+      }
+    }
+    // streamed row of register e: (e&3) + 8*(e>>2) + 4*h
+    op16x8 wf[2];
+    if constexpr (ROLE == ROLE_DQ) {
+      const int row0 = tile * C::BK;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        s[e] = (row < n_str) ? s[e] * p.scale_log2 : -INFINITY;
+        mx = fmaxf(mx, s[e]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      if (__any(m_new > m_run)) {
+        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[d][e] *= alpha;
+        m_run = m_new;
+      }
+      float psum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pe = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(s[e] - m_run);
+        psum += pe;
+        wf[e >> 3][e & 7] = f2op(pe * (dp[e] - delta_own));
+      }
+      l_run += psum;
+    } else {
+      const float* st_lse = stats + cur * 2 * C::BK;
+      const float* st_del = st_lse + C::BK;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const float pe = __builtin_amdgcn_exp2f(s[e] * p.scale_log2 - st_lse[row]);
+        wf[e >> 3][e & 7] = f2op(ROLE == ROLE_DV ? pe : pe * (dp[e] - st_del[row]));
+      }
+    }
+    // out^T[d][owner] += tile^T[d][row] w[row][owner]
+    const unsigned char* trb = (ROLE == ROLE_DV ? base2 : base1) + tr_off;
+#pragma unroll
+    for (int d = 0; d < DBLK; ++d) {
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const unsigned char* a0 = trb + (16 * st) * TRS + d * 64;
+        const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0));
+        const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0 + 8 * TRS));
+        typedef __attribute__((ext_vector_type(8))) short short8_t;
+        short8_t t8;
+        t8[0] = lo[0]; t8[1] = lo[1]; t8[2] = lo[2]; t8[3] = lo[3];
+        t8[4] = hi[0]; t8[5] = hi[1]; t8[6] = hi[2]; t8[7] = hi[3];
+        acc[d] = MSAM2_MFMA_32x32x16(__builtin_bit_cast(op16x8, t8), wf[st], acc[d], 0, 0, 0);
+      }
+    }
+    if (tile + 1 < tiles) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: fp32 rows of the owner (lane = owner row, registers = 4 consecutive channels per group)
+  float factor = 1.f;
+  if (ROLE == ROLE_DQ) {
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    factor = p.scale / l_tot;
+    if (ovalid && h == 0) p.lse[bh * p.Lq + oi] = m_run + __log2f(l_tot);
+  } else if (ROLE == ROLE_DK) {
+    factor = p.scale;
+  }
+  if (!ovalid) return;
+  float* out = ROLE == ROLE_DQ ? p.dq + b * p.dq_bs + head * p.dq_hs + (int64_t)oi * p.dq_ts
+             : ROLE == ROLE_DK ? p.dk + b * p.dk_bs + head * p.dk_hs + (int64_t)oi * p.dk_ts
+                               : p.dv + b * p.dv_bs + head * p.dv_hs + (int64_t)oi * p.dv_ts;
+#pragma unroll
+  for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = acc[d][4 * g + e] * factor;
+      *reinterpret_cast<f32x4*>(out + d * 32 + 8 * g + 4 * h) = w;
+    }
+}
+
+template <int D, int NW, int ROLE>
+void launch_role(const AttnBwdParams& p, hipStream_t s) {
+  using C = BwdCfg<D>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)attn_bwd_kernel<D, NW, ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    attr_set = true;
+  }
+  const int n_own = ROLE == ROLE_DQ ? p.Lq : p.Lk;
+  dim3 grid(cdiv(n_own, NW * 32), p.H, p.B);
+  hipLaunchKernelGGL((attn_bwd_kernel<D, NW, ROLE>), grid, dim3(NW * 64), C::LDS_BYTES, s, p);
+}
+
+// workgroup size by fill: 4 waves per workgroup unless that leaves CUs idle
+template <int D, int ROLE>
+void launch_fill(const AttnBwdParams& p, hipStream_t s) {
+  const int64_t n_own = ROLE == ROLE_DQ ? p.Lq : p.Lk;
+  if (cdiv(n_own, (int64_t)128) * p.H * p.B >= 256 || n_own <= 32) launch_role<D, 4, ROLE>(p, s);
+  else launch_role<D, 2, ROLE>(p, s);
+}
+
+template <int D>
+int launch_all(const AttnBwdParams& p, const float* d_o, const int64_t* gs, const op16* o, const int64_t* os, op16* do16, float* delta,
+               hipStream_t s) {
+  const int64_t rows = (int64_t)p.B * p.H * p.Lq;
+  hipLaunchKernelGGL((attn_bwd_prep_kernel<D>), dim3((unsigned)cdiv(rows, (int64_t)4)), dim3(256), 0, s, d_o, gs[0], gs[1], gs[2], o, os[0], os[1],
+                     os[2], do16, delta, p.H, p.Lq, rows);
+  launch_fill<D, ROLE_DQ>(p, s);
+  launch_fill<D, ROLE_DK>(p, s);
+  launch_fill<D, ROLE_DV>(p, s);
+  return msam2_check_launch("attention_bwd");
+}
+
+}  // namespace
+
+extern "C" size_t msam2_attention_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Lq, int64_t D) {
+  return (size_t)(B * H * Lq) * (size_t)(D * sizeof(op16) + 2 * sizeof(float));
+}
+
+// q / k / v / o: 16-bit, element strides {batch, head, token}, channels contiguous; d_o fp32 with its own strides; dq / dk / dv fp32
+// outputs with their own strides (token stride a multiple of 4 elements, 16-byte aligned rows).  o is the forward's output for the
+// same q, k, v (msam2_attention_fwd).  workspace: msam2_attention_bwd_workspace_bytes.
+extern "C" int msam2_attention_bwd(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides, const void* v,
+                                   const int64_t* v_strides, const void* o, const int64_t* o_strides, const float* d_o,
+                                   const int64_t* do_strides, float* dq, const int64_t* dq_strides, float* dk, const int64_t* dk_strides,
+                                   float* dv, const int64_t* dv_strides, void* workspace, size_t workspace_bytes, int64_t B, int64_t H,
+                                   int64_t Lq, int64_t Lk, int64_t D, float scale, void* stream) {
+  MSAM2_REQUIRE(q && k && v && o && d_o && dq && dk && dv && workspace, "attention_bwd: null pointer");
+  MSAM2_REQUIRE(q_strides && k_strides && v_strides && o_strides && do_strides && dq_strides && dk_strides && dv_strides,
+                "attention_bwd: null strides");
+  MSAM2_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attention_bwd: empty problem");
+  MSAM2_REQUIRE(B <= 65535 && H <= 65535 && Lq < (1ll << 31) && Lk < (1ll << 31), "attention_bwd: problem too large");
+  MSAM2_REQUIRE(D == 64 || D == 96 || D == 128 || D == 256, "attention_bwd: head dim %lld not in {64, 96, 128, 256}", (long long)D);
+  MSAM2_REQUIRE(workspace_bytes >= msam2_attention_bwd_workspace_bytes(B, H, Lq, D), "attention_bwd: workspace too small");
+  const int64_t* in_strides[4] = {q_strides, k_strides, v_strides, o_strides};
+  const void* in_ptrs[4] = {q, k, v, o};
+  for (int i = 0; i < 4; ++i)
+    MSAM2_REQUIRE(in_strides[i][2] % 8 == 0 && in_strides[i][1] % 8 == 0 && in_strides[i][0] % 8 == 0 && ((uintptr_t)in_ptrs[i] & 15) == 0,
+                  "attention_bwd: 16-bit operand %d needs 16-byte aligned rows", i);
+  const int64_t* f_strides[4] = {do_strides, dq_strides, dk_strides, dv_strides};
+  const void* f_ptrs[4] = {d_o, dq, dk, dv};
+  for (int i = 0; i < 4; ++i)
+    MSAM2_REQUIRE(f_strides[i][2] % 4 == 0 && f_strides[i][1] % 4 == 0 && f_strides[i][0] % 4 == 0 && ((uintptr_t)f_ptrs[i] & 15) == 0,
+                  "attention_bwd: fp32 tensor %d needs 16-byte aligned rows", i);
+  AttnBwdParams p;
+  p.q = (const op16*)q; p.k = (const op16*)k; p.v = (const op16*)v;
+  p.q_bs = q_strides[0]; p.q_hs = q_strides[1]; p.q_ts = q_strides[2];
+  p.k_bs = k_strides[0]; p.k_hs = k_strides[1]; p.k_ts = k_strides[2];
+  p.v_bs = v_strides[0]; p.v_hs = v_strides[1]; p.v_ts = v_strides[2];
+  op16* do16 = (op16*)workspace;
+  float* delta = (float*)((char*)workspace + (size_t)(B * H * Lq) * D * sizeof(op16));
+  p.do16 = do16; p.delta = delta; p.lse = delta + B * H * Lq;
+  p.dq = dq; p.dk = dk; p.dv = dv;
+  p.dq_bs = dq_strides[0]; p.dq_hs = dq_strides[1]; p.dq_ts = dq_strides[2];
+  p.dk_bs = dk_strides[0]; p.dk_hs = dk_strides[1]; p.dk_ts = dk_strides[2];
+  p.dv_bs = dv_strides[0]; p.dv_hs = dv_strides[1]; p.dv_ts = dv_strides[2];
+  p.B = (int)B; p.H = (int)H; p.Lq = (int)Lq; p.Lk = (int)Lk;
+  p.scale = scale; p.scale_log2 = scale * 1.4426950408889634f;
+  hipStream_t s = (hipStream_t)stream;
+  switch (D) {
+    case 64: return launch_all<64>(p, d_o, do_strides, (const op16*)o, o_strides, do16, delta, s);
+    case 96: return launch_all<96>(p, d_o, do_strides, (const op16*)o, o_strides, do16, delta, s);
+    case 128: return launch_all<128>(p, d_o, do_strides, (const op16*)o, o_strides, do16, delta, s);
+    default: return launch_all<256>(p, d_o, do_strides, (const op16*)o, o_strides, do16, delta, s);
+  }
+}

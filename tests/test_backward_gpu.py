@@ -107,9 +107,11 @@ def test_mlp_backward(mods, M, C, Hd, act):
     assert rel(dw2, w2.grad) < tol and rel(db2, b2.grad) < 1e-5
 
 
-@pytest.mark.parametrize("B,H,Lq,Lk,D", [(1, 1, 256, 1024, 256), (2, 2, 128, 128, 96), (1, 1, 4096, 4104, 256), (1, 4, 64, 200, 64), (2, 1, 256, 516, 256), (1, 2, 100, 77, 32)])
+@pytest.mark.parametrize("B,H,Lq,Lk,D", [(1, 1, 256, 1024, 256), (2, 2, 128, 128, 96), (1, 1, 4096, 4104, 256), (1, 4, 64, 200, 64), (2, 1, 256, 516, 256), (1, 2, 100, 77, 32),
+                                         (1, 2, 100, 77, 64), (2, 3, 33, 300, 128), (1, 1, 31, 31, 256), (1, 8, 256, 256, 96)])
 def test_attention_backward(mods, B, H, Lq, Lk, D):
-    """materialised attention backward (memory-attention / Hiera-global shapes incl. object-pointer tokens) against autograd"""
+    """attention backward (flash-style for head dims 64-256, materialised otherwise; memory-attention / Hiera-global shapes incl.
+    object-pointer tokens and ragged tails) against autograd"""
     B_, ops = mods
     q16 = lambda t: t.to(ops.OP16)
     q = q16(rnd(B, H, Lq, D, seed=20)).float().requires_grad_(True)
@@ -121,6 +123,25 @@ def test_attention_backward(mods, B, H, Lq, Lk, D):
     dq, dk, dv = B_.attention_backward(d(q), d(k), d(v), do.to(DEV))
     assert dq.shape == q.shape and dk.shape == k.shape and dv.shape == v.shape
     assert rel(dv, v.grad) < 3e-3 and rel(dq, q.grad) < 6e-3 and rel(dk, k.grad) < 6e-3, (rel(dq, q.grad), rel(dk, k.grad), rel(dv, v.grad))
+
+
+def test_attention_backward_flash_strided_and_materialised(mods, monkeypatch):
+    """Token-major [B, L, H*D] storage viewed as [B, H, L, D] (how the projections leave q / k / v), and the materialised path
+    forced by MSAM2_MATERIALISED_BWD on the same problem: both against autograd."""
+    B_, ops = mods
+    B, H, Lq, Lk, D = 2, 2, 200, 333, 64
+    mk = lambda L, seed: rnd(B, L, H * D, seed=seed).to(ops.OP16)
+    q, k, v = mk(Lq, 24), mk(Lk, 25), mk(Lk, 26)
+    do = rnd(B, Lq, H * D, seed=27)
+    heads = lambda t: t.view(B, -1, H, D).permute(0, 2, 1, 3)
+    qr, kr, vr = (heads(t).float().requires_grad_(True) for t in (q, k, v))
+    O.softmax_attention(qr, kr, vr).backward(heads(do))
+    for forced in (False, True):
+        if forced:
+            monkeypatch.setenv("MSAM2_MATERIALISED_BWD", "1")
+        dq, dk, dv = B_.attention_backward(heads(q.to(DEV)), heads(k.to(DEV)), heads(v.to(DEV)), heads(do.to(DEV)))
+        errs = (rel(dq, qr.grad), rel(dk, kr.grad), rel(dv, vr.grad))
+        assert max(errs) < 6e-3, (forced, errs)
 
 
 def test_memory_attention_layer_backward(mods):
