@@ -28,6 +28,7 @@ SIGNATURES = {
     "msam2_layernorm": (c_i, [c_p, c_i, c_l, c_p, c_p, c_p, c_i, c_l, c_l, c_l, c_f, c_i, c_p]),
     "msam2_attention_workspace_bytes": (c_z, [c_l, c_l, c_l, c_l, c_i]),
     "msam2_attention_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_f, c_i, c_p, c_z, c_p]),
+    "msam2_attention_fwd_lse": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_f, c_i, c_p, c_z, c_p, c_p]),
     "msam2_attention_merge": (c_i, [c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_i, c_p, c_z, c_p]),
     "msam2_window_attention_fwd": (c_i, [c_p, c_l, c_l, c_l, c_l, c_l, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_p, c_p, c_p, c_l, c_l,
                                          c_l, c_l, c_l, c_f, c_p]),
@@ -61,7 +62,7 @@ SIGNATURES = {
     "msam2_convt2x2_scatter_grad": (c_i, [c_p, c_i, c_p, c_l, c_l, c_l, c_l, c_p]),
     "msam2_bce_logits": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_p]),
     "msam2_attention_bwd_workspace_bytes": (c_z, [c_l, c_l, c_l, c_l]),
-    "msam2_attention_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_z,
+    "msam2_attention_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_z,
                                   c_l, c_l, c_l, c_l, c_l, c_f, c_p]),
     "msam2_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_l, c_p]),
     "msam2_adam_step_multi": (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_l, c_f, c_p]),

@@ -87,8 +87,8 @@ def mlp_backward(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.
 def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: torch.Tensor, scale: Optional[float] = None):
     """Gradients of o = softmax(q k^T * scale) v for 16-bit q [B,H,Lq,D], k/v [B,H,Lk,D], upstream do [B,H,Lq,D] (any float type).
     Returns (dq, dk, dv) in fp32, shaped like q / k / v.
-    Head dims 64 / 96 / 128 / 256: FLASH-STYLE (`msam2_attention_bwd`, csrc/attention_bwd.hip) -- the forward is re-run for O, then
-    three recomputing passes (dQ + log-sum-exp, dK, dV) keep every score tile in registers; O(L) memory.
+    Head dims 64 / 96 / 128 / 256: FLASH-STYLE (`msam2_attention_bwd`, csrc/attention_bwd.hip) -- the forward is re-run for O and the log-sum-exp rows,
+    then three recomputing passes (dQ, dK, dV) keep every score tile in registers; O(L) memory.
     Other head dims (D % 8 == 0), or MSAM2_MATERIALISED_BWD=1: MATERIALISED form -- per (batch, head) the [Lq, Lk] scores live in
     HBM (fp32 S, 16-bit P / dS), the five products run on the forward GEMM kernel and the softmax and its Jacobian on two row
     kernels (reduction dims zero-padded to multiples of 8)."""
@@ -103,13 +103,14 @@ def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: to
     if D in (64, 96, 128, 256) and not os.environ.get("MSAM2_MATERIALISED_BWD"):
         from .modeling.common import attn_splits
         q, k, v = (t if t.stride(3) == 1 and all(st % 8 == 0 for st in t.stride()[:3]) else t.contiguous() for t in (q, k, v))
-        o = ops.attention(q, k, v, scale=scale, splits=attn_splits(B, H, Lq, Lk))
+        lse = torch.empty(B, H, Lq, dtype=F32, device=q.device)
+        o = ops.attention(q, k, v, scale=scale, splits=attn_splits(B, H, Lq, Lk), lse=lse)
         g = do.to(F32)
         g = g if g.stride(3) == 1 and all(st % 4 == 0 for st in g.stride()[:3]) else g.contiguous()
         nbytes = lib().msam2_attention_bwd_workspace_bytes(B, H, Lq, D)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
         check(lib().msam2_attention_bwd(_p(q), ops._strides3(q), _p(k), ops._strides3(k), _p(v), ops._strides3(v), _p(o), ops._strides3(o),
-                                        _p(g), ops._strides3(g), _p(dq), ops._strides3(dq), _p(dk), ops._strides3(dk), _p(dv),
+                                        _p(lse), _p(g), ops._strides3(g), _p(dq), ops._strides3(dq), _p(dk), ops._strides3(dk), _p(dv),
                                         ops._strides3(dv), _p(ws), nbytes, B, H, Lq, Lk, D, float(scale), _stream()))
         return dq, dk, dv
     # P / dS are GEMM operands with the keys as reduction dim: rows padded to a multiple of 8 keys with zeros (memory banks hold

@@ -42,6 +42,9 @@ struct AttnParams {
   int defer_merge;  // split-KV partials stay in the workspace; msam2_attention_merge finishes (benchmark / overlap use)
   op16* o_part;    // [splits][Bz][H][Lq][D] 16-bit, each split's own softmax-normalised output
   float* ml_part;  // [splits][Bz][H][Lq][2]  (running max in log2 domain, partial sum)
+  // log-sum-exp rows [Bz][H][Lq] (log2 domain) for the backward; written by the merge kernel (split path) or by the
+  // register-staged kernel (single pass); null = not wanted
+  float* lse;
 };
 
 template <int D>
@@ -240,6 +243,9 @@ __global__ __launch_bounds__(NW * 64, (WIN && NW == 4) ? 3 : 1) void attn_fwd_ke
   if (!qvalid) return;
   if (p.splits == 1) {
     const float inv = 1.f / l_tot;
+    if constexpr (!WIN) {
+      if (p.lse && h == 0) p.lse[((int64_t)z * p.H + head) * p.Lq + qi] = m_run + __log2f(l_tot);
+    }
     op16* ob = p.o + (int64_t)b * p.o_bs + (int64_t)head * p.o_hs + qtok * p.o_ts;
 #pragma unroll
     for (int d = 0; d < DBLK; ++d)
@@ -299,6 +305,7 @@ __global__ void attn_merge_kernel(AttnParams p, int Bz) {
       for (int e = 0; e < 4; ++e) acc[e] += w * op2f(t[e]);
     }
   }
+  if (p.lse && lane == 0) p.lse[gw] = M + __log2f(L);
   if (d0 < D) {
     const float inv = 1.f / L;
     op16x4 o;
@@ -695,10 +702,10 @@ extern "C" int msam2_attention_merge(void* o, const int64_t* o_strides, int64_t 
 
 // q,k,v,o: op16 with element strides {batch, head, token}; the head dim D is contiguous.
 // splits > 1: split-KV (flash-decoding) over `splits` key ranges + merge; splits < 0: the split pass only (see above).
-extern "C" int msam2_attention_fwd(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
-                                   const void* v, const int64_t* v_strides, void* o, const int64_t* o_strides, int64_t B,
-                                   int64_t H, int64_t Lq, int64_t Lk, int64_t D, float scale, int splits, void* workspace,
-                                   size_t workspace_bytes, void* stream) {
+static int attention_fwd_impl(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
+                              const void* v, const int64_t* v_strides, void* o, const int64_t* o_strides, int64_t B,
+                              int64_t H, int64_t Lq, int64_t Lk, int64_t D, float scale, int splits, void* workspace,
+                              size_t workspace_bytes, float* lse, void* stream) {
   MSAM2_REQUIRE(q && k && v && o, "attention: null tensor");
   MSAM2_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attention: empty problem");
   MSAM2_REQUIRE(D == 96 || D == 256 || D == 64 || D == 128, "attention: head dim %lld not built (96/256/64/128)", (long long)D);
@@ -706,6 +713,10 @@ extern "C" int msam2_attention_fwd(const void* q, const int64_t* q_strides, cons
   const bool defer = splits < 0;
   if (defer) splits = -splits;
   MSAM2_REQUIRE(splits >= 1 && splits <= 64, "attention: bad split count %d", splits);
+  // the log-sum-exp rows come from the merge kernel: at least two splits whenever the keys allow (the tuned single-pass kernels
+  // stay untouched); a single tile of keys goes through the register-staged kernel, which writes them itself
+  if (lse && splits < 2) splits = 2;
+  MSAM2_REQUIRE(!(lse && defer), "attention: log-sum-exp output and a deferred merge exclude each other");
   for (int i = 0; i < 3; ++i)
     MSAM2_REQUIRE(q_strides[i] % 8 == 0 && k_strides[i] % 8 == 0 && v_strides[i] % 8 == 0 && o_strides[i] % 4 == 0,
                   "attention: strides must keep 16-byte row alignment");
@@ -724,15 +735,36 @@ extern "C" int msam2_attention_fwd(const void* q, const int64_t* q_strides, cons
   p.defer_merge = defer ? 1 : 0;
   p.o_part = (op16*)workspace;
   p.ml_part = workspace ? reinterpret_cast<float*>(p.o_part + (size_t)splits * B * H * Lq * D) : nullptr;
+  p.lse = lse;
+  MSAM2_REQUIRE(splits == 1 || workspace, "attention: split-KV needs a workspace");
   hipStream_t s = (hipStream_t)stream;
   const char* force = getenv("MSAM2_ATTN_V1");
-  const bool v2 = !(force && force[0] == '1') && Lq > 64;
+  const bool v2 = !(force && force[0] == '1') && Lq > 64 && !(lse && splits == 1);
   switch (D) {
     case 96: return (v2 && k_strides[2] * 2 * 32 < (1ll << 31)) ? launch_attn_glds<96>(p, (int)B, s) : dispatch_nw<96, false>(p, (int)B, s);
     case 256: return v2 ? launch_attn_glds<256>(p, (int)B, s) : dispatch_nw<256, false>(p, (int)B, s);
     case 64: return dispatch_nw<64, false>(p, (int)B, s);
     default: return v2 ? launch_attn_glds<128>(p, (int)B, s) : dispatch_nw<128, false>(p, (int)B, s);
   }
+}
+
+extern "C" int msam2_attention_fwd(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
+                                   const void* v, const int64_t* v_strides, void* o, const int64_t* o_strides, int64_t B,
+                                   int64_t H, int64_t Lq, int64_t Lk, int64_t D, float scale, int splits, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  return attention_fwd_impl(q, q_strides, k, k_strides, v, v_strides, o, o_strides, B, H, Lq, Lk, D, scale, splits, workspace, workspace_bytes,
+                            nullptr, stream);
+}
+
+// msam2_attention_fwd that also returns lse [B, H, Lq] fp32 = log2(sum_k 2^(scale * log2(e) * q.k)) per query row (what the
+// backward needs to rebuild the probabilities).  Runs with max(splits, 2) splits: size the workspace for that.
+extern "C" int msam2_attention_fwd_lse(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
+                                       const void* v, const int64_t* v_strides, void* o, const int64_t* o_strides, int64_t B,
+                                       int64_t H, int64_t Lq, int64_t Lk, int64_t D, float scale, int splits, void* workspace,
+                                       size_t workspace_bytes, float* lse, void* stream) {
+  MSAM2_REQUIRE(lse, "attention_fwd_lse: null lse");
+  return attention_fwd_impl(q, q_strides, k, k_strides, v, v_strides, o, o_strides, B, H, Lq, Lk, D, scale, splits, workspace, workspace_bytes,
+                            lse, stream);
 }
 
 // Windowed attention straight from the un-partitioned token image (replaces window_partition + SDPA +

@@ -9,14 +9,17 @@
 // via ds_read_b64_tr_b16), so no score ever leaves the registers:
 //
 //   role   owner (regs)   streamed (LDS)   first products                      second product             statistics
-//   DQ     q, dO          k, v             S^T = K Q^T,  dP^T = V dO^T         dQ^T += K^T  w             online softmax per lane;
-//                                                                                                         w = 2^(s-m) (dP - delta)
+//   DQ     q, dO          k, v             S^T = K Q^T,  dP^T = V dO^T         dQ^T += K^T  dS^T          lse / delta of the lane's own row;
+//                                                                                                         keys split over workgroups
 //   DK     k, v           q, dO            S   = Q K^T,  dP   = dO V^T         dK^T += Q^T  dS            lse / delta per streamed row
 //   DV     k              q, dO            S   = Q K^T                         dV^T += dO^T P             lse per streamed row
 //
-// delta = rowsum(dO o O) comes from a pre-pass that also converts dO to the 16-bit operand type; the DQ pass runs first and
-// writes the log-sum-exp of every query row for the other two (the forward kernels do not keep it).  No atomics: every output row
-// has exactly one owner.  Cost: 8 score-tile products against the minimum of 5 -- the price of three simple passes.
+// delta = rowsum(dO o O) comes from a pre-pass that also converts dO to the 16-bit operand type; the log-sum-exp of every query
+// row comes from the forward (msam2_attention_fwd_lse).  dK / dV rows have exactly one owner (no atomics); the DQ pass has few
+// owner workgroups when Lq is short against Lk (4096 queries x 16k keys), so its key range is split over workgroups whose partial
+// dQ are added with fp32 atomics into the zeroed output.  Cost: 8 score-tile products against the minimum of 5 -- the price of
+// three simple passes (a first version of the DQ pass that found the statistics itself with an online softmax spilled 190 VGPRs
+// and ran 3.5x slower than the DK pass on the same flops).
 #include "common.h"
 
 namespace {
@@ -25,7 +28,8 @@ struct AttnBwdParams {
   const op16 *q, *k, *v, *do16;                       // do16: [B, H, Lq, D] contiguous 16-bit copy of dO (workspace)
   int64_t q_bs, q_hs, q_ts, k_bs, k_hs, k_ts, v_bs, v_hs, v_ts;
   const float* delta;                                 // [B, H, Lq]
-  float* lse;                                         // [B, H, Lq], log2 domain
+  const float* lse;                                   // [B, H, Lq], log2 domain (from the forward)
+  int ksplit;                                         // DQ role: workgroups per owner block over the streamed keys
   float *dq, *dk, *dv;
   int64_t dq_bs, dq_hs, dq_ts, dk_bs, dk_hs, dk_ts, dv_bs, dv_hs, dv_ts;
   int B, H, Lq, Lk;
@@ -105,7 +109,9 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
   const int64_t str2_ts = ROLE == ROLE_DQ ? p.v_ts : (int64_t)D;
 
   // ---- this lane's owner row -> B-operand fragments kept in registers
-  const int oi = blockIdx.x * (NW * 32) + wave * 32 + r;
+  const int nsplit = ROLE == ROLE_DQ ? p.ksplit : 1;
+  const int oblk = blockIdx.x / nsplit, split = blockIdx.x - oblk * nsplit;
+  const int oi = oblk * (NW * 32) + wave * 32 + r;
   const bool ovalid = oi < n_own;
   op16x8 f1[DSTEPS], f2[ROLE == ROLE_DV ? 1 : DSTEPS];
 #pragma unroll
@@ -119,8 +125,12 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
     if constexpr (ROLE != ROLE_DV) f2[s] = __builtin_bit_cast(op16x8, c);
   }
   const float delta_own = (ROLE == ROLE_DQ && ovalid) ? p.delta[bh * p.Lq + oi] : 0.f;
+  const float lse_own = (ROLE == ROLE_DQ && ovalid) ? p.lse[bh * p.Lq + oi] : 0.f;
 
-  const int tiles = (n_str + C::BK - 1) / C::BK;
+  const int tiles_all = (n_str + C::BK - 1) / C::BK;
+  const int tiles_per = (tiles_all + nsplit - 1) / nsplit;
+  const int t_begin = split * tiles_per, tiles = min(tiles_all, t_begin + tiles_per);
+  if (t_begin >= tiles) return;
   uint4 r1[PER], r2[PER];
   float rs_lse = 0.f, rs_del = 0.f;
   auto gload = [&](int tile) {
@@ -167,7 +177,6 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
   for (int d = 0; d < DBLK; ++d)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
 
   // per-lane LDS byte offsets: row reads (A operand of the first products) and transposed reads (A operand of the second)
   const int row1_off = r * C::KS + h * 16;                               // + st*32 per k-step
@@ -177,11 +186,11 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
   constexpr int TRS = ROLE == ROLE_DV ? C::VS : C::KS;                   // stride of the slot the second product transposes
   const int tr_off = tr_row * TRS + tr_col;                              // + (16 st) rows + dblk*64 B; second half + 8 rows
 
-  gload(0);
+  gload(t_begin);
   lstore(0);
   __syncthreads();
   int cur = 0;
-  for (int tile = 0; tile < tiles; ++tile) {
+  for (int tile = t_begin; tile < tiles; ++tile) {
     if (tile + 1 < tiles) gload(tile + 1);
     const unsigned char* base1 = smem + cur * C::STAGE;
     const unsigned char* base2 = base1 + C::BK * C::KS;
@@ -203,33 +212,12 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
     // streamed row of register e: (e&3) + 8*(e>>2) + 4*h
     op16x8 wf[2];
     if constexpr (ROLE == ROLE_DQ) {
-      const int row0 = tile * C::BK;
-      float mx = -INFINITY;
+      // (rows past the end of the keys hold zeros in LDS: whatever weight they get multiplies a zero K^T column)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        s[e] = (row < n_str) ? s[e] * p.scale_log2 : -INFINITY;
-        mx = fmaxf(mx, s[e]);
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      if (__any(m_new > m_run)) {
-        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
-        l_run *= alpha;
-#pragma unroll
-        for (int d = 0; d < DBLK; ++d)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[d][e] *= alpha;
-        m_run = m_new;
-      }
-      float psum = 0.f;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float pe = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(s[e] - m_run);
-        psum += pe;
+        const float pe = __builtin_amdgcn_exp2f(s[e] * p.scale_log2 - lse_own);
         wf[e >> 3][e & 7] = f2op(pe * (dp[e] - delta_own));
       }
-      l_run += psum;
     } else {
       const float* st_lse = stats + cur * 2 * C::BK;
       const float* st_del = st_lse + C::BK;
@@ -262,14 +250,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
   }
 
   // ---- epilogue: fp32 rows of the owner (lane = owner row, registers = 4 consecutive channels per group)
-  float factor = 1.f;
-  if (ROLE == ROLE_DQ) {
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    factor = p.scale / l_tot;
-    if (ovalid && h == 0) p.lse[bh * p.Lq + oi] = m_run + __log2f(l_tot);
-  } else if (ROLE == ROLE_DK) {
-    factor = p.scale;
-  }
+  const float factor = ROLE == ROLE_DV ? 1.f : p.scale;
   if (!ovalid) return;
   float* out = ROLE == ROLE_DQ ? p.dq + b * p.dq_bs + head * p.dq_hs + (int64_t)oi * p.dq_ts
              : ROLE == ROLE_DK ? p.dk + b * p.dk_bs + head * p.dk_hs + (int64_t)oi * p.dk_ts
@@ -281,8 +262,24 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
       f32x4 w;
 #pragma unroll
       for (int e = 0; e < 4; ++e) w[e] = acc[d][4 * g + e] * factor;
-      *reinterpret_cast<f32x4*>(out + d * 32 + 8 * g + 4 * h) = w;
+      if (ROLE == ROLE_DQ && nsplit > 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(out + d * 32 + 8 * g + 4 * h + e, w[e]);
+      } else {
+        *reinterpret_cast<f32x4*>(out + d * 32 + 8 * g + 4 * h) = w;
+      }
     }
+}
+
+// zero fill of strided fp32 rows [B, H, L, D] (a kernel: memset nodes of a captured graph did not order reliably)
+__global__ __launch_bounds__(256) void attn_bwd_zero_kernel(float* __restrict__ x, int64_t bs, int64_t hs, int64_t ts, int H, int L, int D4,
+                                                            int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = i % D4;
+    const int64_t row = i / D4;
+    const int64_t t = row % L, bh = row / L;
+    *reinterpret_cast<f32x4*>(x + (bh / H) * bs + (bh % H) * hs + t * ts + c * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 }
 
 template <int D, int NW, int ROLE>
@@ -294,15 +291,27 @@ void launch_role(const AttnBwdParams& p, hipStream_t s) {
     attr_set = true;
   }
   const int n_own = ROLE == ROLE_DQ ? p.Lq : p.Lk;
-  dim3 grid(cdiv(n_own, NW * 32), p.H, p.B);
+  dim3 grid(cdiv(n_own, NW * 32) * (ROLE == ROLE_DQ ? p.ksplit : 1), p.H, p.B);
   hipLaunchKernelGGL((attn_bwd_kernel<D, NW, ROLE>), grid, dim3(NW * 64), C::LDS_BYTES, s, p);
 }
 
-// workgroup size by fill: 4 waves per workgroup unless that leaves CUs idle
+// workgroup size by fill: 4 waves per workgroup unless that leaves CUs idle; the DQ role additionally splits the keys until there
+// are ~2 workgroups per CU (each split keeps at least 8 key tiles)
 template <int D, int ROLE>
-void launch_fill(const AttnBwdParams& p, hipStream_t s) {
+void launch_fill(AttnBwdParams p, hipStream_t s) {
   const int64_t n_own = ROLE == ROLE_DQ ? p.Lq : p.Lk;
-  if (cdiv(n_own, (int64_t)128) * p.H * p.B >= 256 || n_own <= 32) launch_role<D, 4, ROLE>(p, s);
+  const int64_t blocks4 = cdiv(n_own, (int64_t)128) * p.H * p.B;
+  p.ksplit = 1;
+  if (ROLE == ROLE_DQ && blocks4 < 512) {
+    const int64_t tiles = cdiv((int64_t)p.Lk, (int64_t)32);
+    p.ksplit = (int)max((int64_t)1, min(cdiv((int64_t)512, blocks4), tiles / 8));
+    if (p.ksplit > 1) {
+      const int64_t total = (int64_t)p.B * p.H * p.Lq * (D / 4);
+      hipLaunchKernelGGL(attn_bwd_zero_kernel, dim3((unsigned)min((int64_t)2048, cdiv(total, (int64_t)256))), dim3(256), 0, s, p.dq, p.dq_bs, p.dq_hs,
+                         p.dq_ts, p.H, p.Lq, D / 4, total);
+    }
+  }
+  if (blocks4 * p.ksplit >= 256 || n_own <= 32) launch_role<D, 4, ROLE>(p, s);
   else launch_role<D, 2, ROLE>(p, s);
 }
 
@@ -321,18 +330,18 @@ int launch_all(const AttnBwdParams& p, const float* d_o, const int64_t* gs, cons
 }  // namespace
 
 extern "C" size_t msam2_attention_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Lq, int64_t D) {
-  return (size_t)(B * H * Lq) * (size_t)(D * sizeof(op16) + 2 * sizeof(float));
+  return (size_t)(B * H * Lq) * (size_t)(D * sizeof(op16) + sizeof(float));
 }
 
 // q / k / v / o: 16-bit, element strides {batch, head, token}, channels contiguous; d_o fp32 with its own strides; dq / dk / dv fp32
 // outputs with their own strides (token stride a multiple of 4 elements, 16-byte aligned rows).  o is the forward's output for the
-// same q, k, v (msam2_attention_fwd).  workspace: msam2_attention_bwd_workspace_bytes.
+// same q, k, v and lse [B, H, Lq] its log-sum-exp rows (msam2_attention_fwd_lse).  workspace: msam2_attention_bwd_workspace_bytes.
 extern "C" int msam2_attention_bwd(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides, const void* v,
-                                   const int64_t* v_strides, const void* o, const int64_t* o_strides, const float* d_o,
-                                   const int64_t* do_strides, float* dq, const int64_t* dq_strides, float* dk, const int64_t* dk_strides,
+                                   const int64_t* v_strides, const void* o, const int64_t* o_strides, const float* lse,
+                                   const float* d_o, const int64_t* do_strides, float* dq, const int64_t* dq_strides, float* dk, const int64_t* dk_strides,
                                    float* dv, const int64_t* dv_strides, void* workspace, size_t workspace_bytes, int64_t B, int64_t H,
                                    int64_t Lq, int64_t Lk, int64_t D, float scale, void* stream) {
-  MSAM2_REQUIRE(q && k && v && o && d_o && dq && dk && dv && workspace, "attention_bwd: null pointer");
+  MSAM2_REQUIRE(q && k && v && o && lse && d_o && dq && dk && dv && workspace, "attention_bwd: null pointer");
   MSAM2_REQUIRE(q_strides && k_strides && v_strides && o_strides && do_strides && dq_strides && dk_strides && dv_strides,
                 "attention_bwd: null strides");
   MSAM2_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attention_bwd: empty problem");
@@ -356,7 +365,7 @@ extern "C" int msam2_attention_bwd(const void* q, const int64_t* q_strides, cons
   p.v_bs = v_strides[0]; p.v_hs = v_strides[1]; p.v_ts = v_strides[2];
   op16* do16 = (op16*)workspace;
   float* delta = (float*)((char*)workspace + (size_t)(B * H * Lq) * D * sizeof(op16));
-  p.do16 = do16; p.delta = delta; p.lse = delta + B * H * Lq;
+  p.do16 = do16; p.delta = delta; p.lse = lse; p.ksplit = 1;
   p.dq = dq; p.dk = dk; p.dv = dv;
   p.dq_bs = dq_strides[0]; p.dq_hs = dq_strides[1]; p.dq_ts = dq_strides[2];
   p.dk_bs = dk_strides[0]; p.dk_hs = dk_strides[1]; p.dk_ts = dk_strides[2];

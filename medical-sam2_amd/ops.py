@@ -144,23 +144,31 @@ def _strides3(t: torch.Tensor) -> "ctypes.Array":
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, splits: int = 1,
               out: Optional[torch.Tensor] = None, scale: Optional[float] = None, workspace: Optional[torch.Tensor] = None,
-              defer_merge: bool = False) -> torch.Tensor:
+              defer_merge: bool = False, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
     """softmax(q k^T / sqrt(D)) v.  q [B,H,Lq,D], k/v [B,H,Lk,D] as (possibly strided) bf16 views with D contiguous.
     Returns [B,H,Lq,D] view of a [B,Lq,H,D] buffer (heads recombined for the following out-projection).
-    defer_merge (needs a caller-owned `workspace`): run the split-KV pass only; finish with attention_merge()."""
+    defer_merge (needs a caller-owned `workspace`): run the split-KV pass only; finish with attention_merge().
+    lse (fp32 [B,H,Lq] contiguous): also return the log-sum-exp rows (log2 domain) the backward needs; runs with >= 2 splits."""
     B, H, Lq, D = q.shape
     Lk = k.shape[2]
     for t in (q, k, v):
         _req(t.dtype == OP16 and t.stride(3) == 1, "attention tensors must be 16-bit (ops.OP16) with contiguous head dim")
     if out is None:
         out = torch.empty(B, Lq, H, D, dtype=OP16, device=q.device).permute(0, 2, 1, 3)
+    if lse is not None:
+        _req(lse.dtype == F32 and lse.is_contiguous() and lse.numel() == B * H * Lq and not defer_merge, "attention: lse must be fp32 [B,H,Lq]")
+        splits = max(splits, 2)
     ws_bytes = lib().msam2_attention_workspace_bytes(B, H, Lq, D, splits)
     ws = workspace if workspace is not None else (torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=q.device) if splits > 1 else None)
     _req(not defer_merge or (workspace is not None and splits > 1), "defer_merge needs splits > 1 and a caller-owned workspace")
     _req(ws is None or ws.numel() * ws.element_size() >= ws_bytes, "attention workspace too small")
+    sc = scale if scale is not None else 1.0 / math.sqrt(D)
+    if lse is not None:
+        check(lib().msam2_attention_fwd_lse(_p(q), _strides3(q), _p(k), _strides3(k), _p(v), _strides3(v), _p(out), _strides3(out),
+                                            B, H, Lq, Lk, D, sc, splits, _p(ws), ws_bytes if ws is not None else 0, _p(lse), _stream()))
+        return out
     check(lib().msam2_attention_fwd(_p(q), _strides3(q), _p(k), _strides3(k), _p(v), _strides3(v), _p(out), _strides3(out),
-                                    B, H, Lq, Lk, D, scale if scale is not None else 1.0 / math.sqrt(D),
-                                    -splits if defer_merge else splits, _p(ws), ws_bytes if ws is not None else 0, _stream()))
+                                    B, H, Lq, Lk, D, sc, -splits if defer_merge else splits, _p(ws), ws_bytes if ws is not None else 0, _stream()))
     return out
 
 
