@@ -84,14 +84,25 @@ def mlp_backward(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.
     return dx, dw1, db1, dw2, db2
 
 
-def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: torch.Tensor, scale: Optional[float] = None):
+def attention_forward_lse(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None):
+    """Forward attention on [B,H,L,D] 16-bit views that keeps what the flash-style backward needs: (o 16-bit [B,H,Lq,D] view of a
+    [B,Lq,H,D] buffer, lse fp32 [B,H,Lq] in the log2 domain).  Hand both to `attention_backward(..., o_lse=...)`."""
+    from .modeling.common import attn_splits
+    B, H, Lq, D = q.shape
+    lse = torch.empty(B, H, Lq, dtype=F32, device=q.device)
+    o = ops.attention(q, k, v, scale=scale if scale is not None else D ** -0.5, splits=attn_splits(B, H, Lq, k.shape[2]), lse=lse)
+    return o, lse
+
+
+def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: torch.Tensor, scale: Optional[float] = None, o_lse=None):
     """Gradients of o = softmax(q k^T * scale) v for 16-bit q [B,H,Lq,D], k/v [B,H,Lk,D], upstream do [B,H,Lq,D] (any float type).
     Returns (dq, dk, dv) in fp32, shaped like q / k / v.
     Head dims 64 / 96 / 128 / 256: FLASH-STYLE (`msam2_attention_bwd`, csrc/attention_bwd.hip) -- the forward is re-run for O and the log-sum-exp rows,
     then three recomputing passes (dQ, dK, dV) keep every score tile in registers; O(L) memory.
     Other head dims (D % 8 == 0), or MSAM2_MATERIALISED_BWD=1: MATERIALISED form -- per (batch, head) the [Lq, Lk] scores live in
     HBM (fp32 S, 16-bit P / dS), the five products run on the forward GEMM kernel and the softmax and its Jacobian on two row
-    kernels (reduction dims zero-padded to multiples of 8)."""
+    kernels (reduction dims zero-padded to multiples of 8).
+    o_lse: the (o, lse) pair of `attention_forward_lse` on the same q, k, v when the caller has already run it (saves the re-run)."""
     B, H, Lq, D = q.shape
     Lk = k.shape[2]
     _req(q.dtype == OP16 and k.dtype == OP16 and v.dtype == OP16, "attention_backward: 16-bit q, k, v")
@@ -101,10 +112,8 @@ def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: to
     dk = torch.empty(B, H, Lk, D, dtype=F32, device=q.device)
     dv = torch.empty(B, H, Lk, D, dtype=F32, device=q.device)
     if D in (64, 96, 128, 256) and not os.environ.get("MSAM2_MATERIALISED_BWD"):
-        from .modeling.common import attn_splits
         q, k, v = (t if t.stride(3) == 1 and all(st % 8 == 0 for st in t.stride()[:3]) else t.contiguous() for t in (q, k, v))
-        lse = torch.empty(B, H, Lq, dtype=F32, device=q.device)
-        o = ops.attention(q, k, v, scale=scale, splits=attn_splits(B, H, Lq, Lk), lse=lse)
+        o, lse = o_lse if o_lse is not None else attention_forward_lse(q, k, v, scale)
         g = do.to(F32)
         g = g if g.stride(3) == 1 and all(st % 4 == 0 for st in g.stride()[:3]) else g.contiguous()
         nbytes = lib().msam2_attention_bwd_workspace_bytes(B, H, Lq, D)
@@ -161,7 +170,10 @@ def memory_attention_layer_backward(layer, x: torch.Tensor, mem_k: torch.Tensor,
     q1, k1, v1 = qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
     ops.rope_(q1, L, tab)
     ops.rope_(k1, L, tab)
-    a1 = sa.core(q1, k1, v1)                                                     # 16-bit [B*L, C]
+    u4 = lambda t: t.unsqueeze(1)                                                 # [B, N, C] -> [B, 1, N, C]
+    flash = C in (64, 96, 128, 256) and not os.environ.get("MSAM2_MATERIALISED_BWD")
+    ol1 = attention_forward_lse(u4(q1), u4(k1), u4(v1)) if flash else None
+    a1 = ol1[0].permute(0, 2, 1, 3).reshape(B * L, C) if flash else sa.core(q1, k1, v1)   # 16-bit [B*L, C]
     x1 = sa.out(a1, x)
     t2 = ln("norm2", x1)
     wq, wk, wv = W("qw", ca.q_proj.weight), W("kw", ca.k_proj.weight), W("vw", ca.v_proj.weight)
@@ -171,7 +183,8 @@ def memory_attention_layer_backward(layer, x: torch.Tensor, mem_k: torch.Tensor,
     kk = ops.gemm(mk2, wk, Bv("kb", ca.k_proj.bias)).view(B, Nk, C)
     ops.rope_(kk, Nk - n_ptr_tokens, tab)
     vv = ops.gemm(mv2, wv, Bv("vb", ca.v_proj.bias)).view(B, Nk, C)
-    a2 = ca.core(q2, kk, vv)
+    ol2 = attention_forward_lse(u4(q2), u4(kk), u4(vv)) if flash else None
+    a2 = ol2[0].permute(0, 2, 1, 3).reshape(B * L, C) if flash else ca.core(q2, kk, vv)
     x2 = ca.out(a2, x1)
     t3 = ln("norm3", x2)
     w1, w2 = W("f1", layer.linear1.weight), W("f2", layer.linear2.weight)
@@ -183,8 +196,7 @@ def memory_attention_layer_backward(layer, x: torch.Tensor, mem_k: torch.Tensor,
     dx2 = dy + d                                                                  # residual branch + LayerNorm branch
     # cross attention
     da2, g["cross_attn_image.out_proj.weight"], g["cross_attn_image.out_proj.bias"] = linear_backward(a2, W("ow", ca.out_proj.weight), dx2)
-    u4 = lambda t: t.unsqueeze(1)                                                 # [B, N, C] -> [B, 1, N, C]
-    dq2, dkk, dvv = attention_backward(u4(q2), u4(kk), u4(vv), u4(da2.view(B, L, C)))
+    dq2, dkk, dvv = attention_backward(u4(q2), u4(kk), u4(vv), u4(da2.view(B, L, C)), o_lse=ol2)
     dq2, dkk = _op16(dq2.view(B * L, C)).view(B, L, C), _op16(dkk.view(B * Nk, C)).view(B, Nk, C)
     _rope_adjoint_(dq2, L, tab)
     _rope_adjoint_(dkk, Nk - n_ptr_tokens, tab)
@@ -195,7 +207,7 @@ def memory_attention_layer_backward(layer, x: torch.Tensor, mem_k: torch.Tensor,
     dx1 = dx2 + d
     # self attention
     da1, g["self_attn.out_proj.weight"], g["self_attn.out_proj.bias"] = linear_backward(a1, W("ow_s", sa.out_proj.weight), dx1)
-    dq1, dk1, dv1 = attention_backward(u4(q1), u4(k1), u4(v1), u4(da1.view(B, L, C)))
+    dq1, dk1, dv1 = attention_backward(u4(q1), u4(k1), u4(v1), u4(da1.view(B, L, C)), o_lse=ol1)
     dq16, dk16, dv16 = (_op16(t.view(B * L, C)).view(B, L, C) for t in (dq1, dk1, dv1))
     _rope_adjoint_(dq16, L, tab)
     _rope_adjoint_(dk16, L, tab)
