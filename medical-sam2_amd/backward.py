@@ -148,12 +148,10 @@ def _rope_adjoint_(t: torch.Tensor, n_rope: int, table) -> torch.Tensor:
     return ops.rope_(t, n_rope, (cs, -sn))
 
 
-def memory_attention_layer_backward(layer, x: torch.Tensor, mem_k: torch.Tensor, mem_v: torch.Tensor, B: int, L: int, n_ptr_tokens: int,
-                                    dy: torch.Tensor):
-    """Backward of `MemoryAttentionLayer.run` (memory_attention.py:17-99 in eval mode: pre-LN RoPE self-attention, RoPE cross-attention
-    to the memory bank, ReLU FFN, three residuals).  The forward is recomputed here with its intermediates kept (the inference forward
-    saves nothing).  x fp32 [B*L, C]; mem_k / mem_v 16-bit [B, Nk, 64]; dy fp32 [B*L, C].
-    Returns (dx fp32 [B*L, C], dmem_k fp32 [B, Nk, 64], dmem_v fp32 [B, Nk, 64], {parameter name: fp32 gradient})."""
+def _memory_attention_layer_forward_saved(layer, x: torch.Tensor, mem_k: torch.Tensor, mem_v: torch.Tensor, B: int, L: int,
+                                          n_ptr_tokens: int):
+    """`MemoryAttentionLayer.run` (memory_attention.py:17-99, eval mode) with every intermediate the backward needs kept: returns
+    (y fp32 [B*L, C], context for `_memory_attention_layer_backward_saved`)."""
     from .modeling.common import v_f32, w_bf16
     sa, ca, wc = layer.self_attn, layer.cross_attn_image, layer._wc
     C, Nk = layer.d_model, mem_k.shape[1]
@@ -188,7 +186,23 @@ def memory_attention_layer_backward(layer, x: torch.Tensor, mem_k: torch.Tensor,
     x2 = ca.out(a2, x1)
     t3 = ln("norm3", x2)
     w1, w2 = W("f1", layer.linear1.weight), W("f2", layer.linear2.weight)
-    # ---- backward
+    hid = ops.gemm(t3, w1, Bv("f1b", layer.linear1.bias), act=ops.ACT_RELU)
+    y = ops.gemm(hid, w2, Bv("f2b", layer.linear2.bias), residual=x2, out_dtype=F32)
+    ctx = dict(x=x, t1=t1, w_qkv=w_qkv, q1=q1, k1=k1, v1=v1, ol1=ol1, a1=a1, x1=x1, t2=t2, wq=wq, wk=wk, wv=wv, q2=q2, mk2=mk2, mv2=mv2,
+               kk=kk, vv=vv, ol2=ol2, a2=a2, x2=x2, t3=t3, w1=w1, w2=w2, tab=tab, B=B, L=L, Nk=Nk, C=C, n_ptr=n_ptr_tokens)
+    return y, ctx
+
+
+def _memory_attention_layer_backward_saved(layer, ctx: dict, dy: torch.Tensor):
+    """Backward half of `memory_attention_layer_backward` on the context of `_memory_attention_layer_forward_saved`."""
+    from .modeling.common import v_f32, w_bf16
+    sa, ca, wc = layer.self_attn, layer.cross_attn_image, layer._wc
+    W = lambda key, *ws: w_bf16(wc, key, *ws)
+    Bv = lambda key, *bs: v_f32(wc, key, *bs)
+    u4 = lambda t: t.unsqueeze(1)
+    x, t1, w_qkv, q1, k1, v1, ol1, a1, x1, t2 = (ctx[k] for k in ("x", "t1", "w_qkv", "q1", "k1", "v1", "ol1", "a1", "x1", "t2"))
+    wq, wk, wv, q2, mk2, mv2, kk, vv, ol2, a2, x2, t3 = (ctx[k] for k in ("wq", "wk", "wv", "q2", "mk2", "mv2", "kk", "vv", "ol2", "a2", "x2", "t3"))
+    w1, w2, tab, B, L, Nk, C, n_ptr_tokens = (ctx[k] for k in ("w1", "w2", "tab", "B", "L", "Nk", "C", "n_ptr"))
     g = {}
     dt3, g["linear1.weight"], g["linear1.bias"], g["linear2.weight"], g["linear2.bias"] = mlp_backward(
         t3, w1, Bv("f1b", layer.linear1.bias), w2, Bv("f2b", layer.linear2.bias), dy, ops.ACT_RELU)
@@ -219,6 +233,18 @@ def memory_attention_layer_backward(layer, x: torch.Tensor, mem_k: torch.Tensor,
     return dx1 + d, dmk.view(B, Nk, -1), dmv.view(B, Nk, -1), g
 
 
+
+
+def memory_attention_layer_backward(layer, x: torch.Tensor, mem_k: torch.Tensor, mem_v: torch.Tensor, B: int, L: int, n_ptr_tokens: int,
+                                    dy: torch.Tensor):
+    """Backward of `MemoryAttentionLayer.run` (memory_attention.py:17-99 in eval mode: pre-LN RoPE self-attention, RoPE cross-attention
+    to the memory bank, ReLU FFN, three residuals).  The forward is recomputed here with its intermediates kept (the inference forward
+    saves nothing).  x fp32 [B*L, C]; mem_k / mem_v 16-bit [B, Nk, 64]; dy fp32 [B*L, C].
+    Returns (dx fp32 [B*L, C], dmem_k fp32 [B, Nk, 64], dmem_v fp32 [B, Nk, 64], {parameter name: fp32 gradient})."""
+    _, ctx = _memory_attention_layer_forward_saved(layer, x, mem_k, mem_v, B, L, n_ptr_tokens)
+    return _memory_attention_layer_backward_saved(layer, ctx, dy)
+
+
 def memory_attention_backward(module, curr: torch.Tensor, curr_pos: torch.Tensor, memory: torch.Tensor, memory_pos: torch.Tensor,
                               num_obj_ptr_tokens: int, dy: torch.Tensor):
     """Backward of `MemoryAttention.forward` (memory_attention.py:119-169; seq-first [L, B, C] tensors like the forward): x = curr +
@@ -230,16 +256,17 @@ def memory_attention_backward(module, curr: torch.Tensor, curr_pos: torch.Tensor
     mem_bf = memory.transpose(0, 1)
     mem_k = ops.add_cast(mem_bf, memory_pos.transpose(0, 1), 1.0, OP16)
     mem_v = ops.add_cast(mem_bf, None, 1.0, OP16)
-    xs = []
-    for layer in module.layers:                                                   # forward, keeping every layer's input
-        xs.append(x)
-        x = layer.run(x, mem_k, mem_v, B, L, num_obj_ptr_tokens)
+    ctxs = []
+    for layer in module.layers:                                                   # forward, keeping every layer's intermediates
+        x, ctx = _memory_attention_layer_forward_saved(layer, x, mem_k, mem_v, B, L, num_obj_ptr_tokens)
+        ctxs.append(ctx)
     grads = {}
     d = ops.add_cast(dy.transpose(0, 1), None, 1.0, F32).reshape(B * L, C)
     d, grads["norm.weight"], grads["norm.bias"] = layernorm_backward(x, module.norm.weight.detach().float(), d, module.norm.eps)
     dmk = dmv = None
     for i in range(len(module.layers) - 1, -1, -1):
-        d, gk, gv, g = memory_attention_layer_backward(module.layers[i], xs[i], mem_k, mem_v, B, L, num_obj_ptr_tokens, d)
+        d, gk, gv, g = _memory_attention_layer_backward_saved(module.layers[i], ctxs[i], d)
+        ctxs[i] = None
         dmk = gk if dmk is None else dmk + gk                                     # (tensor adds on small gradient slabs: plumbing)
         dmv = gv if dmv is None else dmv + gv
         grads.update({f"layers.{i}.{k}": v for k, v in g.items()})
