@@ -520,3 +520,135 @@ def mask_decoder_backward(dec, src_tokens: torch.Tensor, pe_tokens: torch.Tensor
     d_out_tok = colsum(d_tok[:, :n_out].reshape(B, n_out * C).contiguous()).view(n_out, C)    # the learned output tokens are shared over the batch
     grads["obj_score_token.weight"], grads["iou_token.weight"], grads["mask_tokens.weight"] = d_out_tok[0:1], d_out_tok[1:2], d_out_tok[2:]
     return d_src, d_tok[:, n_out:], grads
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Memory encoder (memory_encoder.py:17-181; part of train_3d.py's `mem_layers` parameter group): recomputing forward + backward
+# ---------------------------------------------------------------------------------------------------------------------
+def dwconv7x7(x: torch.Tensor, taps: torch.Tensor, bias: Optional[torch.Tensor], n: int, H: int, W: int, flip: bool = False) -> torch.Tensor:
+    """fp32 NHWC tokens [n*H*W, C] -> depthwise 7x7 (pad 3) with taps [49, C]; flip=True: the adjoint (input gradient)."""
+    C = x.shape[1]
+    _req(x.dtype == F32 and x.is_contiguous() and taps.shape == (49, C), "dwconv7x7: fp32 contiguous tokens, taps [49, C]")
+    y = torch.empty_like(x)
+    check(lib().msam2_dwconv7x7(_p(x), _p(taps), _p(bias), _p(y), n, H, W, C, 1 if flip else 0, _stream()))
+    return y
+
+
+def cxblock_backward(blk, x: torch.Tensor, n: int, H: int, W: int, dy: torch.Tensor):
+    """Backward of `CXBlock.run` (memory_encoder.py:62-117: y = x + gamma * pwconv2(gelu(pwconv1(LN(dwconv(x)))))), x / dy fp32
+    [n*H*W, C].  The layer-scale gamma starts at 1e-6, far below the 16-bit operand range for the branch gradient, so the branch is
+    differentiated in units of max|gamma| (a host scalar cached per weight version) and rescaled in fp32 at the end.  The two
+    broadcast products with gamma / the branch output are torch elementwise ops.  Returns (dx fp32, {parameter name: gradient})."""
+    from .modeling.common import v_f32, w_bf16
+    wc, C = blk._wc, x.shape[1]
+    taps = wc.get("dw", [blk.dwconv.weight], lambda: blk.dwconv.weight.detach().reshape(C, 49).t().float().contiguous())
+    lw, lb = v_f32(wc, "lw", blk.norm.weight), v_f32(wc, "lb", blk.norm.bias)
+    w1, b1 = w_bf16(wc, "w1", blk.pwconv1.weight), v_f32(wc, "b1", blk.pwconv1.bias)
+    w2, b2 = w_bf16(wc, "w2", blk.pwconv2.weight), v_f32(wc, "b2", blk.pwconv2.bias)
+    gs = wc.get("gmax", [blk.gamma], lambda: max(float(blk.gamma.detach().abs().max()), 1e-30))
+    gn = wc.get("gnorm", [blk.gamma], lambda: (blk.gamma.detach().float() / gs).contiguous())
+    # ---- forward with intermediates
+    h0 = dwconv7x7(x, taps, v_f32(wc, "dwb", blk.dwconv.bias), n, H, W)
+    t = ops.layernorm(h0, lw, lb, blk.norm.eps)
+    z2 = ops.gemm(ops.gemm(t, w1, b1, act=ops.ACT_GELU), w2, b2, out_dtype=F32)          # branch output before the layer scale
+    # ---- backward (branch in units of gs)
+    g = {"gamma": colsum((dy * z2).contiguous())}
+    dt, dw1, db1, dw2, db2 = mlp_backward(t, w1, b1, w2, b2, dy * gn, ops.ACT_GELU)
+    dh0, dlw, dlb = layernorm_backward(h0, lw, dt, blk.norm.eps)
+    dtaps = torch.zeros(49, C, dtype=F32, device=x.device)
+    check(lib().msam2_dwconv7x7_wgrad(_p(x), _p(dh0), _p(dtaps), n, H, W, C, _stream()))
+    g["dwconv.weight"], g["dwconv.bias"] = dtaps.t().reshape(C, 1, 7, 7) * gs, colsum(dh0) * gs
+    g["norm.weight"], g["norm.bias"] = dlw * gs, dlb * gs
+    g["pwconv1.weight"], g["pwconv1.bias"], g["pwconv2.weight"], g["pwconv2.bias"] = dw1 * gs, db1 * gs, dw2 * gs, db2 * gs
+    dxb = dwconv7x7(dh0, taps, None, n, H, W, flip=True)
+    dx = ops.add_cast(dy.view(1, -1, C), dxb.view(1, -1, C), gs, F32).view(-1, C)
+    return dx, g
+
+
+def memory_encoder_backward(enc, pix_tokens: torch.Tensor, mask: torch.Tensor, mode: int, scale: float, bias: float, n: int, H: int, W: int,
+                            dy: torch.Tensor):
+    """Backward of `MemoryEncoder.run` (memory_encoder.py:138-181 with MaskDownSampler 17-58 and the Fuser's CXBlocks 62-135): pix_tokens
+    [n*H*W, C], mask fp32 [n,1,16H,16W] with the mask transform `mode` of the forward (0 raw, 1 sigmoid * scale + bias, 2 binarised),
+    dy fp32 [n*H*W, out_dim].  The k3 s2 p1 convolutions are differentiated in their im2col GEMM form (`msam2_col2im3x3s2` is the
+    adjoint of the patch gather); the mask transform itself (one elementwise op on the input mask) is done by torch, and the mask
+    receives no gradient.  Returns (d pix_tokens fp32 [n*H*W, C], {parameter name relative to the memory encoder: gradient})."""
+    from .modeling.common import to_bf16, v_f32, w_bf16
+    wc, ds = enc._wc, enc.mask_downsampler
+    dwc, E = ds._wc, ds.encoder
+    S = mask.shape[-1]
+    mt = mask.to(F32)
+    if mode == 1:
+        mt = torch.sigmoid(mt) * scale + bias
+    elif mode == 2:
+        mt = (mt > 0).to(F32) * scale + bias
+    # ---- forward with intermediates: mask down-sampler in GEMM form
+    # (the patch gather moves 4-channel groups: the 1-channel mask rides in channel 0 of a zero-padded 4-channel image)
+    h = torch.zeros(n * S * S, 4, dtype=OP16, device=mask.device)
+    h[:, 0] = mt.reshape(-1).to(OP16)
+    side, stages = S, []
+    for j in range(4):
+        conv, ln = E[3 * j], E[3 * j + 1]
+        cout, cin = conv.weight.shape[0], conv.weight.shape[1]
+        cin_p = h.shape[1]
+        cols = ops.im2col3x3s2(h, n, side, side)
+        np_ = -(-cout // 8) * 8                                                   # GEMM rows of W padded to a multiple of 8 (stage 1: 4)
+
+        def pack(c=conv, ld=cols.shape[1], rows=np_, cp=cin_p):
+            w = torch.zeros(c.weight.shape[0], 3, 3, cp, dtype=F32, device=c.weight.device)
+            w[..., : c.weight.shape[1]] = c.weight.detach().permute(0, 2, 3, 1).float()
+            out = torch.zeros(rows, ld, dtype=OP16, device=w.device)
+            out[: w.shape[0], : 9 * cp] = w.reshape(w.shape[0], -1).to(OP16)
+            return out
+
+        def packb(c=conv, rows=np_):
+            out = torch.zeros(rows, dtype=F32, device=c.bias.device)
+            out[: c.bias.shape[0]] = c.bias.detach().float()
+            return out
+        wpk, bpk = dwc.get(f"bw_cw{j}", [conv.weight], pack), dwc.get(f"bw_cb{j}", [conv.bias], packb)
+        gfull = ops.gemm(cols, wpk, bpk, out_dtype=F32)
+        gj = gfull if np_ == cout else gfull[:, :cout].contiguous()
+        lw, lb = v_f32(dwc, f"lw{j}", ln.weight), v_f32(dwc, f"lb{j}", ln.bias)
+        yln = ops.layernorm(gj, lw, lb, ln.eps, out_dtype=F32)
+        h = ops.layernorm(gj, lw, lb, ln.eps, act=ops.ACT_GELU)
+        stages.append((cols, wpk, gj, yln, lw, cout, cin, side, np_, cin_p))
+        side //= 2
+    pw = w_bf16(dwc, "pw", E[12].weight)
+    m_out = ops.gemm(h, pw, v_f32(dwc, "pb", E[12].bias), out_dtype=F32)
+    pix16 = to_bf16(pix_tokens)
+    ppw = w_bf16(wc, "pw", enc.pix_feat_proj.weight)
+    x = ops.gemm(pix16, ppw, v_f32(wc, "pb", enc.pix_feat_proj.bias), residual=m_out, out_dtype=F32)
+    xs = []
+    for layer in enc.fuser.layers:
+        xs.append(x)
+        x = layer.run(x, n, H, W)
+    # ---- backward
+    g: dict = {}
+    if isinstance(enc.out_proj, torch.nn.Identity):
+        dx = dy.to(F32)
+    else:
+        ow = w_bf16(wc, "ow", enc.out_proj.weight)
+        dx, dw, db = linear_backward(to_bf16(x), ow, dy)
+        g["out_proj.weight"], g["out_proj.bias"] = dw.view_as(enc.out_proj.weight), db
+    for j in range(len(enc.fuser.layers) - 1, -1, -1):
+        dx, gl = cxblock_backward(enc.fuser.layers[j], xs[j], n, H, W, dx)
+        g.update({f"fuser.layers.{j}.{k}": v for k, v in gl.items()})
+    dpix, dw, db = linear_backward(pix16, ppw, dx)
+    g["pix_feat_proj.weight"], g["pix_feat_proj.bias"] = dw.view_as(enc.pix_feat_proj.weight), db
+    pre = "mask_downsampler.encoder"
+    dh, dw, db = linear_backward(h, pw, dx)                                        # the down-sampled mask enters as a residual: dm = dx
+    g[f"{pre}.12.weight"], g[f"{pre}.12.bias"] = dw.view_as(E[12].weight), db
+    for j in range(3, -1, -1):
+        cols, wpk, gj, yln, lw, cout, cin, side_in, np_, cin_p = stages[j]
+        dyln = act_backward(yln, dh, ops.ACT_GELU)
+        dg, g[f"{pre}.{3 * j + 1}.weight"], g[f"{pre}.{3 * j + 1}.bias"] = layernorm_backward(gj, lw, dyln, E[3 * j + 1].eps)
+        if np_ != cout:
+            dgp = torch.zeros(dg.shape[0], np_, dtype=F32, device=dg.device)
+            dgp[:, :cout] = dg
+            dg = dgp
+        dcols, dwp, dbp = linear_backward(cols, wpk, dg, need_dx=j > 0)
+        g[f"{pre}.{3 * j}.weight"] = dwp[:cout, : 9 * cin_p].reshape(cout, 3, 3, cin_p)[..., :cin].permute(0, 3, 1, 2).contiguous()
+        g[f"{pre}.{3 * j}.bias"] = dbp[:cout]
+        if j > 0:
+            dh = torch.empty(n * side_in * side_in, cin, dtype=F32, device=dy.device)
+            check(lib().msam2_col2im3x3s2(_p(dcols), dcols.stride(0), _p(dh), n, side_in, side_in, cin, _stream()))
+    return dpix, g

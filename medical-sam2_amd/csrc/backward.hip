@@ -274,6 +274,120 @@ extern "C" int msam2_convt2x2_scatter_grad(const void* dz, int dz_is_16bit, void
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Memory-encoder backward pieces (memory_encoder.py:17-58 mask down-sampler, 62-117 CXBlock under torch.autograd):
+//   dwconv7x7:        plain depthwise 7x7 (pad 3) on fp32 NHWC tokens, taps [49, C]; flip = 1 correlates with the flipped kernel,
+//                     i.e. the input gradient of the forward convolution
+//   dwconv7x7_wgrad:  dW[tap][c] += sum_pixels dY[p][c] * X[p + offset(tap)][c]   (zeroed fp32 [49, C] output)
+//   col2im3x3s2:      adjoint of im2col3x3s2 (k3 s2 p1): every input pixel gathers its <= 4 (ky, kx) contributions from the column
+//                     gradient [B*(H/2)*(W/2), ld] with columns ordered (ky, kx, c)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dwconv7x7_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ y, int B, int H, int W, int C4, int flip) {
+  const int64_t total = (int64_t)B * H * W * C4;
+  const int C = C4 * 4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    const int64_t pix = i / C4;
+    const int px = (int)(pix % W), py = (int)((pix / W) % H);
+    const int64_t b = pix / ((int64_t)W * H);
+    f32x4 acc = bias ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < 7; ++ky) {
+      const int yy = py + ky - 3;
+      if (yy < 0 || yy >= H) continue;
+      for (int kx = 0; kx < 7; ++kx) {
+        const int xx = px + kx - 3;
+        if (xx < 0 || xx >= W) continue;
+        const int tap = flip ? (6 - ky) * 7 + (6 - kx) : ky * 7 + kx;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + ((b * H + yy) * W + xx) * C + c);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + tap * C + c);
+        acc += xv * wv;
+      }
+    }
+    *reinterpret_cast<f32x4*>(y + pix * C + c) = acc;
+  }
+}
+
+extern "C" int msam2_dwconv7x7(const float* x, const float* w_tap_major, const float* bias, float* y, int64_t B, int64_t H, int64_t W, int64_t C,
+                               int flip, void* stream) {
+  MSAM2_REQUIRE(x && w_tap_major && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "dwconv7x7: bad arguments");
+  const int64_t total = B * H * W * (C / 4);
+  hipLaunchKernelGGL(dwconv7x7_kernel, dim3((unsigned)min((int64_t)16384, cdiv(total, (int64_t)256))), dim3(256), 0, (hipStream_t)stream, x, w_tap_major,
+                     bias, y, (int)B, (int)H, (int)W, (int)(C / 4), flip);
+  return msam2_check_launch("dwconv7x7");
+}
+
+// grid (C / 64, pixel slabs); thread = channel, 49 accumulators in registers
+__global__ __launch_bounds__(64) void dwconv7x7_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, int B,
+                                                             int H, int W, int C) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  const int64_t npix = (int64_t)B * H * W;
+  const int64_t per = (npix + gridDim.y - 1) / gridDim.y, p0 = blockIdx.y * per, p1 = min(npix, p0 + per);
+  float acc[49];
+#pragma unroll
+  for (int t = 0; t < 49; ++t) acc[t] = 0.f;
+  for (int64_t pix = p0; pix < p1; ++pix) {
+    const int px = (int)(pix % W), py = (int)((pix / W) % H);
+    const int64_t b = pix / ((int64_t)W * H);
+    const float g = dy[pix * C + c];
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+      const int yy = py + ky - 3;
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) {
+        const int xx = px + kx - 3;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc[ky * 7 + kx] += g * x[((b * H + yy) * W + xx) * C + c];
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 49; ++t) atomicAdd(dw + t * C + c, acc[t]);
+}
+
+extern "C" int msam2_dwconv7x7_wgrad(const float* x, const float* dy, float* dw_tap_major, int64_t B, int64_t H, int64_t W, int64_t C,
+                                     void* stream) {
+  MSAM2_REQUIRE(x && dy && dw_tap_major && B > 0 && H > 0 && W > 0 && C > 0, "dwconv7x7_wgrad: bad arguments");
+  const int64_t npix = B * H * W;
+  dim3 grid((unsigned)cdiv(C, (int64_t)64), (unsigned)min((int64_t)512, cdiv(npix, (int64_t)32)));
+  hipLaunchKernelGGL(dwconv7x7_wgrad_kernel, grid, dim3(64), 0, (hipStream_t)stream, x, dy, dw_tap_major, (int)B, (int)H, (int)W, (int)C);
+  return msam2_check_launch("dwconv7x7_wgrad");
+}
+
+__global__ __launch_bounds__(256) void col2im3x3s2_kernel(const float* __restrict__ dcols, int64_t ld, float* __restrict__ dx, int B, int H, int W,
+                                                          int C) {
+  const int64_t total = (int64_t)B * H * W * C;
+  const int Ho = H / 2, Wo = W / 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int64_t pix = i / C;
+    const int px = (int)(pix % W), py = (int)((pix / W) % H);
+    const int64_t b = pix / ((int64_t)W * H);
+    float acc = 0.f;
+    // output (oy, ox) reads input (2 oy + ky - 1, 2 ox + kx - 1)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int t = py + 1 - ky;
+      if (t < 0 || (t & 1) || (t >> 1) >= Ho) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int u = px + 1 - kx;
+        if (u < 0 || (u & 1) || (u >> 1) >= Wo) continue;
+        acc += dcols[((b * Ho + (t >> 1)) * Wo + (u >> 1)) * ld + (ky * 3 + kx) * C + c];
+      }
+    }
+    dx[i] = acc;
+  }
+}
+
+extern "C" int msam2_col2im3x3s2(const float* dcols, int64_t ld, float* dx, int64_t B, int64_t H, int64_t W, int64_t C, void* stream) {
+  MSAM2_REQUIRE(dcols && dx && B > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && ld >= 9 * C, "col2im3x3s2: bad arguments");
+  const int64_t total = B * H * W * C;
+  hipLaunchKernelGGL(col2im3x3s2_kernel, dim3((unsigned)min((int64_t)16384, cdiv(total, (int64_t)256))), dim3(256), 0, (hipStream_t)stream, dcols, ld, dx,
+                     (int)B, (int)H, (int)W, (int)C);
+  return msam2_check_launch("col2im3x3s2");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Loss and optimiser pieces of a decoder fine-tuning step (func_3d/function.py:69 `criterion_G = BCEWithLogitsLoss(pos_weight)`,
 // train_3d.py:50 `optim.Adam(sam_layers, lr=1e-4, betas=(0.9, 0.999), eps=1e-8)`):
 //   bce_logits:  loss = mean( pos_weight * y * softplus(-x) + (1 - y) * softplus(x) ),  dx = (pos_weight * y * (s - 1) + (1 - y) * s) / n,

@@ -410,3 +410,79 @@ def test_attention_small_backward(mods, B, H, Lq, Lk, D):
     check(lib().msam2_attention_small_bwd(ops._p(qd), qd.stride(0), qd.stride(1), ops._p(kd), kd.stride(0), kd.stride(1), ops._p(vd), vd.stride(0),
                                           vd.stride(1), ops._p(dod), ops._p(dq), ops._p(dk), ops._p(dv), B, H, Lq, Lk, D, D ** -0.5, ops._stream()))
     assert rel(dv, v.grad) < 1e-4 and rel(dq, q.grad) < 1e-4 and rel(dk, k.grad) < 1e-4, (rel(dq, q.grad), rel(dk, k.grad), rel(dv, v.grad))
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 256), (1, 9, 13, 64)])
+def test_dwconv_and_col2im_kernels(mods, B, H, W, C):
+    """Plain depthwise 7x7 (forward and flipped = input gradient), its weight gradient, and the adjoint of the k3 s2 p1 patch gather,
+    each against autograd of the torch op it differentiates (fp32 kernels: tight tolerance)."""
+    B_, ops = mods
+    from medical_sam2_amd._lib import check, lib
+    from medical_sam2_amd.ops import _p, _stream
+    x = rnd(B, C, H, W, seed=120).requires_grad_(True)
+    w = rnd(C, 1, 7, 7, seed=121, scale=0.2).requires_grad_(True)
+    bias = rnd(C, seed=122)
+    dy = rnd(B, C, H, W, seed=123)
+    y = F.conv2d(x, w, bias, padding=3, groups=C)
+    y.backward(dy)
+    tok = lambda t: t.detach().permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous().to(DEV)
+    taps = w.detach().reshape(C, 49).t().contiguous().to(DEV)
+    out = B_.dwconv7x7(tok(x), taps, bias.to(DEV), B, H, W)
+    assert rel(out, tok(y)) < 1e-5
+    dx = B_.dwconv7x7(tok(dy), taps, None, B, H, W, flip=True)
+    assert rel(dx, tok(x.grad)) < 1e-5
+    dtaps = torch.zeros(49, C, device=DEV)
+    xt, dyt = tok(x), tok(dy)                                                     # (keep the device tensors alive across the raw-pointer call)
+    check(lib().msam2_dwconv7x7_wgrad(_p(xt), _p(dyt), _p(dtaps), B, H, W, C, _stream()))
+    assert rel(dtaps.t().reshape(C, 1, 7, 7), w.grad) < 1e-4
+    # col2im: adjoint of the k3 s2 p1 gather  <=>  input gradient of a stride-2 conv whose weight-side product is done separately
+    He, We, Cc = 2 * (H // 2 + 1), 2 * (W // 2 + 1), 8
+    xi = rnd(B, Cc, He, We, seed=124).requires_grad_(True)
+    cols_ref = F.unfold(xi, kernel_size=3, stride=2, padding=1)                    # [B, Cc*9, Ho*Wo], channel-major (c, ky, kx)
+    dcols = rnd(B * (He // 2) * (We // 2), 9 * Cc + 8, seed=125)                   # our order (ky, kx, c), ld > 9 C
+    d_ref = dcols[:, : 9 * Cc].view(B, -1, 9, Cc).permute(0, 3, 2, 1).reshape(B, Cc * 9, -1)
+    cols_ref.backward(d_ref)
+    dxi = torch.empty(B * He * We, Cc, device=DEV)
+    dc = dcols.to(DEV)
+    check(lib().msam2_col2im3x3s2(_p(dc), dc.stride(0), _p(dxi), B, He, We, Cc, _stream()))
+    assert rel(dxi, tok(xi.grad)) < 1e-5
+
+
+def test_memory_encoder_backward(mods):
+    """MemoryEncoder.forward (memory_encoder.py:138-181; mask down-sampler 17-58, fuser CXBlocks 62-135, the 1x1 projections): gradient
+    w.r.t. the pixel features and every memory-encoder parameter against autograd through oracle.memory_encoder, with the sigmoid mask
+    transform of sam2_base.py:686-696.  The layer scale gamma is drawn at 0.05-0.15 here AND left at its 1e-6 initial value in a second
+    pass (the branch gradient is then 1e-6 of the residual one: below fp16 unless the backward rescales it)."""
+    B_, ops = mods
+    import medical_sam2_amd.build_sam as bs
+    import medical_sam2_amd.weights as wts
+    cfg = O.model_config("hiera_t", 256)
+    n, E, S = 2, 16, 256
+    pix = rnd(n, 256, E, E, seed=130)
+    mask = rnd(n, 1, S, S, seed=131, scale=4.0)
+    dy = rnd(n, 64, E, E, seed=132)
+    sc, bi = cfg["sigmoid_scale_for_mem_enc"], cfg["sigmoid_bias_for_mem_enc"]
+    for learned_gamma in (True, False):
+        sd = wts.init_weights("hiera_t", 0)
+        if learned_gamma:
+            for j in range(2):
+                sd[f"memory_encoder.fuser.layers.{j}.gamma"] = 0.05 + 0.1 * torch.rand(256, generator=torch.Generator().manual_seed(7 + j))
+        m = bs.build_sam2("sam2_hiera_t", device="cpu", hydra_overrides_extra=["++model.image_size=256"])
+        m.load_state_dict(sd, strict=True)
+        enc = m.memory_encoder.to(DEV).eval()
+        pre = "memory_encoder."
+        P = {k: v.clone().float().requires_grad_(k.startswith(pre)) for k, v in sd.items()}
+        pr = pix.clone().requires_grad_(True)
+        y, _ = O.memory_encoder(P, cfg, pr, torch.sigmoid(mask) * sc + bi)
+        y.backward(dy)
+        tm = lambda t: t.detach().permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous().to(DEV)
+        dpix, grads = B_.memory_encoder_backward(enc, tm(pix), mask.to(DEV), 1, sc, bi, n, E, E, tm(dy))
+        report = {"d_pix": rel(dpix.view(n, E * E, 256), pr.grad.flatten(2).permute(0, 2, 1))}
+        names = {k[len(pre):] for k in sd if k.startswith(pre)}
+        assert set(grads) == names, (sorted(names - set(grads)), sorted(set(grads) - names))
+        for name, gt in grads.items():
+            ref = P[pre + name].grad
+            assert ref is not None and gt.shape == ref.shape, (name, gt.shape, ref.shape)
+            report[name] = rel(gt, ref)
+        worst = sorted(report.items(), key=lambda kv: -kv[1])[:6]
+        assert worst[0][1] < 4e-2, (learned_gamma, worst)

@@ -44,6 +44,9 @@ DOC = {
     "msam2_attention_fwd_lse": "msam2_attention_fwd that also writes the log-sum-exp of every query row (log2 domain, fp32 [B, H, Lq]) for msam2_attention_bwd.",
     "msam2_attention_bwd_workspace_bytes": "Scratch needed by msam2_attention_bwd (16-bit copy of dO and the delta rows).",
     "msam2_attention_bwd": "Flash-style dQ / dK / dV of softmax(Q K^T * scale) V (torch.autograd of F.scaled_dot_product_attention at transformer.py:318 and\nhieradet.py:72-76 in the training loops func_3d/function.py:182-191, func_2d/function.py:246-259): head dim 64 / 96 / 128 / 256,\n16-bit q / k / v / o and lse (the outputs of msam2_attention_fwd_lse), fp32 dO in, fp32 gradients out, O(L) memory (no [Lq, Lk] tensor).",
+    "msam2_dwconv7x7": "Plain depthwise 7x7 convolution (pad 3) on fp32 NHWC tokens, taps [49, C]; flip = 1 gives the input gradient of CXBlock.dwconv\n(memory_encoder.py:83-90) -- the forward uses the fused msam2_dwconv7x7_ln.",
+    "msam2_dwconv7x7_wgrad": "Weight gradient of CXBlock.dwconv accumulated into a zeroed fp32 [49, C] buffer.",
+    "msam2_col2im3x3s2": "Adjoint of msam2_im2col3x3s2: input gradient of the mask down-sampler's k3 s2 p1 convolutions (memory_encoder.py:38-47) from the\ncolumn gradient of their GEMM form.",
     "msam2_adam_step": "One torch.optim.Adam step (no weight decay / amsgrad) on a flat fp32 parameter (train_3d.py:50).",
     "msam2_adam_step_multi": "The same Adam step over `count` parameters (host arrays of device pointers and element counts), 24 per launch;\ngradients are multiplied by grad_scale first (1 / loss scale).",
     "msam2_attention_small_bwd": "Backward of the two-way decoder's attention (transformer.py:239-263 under autograd; 8 heads of 16 / 32 channels) when one side has\n<= 32 tokens: dq / dk / dv (fp32, token-major) from 16-bit q / k / v and the fp32 upstream gradient, one workgroup per (batch, head).",
