@@ -245,11 +245,10 @@ def memory_attention_layer_backward(layer, x: torch.Tensor, mem_k: torch.Tensor,
     return _memory_attention_layer_backward_saved(layer, ctx, dy)
 
 
-def memory_attention_backward(module, curr: torch.Tensor, curr_pos: torch.Tensor, memory: torch.Tensor, memory_pos: torch.Tensor,
-                              num_obj_ptr_tokens: int, dy: torch.Tensor):
-    """Backward of `MemoryAttention.forward` (memory_attention.py:119-169; seq-first [L, B, C] tensors like the forward): x = curr +
-    0.1 curr_pos, the layers of `memory_attention_layer_backward` over keys memory + memory_pos / values memory, final LayerNorm.
-    Returns (dcurr [L,B,C], dmemory [Nk,B,64], dmemory_pos [Nk,B,64], {"layers.i.<param>" | "norm.weight|bias": fp32 gradient})."""
+def memory_attention_forward_saved(module, curr: torch.Tensor, curr_pos: torch.Tensor, memory: torch.Tensor, memory_pos: torch.Tensor,
+                                   num_obj_ptr_tokens: int):
+    """`MemoryAttention.forward` (memory_attention.py:119-169; seq-first [L, B, C] tensors) keeping every layer's intermediates:
+    returns (y fp32 [L, B, C], state for `memory_attention_backward_saved`)."""
     from .modeling.common import v_f32
     L, B, C = curr.shape
     x = ops.add_cast(curr.transpose(0, 1), curr_pos.transpose(0, 1), 0.1, F32).reshape(B * L, C)
@@ -257,12 +256,20 @@ def memory_attention_backward(module, curr: torch.Tensor, curr_pos: torch.Tensor
     mem_k = ops.add_cast(mem_bf, memory_pos.transpose(0, 1), 1.0, OP16)
     mem_v = ops.add_cast(mem_bf, None, 1.0, OP16)
     ctxs = []
-    for layer in module.layers:                                                   # forward, keeping every layer's intermediates
+    for layer in module.layers:
         x, ctx = _memory_attention_layer_forward_saved(layer, x, mem_k, mem_v, B, L, num_obj_ptr_tokens)
         ctxs.append(ctx)
+    y = ops.layernorm(x, v_f32(module._wc, "nw", module.norm.weight), v_f32(module._wc, "nb", module.norm.bias), module.norm.eps, out_dtype=F32)
+    return y.view(B, L, C).transpose(0, 1), dict(ctxs=ctxs, x_last=x, B=B, L=L, C=C)
+
+
+def memory_attention_backward_saved(module, state: dict, dy: torch.Tensor):
+    """Backward half of `memory_attention_backward` on the state of `memory_attention_forward_saved` (consumed: the per-layer
+    intermediates are released as the layers are walked back)."""
+    B, L, C, ctxs = state["B"], state["L"], state["C"], state["ctxs"]
     grads = {}
     d = ops.add_cast(dy.transpose(0, 1), None, 1.0, F32).reshape(B * L, C)
-    d, grads["norm.weight"], grads["norm.bias"] = layernorm_backward(x, module.norm.weight.detach().float(), d, module.norm.eps)
+    d, grads["norm.weight"], grads["norm.bias"] = layernorm_backward(state["x_last"], module.norm.weight.detach().float(), d, module.norm.eps)
     dmk = dmv = None
     for i in range(len(module.layers) - 1, -1, -1):
         d, gk, gv, g = _memory_attention_layer_backward_saved(module.layers[i], ctxs[i], d)
@@ -272,6 +279,15 @@ def memory_attention_backward(module, curr: torch.Tensor, curr_pos: torch.Tensor
         grads.update({f"layers.{i}.{k}": v for k, v in g.items()})
     dcurr = d.view(B, L, C).transpose(0, 1)
     return dcurr, (dmk + dmv).transpose(0, 1), dmk.transpose(0, 1), grads
+
+
+def memory_attention_backward(module, curr: torch.Tensor, curr_pos: torch.Tensor, memory: torch.Tensor, memory_pos: torch.Tensor,
+                              num_obj_ptr_tokens: int, dy: torch.Tensor):
+    """Backward of `MemoryAttention.forward` (memory_attention.py:119-169; seq-first [L, B, C] tensors like the forward): x = curr +
+    0.1 curr_pos, the layers of `memory_attention_layer_backward` over keys memory + memory_pos / values memory, final LayerNorm.
+    Returns (dcurr [L,B,C], dmemory [Nk,B,64], dmemory_pos [Nk,B,64], {"layers.i.<param>" | "norm.weight|bias": fp32 gradient})."""
+    _, state = memory_attention_forward_saved(module, curr, curr_pos, memory, memory_pos, num_obj_ptr_tokens)
+    return memory_attention_backward_saved(module, state, dy)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -31,7 +31,8 @@ def bce_with_logits(logits: torch.Tensor, target: torch.Tensor, pos_weight: floa
 
 
 class DecoderAdam:
-    """torch.optim.Adam(params, lr, betas, eps) semantics for the mask decoder's parameters, state kept as flat fp32 tensors."""
+    """torch.optim.Adam(params, lr, betas, eps) semantics for the parameters of one module (the mask decoder, the memory attention, ...:
+    gradient names are relative to it), state kept as flat fp32 tensors."""
 
     def __init__(self, decoder, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8):
         self.decoder, self.lr, self.betas, self.eps, self.t = decoder, lr, betas, eps, 0
@@ -84,4 +85,52 @@ def decoder_finetune_step(decoder, optimizer: DecoderAdam, src_tokens, pe_tokens
     d_masks.mul_(scale)
     _, _, grads = bwd.mask_decoder_backward(decoder, src_tokens, pe_tokens, sparse, feat_s0, feat_s1, B, h, w, d_masks)
     optimizer.step(grads, grad_scale=1.0 / scale)
+    return float(loss.item()) if sync else loss
+
+
+@torch.no_grad()
+def memory_decoder_loss_grads(memory_attention, decoder, curr, curr_pos, memory, memory_pos, num_obj_ptr_tokens: int, pe_tokens, sparse,
+                              feat_s0, feat_s1, B: int, h: int, w: int, target_masks: torch.Tensor, dense_tokens=None,
+                              pos_weight: float = 1.0, mem_scale: float = None):
+    """Forward + backward of the memory-conditioned slice step (func_2d/function.py:70-191 / sam2_base.py:705-790 with a frozen image
+    encoder and a detached memory bank, as func_2d/function.py:204-243 stores it): curr / curr_pos [L, B, C] current-slice features,
+    memory / memory_pos [Nk, B, 64] the assembled bank -> memory attention -> (+ dense prompt embedding) -> mask decoder -> mean BCE with
+    logits on its mask logits.  Returns (loss 1-element tensor, decoder loss scale, memory loss scale, decoder gradients,
+    memory-attention gradients, dcurr); each group's gradients (and dcurr) carry its loss scale (see `decoder_finetune_step`).
+    The gradient that leaves the decoder towards the memory attention is orders of magnitude smaller than the one that entered it
+    (it has crossed two attention blocks and two transposed convolutions), again below the fp16 operand range, so it is re-scaled by a
+    second power of two: `mem_scale` if given (a captured graph must pass the value calibrated on an eager step), else chosen from
+    max|d_src| -- one host synchronisation."""
+    L, _, C = curr.shape
+    y, state = bwd.memory_attention_forward_saved(memory_attention, curr, curr_pos, memory, memory_pos, num_obj_ptr_tokens)
+    src = y.transpose(0, 1).reshape(B * L, C)
+    if dense_tokens is not None:                                                  # [L, C] or [1, C] (no_mask_embed), broadcast over the batch
+        d2 = dense_tokens.reshape(-1, C).to(F32)
+        src = ops.add_cast(src.view(B, L, C), d2.view(1, -1, C).expand(B, L, C), 1.0, F32).view(B * L, C)
+    else:
+        src = src.contiguous()
+    masks, _, _, _ = decoder.predict_masks_tokens(src, pe_tokens, sparse, feat_s0, feat_s1, B, h, w)
+    loss, d_masks = bce_with_logits(masks, target_masks, pos_weight)
+    scale = 2.0 ** (math.floor(math.log2(masks.numel() / max(float(pos_weight), 1.0))) - 4)
+    d_masks.mul_(scale)
+    d_src, _, g_dec = bwd.mask_decoder_backward(decoder, src, pe_tokens, sparse, feat_s0, feat_s1, B, h, w, d_masks)
+    if mem_scale is None:
+        amax = float(d_src.abs().max().item())
+        mem_scale = 2.0 ** (-3 - math.ceil(math.log2(amax))) if amax > 0 and math.isfinite(amax) else 1.0
+    d_src = d_src * mem_scale
+    dcurr, _, _, g_mem = bwd.memory_attention_backward_saved(memory_attention, state, d_src.view(B, L, C).transpose(0, 1))
+    return loss, scale, scale * mem_scale, g_dec, g_mem, dcurr
+
+
+@torch.no_grad()
+def memory_decoder_finetune_step(memory_attention, decoder, opt_mem: DecoderAdam, opt_dec: DecoderAdam, *args, sync: bool = True, **kwargs):
+    """One optimisation step of both parameter groups train_3d.py:34-54 builds around the frozen image encoder -- the mask decoder
+    (`sam_layers`) and the memory attention (the bulk of `mem_layers`) -- on the loss of `memory_decoder_loss_grads` (same arguments).  The first call calibrates the memory group's loss scale (one host
+    synchronisation) and stores it on `opt_mem`; later calls -- and a hipGraph captured after it -- reuse it."""
+    if kwargs.get("mem_scale") is None:
+        kwargs["mem_scale"] = getattr(opt_mem, "calibrated_loss_scale", None)     # calibrated on the first (eager) step, then reused
+    loss, scale, scale_mem, g_dec, g_mem, _ = memory_decoder_loss_grads(memory_attention, decoder, *args, **kwargs)
+    opt_mem.calibrated_loss_scale = scale_mem / scale
+    opt_dec.step(g_dec, grad_scale=1.0 / scale)
+    opt_mem.step(g_mem, grad_scale=1.0 / scale_mem)
     return float(loss.item()) if sync else loss

@@ -412,6 +412,24 @@ def run_grads_case():
             keep("dec_param." + k, p.grad)
             n_with_grad += 1
     meta["dec"] = {"B": B, "E": E, "P": Pp, "pos_weight": pos_weight, "seeds": [160, 161, 162, 163, 164, 165], "n_params_with_grad": n_with_grad}
+    for p in dec.parameters():
+        p.requires_grad_(False)
+    # ---- memory encoder (memory_encoder.py:138-181) with the sigmoid mask transform of sam2_base.py:686-696
+    me = m.memory_encoder
+    for p in me.parameters():
+        p.requires_grad_(True)
+    pix = rnd(B, C, E, E, seed=180).requires_grad_(True)
+    mask = rnd(B, 1, 16 * E, 16 * E, seed=181, scale=4.0)
+    dyo = rnd(B, 64, E, E, seed=182)
+    mask_for_mem = torch.sigmoid(mask) * m.sigmoid_scale_for_mem_enc + m.sigmoid_bias_for_mem_enc
+    y = me(pix, mask_for_mem, skip_mask_sigmoid=True)["vision_features"]
+    y.backward(dyo)
+    out["memenc_out_sub"] = sub(y, 1024)
+    keep("memenc_d_pix", pix.grad)
+    for k, p in me.named_parameters():
+        keep("memenc_param." + k, p.grad)
+    meta["memenc"] = {"B": B, "E": E, "seeds": [180, 181, 182], "scale": float(m.sigmoid_scale_for_mem_enc),
+                      "bias": float(m.sigmoid_bias_for_mem_enc), "n_params": len(list(me.named_parameters()))}
     return out, meta
 
 

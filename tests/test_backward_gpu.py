@@ -486,3 +486,65 @@ def test_memory_encoder_backward(mods):
             report[name] = rel(gt, ref)
         worst = sorted(report.items(), key=lambda kv: -kv[1])[:6]
         assert worst[0][1] < 4e-2, (learned_gamma, worst)
+
+
+def test_memory_decoder_loss_grads(mods):
+    """The memory-conditioned slice step end to end (memory attention -> + dense prompt -> mask decoder -> BCE with logits): loss and
+    the gradients of BOTH parameter groups against autograd through oracle.memory_attention + oracle.mask_decoder_predict, then one
+    Adam step of each group lowers the loss.
+    The reference is linearised at the HIP forward's own memory-attention output: at this (random-init) point the decoder's input
+    gradient dL/dy moves by 8.5 % when y moves by 0.05 % along the direction of the 16-bit forward's rounding error (measured with
+    fp32 autograd alone, tools/chain_grad_debug.py; white noise of the same size moves it by 0.05 %), so fp32 autograd evaluated at the
+    oracle's y is not the gradient of the function the HIP path computes -- every link checked at a common point agrees to < 1 %."""
+    B_, ops = mods
+    import medical_sam2_amd.build_sam as bs
+    import medical_sam2_amd.training as T
+    import medical_sam2_amd.weights as wts
+    m = bs.build_sam2("sam2_hiera_t", device="cpu", hydra_overrides_extra=["++model.image_size=256"])
+    sd = wts.init_weights("hiera_t", 0)
+    m.load_state_dict(sd, strict=True)
+    mod, dec = m.memory_attention.to(DEV).eval(), m.sam_mask_decoder.to(DEV).eval()
+    cfg = O.model_config("hiera_t", 256)
+    P = {k: v.clone().float().requires_grad_(k.startswith("memory_attention.") or k.startswith("sam_mask_decoder.")) for k, v in sd.items()}
+    B, E, C, n_ptr = 2, 16, 256, 4
+    L, Nk = E * E, E * E + 4
+    q16 = lambda t: t.to(ops.OP16).float()
+    curr, curr_pos = rnd(L, B, C, seed=140), rnd(L, B, C, seed=141)
+    memory, memory_pos = rnd(Nk, B, 64, seed=142), rnd(Nk, B, 64, seed=143)
+    pe, sparse, dense = rnd(1, C, E, E, seed=144), rnd(B, 2, C, seed=145), rnd(1, C, seed=146, scale=0.3)
+    f0, f1 = q16(rnd(B, 32, 4 * E, 4 * E, seed=147)), q16(rnd(B, 64, 2 * E, 2 * E, seed=148))
+    target = (rnd(B, 4, 4 * E, 4 * E, seed=149) > 0.4).float()
+    d = lambda t: t.detach().to(DEV)
+    tm = lambda t: d(t).permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()
+    with torch.no_grad():
+        y_hip, _ = B_.memory_attention_forward_saved(mod, d(curr), d(curr_pos), d(memory), d(memory_pos), n_ptr)
+    y_o = O.memory_attention(P, cfg, curr, memory, curr_pos, memory_pos, n_ptr)            # [L, B, C]
+    assert rel(y_hip, y_o) < 2e-3
+    y_lin = y_hip.detach().cpu().float().contiguous().requires_grad_(True)               # the decoder is linearised at the HIP forward's point
+    emb = y_lin.permute(1, 2, 0).reshape(B, C, E, E)
+    masks, _, _, _ = O.mask_decoder_predict(P, emb, pe, sparse, dense.view(1, C, 1, 1).expand(B, C, E, E), [f0, f1])
+    ref_loss = F.binary_cross_entropy_with_logits(masks, target)
+    ref_loss.backward()
+    y_o.backward(y_lin.grad)
+    args = (d(curr), d(curr_pos), d(memory), d(memory_pos), n_ptr, tm(pe), d(sparse), tm(f0).to(ops.OP16), tm(f1).to(ops.OP16), B, E, E, d(target))
+    loss, scale, scale_mem, g_dec, g_mem, dcurr = T.memory_decoder_loss_grads(mod, dec, *args, dense_tokens=d(dense))
+    assert abs(loss.item() - ref_loss.item()) < 2e-3 * abs(ref_loss.item())
+    report, num, den = {}, {}, {}
+    for pre, grads, sc in (("memory_attention.", g_mem, scale_mem), ("sam_mask_decoder.", g_dec, scale)):
+        for name, g in grads.items():
+            ref = P[pre + name].grad
+            assert ref is not None and g.shape == ref.shape, name
+            if name.endswith("k_proj.bias"):
+                continue                                                        # identically zero up to round-off (softmax shift invariance)
+            report[pre + name] = rel(g / sc, ref)
+            num[pre] = num.get(pre, 0.0) + (g.cpu().double() / sc - ref.double()).pow(2).sum().item()
+            den[pre] = den.get(pre, 0.0) + ref.double().pow(2).sum().item()
+    assert len(g_mem) == 106
+    for pre in num:                                                             # the whole gradient of each group within 2 %
+        assert (num[pre] / den[pre]) ** 0.5 < 2e-2, (pre, (num[pre] / den[pre]) ** 0.5)
+    worst = sorted(report.items(), key=lambda kv: -kv[1])[:6]
+    assert worst[0][1] < 5e-2, worst
+    opt_mem, opt_dec = T.DecoderAdam(mod, lr=1e-4), T.DecoderAdam(dec, lr=1e-4)
+    l1 = T.memory_decoder_finetune_step(mod, dec, opt_mem, opt_dec, *args, dense_tokens=d(dense))
+    l2 = T.memory_decoder_finetune_step(mod, dec, opt_mem, opt_dec, *args, dense_tokens=d(dense))
+    assert abs(l1 - ref_loss.item()) < 2e-3 * abs(ref_loss.item()) and l2 < l1

@@ -1,5 +1,5 @@
 """Gradient fixtures of the REFERENCE (tests/golden/grads_t256.npz, made by `make_golden.py grads`: `.grad` of every `memory_attention`
-and `sam_mask_decoder` parameter and of the inputs under torch.autograd, 2-slice toy problem, eval-mode dropout -- SURVEY.md 8(f) rank 2).
+`sam_mask_decoder` and `memory_encoder` parameter and of the inputs under torch.autograd, 2-slice toy problem, eval-mode dropout -- SURVEY.md 8(f) rank 2).
 
   * CPU: autograd through the oracle reproduces them at fp32 round-off (pins the oracle as the gradient checker of test_backward_gpu.py);
   * GPU: the HIP backward (`medical_sam2_amd.backward`, `training.bce_with_logits`) reproduces them within the 16-bit-operand tolerance.
@@ -50,6 +50,12 @@ def dec_inputs(meta):
     s = meta["seeds"]
     return (rnd(B, 256, E, E, seed=s[0]), rnd(1, 256, E, E, seed=s[1]), rnd(B, Pp, 256, seed=s[2]), rnd(B, 32, 4 * E, 4 * E, seed=s[3]),
             rnd(B, 64, 2 * E, 2 * E, seed=s[4]), (rnd(B, 4, 4 * E, 4 * E, seed=s[5]) > 0.3).float())
+
+
+def memenc_inputs(meta):
+    B, E = meta["B"], meta["E"]
+    s = meta["seeds"]
+    return rnd(B, 256, E, E, seed=s[0]), rnd(B, 1, 16 * E, 16 * E, seed=s[1], scale=4.0), rnd(B, 64, E, E, seed=s[2])
 
 
 def test_oracle_autograd_matches_reference_gradients():
@@ -104,6 +110,22 @@ def test_oracle_autograd_matches_reference_gradients():
                 assert np.abs(sub(g, SUBN) - G[k]).max() <= 1e-3 * np.abs(G[qn]).max() + 1e-9, name
             n += 1
     assert n == meta["dec"]["n_params_with_grad"]
+    worst = sorted(rep.items(), key=lambda kv: -kv[1])[:5]
+    assert worst[0][1] < 2e-3, worst
+    # ---- memory encoder
+    P = {k: v.clone().float().requires_grad_(k.startswith("memory_encoder.")) for k, v in sd.items()}
+    pix, mask, dyo = memenc_inputs(meta["memenc"])
+    pix.requires_grad_(True)
+    y, _ = O.memory_encoder(P, cfg, pix, torch.sigmoid(mask) * meta["memenc"]["scale"] + meta["memenc"]["bias"])
+    assert np.allclose(sub(y, 1024), G["memenc_out_sub"], rtol=1e-4, atol=1e-4)
+    y.backward(dyo)
+    rep = {"d_pix": rel_sub(pix.grad, G["memenc_d_pix"])}
+    n = 0
+    for k in G:
+        if k.startswith("memenc_param."):
+            rep[k[13:]] = rel_sub(P["memory_encoder." + k[13:]].grad, G[k])
+            n += 1
+    assert n == meta["memenc"]["n_params"]
     worst = sorted(rep.items(), key=lambda kv: -kv[1])[:5]
     assert worst[0][1] < 2e-3, worst
 
@@ -169,3 +191,14 @@ def test_hip_backward_matches_reference_gradients():
         print("worst relative gradient errors, unscaled:", plain[:3], " loss-scaled:", scaled[:3])
         assert plain[0][1] < 5e-2, plain
         assert scaled[0][1] < 4e-2, scaled
+        # ---- memory encoder
+        enc = m.memory_encoder.to(DEV).eval()
+        pix, mask, dyo = memenc_inputs(meta["memenc"])
+        Bm, Em = meta["memenc"]["B"], meta["memenc"]["E"]
+        dpix, grads = bwd.memory_encoder_backward(enc, tm(pix), d(mask), 1, meta["memenc"]["scale"], meta["memenc"]["bias"], Bm, Em, Em, tm(dyo))
+        rep = {"d_pix": rel_sub(dpix.view(Bm, Em * Em, 256).permute(0, 2, 1).reshape(Bm, 256, Em, Em), G["memenc_d_pix"])}
+        assert len(grads) == meta["memenc"]["n_params"]
+        for name, g in grads.items():
+            rep[name] = rel_sub(g, G["memenc_param." + name])
+        worst = sorted(rep.items(), key=lambda kv: -kv[1])[:5]
+        assert worst[0][1] < 4e-2, worst
