@@ -149,7 +149,7 @@ def pmc_traffic():
 
 def host_cpu_share() -> int:
     """CPUs this process may actually use: the cgroup quota when there is one (the GPU box gives 16 of its 256 hardware threads;
-    running the oracle on all 256 is 3x SLOWER than on 16: tools/cpu_threads_probe.py), else the affinity mask."""
+    running the oracle on all 256 is 3x SLOWER than on 16: tests/probes/cpu_threads_probe.py), else the affinity mask."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()

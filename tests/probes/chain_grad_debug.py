@@ -1,6 +1,6 @@
 """Where does the gradient error of the memory-attention -> decoder chain come from (debug aid)."""
 import os, sys, torch, torch.nn.functional as F
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import sam2_oracle as O
 import medical_sam2_amd.build_sam as bs, medical_sam2_amd.weights as wts, medical_sam2_amd.training as T, medical_sam2_amd.ops as ops
 import medical_sam2_amd.backward as bwd

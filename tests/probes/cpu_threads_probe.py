@@ -1,6 +1,6 @@
 """Which host thread count gives the best CPU-oracle time on this box (bench.py's cpu_baseline uses the result's rule)."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 print("cpu_count", os.cpu_count(), "affinity", len(os.sched_getaffinity(0)))
 for p in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
     if os.path.exists(p): print(p, open(p).read().strip())

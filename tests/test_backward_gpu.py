@@ -494,7 +494,7 @@ def test_memory_decoder_loss_grads(mods):
     Adam step of each group lowers the loss.
     The reference is linearised at the HIP forward's own memory-attention output: at this (random-init) point the decoder's input
     gradient dL/dy moves by 8.5 % when y moves by 0.05 % along the direction of the 16-bit forward's rounding error (measured with
-    fp32 autograd alone, tools/chain_grad_debug.py; white noise of the same size moves it by 0.05 %), so fp32 autograd evaluated at the
+    fp32 autograd alone, tests/probes/chain_grad_debug.py; white noise of the same size moves it by 0.05 %), so fp32 autograd evaluated at the
     oracle's y is not the gradient of the function the HIP path computes -- every link checked at a common point agrees to < 1 %."""
     B_, ops = mods
     import medical_sam2_amd.build_sam as bs
