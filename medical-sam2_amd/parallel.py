@@ -95,3 +95,32 @@ def gather_cond_memories(local: Dict[int, dict], frame_ids: List[int], group=Non
                 out[fid] = {"maskmem_features": all_f[r][i - b], "maskmem_pos_enc": pos, "obj_ptr": all_p[r][i - b],
                             "pred_masks": None, "pred_masks_high_res": None, "point_inputs": None, "mask_inputs": None}
     return out
+
+
+def allreduce_gradients(grads: Dict[str, torch.Tensor], group=None, bucket_bytes: int = 64 << 20) -> Tuple[Dict[str, torch.Tensor], float]:
+    """Data-parallel fine-tuning (the reference's `args.distributed` switch wraps the net in nn.DataParallel, utils.py get_network):
+    sum the per-rank gradients of `training.*_loss_grads` over the ranks with a few LARGE all-reduces instead of one per parameter --
+    gradients are packed (sorted by name, so every rank packs identically) into flat fp32 buckets of <= `bucket_bytes` (64 MiB: the
+    whole mask decoder is 16 MB, the memory attention 23 MB, i.e. one ring all-reduce each; xGMI rings are per-link bound, so fewer and
+    larger messages win).  Returns ({name: view into its bucket}, 1 / world): pass the second value on as the optimiser's `grad_scale`
+    (times the inverse loss scale), which turns the sum into the mean without another pass over the gradients."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return dict(grads), 1.0
+    world = dist.get_world_size(group)
+    names = sorted(grads)
+    out: Dict[str, torch.Tensor] = {}
+    i = 0
+    while i < len(names):
+        j, size = i, 0
+        while j < len(names) and (j == i or size + grads[names[j]].numel() * 4 <= bucket_bytes):
+            size += grads[names[j]].numel() * 4
+            j += 1
+        flat = torch.cat([grads[n].detach().reshape(-1).float() for n in names[i:j]])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        off = 0
+        for n in names[i:j]:
+            k = grads[n].numel()
+            out[n] = flat[off:off + k].view(grads[n].shape)
+            off += k
+        i = j
+    return out, 1.0 / world

@@ -16,6 +16,7 @@ import torch
 
 from . import backward as bwd
 from . import ops
+from . import parallel
 from ._lib import check, lib
 from .ops import F32, _p, _stream
 
@@ -72,10 +73,11 @@ class DecoderAdam:
 
 @torch.no_grad()
 def decoder_finetune_step(decoder, optimizer: DecoderAdam, src_tokens, pe_tokens, sparse, feat_s0, feat_s1, B: int, h: int, w: int,
-                          target_masks: torch.Tensor, pos_weight: float = 1.0, sync: bool = True):
+                          target_masks: torch.Tensor, pos_weight: float = 1.0, sync: bool = True, data_parallel: bool = False):
     """One optimisation step of the mask decoder.  Inputs as for `MaskDecoder.predict_masks_tokens`; target_masks [B, nm, 4h, 4w] in
     {0, 1}.  Returns the loss value before the update (a Python float; with sync=False the 1-element device tensor, so that the whole
-    step -- ~3000 small launches -- can be captured in a hipGraph and replayed without host work)."""
+    step -- ~3000 small launches -- can be captured in a hipGraph and replayed without host work).  data_parallel: one process per GPU,
+    each on its own slices; the gradients are averaged with `parallel.allreduce_gradients` (one bucketed RCCL all-reduce) before Adam."""
     masks, _, _, _ = decoder.predict_masks_tokens(src_tokens, pe_tokens, sparse, feat_s0, feat_s1, B, h, w)
     loss, d_masks = bce_with_logits(masks, target_masks, pos_weight)
     # Loss scale: |dloss/dlogit| <= max(pos_weight, 1) / n is ~1e-6 at 1024^2 -- below the 16-bit operand's normal range (fp16: 6e-5).
@@ -84,7 +86,10 @@ def decoder_finetune_step(decoder, optimizer: DecoderAdam, src_tokens, pe_tokens
     scale = 2.0 ** (math.floor(math.log2(masks.numel() / max(float(pos_weight), 1.0))) - 4)
     d_masks.mul_(scale)
     _, _, grads = bwd.mask_decoder_backward(decoder, src_tokens, pe_tokens, sparse, feat_s0, feat_s1, B, h, w, d_masks)
-    optimizer.step(grads, grad_scale=1.0 / scale)
+    inv_world = 1.0
+    if data_parallel:                                   # each rank on its own slices: mean of the per-rank gradients over RCCL
+        grads, inv_world = parallel.allreduce_gradients(grads)
+    optimizer.step(grads, grad_scale=inv_world / scale)
     return float(loss.item()) if sync else loss
 
 
@@ -123,7 +128,8 @@ def memory_decoder_loss_grads(memory_attention, decoder, curr, curr_pos, memory,
 
 
 @torch.no_grad()
-def memory_decoder_finetune_step(memory_attention, decoder, opt_mem: DecoderAdam, opt_dec: DecoderAdam, *args, sync: bool = True, **kwargs):
+def memory_decoder_finetune_step(memory_attention, decoder, opt_mem: DecoderAdam, opt_dec: DecoderAdam, *args, sync: bool = True,
+                                 data_parallel: bool = False, **kwargs):
     """One optimisation step of both parameter groups train_3d.py:34-54 builds around the frozen image encoder -- the mask decoder
     (`sam_layers`) and the memory attention (the bulk of `mem_layers`) -- on the loss of `memory_decoder_loss_grads` (same arguments).  The first call calibrates the memory group's loss scale (one host
     synchronisation) and stores it on `opt_mem`; later calls -- and a hipGraph captured after it -- reuse it."""
@@ -131,6 +137,10 @@ def memory_decoder_finetune_step(memory_attention, decoder, opt_mem: DecoderAdam
         kwargs["mem_scale"] = getattr(opt_mem, "calibrated_loss_scale", None)     # calibrated on the first (eager) step, then reused
     loss, scale, scale_mem, g_dec, g_mem, _ = memory_decoder_loss_grads(memory_attention, decoder, *args, **kwargs)
     opt_mem.calibrated_loss_scale = scale_mem / scale
-    opt_dec.step(g_dec, grad_scale=1.0 / scale)
-    opt_mem.step(g_mem, grad_scale=1.0 / scale_mem)
+    inv_world = 1.0
+    if data_parallel:                                   # (ranks must share the calibrated loss scale: calibrate on rank 0's value or pass mem_scale)
+        g_dec, inv_world = parallel.allreduce_gradients(g_dec)
+        g_mem, _ = parallel.allreduce_gradients(g_mem)
+    opt_dec.step(g_dec, grad_scale=inv_world / scale)
+    opt_mem.step(g_mem, grad_scale=inv_world / scale_mem)
     return float(loss.item()) if sync else loss

@@ -50,6 +50,15 @@ def _worker(rank, world, port, q):
         g = torch.Generator().manual_seed(f)
         ok &= torch.equal(full[f]["maskmem_features"], torch.randn(2, 64, 4, 4, generator=g))
         ok &= torch.equal(full[f]["obj_ptr"], torch.randn(2, 256, generator=g))
+    # data-parallel gradient reduction: ragged shapes, two buckets forced by a small bucket size
+    gen = lambda r, n, shape: torch.randn(*shape, generator=torch.Generator().manual_seed(100 * r + n))
+    shapes = {"b.weight": (7, 5), "a.bias": (3,), "c.gamma": (1, 2, 3), "d.w": (40, 10)}
+    mine = {k: gen(rank, i, sh) for i, (k, sh) in enumerate(shapes.items())}
+    red, inv = par.allreduce_gradients(mine, bucket_bytes=1024)
+    assert inv == 1.0 / world and set(red) == set(shapes)
+    for i, (k, sh) in enumerate(shapes.items()):
+        want = sum(gen(r, i, sh) for r in range(world))
+        ok &= red[k].shape == want.shape and torch.allclose(red[k], want, atol=1e-6)
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
