@@ -32,6 +32,143 @@ extern "C" int msam2_transpose16(const void* in, int64_t ldi, void* out, int64_t
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Weight-gradient GEMM without transposes: C[M, N] (fp32) = sum_k A[k][m] * B[k][n] with BOTH operands stored k-major
+// (A = dY [tokens, out], B = X [tokens, in] exactly as the forward left them; C = dW [out, in]).  128x128x32 tiles, the 32 x 128
+// operand slabs go row-major into LDS (row pitch 320 B = 64 mod 128) and both MFMA operands are read transposed with
+// ds_read_b64_tr_b16 (the same k-order for both, so the dot products pair up).  The reduction (tokens: 16k..64k) is split over
+// gridDim.z workgroups that add into the kernel-zeroed output with fp32 atomics.
+// ------------------------------------------------------------------------------------------------------------------
+struct GemmTTParams {
+  const op16 *A, *B;
+  float* C;
+  int64_t lda, ldb, ldc;
+  int M, N, K, ktiles_per_split;
+};
+
+constexpr int TT_PITCH = 320;                 // bytes per LDS row (128 op16 + 64 B pad)
+constexpr int TT_SLAB = 32 * TT_PITCH;        // one operand, one stage
+
+__global__ __launch_bounds__(256) void gemm_tt_kernel(GemmTTParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * TT_SLAB];   // [stage][A | B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5, li = lane & 15;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  const int nk_all = (p.K + 31) / 32;
+  const int kt0 = blockIdx.z * p.ktiles_per_split, kt1 = min(nk_all, kt0 + p.ktiles_per_split);
+  if (kt0 >= kt1) return;
+  uint4 ra[2], rb[2];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 256;
+      const int row = c >> 4, col = (c & 15) * 8;
+      const int64_t k = (int64_t)kt * 32 + row;
+      uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+      if (k < p.K) {
+        if (m0 + col < p.M) a = *reinterpret_cast<const uint4*>(p.A + k * p.lda + m0 + col);
+        if (n0 + col < p.N) b = *reinterpret_cast<const uint4*>(p.B + k * p.ldb + n0 + col);
+      }
+      ra[i] = a;
+      rb[i] = b;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 256;
+      const int row = c >> 4, col = (c & 15) * 8;
+      *reinterpret_cast<uint4*>(lds + (2 * buf) * TT_SLAB + row * TT_PITCH + col * 2) = ra[i];
+      *reinterpret_cast<uint4*>(lds + (2 * buf + 1) * TT_SLAB + row * TT_PITCH + col * 2) = rb[i];
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // transposed-read lane offsets (same pattern as the attention kernels' V^T fragments): rows = k, columns = m / n
+  const int tr_off = (4 * h + (li >> 2)) * TT_PITCH + (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
+  auto frag = [&](const unsigned char* slab, int st, int col0) -> op16x8 {
+    const unsigned char* a0 = slab + tr_off + (16 * st) * TT_PITCH + col0 * 2;
+    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0));
+    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0 + 8 * TT_PITCH));
+    typedef __attribute__((ext_vector_type(8))) short short8_t;
+    short8_t t8;
+    t8[0] = lo[0]; t8[1] = lo[1]; t8[2] = lo[2]; t8[3] = lo[3];
+    t8[4] = hi[0]; t8[5] = hi[1]; t8[6] = hi[2]; t8[7] = hi[3];
+    return __builtin_bit_cast(op16x8, t8);
+  };
+  gload(kt0);
+  lstore(0);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    if (kt + 1 < kt1) gload(kt + 1);
+    const unsigned char* sa = lds + (2 * cur) * TT_SLAB;
+    const unsigned char* sb = sa + TT_SLAB;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      op16x8 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = frag(sa, st, wm * 64 + i * 32);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = frag(sb, st, wn * 64 + j * 32);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = MSAM2_MFMA_32x32x16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < kt1) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  const bool atomic = gridDim.z > 1;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + r;
+    if (n >= p.N) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m < p.M) {
+          if (atomic) atomicAdd(p.C + (int64_t)m * p.ldc + n, acc[i][j][e]);
+          else p.C[(int64_t)m * p.ldc + n] = acc[i][j][e];
+        }
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm_tt_zero_kernel(float* __restrict__ C, int64_t ldc, int M, int N) {
+  const int64_t total = (int64_t)M * N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) C[(i / N) * ldc + i % N] = 0.f;
+}
+
+extern "C" int msam2_gemm_tt(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                             void* stream) {
+  MSAM2_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "gemm_tt: bad arguments");
+  MSAM2_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0,
+                "gemm_tt: M, N, lda, ldb must be multiples of 8 and the operands 16-byte aligned");
+  MSAM2_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31) && lda >= M && ldb >= N && ldc >= N, "gemm_tt: bad sizes");
+  GemmTTParams p;
+  p.A = (const op16*)A; p.B = (const op16*)B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  const int64_t tiles = (int64_t)cdiv(M, 128) * cdiv(N, 128), nk = cdiv(K, 32);
+  int64_t splits = max((int64_t)1, min(min((int64_t)128, cdiv(512, tiles)), nk / 8));
+  p.ktiles_per_split = (int)cdiv(nk, splits);
+  splits = cdiv(nk, p.ktiles_per_split);
+  hipStream_t s = (hipStream_t)stream;
+  if (splits > 1)
+    hipLaunchKernelGGL(gemm_tt_zero_kernel, dim3((unsigned)min((int64_t)1024, (M * N + 255) / 256)), dim3(256), 0, s, C, ldc, (int)M, (int)N);
+  hipLaunchKernelGGL(gemm_tt_kernel, dim3(cdiv(N, 128), cdiv(M, 128), (unsigned)splits), dim3(256), 0, s, p);
+  return msam2_check_launch("gemm_tt");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Column sums (bias gradient): out[c] (+)= sum_r x[r][c].  grid (C/64, row slabs); fp32 atomics into a zeroed output.
 // ------------------------------------------------------------------------------------------------------------------
 template <typename T>

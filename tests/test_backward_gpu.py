@@ -74,6 +74,22 @@ def test_act_backward(mods, act):
     assert (out.float().cpu() - pre.grad).abs().max().item() < 4e-3             # 16-bit output rounding
 
 
+@pytest.mark.parametrize("K,M,N", [(16384, 256, 256), (65536, 128, 64), (300, 200, 40), (28, 8, 2048), (4097, 264, 136)])
+def test_gemm_tt(mods, K, M, N):
+    """dW-shaped product on k-major operands (a^T b): integer operands make every partial sum exact, so the split-K atomics must
+    reproduce the fp64 result bit for bit; strided rows (column slices of wider buffers)."""
+    B_, ops = mods
+    g = torch.Generator().manual_seed(K + M)
+    a = torch.randint(-2, 3, (K, M + 8), generator=g).float()
+    b = torch.randint(-2, 3, (K, N + 16), generator=g).float()
+    a[:, 8] += torch.arange(K).float() % 3
+    b[-1] += torch.arange(N + 16).float() % 5
+    ref = a[:, 8:].double().t() @ b[:, 16:].double()
+    ad, bd = a.to(ops.OP16).to(DEV), b.to(ops.OP16).to(DEV)
+    out = B_.gemm_tt(ad[:, 8:], bd[:, 16:])
+    assert out.shape == ref.shape and torch.equal(out.cpu().double(), ref), (out.cpu().double() - ref).abs().max()
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 384, 96), (4096, 96, 384), (1000, 256, 2048), (64, 32, 64)])
 def test_linear_backward(mods, M, N, K):
     B, ops = mods
