@@ -15,9 +15,9 @@
 //   DV     k              q, dO            S   = Q K^T                         dV^T += dO^T P             lse per streamed row
 //
 // delta = rowsum(dO o O) comes from a pre-pass that also converts dO to the 16-bit operand type; the log-sum-exp of every query
-// row comes from the forward (msam2_attention_fwd_lse).  dK / dV rows have exactly one owner (no atomics); the DQ pass has few
-// owner workgroups when Lq is short against Lk (4096 queries x 16k keys), so its key range is split over workgroups whose partial
-// dQ are added with fp32 atomics into the zeroed output.  Cost: 8 score-tile products against the minimum of 5 -- the price of
+// row comes from the forward (msam2_attention_fwd_lse).  dK / dV rows have exactly one owner; the DQ pass has few owner workgroups
+// when Lq is short against Lk (4096 queries x 16k keys), so its key range is split over workgroups whose partial dQ go to the
+// workspace and are summed by a small reduction pass (no atomics anywhere: the gradients are run-to-run reproducible).  Cost: 8 score-tile products against the minimum of 5 -- the price of
 // three simple passes (a first version of the DQ pass that found the statistics itself with an online softmax spilled 190 VGPRs
 // and ran 3.5x slower than the DK pass on the same flops).
 #include "common.h"
@@ -30,6 +30,7 @@ struct AttnBwdParams {
   const float* delta;                                 // [B, H, Lq]
   const float* lse;                                   // [B, H, Lq], log2 domain (from the forward)
   int ksplit;                                         // DQ role: workgroups per owner block over the streamed keys
+  float* dq_part;                                     // DQ role, ksplit > 1: partial dQ [ksplit][B*H*Lq][D] (workspace)
   float *dq, *dk, *dv;
   int64_t dq_bs, dq_hs, dq_ts, dk_bs, dk_hs, dk_ts, dv_bs, dv_hs, dv_ts;
   int B, H, Lq, Lk;
@@ -263,22 +264,25 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) w[e] = acc[d][4 * g + e] * factor;
       if (ROLE == ROLE_DQ && nsplit > 1) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(out + d * 32 + 8 * g + 4 * h + e, w[e]);
+        float* part = p.dq_part + (((int64_t)split * p.B * p.H + bh) * p.Lq + oi) * D;
+        *reinterpret_cast<f32x4*>(part + d * 32 + 8 * g + 4 * h) = w;
       } else {
         *reinterpret_cast<f32x4*>(out + d * 32 + 8 * g + 4 * h) = w;
       }
     }
 }
 
-// zero fill of strided fp32 rows [B, H, L, D] (a kernel: memset nodes of a captured graph did not order reliably)
-__global__ __launch_bounds__(256) void attn_bwd_zero_kernel(float* __restrict__ x, int64_t bs, int64_t hs, int64_t ts, int H, int L, int D4,
-                                                            int64_t total) {
+// dq[row] = sum over the key splits of the DQ pass's partial rows (16M fp32 atomics cost ~0.5 ms at 4096 x 256 x 4 x 4 splits; this
+// pass moves 80 MB instead)
+__global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ x, int64_t bs, int64_t hs,
+                                                              int64_t ts, int H, int L, int D4, int nsplit, int64_t total) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int c = i % D4;
     const int64_t row = i / D4;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(part + i * 4);
+    for (int s = 1; s < nsplit; ++s) acc += *reinterpret_cast<const f32x4*>(part + ((int64_t)s * total + i) * 4);
     const int64_t t = row % L, bh = row / L;
-    *reinterpret_cast<f32x4*>(x + (bh / H) * bs + (bh % H) * hs + t * ts + c * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(x + (bh / H) * bs + (bh % H) * hs + t * ts + c * 4) = acc;
   }
 }
 
@@ -295,24 +299,28 @@ void launch_role(const AttnBwdParams& p, hipStream_t s) {
   hipLaunchKernelGGL((attn_bwd_kernel<D, NW, ROLE>), grid, dim3(NW * 64), C::LDS_BYTES, s, p);
 }
 
-// workgroup size by fill: 4 waves per workgroup unless that leaves CUs idle; the DQ role additionally splits the keys until there
-// are ~2 workgroups per CU (each split keeps at least 8 key tiles)
+// DQ role: key splits per owner block -- until there are ~2 workgroups per CU, each split keeping at least 8 key tiles, at most
+// DQ_MAX_SPLIT (the workspace holds that many partial dQ)
+constexpr int DQ_MAX_SPLIT = 8;
+int dq_key_splits(int64_t B, int64_t H, int64_t Lq, int64_t Lk) {
+  const int64_t blocks4 = cdiv(Lq, (int64_t)128) * H * B;
+  if (blocks4 >= 512) return 1;
+  return (int)max((int64_t)1, min(min((int64_t)DQ_MAX_SPLIT, (int64_t)cdiv((int64_t)512, blocks4)), cdiv(Lk, (int64_t)32) / 8));
+}
+
+// workgroup size by fill: 4 waves per workgroup unless that leaves CUs idle
 template <int D, int ROLE>
 void launch_fill(AttnBwdParams p, hipStream_t s) {
   const int64_t n_own = ROLE == ROLE_DQ ? p.Lq : p.Lk;
   const int64_t blocks4 = cdiv(n_own, (int64_t)128) * p.H * p.B;
-  p.ksplit = 1;
-  if (ROLE == ROLE_DQ && blocks4 < 512) {
-    const int64_t tiles = cdiv((int64_t)p.Lk, (int64_t)32);
-    p.ksplit = (int)max((int64_t)1, min(cdiv((int64_t)512, blocks4), tiles / 8));
-    if (p.ksplit > 1) {
-      const int64_t total = (int64_t)p.B * p.H * p.Lq * (D / 4);
-      hipLaunchKernelGGL(attn_bwd_zero_kernel, dim3((unsigned)min((int64_t)2048, cdiv(total, (int64_t)256))), dim3(256), 0, s, p.dq, p.dq_bs, p.dq_hs,
-                         p.dq_ts, p.H, p.Lq, D / 4, total);
-    }
-  }
+  p.ksplit = ROLE == ROLE_DQ ? dq_key_splits(p.B, p.H, p.Lq, p.Lk) : 1;
   if (blocks4 * p.ksplit >= 256 || n_own <= 32) launch_role<D, 4, ROLE>(p, s);
   else launch_role<D, 2, ROLE>(p, s);
+  if (p.ksplit > 1) {
+    const int64_t total = (int64_t)p.B * p.H * p.Lq * (D / 4);
+    hipLaunchKernelGGL(attn_bwd_reduce_kernel, dim3((unsigned)min((int64_t)4096, cdiv(total, (int64_t)256))), dim3(256), 0, s, p.dq_part, p.dq, p.dq_bs,
+                       p.dq_hs, p.dq_ts, p.H, p.Lq, D / 4, p.ksplit, total);
+  }
 }
 
 template <int D>
@@ -330,7 +338,11 @@ int launch_all(const AttnBwdParams& p, const float* d_o, const int64_t* gs, cons
 }  // namespace
 
 extern "C" size_t msam2_attention_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Lq, int64_t D) {
-  return (size_t)(B * H * Lq) * (size_t)(D * sizeof(op16) + sizeof(float));
+  const size_t rows = (size_t)(B * H * Lq);
+  const size_t base = rows * (size_t)(D * sizeof(op16) + sizeof(float));
+  // partial dQ of the key-split DQ pass (only taken when the queries alone do not fill the chip)
+  const size_t parts = cdiv(Lq, (int64_t)128) * H * B < 512 ? (size_t)DQ_MAX_SPLIT * rows * D * sizeof(float) : 0;
+  return ((base + 255) & ~(size_t)255) + parts;
 }
 
 // q / k / v / o: 16-bit, element strides {batch, head, token}, channels contiguous; d_o fp32 with its own strides; dq / dk / dv fp32
@@ -366,6 +378,7 @@ extern "C" int msam2_attention_bwd(const void* q, const int64_t* q_strides, cons
   op16* do16 = (op16*)workspace;
   float* delta = (float*)((char*)workspace + (size_t)(B * H * Lq) * D * sizeof(op16));
   p.do16 = do16; p.delta = delta; p.lse = lse; p.ksplit = 1;
+  p.dq_part = reinterpret_cast<float*>((char*)workspace + (((size_t)(B * H * Lq) * (size_t)(D * sizeof(op16) + sizeof(float)) + 255) & ~(size_t)255));
   p.dq = dq; p.dk = dk; p.dv = dv;
   p.dq_bs = dq_strides[0]; p.dq_hs = dq_strides[1]; p.dq_ts = dq_strides[2];
   p.dk_bs = dk_strides[0]; p.dk_hs = dk_strides[1]; p.dk_ts = dk_strides[2];
