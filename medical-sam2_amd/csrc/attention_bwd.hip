@@ -44,7 +44,7 @@ struct BwdCfg {
   static constexpr int BK = 32;
   static constexpr int KS = D * 2 + 16;                                  // slot-1 tile row stride (bytes)
   static constexpr int VS = D * 2 + (((D * 2) % 128 == 64) ? 0 : 64);    // slot-2 tile row stride: VS % 128 == 64
-  static constexpr int STAGE = BK * (KS + VS);
+  static constexpr int STAGE = BK * (KS + (VS > KS ? VS : KS));          // slot 2 is pitched KS or VS depending on the role
   static constexpr int STATS = 2 * 2 * BK * 4;                           // (lse, delta) of the streamed rows, double buffered
   static constexpr int LDS_BYTES = 2 * STAGE + STATS;
 };
@@ -85,6 +85,9 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
   constexpr int CPR = D / 8;       // 16-byte chunks per tile row
   constexpr int CHUNKS = C::BK * CPR;
   constexpr int PER = (CHUNKS + NT - 1) / NT;
+  // slot-2 row pitch by role: the DV role reads it transposed (conflict-free at pitch = 64 mod 128 bytes), the other two read it row
+  // by row with ds_read_b128 (conflict-free at the slot-1 pitch; 4-way conflicts at the other one)
+  constexpr int VS2 = ROLE == ROLE_DV ? C::VS : C::KS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* stats = reinterpret_cast<float*>(smem + 2 * C::STAGE);          // [2 buffers][lse 32 | delta 32]
 
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
       if (c < CHUNKS) {
         const int row = c / CPR, dc = (c % CPR) * 16;
         *reinterpret_cast<uint4*>(base + row * C::KS + dc) = r1[i];
-        *reinterpret_cast<uint4*>(base + C::BK * C::KS + row * C::VS + dc) = r2[i];
+        *reinterpret_cast<uint4*>(base + C::BK * C::KS + row * VS2 + dc) = r2[i];
       }
     }
     if (ROLE != ROLE_DQ && tid < C::BK) {
@@ -181,10 +184,10 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
 
   // per-lane LDS byte offsets: row reads (A operand of the first products) and transposed reads (A operand of the second)
   const int row1_off = r * C::KS + h * 16;                               // + st*32 per k-step
-  const int row2_off = r * C::VS + h * 16;
+  const int row2_off = r * VS2 + h * 16;
   const int li = lane & 15;
   const int tr_row = 4 * h + (li >> 2), tr_col = (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
-  constexpr int TRS = ROLE == ROLE_DV ? C::VS : C::KS;                   // stride of the slot the second product transposes
+  constexpr int TRS = ROLE == ROLE_DV ? VS2 : C::KS;                     // stride of the slot the second product transposes
   const int tr_off = tr_row * TRS + tr_col;                              // + (16 st) rows + dblk*64 B; second half + 8 rows
 
   gload(t_begin);
