@@ -68,17 +68,20 @@ def linear_backward(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, need_dx:
     dy16 = _op16(dy)
     _req(w.shape[0] % 8 == 0, "linear_backward: out_features must be a multiple of 8 (GEMM reduction length of dX)")
     dx = ops.gemm(dy16, transpose16(w), out_dtype=dx_dtype) if need_dx else None          # [M,N] @ (W^T [K,N])^T
-    return dx, gemm_tt(dy16, x), colsum(dy16)
+    dw, db = gemm_tt(dy16, x, a_colsum=True)
+    return dx, dw, db
 
 
-def gemm_tt(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+def gemm_tt(a: torch.Tensor, b: torch.Tensor, a_colsum: bool = False):
     """fp32 [Ma, Nb] = a^T b for 16-bit a [K, Ma], b [K, Nb] (both k-major, rows possibly strided): dW = dY^T X without transposed
-    copies of the token-major operands (`msam2_gemm_tt`; the reduction over the K tokens is split over workgroups)."""
+    copies of the token-major operands (`msam2_gemm_tt`; the reduction over the K tokens is split over workgroups).  a_colsum=True also
+    returns the column sums of a (fp32 [Ma]: the bias gradient when a = dY) from the same pass."""
     _req(a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0] and a.dtype == OP16 and b.dtype == OP16, "gemm_tt: 16-bit [K, M], [K, N]")
     _req(a.stride(1) == 1 and b.stride(1) == 1, "gemm_tt: row-major operands")
     out = torch.empty(a.shape[1], b.shape[1], dtype=F32, device=a.device)
-    check(lib().msam2_gemm_tt(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), a.shape[1], b.shape[1], a.shape[0], _stream()))
-    return out
+    cs = torch.empty(a.shape[1], dtype=F32, device=a.device) if a_colsum else None     # (zeroed by the library)
+    check(lib().msam2_gemm_tt(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), _p(cs), a.shape[1], b.shape[1], a.shape[0], _stream()))
+    return (out, cs) if a_colsum else out
 
 
 def mlp_backward(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: Optional[torch.Tensor], dy: torch.Tensor,

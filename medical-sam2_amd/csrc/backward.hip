@@ -41,6 +41,7 @@ extern "C" int msam2_transpose16(const void* in, int64_t ldi, void* out, int64_t
 struct GemmTTParams {
   const op16 *A, *B;
   float* C;
+  float* a_colsum;   // optional [M]: sum_k A[k][m] (the bias gradient when A = dY), accumulated by the n-tile-0 workgroups into a zeroed vector
   int64_t lda, ldb, ldc;
   int M, N, K, ktiles_per_split;
 };
@@ -58,6 +59,10 @@ __global__ __launch_bounds__(256) void gemm_tt_kernel(GemmTTParams p) {
   const int kt0 = blockIdx.z * p.ktiles_per_split, kt1 = min(nk_all, kt0 + p.ktiles_per_split);
   if (kt0 >= kt1) return;
   uint4 ra[2], rb[2];
+  const bool want_cs = p.a_colsum != nullptr && blockIdx.x == 0;
+  float cs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs[e] = 0.f;
   auto gload = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -71,6 +76,11 @@ __global__ __launch_bounds__(256) void gemm_tt_kernel(GemmTTParams p) {
       }
       ra[i] = a;
       rb[i] = b;
+      if (want_cs) {                                   // (workgroup-uniform branch)
+        const op16x8 av = __builtin_bit_cast(op16x8, a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] += op2f(av[e]);
+      }
     }
   };
   auto lstore = [&](int buf) {
@@ -125,6 +135,19 @@ __global__ __launch_bounds__(256) void gemm_tt_kernel(GemmTTParams p) {
     __syncthreads();
     cur ^= 1;
   }
+  if (want_cs) {
+    // thread (tid & 15) holds the sums of columns 8 (tid & 15) .. +8 over its rows: reduce the 16 row groups through LDS
+    float* red = reinterpret_cast<float*>(lds);          // [16][128]; every wave is past its last fragment read (loop-end barrier)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(tid >> 4) * 128 + (tid & 15) * 8 + e] = cs[e];
+    __syncthreads();
+    if (tid < 128 && m0 + tid < p.M) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t += red[g * 128 + tid];
+      atomicAdd(p.a_colsum + m0 + tid, t);
+    }
+  }
   const bool atomic = gridDim.z > 1;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -143,27 +166,30 @@ __global__ __launch_bounds__(256) void gemm_tt_kernel(GemmTTParams p) {
   }
 }
 
-__global__ __launch_bounds__(256) void gemm_tt_zero_kernel(float* __restrict__ C, int64_t ldc, int M, int N) {
-  const int64_t total = (int64_t)M * N;
+__global__ __launch_bounds__(256) void gemm_tt_zero_kernel(float* __restrict__ C, int64_t ldc, int M, int N, float* __restrict__ colsum, int zero_c) {
+  const int64_t total = zero_c ? (int64_t)M * N : 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) C[(i / N) * ldc + i % N] = 0.f;
+  if (colsum)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256) colsum[i] = 0.f;
 }
 
-extern "C" int msam2_gemm_tt(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-                             void* stream) {
+extern "C" int msam2_gemm_tt(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* a_colsum, int64_t M, int64_t N,
+                             int64_t K, void* stream) {
   MSAM2_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "gemm_tt: bad arguments");
   MSAM2_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0,
                 "gemm_tt: M, N, lda, ldb must be multiples of 8 and the operands 16-byte aligned");
   MSAM2_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31) && lda >= M && ldb >= N && ldc >= N, "gemm_tt: bad sizes");
   GemmTTParams p;
-  p.A = (const op16*)A; p.B = (const op16*)B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.A = (const op16*)A; p.B = (const op16*)B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.a_colsum = a_colsum;
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
   const int64_t tiles = (int64_t)cdiv(M, 128) * cdiv(N, 128), nk = cdiv(K, 32);
   int64_t splits = max((int64_t)1, min(min((int64_t)128, cdiv(512, tiles)), nk / 8));
   p.ktiles_per_split = (int)cdiv(nk, splits);
   splits = cdiv(nk, p.ktiles_per_split);
   hipStream_t s = (hipStream_t)stream;
-  if (splits > 1)
-    hipLaunchKernelGGL(gemm_tt_zero_kernel, dim3((unsigned)min((int64_t)1024, (M * N + 255) / 256)), dim3(256), 0, s, C, ldc, (int)M, (int)N);
+  if (splits > 1 || a_colsum)
+    hipLaunchKernelGGL(gemm_tt_zero_kernel, dim3((unsigned)min((int64_t)1024, (M * N + 255) / 256)), dim3(256), 0, s, C, ldc, (int)M, (int)N, a_colsum,
+                       splits > 1 ? 1 : 0);
   hipLaunchKernelGGL(gemm_tt_kernel, dim3(cdiv(N, 128), cdiv(M, 128), (unsigned)splits), dim3(256), 0, s, p);
   return msam2_check_launch("gemm_tt");
 }

@@ -88,6 +88,8 @@ def test_gemm_tt(mods, K, M, N):
     ad, bd = a.to(ops.OP16).to(DEV), b.to(ops.OP16).to(DEV)
     out = B_.gemm_tt(ad[:, 8:], bd[:, 16:])
     assert out.shape == ref.shape and torch.equal(out.cpu().double(), ref), (out.cpu().double() - ref).abs().max()
+    out2, cs = B_.gemm_tt(ad[:, 8:], bd[:, 16:], a_colsum=True)
+    assert torch.equal(out2, out) and torch.equal(cs.cpu().double(), a[:, 8:].double().sum(0))
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 384, 96), (4096, 96, 384), (1000, 256, 2048), (64, 32, 64)])
