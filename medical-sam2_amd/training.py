@@ -96,7 +96,7 @@ def decoder_finetune_step(decoder, optimizer: DecoderAdam, src_tokens, pe_tokens
 @torch.no_grad()
 def memory_decoder_loss_grads(memory_attention, decoder, curr, curr_pos, memory, memory_pos, num_obj_ptr_tokens: int, pe_tokens, sparse,
                               feat_s0, feat_s1, B: int, h: int, w: int, target_masks: torch.Tensor, dense_tokens=None,
-                              pos_weight: float = 1.0, mem_scale: float = None):
+                              pos_weight: float = 1.0, mem_scale: float = None, aux: dict = None):
     """Forward + backward of the memory-conditioned slice step (func_2d/function.py:70-191 / sam2_base.py:705-790 with a frozen image
     encoder and a detached memory bank, as func_2d/function.py:204-243 stores it): curr / curr_pos [L, B, C] current-slice features,
     memory / memory_pos [Nk, B, 64] the assembled bank -> memory attention -> (+ dense prompt embedding) -> mask decoder -> mean BCE with
@@ -115,6 +115,8 @@ def memory_decoder_loss_grads(memory_attention, decoder, curr, curr_pos, memory,
     else:
         src = src.contiguous()
     masks, _, _, _ = decoder.predict_masks_tokens(src, pe_tokens, sparse, feat_s0, feat_s1, B, h, w)
+    if aux is not None:
+        aux["masks"] = masks                                                     # [B, num_mask_tokens, 4h, 4w] logits of this forward
     loss, d_masks = bce_with_logits(masks, target_masks, pos_weight)
     scale = 2.0 ** (math.floor(math.log2(masks.numel() / max(float(pos_weight), 1.0))) - 4)
     d_masks.mul_(scale)
@@ -144,3 +146,36 @@ def memory_decoder_finetune_step(memory_attention, decoder, opt_mem: DecoderAdam
     opt_dec.step(g_dec, grad_scale=inv_world / scale)
     opt_mem.step(g_mem, grad_scale=inv_world / scale_mem)
     return float(loss.item()) if sync else loss
+
+
+@torch.no_grad()
+def train_step_2d(model, opt_mem: DecoderAdam, opt_dec: DecoderAdam, imgs, pts, labels, memory, memory_pos, target_masks, sync: bool = True):
+    """One training iteration of the 2-D flow (func_2d/function.py:70-259) on the HIP path with the image and prompt encoders frozen
+    (train_3d.py:34-37's choice of trainable groups): image encoder forward -> memory attention over the (detached) bank -> prompt
+    encoder -> mask decoder -> BCE on the mask logits -> backward of decoder + memory attention -> Adam on both -> the new memory is
+    encoded from the predicted mask for the bank (forward only, stored detached as func_2d/function.py:204-243 does).
+    imgs [B,3,S,S] normalised, pts [B,P,2] / labels [B,P] clicks, memory / memory_pos [Nk,B,64] (bench.assemble_memory layout),
+    target_masks [B, num_mask_tokens, S/4, S/4].  Returns (loss, maskmem_features [B,64,S/16,S/16])."""
+    from .modeling.common import to_bf16, tokens_of
+    B = imgs.shape[0]
+    backbone_out = model.forward_image(imgs)
+    _, vision_feats, vision_pos_embeds, feat_sizes = model._prepare_backbone_features(backbone_out)
+    h, w = feat_sizes[-1]
+    se, _ = model.sam_prompt_encoder(points=(pts, labels), boxes=None, masks=None, batch_size=B)
+    pe = tokens_of(model.sam_prompt_encoder.get_dense_pe().to(torch.float32))[: h * w]
+    hr = [f.permute(1, 2, 0).view(B, -1, *s) for f, s in zip(vision_feats[:-1], feat_sizes[:-1])]
+    f0, f1 = to_bf16(tokens_of(hr[0])), to_bf16(tokens_of(hr[1]))
+    dense = model.sam_prompt_encoder.no_mask_embed.weight.detach().reshape(1, -1)
+    aux: dict = {}
+    kwargs = dict(dense_tokens=dense, aux=aux, mem_scale=getattr(opt_mem, "calibrated_loss_scale", None))
+    loss, scale, scale_mem, g_dec, g_mem, _ = memory_decoder_loss_grads(
+        model.memory_attention, model.sam_mask_decoder, vision_feats[-1], vision_pos_embeds[-1], memory, memory_pos, 0, pe, se.to(torch.float32),
+        f0, f1, B, h, w, target_masks, **kwargs)
+    opt_mem.calibrated_loss_scale = scale_mem / scale
+    opt_dec.step(g_dec, grad_scale=1.0 / scale)
+    opt_mem.step(g_mem, grad_scale=1.0 / scale_mem)
+    low_res = aux["masks"][:, :1].contiguous()                                   # single-mask output token (multimask_output=False)
+    high_res = ops.bilinear_upsample(low_res, model.image_size, model.image_size)
+    maskmem_features, _ = model._encode_new_memory(current_vision_feats=vision_feats, feat_sizes=feat_sizes, pred_masks_high_res=high_res,
+                                                   is_mask_from_pts=True)
+    return (float(loss.item()) if sync else loss), maskmem_features

@@ -566,3 +566,48 @@ def test_memory_decoder_loss_grads(mods):
     l1 = T.memory_decoder_finetune_step(mod, dec, opt_mem, opt_dec, *args, dense_tokens=d(dense))
     l2 = T.memory_decoder_finetune_step(mod, dec, opt_mem, opt_dec, *args, dense_tokens=d(dense))
     assert abs(l1 - ref_loss.item()) < 2e-3 * abs(ref_loss.item()) and l2 < l1
+
+
+def test_train_step_2d(mods):
+    """One full training iteration of the 2-D flow (frozen encoders; memory attention + mask decoder trained; new memory encoded from the
+    prediction): the loss falls over three iterations, only the two trainable groups move, and the first loss equals the oracle's
+    forward on the same inputs."""
+    B_, ops = mods
+    import medical_sam2_amd.build_sam as bs
+    import medical_sam2_amd.synthetic as syn
+    import medical_sam2_amd.training as T
+    import medical_sam2_amd.weights as wts
+    m = bs.build_sam2("sam2_hiera_t", device="cpu", hydra_overrides_extra=["++model.image_size=256"])
+    sd = wts.init_weights("hiera_t", 0)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    B, S, E = 2, 256, 16
+    imgs = torch.stack([syn.normalize_image(syn.blob_image(i, S)[0]) for i in range(B)])
+    pts = torch.tensor([[[100.0, 120.0]], [[60.0, 200.0]]])
+    labels = torch.ones(B, 1, dtype=torch.int32)
+    memory, memory_pos = rnd(2 * E * E, B, 64, seed=150, scale=0.5), rnd(2 * E * E, B, 64, seed=151)
+    target = (rnd(B, 4, S // 4, S // 4, seed=152) > 0.3).float()
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    om, od = T.DecoderAdam(m.memory_attention, lr=1e-5), T.DecoderAdam(m.sam_mask_decoder, lr=1e-4)
+    d = lambda t: t.to(DEV)
+    with torch.no_grad():
+        losses = []
+        for _ in range(3):
+            loss, mem = T.train_step_2d(m, om, od, d(imgs), d(pts), d(labels), d(memory), d(memory_pos), d(target))
+            losses.append(loss)
+        assert mem.shape == (B, 64, E, E) and torch.isfinite(mem).all()
+        assert losses[1] < losses[0] and losses[2] < losses[0], losses      # (Adam sign-like first steps: not necessarily monotone)
+        moved = {k.split(".")[0] for k, v in m.state_dict().items() if not torch.equal(v, before[k])}
+        assert moved == {"memory_attention", "sam_mask_decoder"}, moved
+    # the first loss against the oracle's forward (weights before any update)
+    with torch.no_grad():
+        P = {k: v.float() for k, v in sd.items()}
+        cfg = O.model_config("hiera_t", 256)
+        feats, poss, sizes = O.prepare_backbone_features(O.forward_image(P, cfg, imgs))
+        y = O.memory_attention(P, cfg, feats[-1] , memory, poss[-1], memory_pos, 0)
+        emb = y.permute(1, 2, 0).reshape(B, 256, E, E)
+        hr = [f.permute(1, 2, 0).reshape(B, -1, *sz) for f, sz in zip(feats[:-1], sizes[:-1])]
+        se, de = O.prompt_encoder(P, cfg, (pts, labels), None, None)
+        masks, _, _, _ = O.mask_decoder_predict(P, emb, O.dense_pe(P, E, E), se, de, hr)
+        ref = F.binary_cross_entropy_with_logits(masks, target).item()
+    assert abs(losses[0] - ref) < 5e-3 * abs(ref), (losses[0], ref)
