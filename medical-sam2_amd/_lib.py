@@ -55,7 +55,7 @@ SIGNATURES = {
     "msam2_transpose16": (c_i, [c_p, c_l, c_p, c_l, c_l, c_l, c_p]),
     "msam2_colsum": (c_i, [c_p, c_i, c_l, c_p, c_l, c_l, c_p]),
     "msam2_act_bwd": (c_i, [c_p, c_i, c_p, c_i, c_p, c_l, c_i, c_p]),
-    "msam2_layernorm_bwd": (c_i, [c_p, c_l, c_p, c_i, c_l, c_p, c_p, c_l, c_p, c_p, c_l, c_l, c_f, c_p]),
+    "msam2_layernorm_bwd": (c_i, [c_p, c_l, c_p, c_i, c_l, c_p, c_p, c_l, c_p, c_p, c_l, c_l, c_f, c_p, c_l, c_p]),
     "msam2_softmax_rows": (c_i, [c_p, c_l, c_p, c_l, c_l, c_l, c_f, c_p]),
     "msam2_softmax_bwd_rows": (c_i, [c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_l, c_f, c_p]),
     "msam2_convt2x2_gather": (c_i, [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_p]),

@@ -46,16 +46,18 @@ def act_backward(pre: torch.Tensor, dy: torch.Tensor, act: int) -> torch.Tensor:
     return out
 
 
-def layernorm_backward(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, eps: float) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """x fp32 [rows, C] (the LayerNorm input), dy [rows, C] (16-bit or fp32) -> (dx fp32, dgamma fp32 [C], dbeta fp32 [C])."""
+def layernorm_backward(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, eps: float,
+                       add: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """x fp32 [rows, C] (the LayerNorm input), dy [rows, C] (16-bit or fp32) -> (dx fp32, dgamma fp32 [C], dbeta fp32 [C]).
+    add (fp32 [rows, C]): gradient of a residual path around the norm, added into dx in the same pass (pre-LN blocks: dx = d_res + LN'(dy))."""
     _req(x.dim() == 2 and x.dtype == F32 and x.stride(1) == 1 and dy.shape == x.shape and dy.stride(1) == 1, "layernorm_backward shapes")
+    _req(add is None or (add.dtype == F32 and add.shape == x.shape and add.stride(1) == 1), "layernorm_backward: add must be fp32 [rows, C]")
     rows, C = x.shape
     dx = torch.empty(rows, C, dtype=F32, device=x.device)
-    dg = torch.zeros(C, dtype=F32, device=x.device)
-    db = torch.zeros(C, dtype=F32, device=x.device)
-    check(lib().msam2_layernorm_bwd(_p(x), x.stride(0), _p(dy), _is_bf16(dy), dy.stride(0), _p(gamma), _p(dx), dx.stride(0), _p(dg), _p(db),
-                                    rows, C, eps, _stream()))
-    return dx, dg, db
+    dgb = torch.zeros(2, C, dtype=F32, device=x.device)
+    check(lib().msam2_layernorm_bwd(_p(x), x.stride(0), _p(dy), _is_bf16(dy), dy.stride(0), _p(gamma), _p(dx), dx.stride(0), _p(dgb[0]), _p(dgb[1]),
+                                    rows, C, eps, _p(add), add.stride(0) if add is not None else 0, _stream()))
+    return dx, dgb[0], dgb[1]
 
 
 def _op16(t: torch.Tensor) -> torch.Tensor:
@@ -218,8 +220,8 @@ def _memory_attention_layer_backward_saved(layer, ctx: dict, dy: torch.Tensor):
     g = {}
     dt3, g["linear1.weight"], g["linear1.bias"], g["linear2.weight"], g["linear2.bias"] = mlp_backward(
         t3, w1, Bv("f1b", layer.linear1.bias), w2, Bv("f2b", layer.linear2.bias), dy, ops.ACT_RELU)
-    d, g["norm3.weight"], g["norm3.bias"] = layernorm_backward(x2, layer.norm3.weight.detach().float(), dt3, layer.norm3.eps)
-    dx2 = dy + d                                                                  # residual branch + LayerNorm branch
+    dx2, g["norm3.weight"], g["norm3.bias"] = layernorm_backward(x2, layer.norm3.weight.detach().float(), dt3, layer.norm3.eps,
+                                                                 add=dy)          # residual branch + LayerNorm branch
     # cross attention
     da2, g["cross_attn_image.out_proj.weight"], g["cross_attn_image.out_proj.bias"] = linear_backward(a2, W("ow", ca.out_proj.weight), dx2)
     dq2, dkk, dvv = attention_backward(u4(q2), u4(kk), u4(vv), u4(da2.view(B, L, C)), o_lse=ol2)
@@ -229,8 +231,7 @@ def _memory_attention_layer_backward_saved(layer, ctx: dict, dy: torch.Tensor):
     dt2, g["cross_attn_image.q_proj.weight"], g["cross_attn_image.q_proj.bias"] = linear_backward(t2, wq, dq2.view(B * L, C))
     dmk, g["cross_attn_image.k_proj.weight"], g["cross_attn_image.k_proj.bias"] = linear_backward(mk2, wk, dkk.view(B * Nk, C))
     dmv, g["cross_attn_image.v_proj.weight"], g["cross_attn_image.v_proj.bias"] = linear_backward(mv2, wv, dvv.view(B * Nk, C))
-    d, g["norm2.weight"], g["norm2.bias"] = layernorm_backward(x1, layer.norm2.weight.detach().float(), dt2, layer.norm2.eps)
-    dx1 = dx2 + d
+    dx1, g["norm2.weight"], g["norm2.bias"] = layernorm_backward(x1, layer.norm2.weight.detach().float(), dt2, layer.norm2.eps, add=dx2)
     # self attention
     da1, g["self_attn.out_proj.weight"], g["self_attn.out_proj.bias"] = linear_backward(a1, W("ow_s", sa.out_proj.weight), dx1)
     dq1, dk1, dv1 = attention_backward(u4(q1), u4(k1), u4(v1), u4(da1.view(B, L, C)), o_lse=ol1)
@@ -241,8 +242,8 @@ def _memory_attention_layer_backward_saved(layer, ctx: dict, dy: torch.Tensor):
     dt1, dw_qkv, db_qkv = linear_backward(t1, w_qkv, dqkv.view(B * L, 3 * C))
     for i, nm in enumerate(("q", "k", "v")):
         g[f"self_attn.{nm}_proj.weight"], g[f"self_attn.{nm}_proj.bias"] = dw_qkv[i * C:(i + 1) * C], db_qkv[i * C:(i + 1) * C]
-    d, g["norm1.weight"], g["norm1.bias"] = layernorm_backward(x, layer.norm1.weight.detach().float(), dt1, layer.norm1.eps)
-    return dx1 + d, dmk.view(B, Nk, -1), dmv.view(B, Nk, -1), g
+    dx0, g["norm1.weight"], g["norm1.bias"] = layernorm_backward(x, layer.norm1.weight.detach().float(), dt1, layer.norm1.eps, add=dx1)
+    return dx0, dmk.view(B, Nk, -1), dmv.view(B, Nk, -1), g
 
 
 

@@ -250,14 +250,15 @@ extern "C" int msam2_act_bwd(const void* pre, int pre_is_16bit, const void* dy, 
 
 // ------------------------------------------------------------------------------------------------------------------
 // LayerNorm backward, one wave per row (C <= 1024):  xhat = (x - mean) rstd,  g = dy * gamma,
-//   dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)),   dgamma += dy * xhat,   dbeta += dy   (fp32 atomics, zeroed by the caller)
+//   dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)) [+ add: the gradient of the residual path around the norm],
+//   dgamma += dy * xhat,   dbeta += dy   (fp32 atomics, zeroed by the caller)
 // The statistics are recomputed from x (fp32 residual stream), so the forward saves nothing.
 // ------------------------------------------------------------------------------------------------------------------
 template <typename TD, int NI>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int64_t ldx, const TD* __restrict__ dy, int64_t ldd,
                                                             const float* __restrict__ gamma, float* __restrict__ dx, int64_t ldo,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int C,
-                                                            float eps) {
+                                                            float eps, const float* __restrict__ add, int64_t lda) {
   // a lane always handles the same NI columns (lane + 64 i), so dgamma / dbeta accumulate in registers over the workgroup's rows;
   // the four waves are combined through LDS once at the end (the first version did two LDS atomics per element: 50 us for 16k x 256)
   __shared__ float sg[4][NI * 64], sb[4][NI * 64];
@@ -304,10 +305,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
     const float m1 = wave_sum(s1) * inv_c, m2 = wave_sum(s2) * inv_c;
     float* o = dx + row * ldo;
+    const float* ar = add ? add + row * lda : nullptr;     // gradient of the residual branch that by-passes the LayerNorm
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int c = lane + 64 * i;
-      if (c < C) o[c] = rstd * (gv[i] - m1 - xv[i] * m2);
+      if (c < C) o[c] = rstd * (gv[i] - m1 - xv[i] * m2) + (ar ? ar[c] : 0.f);
     }
   }
 #pragma unroll
@@ -324,9 +326,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 
 template <typename TD>
 static void layernorm_bwd_launch(const float* x, int64_t ldx, const TD* dy, int64_t ldd, const float* gamma, float* dx, int64_t ldo, float* dgamma,
-                                 float* dbeta, int64_t rows, int C, float eps, hipStream_t s) {
+                                 float* dbeta, int64_t rows, int C, float eps, const float* add, int64_t lda, hipStream_t s) {
   const dim3 grid((unsigned)min((int64_t)1024, cdiv(rows, 16))), block(256);
-#define LNB(NI) hipLaunchKernelGGL((layernorm_bwd_kernel<TD, NI>), grid, block, 0, s, x, ldx, dy, ldd, gamma, dx, ldo, dgamma, dbeta, rows, C, eps)
+#define LNB(NI) hipLaunchKernelGGL((layernorm_bwd_kernel<TD, NI>), grid, block, 0, s, x, ldx, dy, ldd, gamma, dx, ldo, dgamma, dbeta, rows, C, eps, add, lda)
   const int ni = cdiv(C, 64);
   if (ni <= 1) LNB(1);
   else if (ni <= 2) LNB(2);
@@ -339,11 +341,13 @@ static void layernorm_bwd_launch(const float* x, int64_t ldx, const TD* dy, int6
 }
 
 extern "C" int msam2_layernorm_bwd(const float* x, int64_t ldx, const void* dy, int dy_is_16bit, int64_t ldd, const float* gamma, float* dx,
-                                   int64_t ldo, float* dgamma, float* dbeta, int64_t rows, int64_t C, float eps, void* stream) {
+                                   int64_t ldo, float* dgamma, float* dbeta, int64_t rows, int64_t C, float eps, const float* add, int64_t ld_add,
+                                   void* stream) {
   MSAM2_REQUIRE(x && dy && gamma && dx && dgamma && dbeta, "layernorm_bwd: null tensor");
   MSAM2_REQUIRE(rows > 0 && C > 0 && C <= 1024, "layernorm_bwd: C <= 1024");
-  if (dy_is_16bit) layernorm_bwd_launch<op16>(x, ldx, (const op16*)dy, ldd, gamma, dx, ldo, dgamma, dbeta, rows, (int)C, eps, (hipStream_t)stream);
-  else layernorm_bwd_launch<float>(x, ldx, (const float*)dy, ldd, gamma, dx, ldo, dgamma, dbeta, rows, (int)C, eps, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  if (dy_is_16bit) layernorm_bwd_launch<op16>(x, ldx, (const op16*)dy, ldd, gamma, dx, ldo, dgamma, dbeta, rows, (int)C, eps, add, ld_add, s);
+  else layernorm_bwd_launch<float>(x, ldx, (const float*)dy, ldd, gamma, dx, ldo, dgamma, dbeta, rows, (int)C, eps, add, ld_add, s);
   return msam2_check_launch("layernorm_bwd");
 }
 

@@ -62,6 +62,9 @@ def test_layernorm_backward(mods, rows, C, eps):
     assert rel(dx, x.grad) < 1e-5 and rel(dg, g.grad) < 1e-5 and rel(db, b.grad) < 1e-5
     dx2, _, _ = B.layernorm_backward(x.detach().to(DEV), g.detach().to(DEV), dy.to(ops.OP16).to(DEV), eps)
     assert rel(dx2, x.grad) < 2e-3                                               # 16-bit upstream gradient
+    res = rnd(rows, C, seed=8)
+    dx3, dg3, _ = B.layernorm_backward(x.detach().to(DEV), g.detach().to(DEV), dy.to(DEV), eps, add=res.to(DEV))
+    assert rel(dx3, x.grad + res) < 1e-5 and rel(dg3, g.grad) < 1e-5             # residual-path gradient fused into the store
 
 
 @pytest.mark.parametrize("act", [1, 2])
