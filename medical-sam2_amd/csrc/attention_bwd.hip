@@ -93,7 +93,16 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, h = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
+  // XCD-aware placement (as in the forward): workgroups are dealt round-robin over the 8 XCDs, each with a private L2; all owner
+  // blocks of one (batch, head) stream the SAME rows, so they go to one XCD (a contiguous slice of the remapped id space).
+  const int gx = gridDim.x, gy = gridDim.y;
+  int lid = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  {
+    const int nwg = gx * gy * gridDim.z;
+    const int q8 = nwg / 8, rem = nwg % 8, xcd = lid % 8;
+    lid = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + lid / 8;
+  }
+  const int bx = lid % gx, head = (lid / gx) % gy, b = lid / (gx * gy);
   const int64_t bh = (int64_t)b * p.H + head;
 
   // ---- roles: owner rows (registers) and streamed rows (LDS slots 1 / 2)
@@ -114,7 +123,8 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
 
   // ---- this lane's owner row -> B-operand fragments kept in registers
   const int nsplit = ROLE == ROLE_DQ ? p.ksplit : 1;
-  const int oblk = blockIdx.x / nsplit, split = blockIdx.x - oblk * nsplit;
+  const int nob = gx / nsplit;                         // owner blocks; neighbouring workgroups share a key range (L2 reuse), not an owner block
+  const int split = bx / nob, oblk = bx - split * nob;
   const int oi = oblk * (NW * 32) + wave * 32 + r;
   const bool ovalid = oi < n_own;
   op16x8 f1[DSTEPS], f2[ROLE == ROLE_DV ? 1 : DSTEPS];
