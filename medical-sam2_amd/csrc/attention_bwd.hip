@@ -21,6 +21,7 @@
 // three simple passes (a first version of the DQ pass that found the statistics itself with an online softmax spilled 190 VGPRs
 // and ran 3.5x slower than the DK pass on the same flops).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -285,6 +286,269 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant (D = 128 / 256): the streamed tiles go global -> LDS with buffer_load ... lds (no staging registers, no LDS store
+// instructions), in the forward kernel's swizzled images so that every fragment read is bank-conflict free:
+//   row image  (ds_read_b128 rows):        16-byte chunk c of row r sits at (c & ~15) | ((c & 15) ^ (r & 15))
+//   tr image   (ds_read_b64_tr_b16):       chunk c of row r sits at c ^ ((r & 3) << 2)
+// Slot 1 is read both ways by the DQ / DK roles, so it is streamed twice (one image of each kind, 16 KB each at D = 256); slot 2 is
+// a row image for DQ / DK and a tr image for DV.  One barrier per tile: tile t+1 is issued right after the barrier that says
+// "tile t has landed and everybody is done with tile t-1".
+// ------------------------------------------------------------------------------------------------------------------
+template <int D, int NW, int ROLE>
+__global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dma_kernel(AttnBwdParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BK = 32, RB = D * 2, CPR = D / 8;
+  constexpr int IMG = BK * RB;
+  constexpr int NIMG = ROLE == ROLE_DV ? 2 : 3;          // [slot-1 row image][slot-1 tr image (DQ / DK)][slot-2 image]
+  constexpr int STAGE = NIMG * IMG;
+  constexpr int KI = IMG / 1024, PW = KI / NW;
+  constexpr int DSTEPS = D / 16, DBLK = D / 32;
+  static_assert(KI % NW == 0, "image must split evenly over the waves");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  float* stats = reinterpret_cast<float*>(smem + 2 * STAGE);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int gx = gridDim.x, gy = gridDim.y;
+  int lid = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  {
+    const int nwg = gx * gy * gridDim.z;
+    const int q8 = nwg / 8, rem = nwg % 8, xcd = lid % 8;
+    lid = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + lid / 8;
+  }
+  const int bx = lid % gx, head = (lid / gx) % gy, b = lid / (gx * gy);
+  const int64_t bh = (int64_t)b * p.H + head;
+
+  const int n_own = ROLE == ROLE_DQ ? p.Lq : p.Lk;
+  const int n_str = ROLE == ROLE_DQ ? p.Lk : p.Lq;
+  const op16* qb = p.q + b * p.q_bs + head * p.q_hs;
+  const op16* kb = p.k + b * p.k_bs + head * p.k_hs;
+  const op16* vb = p.v + b * p.v_bs + head * p.v_hs;
+  const op16* gb = p.do16 + bh * p.Lq * D;
+  const op16* own1 = ROLE == ROLE_DQ ? qb : kb;
+  const int64_t own1_ts = ROLE == ROLE_DQ ? p.q_ts : p.k_ts;
+  const op16* own2 = ROLE == ROLE_DQ ? gb : vb;
+  const int64_t own2_ts = ROLE == ROLE_DQ ? (int64_t)D : p.v_ts;
+  const op16* str1 = ROLE == ROLE_DQ ? kb : qb;
+  const int str1_rb = (int)(ROLE == ROLE_DQ ? p.k_ts : p.q_ts) * 2;      // streamed row pitch in bytes
+  const op16* str2 = ROLE == ROLE_DQ ? vb : gb;
+  const int str2_rb = (int)(ROLE == ROLE_DQ ? p.v_ts : (int64_t)D) * 2;
+
+  const int nsplit = ROLE == ROLE_DQ ? p.ksplit : 1;
+  const int nob = gx / nsplit;
+  const int split = bx / nob, oblk = bx - split * nob;
+  const int oi = oblk * (NW * 32) + wave * 32 + r;
+  const bool ovalid = oi < n_own;
+  op16x8 f1[DSTEPS], f2[ROLE == ROLE_DV ? 1 : DSTEPS];
+#pragma unroll
+  for (int s = 0; s < DSTEPS; ++s) {
+    uint4 a = make_uint4(0, 0, 0, 0), c = make_uint4(0, 0, 0, 0);
+    if (ovalid) {
+      a = *reinterpret_cast<const uint4*>(own1 + (int64_t)oi * own1_ts + s * 16 + h * 8);
+      if constexpr (ROLE != ROLE_DV) c = *reinterpret_cast<const uint4*>(own2 + (int64_t)oi * own2_ts + s * 16 + h * 8);
+    }
+    f1[s] = __builtin_bit_cast(op16x8, a);
+    if constexpr (ROLE != ROLE_DV) f2[s] = __builtin_bit_cast(op16x8, c);
+  }
+  const float delta_own = (ROLE == ROLE_DQ && ovalid) ? p.delta[bh * p.Lq + oi] : 0.f;
+  const float lse_own = (ROLE == ROLE_DQ && ovalid) ? p.lse[bh * p.Lq + oi] : 0.f;
+
+  const int tiles_all = (n_str + BK - 1) / BK;
+  const int tiles_per = (tiles_all + nsplit - 1) / nsplit;
+  const int t_begin = split * tiles_per, t_end = min(tiles_all, t_begin + tiles_per);
+  if (t_begin >= t_end) return;
+  const int t_full_end = min(t_end, n_str / BK);
+
+  const auto rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void*)str1, 0, 0x7fffffff, 0x00020000);
+  const auto rsrc2 = __builtin_amdgcn_make_buffer_rsrc((void*)str2, 0, 0x7fffffff, 0x00020000);
+  // per-lane source offsets: LDS slot f = (wave*PW + j)*64 + lane of an image holds global chunk swz(c) of row f / CPR
+  auto src_off = [&](int j, int row_bytes, bool tr_image, int clamp_last) -> unsigned {
+    const int f = (wave * PW + j) * 64 + lane;
+    const int row = f / CPR, c = f % CPR;
+    const int gc = tr_image ? (c ^ ((row & 3) << 2)) : ((c & ~15) | ((c & 15) ^ (row & 15)));
+    return (unsigned)(min(row, clamp_last) * row_bytes + (gc << 4));
+  };
+  unsigned o1r[PW], o1t[ROLE == ROLE_DV ? 1 : PW], o2[PW];
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    o1r[j] = src_off(j, str1_rb, false, BK);
+    if constexpr (ROLE != ROLE_DV) o1t[j] = src_off(j, str1_rb, true, BK);
+    o2[j] = src_off(j, str2_rb, ROLE == ROLE_DV, BK);
+  }
+  auto issue = [&](int tile, int stage) {
+    unsigned char* base = smem + stage * STAGE + wave * PW * 1024;
+    const unsigned s1 = (unsigned)(tile * BK) * (unsigned)str1_rb, s2 = (unsigned)(tile * BK) * (unsigned)str2_rb;
+#pragma unroll
+    for (int j = 0; j < PW; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (__attribute__((address_space(3))) void*)(base + j * 1024), 16, o1r[j], s1, 0, 0);
+    if constexpr (ROLE != ROLE_DV) {
+#pragma unroll
+      for (int j = 0; j < PW; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (__attribute__((address_space(3))) void*)(base + IMG + j * 1024), 16, o1t[j], s1, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < PW; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc2, (__attribute__((address_space(3))) void*)(base + (NIMG - 1) * IMG + j * 1024), 16, o2[j], s2, 0, 0);
+  };
+  // statistics of the streamed rows (DK / DV): loaded by 32 lanes, parked in LDS next to the stage they belong to
+  float rs_lse = 0.f, rs_del = 0.f;
+  auto stat_load = [&](int tile) {
+    if (ROLE != ROLE_DQ && tid < BK) {
+      const int row = tile * BK + tid;
+      rs_lse = row < n_str ? p.lse[bh * p.Lq + row] : INFINITY;
+      rs_del = row < n_str ? p.delta[bh * p.Lq + row] : 0.f;
+    }
+  };
+  auto stat_store = [&](int buf) {
+    if (ROLE != ROLE_DQ && tid < BK) {
+      stats[buf * 2 * BK + tid] = rs_lse;
+      stats[buf * 2 * BK + BK + tid] = rs_del;
+    }
+  };
+
+  f32x16 acc[DBLK];
+#pragma unroll
+  for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
+
+  // fragment read offsets (see attention.hip: K image rows / V image transposed reads)
+  const int k_row = r * RB, k_x = r & 15;
+  const int li = lane & 15, vq = li >> 2, vp = li & 3, cgrp = (lane >> 4) & 1;
+  const int v_row = (4 * h + vq) * RB + ((vp & 1) << 3);
+  const int v_sw = vq << 2, v_c0 = 2 * cgrp + (vp >> 1);
+  auto row_frag = [&](const unsigned char* img, int st) -> op16x8 {
+    const int c = 2 * st + h;
+    return *reinterpret_cast<const op16x8*>(img + k_row + (((c & ~15) | ((c & 15) ^ k_x)) << 4));
+  };
+
+  auto compute = [&](int stage, int row0, const bool masked) __attribute__((always_inline)) {
+    const unsigned char* img1r = smem + stage * STAGE;
+    const unsigned char* img2 = img1r + (NIMG - 1) * IMG;
+    const unsigned char* imgt = ROLE == ROLE_DV ? img2 : img1r + IMG;
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+    for (int g2 = 0; g2 < DSTEPS; g2 += 2) {
+      op16x8 a[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) a[u] = row_frag(img1r, g2 + u);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) s = MSAM2_MFMA_32x32x16(a[u], f1[g2 + u], s, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (ROLE != ROLE_DV) {
+#pragma unroll
+      for (int g2 = 0; g2 < DSTEPS; g2 += 2) {
+        op16x8 a[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) a[u] = row_frag(img2, g2 + u);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) dp = MSAM2_MFMA_32x32x16(a[u], f2[g2 + u], dp, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    op16x8 wf[2];
+    if constexpr (ROLE == ROLE_DQ) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float pe = __builtin_amdgcn_exp2f(s[e] * p.scale_log2 - lse_own);
+        if (masked && row0 + (e & 3) + 8 * (e >> 2) + 4 * h >= n_str) pe = 0.f;   // tail tile: clamped duplicates of the last key
+        wf[e >> 3][e & 7] = f2op(pe * (dp[e] - delta_own));
+      }
+    } else {
+      const float* st_lse = stats + (stage & 1) * 2 * BK;
+      const float* st_del = st_lse + BK;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const float pe = __builtin_amdgcn_exp2f(s[e] * p.scale_log2 - st_lse[row]);   // lse = +inf past the end: weight 0
+        wf[e >> 3][e & 7] = f2op(ROLE == ROLE_DV ? pe : pe * (dp[e] - st_del[row]));
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < DBLK; ++d) {
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        typedef __attribute__((ext_vector_type(8))) short short8_t;
+        const int cch = (d * 4 + v_c0) ^ v_sw;
+        const unsigned char* a0 = imgt + v_row + (16 * st) * RB + (cch << 4);
+        const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0));
+        const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0 + 8 * RB));
+        short8_t t8;
+        t8[0] = lo[0]; t8[1] = lo[1]; t8[2] = lo[2]; t8[3] = lo[3];
+        t8[4] = hi[0]; t8[5] = hi[1]; t8[6] = hi[2]; t8[7] = hi[3];
+        acc[d] = MSAM2_MFMA_32x32x16(__builtin_bit_cast(op16x8, t8), wf[st], acc[d], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  if (t_begin < t_full_end) {
+    issue(t_begin, 0);
+    stat_load(t_begin);
+    stat_store(0);
+  }
+  for (int tile = t_begin; tile < t_full_end; ++tile) {
+    const int st_i = (tile - t_begin) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tile + 1 < t_full_end) {
+      issue(tile + 1, st_i ^ 1);
+      stat_load(tile + 1);
+    }
+    compute(st_i, tile * BK, false);
+    if (tile + 1 < t_full_end) stat_store(st_i ^ 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  if (t_full_end < t_end) {
+    // partial last tile: rows past the end re-read the last valid row (their weights are zero: masked / lse = +inf)
+    const int row0 = t_full_end * BK, last = n_str - 1 - row0;
+    __builtin_amdgcn_s_barrier();                             // every wave is done with the last full tile's stage
+    unsigned char* base = smem + wave * PW * 1024;
+    const unsigned s1 = (unsigned)row0 * (unsigned)str1_rb, s2 = (unsigned)row0 * (unsigned)str2_rb;
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (__attribute__((address_space(3))) void*)(base + j * 1024), 16,
+                                               src_off(j, str1_rb, false, last), s1, 0, 0);
+      if constexpr (ROLE != ROLE_DV)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (__attribute__((address_space(3))) void*)(base + IMG + j * 1024), 16,
+                                                 src_off(j, str1_rb, true, last), s1, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc2, (__attribute__((address_space(3))) void*)(base + (NIMG - 1) * IMG + j * 1024), 16,
+                                               src_off(j, str2_rb, ROLE == ROLE_DV, last), s2, 0, 0);
+    }
+    stat_load(t_full_end);
+    stat_store(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    compute(0, row0, true);
+  }
+
+  const float factor = ROLE == ROLE_DV ? 1.f : p.scale;
+  if (!ovalid) return;
+  float* out = ROLE == ROLE_DQ ? p.dq + b * p.dq_bs + head * p.dq_hs + (int64_t)oi * p.dq_ts
+             : ROLE == ROLE_DK ? p.dk + b * p.dk_bs + head * p.dk_hs + (int64_t)oi * p.dk_ts
+                               : p.dv + b * p.dv_bs + head * p.dv_hs + (int64_t)oi * p.dv_ts;
+#pragma unroll
+  for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = acc[d][4 * g + e] * factor;
+      if (ROLE == ROLE_DQ && nsplit > 1) {
+        float* part = p.dq_part + (((int64_t)split * p.B * p.H + bh) * p.Lq + oi) * D;
+        *reinterpret_cast<f32x4*>(part + d * 32 + 8 * g + 4 * h) = w;
+      } else {
+        *reinterpret_cast<f32x4*>(out + d * 32 + 8 * g + 4 * h) = w;
+      }
+    }
+#endif
+}
+
 // dq[row] = sum over the key splits of the DQ pass's partial rows (16M fp32 atomics cost ~0.5 ms at 4096 x 256 x 4 x 4 splits; this
 // pass moves 80 MB instead)
 __global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ x, int64_t bs, int64_t hs,
@@ -302,13 +566,28 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(const float* __res
 template <int D, int NW, int ROLE>
 void launch_role(const AttnBwdParams& p, hipStream_t s) {
   using C = BwdCfg<D>;
+  const int n_own = ROLE == ROLE_DQ ? p.Lq : p.Lk;
+  dim3 grid(cdiv(n_own, NW * 32) * (ROLE == ROLE_DQ ? p.ksplit : 1), p.H, p.B);
+  if constexpr (D == 128 || D == 256) {
+    // LDS-DMA variant: 32-bit source offsets (rows * pitch < 2^31 bytes), 16-byte aligned rows (checked by the entry point)
+    static const bool no_dma = getenv("MSAM2_BWD_NO_DMA") != nullptr;
+    const int64_t max_bytes = (int64_t)max(p.Lq, p.Lk) * max(max(p.q_ts, p.k_ts), max(p.v_ts, (int64_t)D)) * 2;
+    if (!no_dma && max_bytes < (1ll << 31)) {
+      constexpr int LDSB = 2 * (ROLE == ROLE_DV ? 2 : 3) * 32 * D * 2 + BwdCfg<D>::STATS;
+      static bool attr_dma = false;
+      if (!attr_dma) {
+        hipFuncSetAttribute((const void*)attn_bwd_dma_kernel<D, NW, ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+        attr_dma = true;
+      }
+      hipLaunchKernelGGL((attn_bwd_dma_kernel<D, NW, ROLE>), grid, dim3(NW * 64), LDSB, s, p);
+      return;
+    }
+  }
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)attn_bwd_kernel<D, NW, ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     attr_set = true;
   }
-  const int n_own = ROLE == ROLE_DQ ? p.Lq : p.Lk;
-  dim3 grid(cdiv(n_own, NW * 32) * (ROLE == ROLE_DQ ? p.ksplit : 1), p.H, p.B);
   hipLaunchKernelGGL((attn_bwd_kernel<D, NW, ROLE>), grid, dim3(NW * 64), C::LDS_BYTES, s, p);
 }
 
