@@ -438,7 +438,6 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dma_kernel(AttnBwdParams 
       for (int u = 0; u < 2; ++u) a[u] = row_frag(img1r, g2 + u);
 #pragma unroll
       for (int u = 0; u < 2; ++u) s = MSAM2_MFMA_32x32x16(a[u], f1[g2 + u], s, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (ROLE != ROLE_DV) {
 #pragma unroll
@@ -448,8 +447,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dma_kernel(AttnBwdParams 
         for (int u = 0; u < 2; ++u) a[u] = row_frag(img2, g2 + u);
 #pragma unroll
         for (int u = 0; u < 2; ++u) dp = MSAM2_MFMA_32x32x16(a[u], f2[g2 + u], dp, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+        }
     }
     op16x8 wf[2];
     if constexpr (ROLE == ROLE_DQ) {
@@ -483,7 +481,6 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dma_kernel(AttnBwdParams 
         t8[4] = hi[0]; t8[5] = hi[1]; t8[6] = hi[2]; t8[7] = hi[3];
         acc[d] = MSAM2_MFMA_32x32x16(__builtin_bit_cast(op16x8, t8), wf[st], acc[d], 0, 0, 0);
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
