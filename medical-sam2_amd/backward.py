@@ -1,10 +1,14 @@
-"""First slice of the backward pass ("fused LN/MLP backward"): gradients of nn.LayerNorm, nn.Linear and
-the Linear-act-Linear MLP (sam2_utils.py:108-132; hieradet.py:96-106,160-166; memory_attention.py:43-47,96) on the HIP path.  The
-gradient GEMMs are the forward GEMM kernel on transposed operands (`ops.gemm(dy, W^T)` / `ops.gemm(dy^T, x^T)`), the rest are the
-kernels of csrc/backward.hip.  The attention backward is flash-style for head dims 64-256 (csrc/attention_bwd.hip), fused for the decoder's small heads, materialised otherwise.
+"""Explicit, recomputing backward pass on the HIP path: nn.LayerNorm, nn.Linear, the Linear-act-Linear MLP
+(sam2_utils.py:108-132; hieradet.py:96-106,160-166; memory_attention.py:43-47,96), attention (flash-style `msam2_attention_bwd` for head
+dims 64-256, the fused `msam2_attention_small_bwd` for the decoder's 16 / 32-wide heads, a materialised GEMM-composed fallback otherwise),
+and on top of them the whole `MemoryAttention`, `MaskDecoder` (two-way transformer, transposed convolutions, hyper-network MLPs) and
+`MemoryEncoder` modules.  Input gradients run on the forward GEMM kernels (`ops.gemm(dy, W^T)`), weight and bias gradients on
+`msam2_gemm_tt` (k-major operands: no transposed copies), the rest on the kernels of csrc/backward.hip / csrc/attention_bwd.hip.
+The forward saves nothing: each module backward re-runs its forward keeping the intermediates it needs.
 
-Operands are 16-bit (ops.OP16) like the forward: with the default fp16 build callers must keep gradients in fp16 range (loss scaling);
-the bf16 build has fp32's range.  Parity: tests/test_backward_gpu.py against torch.autograd on the fp32 oracle primitives.
+Operands are 16-bit (ops.OP16) like the forward: with the default fp16 build callers must keep gradients in fp16 range (loss scaling:
+see training.py); the bf16 build has fp32's range.  Parity: tests/test_backward_gpu.py against torch.autograd on the fp32 oracle
+primitives, tests/test_grads_golden.py against the reference's own `.grad`.
 """
 from __future__ import annotations
 

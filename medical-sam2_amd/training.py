@@ -1,11 +1,20 @@
-"""Decoder fine-tuning step on the HIP path (the `sam_layers` group of train_3d.py:34-50: every parameter of `sam_mask_decoder`, Adam at
-lr 1e-4, with the image encoder, memory and prompt encoder frozen): forward of the mask decoder, BCE-with-logits loss on its mask logits
-(func_3d/function.py:69, `criterion_G`), `backward.mask_decoder_backward`, Adam update -- all kernels from libmsam2_hip.so.
+"""Training steps on the HIP path for the parameter groups train_3d.py:34-54 optimises around the frozen image
+and prompt encoders -- no autograd graph: explicit recomputing backward (`backward.py`), BCE-with-logits loss (func_3d/function.py:69,
+`criterion_G`) and Adam (`train_3d.py:50-54`) as kernels of libmsam2_hip.so.
 
-Scope (partial): the loss is taken on the decoder's low-resolution logits of all `num_mask_tokens` masks
-against one target per mask token; the reference additionally up-samples to the video resolution and selects one mask per object, and it
-back-propagates through the memory bank for its second parameter group (lr 1e-8) -- neither is built.  The IoU / object-score heads do not
-receive a gradient from this loss.  Pinned by tests/test_backward_gpu.py::test_decoder_finetune_step against oracle + autograd + torch.optim.
+  decoder_finetune_step          mask decoder only (`sam_layers`, lr 1e-4)
+  memory_decoder_finetune_step   memory attention (the bulk of `mem_layers`) + mask decoder, memory bank detached as
+                                 func_2d/function.py:204-243 stores it
+  train_step_2d                  one whole iteration of the 2-D flow: frozen encoders forward, the joint step, memory encoding of the new
+                                 prediction (`backward.memory_encoder_backward` exists for the third group; it sees no gradient in the 2-D
+                                 flow because the bank is detached)
+  data_parallel=True             gradients averaged over the ranks with one bucketed all-reduce (`parallel.allreduce_gradients`)
+
+Scope: the loss is taken on the decoder's low-resolution logits of all `num_mask_tokens` masks against one target per mask token; the
+reference additionally up-samples to the video resolution and selects one mask per object, and its 3-D loop back-propagates through the
+memory bank (`non_prompt_loss`, func_3d/function.py:182-184) -- neither is built.  The IoU / object-score heads do not receive a gradient
+from this loss.  16-bit operands: the loss gradient is scaled by a fixed power of two and un-scaled inside the Adam kernel.
+Pinned by tests/test_backward_gpu.py (oracle + autograd + torch.optim) and tests/test_grads_golden.py (the reference's own `.grad`).
 """
 from __future__ import annotations
 
