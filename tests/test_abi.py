@@ -57,3 +57,32 @@ def test_product_package_never_imports_oracle():
             if fn.endswith(".py"):
                 src = open(os.path.join(dp, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{fn} imports the oracle"
+
+
+def test_argument_errors_cross_the_abi_as_codes_not_exceptions():
+    """Reference behaviour: AT_ASSERTM -> RuntimeError (connected_components.cu:215-228).  Here every entry validates its arguments
+    on the host BEFORE touching the device and returns < 0 with a message in msam2_last_error(); checked without a GPU on entries of
+    every kernel family (the wrappers in ops.py turn the code into RuntimeError)."""
+    from medical_sam2_amd import _lib
+    L = _lib.lib()
+    L.msam2_last_error.restype = ctypes.c_char_p
+    i64x3 = (ctypes.c_int64 * 3)(256, 256, 256)
+    buf = ctypes.create_string_buffer(4096)              # a valid, 16-byte alignable host address: never dereferenced by the checks
+    ptr = (ctypes.addressof(buf) + 15) & ~15
+    cases = {
+        "gemm: K": lambda: L.msam2_gemm(ptr, 12, ptr, 12, None, None, None, 0, 0, 0, ptr, 16, 0, 4, 4, 12, 0, None),
+        "cc_label: height": lambda: L.msam2_cc_label(ptr, ptr, ptr, 1, 3, 4, ptr, 1 << 20, None),
+        "attention: head dim": lambda: L.msam2_attention_fwd(ptr, i64x3, ptr, i64x3, ptr, i64x3, ptr, i64x3, 1, 1, 32, 32, 80, 0.1, 1, None, 0, None),
+        "attention_bwd: head dim": lambda: L.msam2_attention_bwd(ptr, i64x3, ptr, i64x3, ptr, i64x3, ptr, i64x3, ptr, ptr, i64x3, ptr, i64x3, ptr,
+                                                               i64x3, ptr, i64x3, ptr, 1 << 30, 1, 1, 32, 32, 80, 0.1, None),
+        "attention_small_bwd: one side": lambda: L.msam2_attention_small_bwd(ptr, 0, 0, ptr, 0, 0, ptr, 0, 0, ptr, ptr, ptr, ptr, 1, 8, 64, 64, 16, 0.25, None),
+        "gemm_tt: M, N": lambda: L.msam2_gemm_tt(ptr, 12, ptr, 16, ptr, 16, None, 12, 16, 64, None),
+        "layernorm_bwd: C": lambda: L.msam2_layernorm_bwd(ptr, 2048, ptr, 0, 2048, ptr, ptr, 2048, ptr, ptr, 4, 2048, 1e-6, None, 0, None),
+        "col2im3x3s2": lambda: L.msam2_col2im3x3s2(ptr, 8, ptr, 1, 3, 4, 4, None),
+        "adam_step_multi": lambda: L.msam2_adam_step_multi(None, None, None, None, None, 0, 1e-4, 0.9, 0.999, 1e-8, 1, 1.0, None),
+    }
+    for what, call in cases.items():
+        rc = call()
+        msg = L.msam2_last_error().decode()
+        assert rc < 0, (what, rc)
+        assert what.split(":")[0] in msg, (what, msg)
