@@ -4,6 +4,7 @@
 // kernels.  Reference semantics: torch.autograd of nn.LayerNorm (hieradet.py:101-102, memory_attention.py:43-45), nn.GELU (exact
 // erf) / nn.ReLU and nn.Linear (sam2_utils.py:108-132).
 #include "common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------------------------
 // out[c][r] = in[r][c], 16-bit, 64x64 tiles through LDS (row pitch 66 halves: conflict-free both ways)
@@ -183,7 +184,8 @@ extern "C" int msam2_gemm_tt(const void* A, int64_t lda, const void* B, int64_t 
   p.A = (const op16*)A; p.B = (const op16*)B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.a_colsum = a_colsum;
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
   const int64_t tiles = (int64_t)cdiv(M, 128) * cdiv(N, 128), nk = cdiv(K, 32);
-  int64_t splits = max((int64_t)1, min(min((int64_t)128, cdiv(512, tiles)), nk / 8));
+  // ~2 workgroups per CU, each split at least 16 k-tiles long (swept on the training step's shapes: tools/gemm_tt_bench.py)
+  int64_t splits = max((int64_t)1, min(min((int64_t)128, cdiv(512, tiles)), nk / 16));
   p.ktiles_per_split = (int)cdiv(nk, splits);
   splits = cdiv(nk, p.ktiles_per_split);
   hipStream_t s = (hipStream_t)stream;
