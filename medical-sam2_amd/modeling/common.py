@@ -38,6 +38,10 @@ def w_bf16(cache: WeightCache, key: str, *weights: torch.Tensor) -> torch.Tensor
 
 
 def v_f32(cache: WeightCache, key: str, *vecs: torch.Tensor) -> torch.Tensor:
+    """fp32 vector from one or more parameter vectors (biases, norm weights).  A single fp32 contiguous parameter is used in place (a
+    view: nothing to repack after an optimiser step); several are concatenated into a cached copy."""
+    if len(vecs) == 1 and vecs[0].dtype == F32 and vecs[0].is_contiguous():
+        return vecs[0].detach().reshape(-1)
     return cache.get(key, vecs, lambda: torch.cat([v.detach().reshape(-1) for v in vecs], 0).to(F32).contiguous())
 
 
