@@ -8,11 +8,13 @@ and prompt encoders -- no autograd graph: explicit recomputing backward (`backwa
   train_step_2d                  one whole iteration of the 2-D flow: frozen encoders forward, the joint step, memory encoding of the new
                                  prediction (`backward.memory_encoder_backward` exists for the third group; it sees no gradient in the 2-D
                                  flow because the bank is detached)
+  memory_bank_finetune_step      one level of BPTT through the memory bank (the `non_prompt_loss` path of func_3d/function.py:160-184): the
+                                 current slice's loss also trains the memory encoder that produced the previous slice's memory
   data_parallel=True             gradients averaged over the ranks with one bucketed all-reduce (`parallel.allreduce_gradients`)
 
 Scope: the loss is taken on the decoder's low-resolution logits of all `num_mask_tokens` masks against one target per mask token; the
-reference additionally up-samples to the video resolution and selects one mask per object, and its 3-D loop back-propagates through the
-memory bank (`non_prompt_loss`, func_3d/function.py:182-184) -- neither is built.  The IoU / object-score heads do not receive a gradient
+reference additionally up-samples to the video resolution and selects one mask per object, and its 3-D loop back-propagates through
+the whole memory bank including the previous slices' decoders and object pointers -- only the first level is built.  The IoU / object-score heads do not receive a gradient
 from this loss.  16-bit operands: the loss gradient is scaled by a fixed power of two and un-scaled inside the Adam kernel.
 Pinned by tests/test_backward_gpu.py (oracle + autograd + torch.optim) and tests/test_grads_golden.py (the reference's own `.grad`).
 """
@@ -134,7 +136,9 @@ def memory_decoder_loss_grads(memory_attention, decoder, curr, curr_pos, memory,
         amax = float(d_src.abs().max().item())
         mem_scale = 2.0 ** (-3 - math.ceil(math.log2(amax))) if amax > 0 and math.isfinite(amax) else 1.0
     d_src = d_src * mem_scale
-    dcurr, _, _, g_mem = bwd.memory_attention_backward_saved(memory_attention, state, d_src.view(B, L, C).transpose(0, 1))
+    dcurr, dmemory, dmemory_pos, g_mem = bwd.memory_attention_backward_saved(memory_attention, state, d_src.view(B, L, C).transpose(0, 1))
+    if aux is not None:
+        aux["dmemory"], aux["dmemory_pos"] = dmemory, dmemory_pos                # [Nk, B, 64] each, carrying scale * mem_scale
     return loss, scale, scale * mem_scale, g_dec, g_mem, dcurr
 
 
@@ -188,3 +192,47 @@ def train_step_2d(model, opt_mem: DecoderAdam, opt_dec: DecoderAdam, imgs, pts, 
     maskmem_features, _ = model._encode_new_memory(current_vision_feats=vision_feats, feat_sizes=feat_sizes, pred_masks_high_res=high_res,
                                                    is_mask_from_pts=True)
     return (float(loss.item()) if sync else loss), maskmem_features
+
+
+@torch.no_grad()
+def memory_bank_loss_grads(model, curr, curr_pos, prev_pix_tokens, prev_mask_logits, prev_is_mask_from_pts: bool, memory_pos, pe_tokens, sparse,
+                           feat_s0, feat_s1, B: int, h: int, w: int, target_masks: torch.Tensor, dense_tokens=None, pos_weight: float = 1.0,
+                           mem_scale: float = None):
+    """One level of back-propagation through the memory bank -- the path of the 3-D loop's `non_prompt_loss` (func_3d/function.py:160-184)
+    that trains the memory ENCODER: the previous slice's memory is encoded here from its pixel features and predicted mask
+    (`_encode_new_memory`, sam2_base.py:665-703), the current (unprompted) slice attends to it, and the mask loss of the current slice
+    flows back through decoder -> memory attention -> memory tokens -> memory encoder.  Truncated where the reference's graph goes on
+    into the previous slice's decoder: the previous mask and both slices' image features are treated as constants.
+    curr / curr_pos [L, B, C]; prev_pix_tokens [B*L, C]; prev_mask_logits fp32 [B, 1, 16h, 16w]; memory_pos [L, B, 64] (position +
+    temporal encoding of that bank entry, a constant).  Returns (loss, {group: loss scale}, {group: {parameter: gradient}}) for the
+    groups "decoder", "memory_attention", "memory_encoder"."""
+    enc = model.memory_encoder
+    # (sam2_base.py:686-688: masks from clicks are binarised only in eval mode; binarisation has no gradient anyway)
+    mode = 2 if (model.binarize_mask_from_pts_for_mem_enc and prev_is_mask_from_pts and not model.training) else 1
+    sc, bi = float(model.sigmoid_scale_for_mem_enc), float(model.sigmoid_bias_for_mem_enc)
+    L, _, C = curr.shape
+    mem = enc.run(prev_pix_tokens, prev_mask_logits, mode, sc, bi, B, h, w)                  # fp32 [B*L, 64]
+    memory = mem.view(B, L, -1).transpose(0, 1)                                              # [L, B, 64] like the bank's flattened entries
+    aux: dict = {}
+    loss, scale, scale_mem, g_dec, g_mem, _ = memory_decoder_loss_grads(
+        model.memory_attention, model.sam_mask_decoder, curr, curr_pos, memory, memory_pos, 0, pe_tokens, sparse, feat_s0, feat_s1, B, h, w,
+        target_masks, dense_tokens=dense_tokens, pos_weight=pos_weight, mem_scale=mem_scale, aux=aux)
+    d_mem = aux["dmemory"].transpose(0, 1).reshape(B * L, -1).contiguous()                    # [B*L, 64], scaled by scale_mem
+    _, g_enc = bwd.memory_encoder_backward(enc, prev_pix_tokens, prev_mask_logits, mode, sc, bi, B, h, w, d_mem)
+    return loss, {"decoder": scale, "memory_attention": scale_mem, "memory_encoder": scale_mem}, \
+        {"decoder": g_dec, "memory_attention": g_mem, "memory_encoder": g_enc}
+
+
+@torch.no_grad()
+def memory_bank_finetune_step(model, optimizers: Dict[str, DecoderAdam], *args, sync: bool = True, **kwargs):
+    """Adam step of the three groups on `memory_bank_loss_grads` (same arguments).  `optimizers` maps "decoder" / "memory_attention" /
+    "memory_encoder" to a DecoderAdam over `model.sam_mask_decoder` / `model.memory_attention` / `model.memory_encoder` (train_3d.py:50-54
+    runs the first at lr 1e-4 and the memory groups at 1e-8); groups without an optimiser are left alone."""
+    if kwargs.get("mem_scale") is None and "memory_attention" in optimizers:
+        kwargs["mem_scale"] = getattr(optimizers["memory_attention"], "calibrated_loss_scale", None)
+    loss, scales, grads = memory_bank_loss_grads(model, *args, **kwargs)
+    if "memory_attention" in optimizers:
+        optimizers["memory_attention"].calibrated_loss_scale = scales["memory_attention"] / scales["decoder"]
+    for grp, opt in optimizers.items():
+        opt.step(grads[grp], grad_scale=1.0 / scales[grp])
+    return float(loss.item()) if sync else loss

@@ -614,3 +614,80 @@ def test_train_step_2d(mods):
         masks, _, _, _ = O.mask_decoder_predict(P, emb, O.dense_pe(P, E, E), se, de, hr)
         ref = F.binary_cross_entropy_with_logits(masks, target).item()
     assert abs(losses[0] - ref) < 5e-3 * abs(ref), (losses[0], ref)
+
+
+def test_memory_bank_loss_grads(mods):
+    """One level of BPTT through the memory bank (the path of `non_prompt_loss` that trains the memory encoder): the mask loss of an
+    unprompted slice flows back through decoder -> memory attention -> the previous slice's memory tokens -> memory encoder.  All three
+    groups against autograd through the oracle chain with the same truncation (previous mask and image features constant); like
+    test_memory_decoder_loss_grads the decoder is linearised at the HIP forward's own memory-attention output."""
+    B_, ops = mods
+    import medical_sam2_amd.build_sam as bs
+    import medical_sam2_amd.training as T
+    import medical_sam2_amd.weights as wts
+    sd = wts.init_weights("hiera_t", 0)
+    for j in range(2):      # a learned layer scale: at its 1e-6 initial value the encoder's branch gradients drown in the residual path
+        sd[f"memory_encoder.fuser.layers.{j}.gamma"] = 0.05 + 0.1 * torch.rand(256, generator=torch.Generator().manual_seed(17 + j))
+    m = bs.build_sam2("sam2_hiera_t", device="cpu", hydra_overrides_extra=["++model.image_size=256"])
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    cfg = O.model_config("hiera_t", 256)
+    groups = {"decoder": "sam_mask_decoder.", "memory_attention": "memory_attention.", "memory_encoder": "memory_encoder."}
+    P = {k: v.clone().float().requires_grad_(any(k.startswith(g) for g in groups.values())) for k, v in sd.items()}
+    B, E, C = 2, 16, 256
+    L = E * E
+    q16 = lambda t: t.to(ops.OP16).float()
+    curr, curr_pos = rnd(L, B, C, seed=160), rnd(L, B, C, seed=161)
+    prev_pix = rnd(B, C, E, E, seed=162)
+    prev_mask = rnd(B, 1, 16 * E, 16 * E, seed=163, scale=4.0)
+    memory_pos = rnd(L, B, 64, seed=164)
+    pe, sparse, dense = rnd(1, C, E, E, seed=165), rnd(B, 2, C, seed=166), rnd(1, C, seed=167, scale=0.3)
+    f0, f1 = q16(rnd(B, 32, 4 * E, 4 * E, seed=168)), q16(rnd(B, 64, 2 * E, 2 * E, seed=169))
+    target = (rnd(B, 4, 4 * E, 4 * E, seed=170) > 0.4).float()
+    d = lambda t: t.detach().to(DEV)
+    tm = lambda t: d(t).permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()
+    sc, bi = cfg["sigmoid_scale_for_mem_enc"], cfg["sigmoid_bias_for_mem_enc"]
+    # HIP forward point of the memory-attention output (for the linearisation of the decoder)
+    with torch.no_grad():
+        mem_hip = m.memory_encoder.run(tm(prev_pix), d(prev_mask), 1, sc, bi, B, E, E).view(B, L, 64).transpose(0, 1)
+        y_hip, _ = B_.memory_attention_forward_saved(m.memory_attention, d(curr), d(curr_pos), mem_hip, d(memory_pos), 0)
+    mem_o, _ = O.memory_encoder(P, cfg, prev_pix, torch.sigmoid(prev_mask) * sc + bi)       # [B, 64, E, E]
+    memory_o = mem_o.flatten(2).permute(2, 0, 1)                                             # [L, B, 64]
+    y_o = O.memory_attention(P, cfg, curr, memory_o, curr_pos, memory_pos, 0)
+    assert rel(y_hip, y_o) < 2e-3
+    y_lin = y_hip.detach().cpu().float().contiguous().requires_grad_(True)
+    emb = y_lin.permute(1, 2, 0).reshape(B, C, E, E)
+    masks, _, _, _ = O.mask_decoder_predict(P, emb, pe, sparse, dense.view(1, C, 1, 1).expand(B, C, E, E), [f0, f1])
+    ref_loss = F.binary_cross_entropy_with_logits(masks, target)
+    ref_loss.backward()
+    y_o.backward(y_lin.grad)
+    with torch.no_grad():
+        loss, scales, grads = T.memory_bank_loss_grads(m, d(curr), d(curr_pos), tm(prev_pix), d(prev_mask), False, d(memory_pos), tm(pe), d(sparse),
+                                                       tm(f0).to(ops.OP16), tm(f1).to(ops.OP16), B, E, E, d(target), dense_tokens=d(dense))
+    assert abs(loss.item() - ref_loss.item()) < 2e-3 * abs(ref_loss.item())
+    n_enc = sum(1 for k in sd if k.startswith("memory_encoder."))
+    assert len(grads["memory_encoder"]) == n_enc and len(grads["memory_attention"]) == 106
+    for grp, pre in groups.items():
+        num = den = 0.0
+        worst = (0.0, "")
+        for name, g in grads[grp].items():
+            ref = P[pre + name].grad
+            assert ref is not None and g.shape == ref.shape, (grp, name)
+            if name.endswith("k_proj.bias"):
+                continue
+            e = g.cpu().double() / scales[grp] - ref.double()
+            num, den = num + e.pow(2).sum().item(), den + ref.double().pow(2).sum().item()
+            worst = max(worst, (rel(g / scales[grp], ref), name))
+        assert (num / den) ** 0.5 < 3e-2, (grp, (num / den) ** 0.5, worst)
+    # and one Adam step of all three groups moves exactly those groups and lowers the loss
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    opts = {"decoder": T.DecoderAdam(m.sam_mask_decoder, lr=1e-4), "memory_attention": T.DecoderAdam(m.memory_attention, lr=1e-5),
+            "memory_encoder": T.DecoderAdam(m.memory_encoder, lr=1e-5)}
+    args = (d(curr), d(curr_pos), tm(prev_pix), d(prev_mask), False, d(memory_pos), tm(pe), d(sparse), tm(f0).to(ops.OP16), tm(f1).to(ops.OP16),
+            B, E, E, d(target))
+    with torch.no_grad():
+        l1 = T.memory_bank_finetune_step(m, opts, *args, dense_tokens=d(dense))
+        l2 = T.memory_bank_finetune_step(m, opts, *args, dense_tokens=d(dense))
+    assert l2 < l1
+    moved = {k.split(".")[0] for k, v in m.state_dict().items() if not torch.equal(v, before[k])}
+    assert moved == {"sam_mask_decoder", "memory_attention", "memory_encoder"}, moved
