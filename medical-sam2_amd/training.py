@@ -197,15 +197,18 @@ def train_step_2d(model, opt_mem: DecoderAdam, opt_dec: DecoderAdam, imgs, pts, 
 @torch.no_grad()
 def memory_bank_loss_grads(model, curr, curr_pos, prev_pix_tokens, prev_mask_logits, prev_is_mask_from_pts: bool, memory_pos, pe_tokens, sparse,
                            feat_s0, feat_s1, B: int, h: int, w: int, target_masks: torch.Tensor, dense_tokens=None, pos_weight: float = 1.0,
-                           mem_scale: float = None):
+                           mem_scale: float = None, prev_sam_token: torch.Tensor = None):
     """One level of back-propagation through the memory bank -- the path of the 3-D loop's `non_prompt_loss` (func_3d/function.py:160-184)
     that trains the memory ENCODER: the previous slice's memory is encoded here from its pixel features and predicted mask
     (`_encode_new_memory`, sam2_base.py:665-703), the current (unprompted) slice attends to it, and the mask loss of the current slice
     flows back through decoder -> memory attention -> memory tokens -> memory encoder.  Truncated where the reference's graph goes on
     into the previous slice's decoder: the previous mask and both slices' image features are treated as constants.
     curr / curr_pos [L, B, C]; prev_pix_tokens [B*L, C]; prev_mask_logits fp32 [B, 1, 16h, 16w]; memory_pos [L, B, 64] (position +
-    temporal encoding of that bank entry, a constant).  Returns (loss, {group: loss scale}, {group: {parameter: gradient}}) for the
-    groups "decoder", "memory_attention", "memory_encoder"."""
+    temporal encoding of that bank entry, a constant).  prev_sam_token (fp32 [B, C], optional): the previous slice's SAM output token; its
+    object pointer `obj_ptr_proj(token)` then joins the bank as C / 64 extra tokens without position encoding (sam2_base.py:591-635 with
+    add_tpos_enc_to_obj_ptrs = False, object present) and the pointer projection is trained too.
+    Returns (loss, {group: loss scale}, {group: {parameter: gradient}}) for the groups "decoder", "memory_attention", "memory_encoder"
+    (+ "obj_ptr_proj")."""
     enc = model.memory_encoder
     # (sam2_base.py:686-688: masks from clicks are binarised only in eval mode; binarisation has no gradient anyway)
     mode = 2 if (model.binarize_mask_from_pts_for_mem_enc and prev_is_mask_from_pts and not model.training) else 1
@@ -213,14 +216,30 @@ def memory_bank_loss_grads(model, curr, curr_pos, prev_pix_tokens, prev_mask_log
     L, _, C = curr.shape
     mem = enc.run(prev_pix_tokens, prev_mask_logits, mode, sc, bi, B, h, w)                  # fp32 [B*L, 64]
     memory = mem.view(B, L, -1).transpose(0, 1)                                              # [L, B, 64] like the bank's flattened entries
+    n_ptr = 0
+    if prev_sam_token is not None:
+        from .modeling.common import to_bf16
+        md = memory.shape[2]
+        n_ptr = C // md
+        tok16 = to_bf16(prev_sam_token.reshape(B, C).contiguous())
+        ptr = model.obj_ptr_proj.run(tok16)                                                  # fp32 [B, C]
+        memory = torch.cat([memory, ptr.view(B, n_ptr, md).transpose(0, 1)], dim=0)           # (bank assembly: data movement)
+        memory_pos = torch.cat([memory_pos, torch.zeros(n_ptr, B, md, dtype=memory_pos.dtype, device=memory_pos.device)], dim=0)
     aux: dict = {}
     loss, scale, scale_mem, g_dec, g_mem, _ = memory_decoder_loss_grads(
-        model.memory_attention, model.sam_mask_decoder, curr, curr_pos, memory, memory_pos, 0, pe_tokens, sparse, feat_s0, feat_s1, B, h, w,
+        model.memory_attention, model.sam_mask_decoder, curr, curr_pos, memory, memory_pos, n_ptr, pe_tokens, sparse, feat_s0, feat_s1, B, h, w,
         target_masks, dense_tokens=dense_tokens, pos_weight=pos_weight, mem_scale=mem_scale, aux=aux)
-    d_mem = aux["dmemory"].transpose(0, 1).reshape(B * L, -1).contiguous()                    # [B*L, 64], scaled by scale_mem
+    dmem = aux["dmemory"]                                                                    # [L + n_ptr, B, 64], scaled by scale_mem
+    d_mem = dmem[:L].transpose(0, 1).reshape(B * L, -1).contiguous()
     _, g_enc = bwd.memory_encoder_backward(enc, prev_pix_tokens, prev_mask_logits, mode, sc, bi, B, h, w, d_mem)
-    return loss, {"decoder": scale, "memory_attention": scale_mem, "memory_encoder": scale_mem}, \
-        {"decoder": g_dec, "memory_attention": g_mem, "memory_encoder": g_enc}
+    scales = {"decoder": scale, "memory_attention": scale_mem, "memory_encoder": scale_mem}
+    grads = {"decoder": g_dec, "memory_attention": g_mem, "memory_encoder": g_enc}
+    if n_ptr:
+        d_ptr = dmem[L:].transpose(0, 1).reshape(B, C).contiguous()
+        g_ptr: dict = {}
+        bwd.mlp_layers_backward(model.obj_ptr_proj, tok16, d_ptr, "p", g_ptr)
+        scales["obj_ptr_proj"], grads["obj_ptr_proj"] = scale_mem, {k[2:]: v for k, v in g_ptr.items()}
+    return loss, scales, grads
 
 
 @torch.no_grad()

@@ -632,7 +632,8 @@ def test_memory_bank_loss_grads(mods):
     m.load_state_dict(sd, strict=True)
     m = m.to(DEV).eval()
     cfg = O.model_config("hiera_t", 256)
-    groups = {"decoder": "sam_mask_decoder.", "memory_attention": "memory_attention.", "memory_encoder": "memory_encoder."}
+    groups = {"decoder": "sam_mask_decoder.", "memory_attention": "memory_attention.", "memory_encoder": "memory_encoder.",
+              "obj_ptr_proj": "obj_ptr_proj."}
     P = {k: v.clone().float().requires_grad_(any(k.startswith(g) for g in groups.values())) for k, v in sd.items()}
     B, E, C = 2, 16, 256
     L = E * E
@@ -644,16 +645,20 @@ def test_memory_bank_loss_grads(mods):
     pe, sparse, dense = rnd(1, C, E, E, seed=165), rnd(B, 2, C, seed=166), rnd(1, C, seed=167, scale=0.3)
     f0, f1 = q16(rnd(B, 32, 4 * E, 4 * E, seed=168)), q16(rnd(B, 64, 2 * E, 2 * E, seed=169))
     target = (rnd(B, 4, 4 * E, 4 * E, seed=170) > 0.4).float()
+    sam_tok = q16(rnd(B, C, seed=171))                                                       # previous slice's SAM output token
     d = lambda t: t.detach().to(DEV)
     tm = lambda t: d(t).permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()
     sc, bi = cfg["sigmoid_scale_for_mem_enc"], cfg["sigmoid_bias_for_mem_enc"]
     # HIP forward point of the memory-attention output (for the linearisation of the decoder)
     with torch.no_grad():
         mem_hip = m.memory_encoder.run(tm(prev_pix), d(prev_mask), 1, sc, bi, B, E, E).view(B, L, 64).transpose(0, 1)
-        y_hip, _ = B_.memory_attention_forward_saved(m.memory_attention, d(curr), d(curr_pos), mem_hip, d(memory_pos), 0)
+        ptr_hip = m.obj_ptr_proj.run(d(sam_tok).to(ops.OP16)).view(B, 4, 64).transpose(0, 1)
+        pos_all = torch.cat([d(memory_pos), torch.zeros(4, B, 64, device=DEV)], 0)
+        y_hip, _ = B_.memory_attention_forward_saved(m.memory_attention, d(curr), d(curr_pos), torch.cat([mem_hip, ptr_hip], 0), pos_all, 4)
     mem_o, _ = O.memory_encoder(P, cfg, prev_pix, torch.sigmoid(prev_mask) * sc + bi)       # [B, 64, E, E]
-    memory_o = mem_o.flatten(2).permute(2, 0, 1)                                             # [L, B, 64]
-    y_o = O.memory_attention(P, cfg, curr, memory_o, curr_pos, memory_pos, 0)
+    ptr_o = O.mlp(P, "obj_ptr_proj", sam_tok, 3, torch.relu).view(B, 4, 64).transpose(0, 1)  # [4, B, 64]
+    memory_o = torch.cat([mem_o.flatten(2).permute(2, 0, 1), ptr_o], 0)                      # [L + 4, B, 64]
+    y_o = O.memory_attention(P, cfg, curr, memory_o, curr_pos, torch.cat([memory_pos, torch.zeros(4, B, 64)], 0), 4)
     assert rel(y_hip, y_o) < 2e-3
     y_lin = y_hip.detach().cpu().float().contiguous().requires_grad_(True)
     emb = y_lin.permute(1, 2, 0).reshape(B, C, E, E)
@@ -663,10 +668,11 @@ def test_memory_bank_loss_grads(mods):
     y_o.backward(y_lin.grad)
     with torch.no_grad():
         loss, scales, grads = T.memory_bank_loss_grads(m, d(curr), d(curr_pos), tm(prev_pix), d(prev_mask), False, d(memory_pos), tm(pe), d(sparse),
-                                                       tm(f0).to(ops.OP16), tm(f1).to(ops.OP16), B, E, E, d(target), dense_tokens=d(dense))
+                                                       tm(f0).to(ops.OP16), tm(f1).to(ops.OP16), B, E, E, d(target), dense_tokens=d(dense),
+                                                       prev_sam_token=d(sam_tok))
     assert abs(loss.item() - ref_loss.item()) < 2e-3 * abs(ref_loss.item())
     n_enc = sum(1 for k in sd if k.startswith("memory_encoder."))
-    assert len(grads["memory_encoder"]) == n_enc and len(grads["memory_attention"]) == 106
+    assert len(grads["memory_encoder"]) == n_enc and len(grads["memory_attention"]) == 106 and len(grads["obj_ptr_proj"]) == 6
     for grp, pre in groups.items():
         num = den = 0.0
         worst = (0.0, "")
@@ -682,12 +688,12 @@ def test_memory_bank_loss_grads(mods):
     # and one Adam step of all three groups moves exactly those groups and lowers the loss
     before = {k: v.detach().clone() for k, v in m.state_dict().items()}
     opts = {"decoder": T.DecoderAdam(m.sam_mask_decoder, lr=1e-4), "memory_attention": T.DecoderAdam(m.memory_attention, lr=1e-5),
-            "memory_encoder": T.DecoderAdam(m.memory_encoder, lr=1e-5)}
+            "memory_encoder": T.DecoderAdam(m.memory_encoder, lr=1e-5), "obj_ptr_proj": T.DecoderAdam(m.obj_ptr_proj, lr=1e-5)}
     args = (d(curr), d(curr_pos), tm(prev_pix), d(prev_mask), False, d(memory_pos), tm(pe), d(sparse), tm(f0).to(ops.OP16), tm(f1).to(ops.OP16),
             B, E, E, d(target))
     with torch.no_grad():
-        l1 = T.memory_bank_finetune_step(m, opts, *args, dense_tokens=d(dense))
-        l2 = T.memory_bank_finetune_step(m, opts, *args, dense_tokens=d(dense))
+        l1 = T.memory_bank_finetune_step(m, opts, *args, dense_tokens=d(dense), prev_sam_token=d(sam_tok))
+        l2 = T.memory_bank_finetune_step(m, opts, *args, dense_tokens=d(dense), prev_sam_token=d(sam_tok))
     assert l2 < l1
     moved = {k.split(".")[0] for k, v in m.state_dict().items() if not torch.equal(v, before[k])}
-    assert moved == {"sam_mask_decoder", "memory_attention", "memory_encoder"}, moved
+    assert moved == {"sam_mask_decoder", "memory_attention", "memory_encoder", "obj_ptr_proj"}, moved
