@@ -430,6 +430,40 @@ def run_grads_case():
         keep("memenc_param." + k, p.grad)
     meta["memenc"] = {"B": B, "E": E, "seeds": [180, 181, 182], "scale": float(m.sigmoid_scale_for_mem_enc),
                       "bias": float(m.sigmoid_bias_for_mem_enc), "n_params": len(list(me.named_parameters()))}
+    # ---- one level of BPTT through the memory bank (func_3d/function.py:160-184's non_prompt_loss path): the previous slice's memory
+    #      (memory encoder) and object pointer (obj_ptr_proj) feed the current slice's memory attention -> decoder -> BCE
+    for p in me.parameters():
+        p.grad = None
+    for mod in (m.memory_attention, m.sam_mask_decoder, m.obj_ptr_proj):
+        for p in mod.parameters():
+            p.requires_grad_(True)
+            p.grad = None
+    L = E * E
+    curr, curr_pos = rnd(L, B, C, seed=200), rnd(L, B, C, seed=201)
+    prev_pix, prev_mask = rnd(B, C, E, E, seed=202), rnd(B, 1, 16 * E, 16 * E, seed=203, scale=4.0)
+    mpos = rnd(L, B, 64, seed=204)
+    pe2, sparse2, dense2 = rnd(1, C, E, E, seed=205), rnd(B, 2, C, seed=206), rnd(1, C, seed=207, scale=0.3)
+    g0, g1 = rnd(B, 32, 4 * E, 4 * E, seed=208), rnd(B, 64, 2 * E, 2 * E, seed=209)
+    tgt = (rnd(B, 4, 4 * E, 4 * E, seed=210) > 0.4).float()
+    sam_tok = rnd(B, C, seed=211)
+    mem = me(prev_pix, torch.sigmoid(prev_mask) * m.sigmoid_scale_for_mem_enc + m.sigmoid_bias_for_mem_enc, skip_mask_sigmoid=True)["vision_features"]
+    ptr = m.obj_ptr_proj(sam_tok).view(B, 4, 64).transpose(0, 1)
+    memory = torch.cat([mem.flatten(2).permute(2, 0, 1), ptr], 0)
+    y = m.memory_attention(curr=[curr], curr_pos=[curr_pos], memory=memory, memory_pos=torch.cat([mpos, torch.zeros(4, B, 64)], 0),
+                           num_obj_ptr_tokens=4)
+    emb2 = y.permute(1, 2, 0).reshape(B, C, E, E)
+    masks2, _, _, _ = dec.predict_masks(image_embeddings=emb2, image_pe=pe2, sparse_prompt_embeddings=sparse2,
+                                        dense_prompt_embeddings=dense2.view(1, C, 1, 1).expand(B, C, E, E), repeat_image=False, cell_nums=None,
+                                        high_res_features=[g0, g1])
+    loss2 = torch.nn.BCEWithLogitsLoss()(masks2, tgt)
+    loss2.backward()
+    out["bank_loss"] = np.array([loss2.item()])
+    n_bank = 0
+    for pre, mod in (("memory_encoder.", me), ("obj_ptr_proj.", m.obj_ptr_proj), ("memory_attention.", m.memory_attention)):
+        for k, p in mod.named_parameters():
+            keep("bank_param." + pre + k, p.grad)
+            n_bank += 1
+    meta["bank"] = {"B": B, "E": E, "seeds": list(range(200, 212)), "n_params": n_bank}
     return out, meta
 
 

@@ -128,6 +128,39 @@ def test_oracle_autograd_matches_reference_gradients():
     assert n == meta["memenc"]["n_params"]
     worst = sorted(rep.items(), key=lambda kv: -kv[1])[:5]
     assert worst[0][1] < 2e-3, worst
+    # ---- one level of BPTT through the memory bank: memory encoder + object pointer -> memory attention -> decoder -> BCE
+    #      (the oracle chain that tests/test_backward_gpu.py::test_memory_bank_loss_grads differentiates)
+    mb = meta["bank"]
+    B, E, C = mb["B"], mb["E"], 256
+    L, sds = E * E, mb["seeds"]
+    trained = ("memory_encoder.", "obj_ptr_proj.", "memory_attention.", "sam_mask_decoder.")
+    P = {k: v.clone().float().requires_grad_(k.startswith(trained)) for k, v in sd.items()}
+    curr, curr_pos = rnd(L, B, C, seed=sds[0]), rnd(L, B, C, seed=sds[1])
+    prev_pix, prev_mask = rnd(B, C, E, E, seed=sds[2]), rnd(B, 1, 16 * E, 16 * E, seed=sds[3], scale=4.0)
+    mpos = rnd(L, B, 64, seed=sds[4])
+    pe2, sparse2, dense2 = rnd(1, C, E, E, seed=sds[5]), rnd(B, 2, C, seed=sds[6]), rnd(1, C, seed=sds[7], scale=0.3)
+    g0, g1 = rnd(B, 32, 4 * E, 4 * E, seed=sds[8]), rnd(B, 64, 2 * E, 2 * E, seed=sds[9])
+    tgt = (rnd(B, 4, 4 * E, 4 * E, seed=sds[10]) > 0.4).float()
+    sam_tok = rnd(B, C, seed=sds[11])
+    mem, _ = O.memory_encoder(P, cfg, prev_pix, torch.sigmoid(prev_mask) * meta["memenc"]["scale"] + meta["memenc"]["bias"])
+    ptr = O.mlp(P, "obj_ptr_proj", sam_tok, 3, torch.relu).view(B, 4, 64).transpose(0, 1)
+    y = O.memory_attention(P, cfg, curr, torch.cat([mem.flatten(2).permute(2, 0, 1), ptr], 0), curr_pos,
+                           torch.cat([mpos, torch.zeros(4, B, 64)], 0), 4)
+    masks, _, _, _ = O.mask_decoder_predict(P, y.permute(1, 2, 0).reshape(B, C, E, E), pe2, sparse2, dense2.view(1, C, 1, 1).expand(B, C, E, E), [g0, g1])
+    loss = torch.nn.BCEWithLogitsLoss()(masks, tgt)
+    assert abs(loss.item() - float(G["bank_loss"][0])) < 1e-5
+    loss.backward()
+    rep, n = {}, 0
+    for k in G:
+        if k.startswith("bank_param."):
+            name = k[len("bank_param."):]
+            n += 1
+            if name.endswith("k_proj.bias"):
+                continue
+            rep[name] = rel_sub(P[name].grad, G[k])
+    assert n == mb["n_params"]
+    worst = sorted(rep.items(), key=lambda kv: -kv[1])[:5]
+    assert worst[0][1] < 5e-3, worst
 
 
 @pytest.mark.gpu
