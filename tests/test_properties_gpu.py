@@ -98,3 +98,32 @@ def test_layernorm_statistics_full_size(ops):
     y = ops.layernorm(x, torch.ones(96, device=DEV), torch.zeros(96, device=DEV), 1e-6, out_dtype=torch.float32)
     assert y.mean(1).abs().max().item() < 1e-4
     assert (y.var(1, unbiased=False) - 1).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,D", [(4, 1, 4096, 16384, 256), (4, 1, 4096, 4096, 256), (1, 1, 4096, 28704, 256), (2, 4, 1024, 1024, 96),
+                                         (3, 2, 777, 2051, 128), (1, 1, 130, 9000, 256), (2, 2, 4100, 96, 64), (1, 3, 33, 65, 128)])
+def test_attention_backward_identities_at_full_size(ops, B, H, Lq, Lk, D, monkeypatch):
+    """Flash-style backward at the benchmark's sizes (where the CPU oracle is too slow) through identities of the operation:
+      * the rows of dP are orthogonal to the constant vector: sum_k dS_k = 0  =>  dQ = 0 when every key is the same vector,
+      * V-linearity: dV = P^T dO  =>  sum over keys of dV equals sum over queries of dO (the softmax rows sum to 1),
+      * and against the materialised (GEMM-composed) path on the same inputs."""
+    import medical_sam2_amd.backward as bwd
+    q = rnd(B, H, Lq, D, seed=11).to(ops.OP16).to(DEV)
+    k = rnd(B, H, Lk, D, seed=12).to(ops.OP16).to(DEV)
+    v = rnd(B, H, Lk, D, seed=13).to(ops.OP16).to(DEV)
+    do = rnd(B, H, Lq, D, seed=14).to(ops.OP16).float().to(DEV)
+    dq, dk, dv = bwd.attention_backward(q, k, v, do)
+    assert torch.isfinite(dq).all() and torch.isfinite(dk).all() and torch.isfinite(dv).all()
+    # column sums of dV: sum_k dV[k] = sum_q (sum_k P[q,k]) dO[q] = sum_q dO[q]
+    lhs, rhs = dv.sum(dim=2), do.sum(dim=2)
+    assert (lhs - rhs).abs().max().item() < 2e-2 * rhs.abs().max().item() + 1e-3 * (Lq ** 0.5)
+    # identical keys: the scores of a row are constant, softmax is flat, dS = P (dP - sum P dP) sums to zero against identical K rows
+    k_same = k[:, :, :1].expand(B, H, Lk, D).contiguous()
+    dq0, _, _ = bwd.attention_backward(q, k_same, v, do)
+    assert dq0.abs().max().item() < 5e-3 * dq.abs().max().item() + 1e-4
+    if Lq * Lk <= 4096 * 16384:
+        monkeypatch.setenv("MSAM2_MATERIALISED_BWD", "1")
+        rq, rk, rv = bwd.attention_backward(q, k, v, do)
+        monkeypatch.delenv("MSAM2_MATERIALISED_BWD")
+        rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+        assert rel(dq, rq) < 8e-3 and rel(dk, rk) < 8e-3 and rel(dv, rv) < 8e-3, (rel(dq, rq), rel(dk, rk), rel(dv, rv))
