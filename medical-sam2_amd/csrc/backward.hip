@@ -577,6 +577,54 @@ extern "C" int msam2_col2im3x3s2(const float* dcols, int64_t ld, float* dx, int6
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Adjoint of msam2_bilinear_upsample (align_corners = False): the reference's training loss is taken on the mask logits up-sampled to
+// the video resolution (sam2_video_predictor.py:724-744 `_get_orig_video_res_output` -> func_3d/function.py:137-170), so the loss
+// gradient has to come back down.  Gather form: every low-res pixel visits the high-res pixels whose two source taps can include
+// it and re-derives their weights exactly as the forward does (no atomics, run-to-run reproducible).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int P, int h, int w, int H, int W) {
+  const float sy = (float)h / H, sx = (float)w / W;
+  const float ry = (float)H / h, rx = (float)W / w;
+  const int64_t total = (int64_t)P * h * w;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int x = (int)(i % w);
+    const int y = (int)((i / w) % h);
+    const int64_t pl = i / ((int64_t)w * h);
+    // outputs whose source coordinate lies in (y - 1, y + 1): Y in ((y - 0.5) r - 0.5, (y + 1.5) r - 0.5); one extra on each side
+    // for the clamping at the borders
+    const int Y0 = max(0, (int)floorf((y - 0.5f) * ry - 1.5f)), Y1 = min(H - 1, (int)ceilf((y + 1.5f) * ry + 0.5f));
+    const int X0 = max(0, (int)floorf((x - 0.5f) * rx - 1.5f)), X1 = min(W - 1, (int)ceilf((x + 1.5f) * rx + 0.5f));
+    const float* g = dy + pl * (int64_t)H * W;
+    float acc = 0.f;
+    for (int Y = Y0; Y <= Y1; ++Y) {
+      const float fy = fmaxf((Y + 0.5f) * sy - 0.5f, 0.f);
+      const int y0 = (int)fy, y1 = min(y0 + 1, h - 1);
+      const float ly = fy - y0;
+      const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+      if (wy == 0.f) continue;
+      float row = 0.f;
+      for (int X = X0; X <= X1; ++X) {
+        const float fx = fmaxf((X + 0.5f) * sx - 0.5f, 0.f);
+        const int x0 = (int)fx, x1 = min(x0 + 1, w - 1);
+        const float lx = fx - x0;
+        const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+        row += wx * g[(int64_t)Y * W + X];
+      }
+      acc += wy * row;
+    }
+    dx[i] = acc;
+  }
+}
+
+extern "C" int msam2_bilinear_upsample_bwd(const float* dy, float* dx, int64_t planes, int64_t h, int64_t w, int64_t H, int64_t W, void* stream) {
+  MSAM2_REQUIRE(dy && dx && planes > 0 && h > 0 && w > 0 && H >= h && W >= w, "bilinear_upsample_bwd: bad arguments (up-sampling only)");
+  const int64_t total = planes * h * w;
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3((unsigned)min((int64_t)16384, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, dx,
+                     (int)planes, (int)h, (int)w, (int)H, (int)W);
+  return msam2_check_launch("bilinear_upsample_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Loss and optimiser pieces of a decoder fine-tuning step (func_3d/function.py:69 `criterion_G = BCEWithLogitsLoss(pos_weight)`,
 // train_3d.py:50 `optim.Adam(sam_layers, lr=1e-4, betas=(0.9, 0.999), eps=1e-8)`):
 //   bce_logits:  loss = mean( pos_weight * y * softplus(-x) + (1 - y) * softplus(x) ),  dx = (pos_weight * y * (s - 1) + (1 - y) * s) / n,

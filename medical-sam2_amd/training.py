@@ -12,9 +12,9 @@ and prompt encoders -- no autograd graph: explicit recomputing backward (`backwa
                                  current slice's loss also trains the memory encoder that produced the previous slice's memory
   data_parallel=True             gradients averaged over the ranks with one bucketed all-reduce (`parallel.allreduce_gradients`)
 
-Scope: the loss is taken on the decoder's low-resolution logits of all `num_mask_tokens` masks against one target per mask token; the
-reference additionally up-samples to the video resolution and selects one mask per object, and its 3-D loop back-propagates through
-the whole memory bank including the previous slices' decoders and object pointers -- only the first level is built.  The IoU / object-score heads do not receive a gradient
+Scope: the loss is taken either on the decoder's low-resolution logits of all `num_mask_tokens` masks against one target per mask token,
+or -- `mask_index` / `upsampled_mask_loss`, the reference's form -- on one mask up-sampled to the video resolution.  The reference's 3-D
+loop back-propagates through the whole memory bank including the previous slices' decoders -- only the first level is built.  The IoU / object-score heads do not receive a gradient
 from this loss.  16-bit operands: the loss gradient is scaled by a fixed power of two and un-scaled inside the Adam kernel.
 Pinned by tests/test_backward_gpu.py (oracle + autograd + torch.optim) and tests/test_grads_golden.py (the reference's own `.grad`).
 """
@@ -40,6 +40,23 @@ def bce_with_logits(logits: torch.Tensor, target: torch.Tensor, pos_weight: floa
     loss = torch.zeros(1, dtype=F32, device=x.device)
     check(lib().msam2_bce_logits(_p(x), _p(y), _p(dx), _p(loss), x.numel(), float(pos_weight), _stream()))
     return loss, dx
+
+
+def upsampled_mask_loss(masks: torch.Tensor, target_highres: torch.Tensor, mask_index: int = 0, pos_weight: float = 1.0):
+    """The reference's training loss (func_3d/function.py:137-170 on `_get_orig_video_res_output`, sam2_video_predictor.py:724-744):
+    mean BCE-with-logits between ONE mask of the decoder ([B, num_mask_tokens, h4, w4] logits -> token `mask_index`) bilinearly
+    up-sampled to the target's resolution and target_highres [B, 1, S, S] in {0, 1}.
+    Returns (loss 1-element tensor, d loss / d masks [B, num_mask_tokens, h4, w4] -- zero for the other tokens)."""
+    Bn, nm, h4, w4 = masks.shape
+    S_h, S_w = target_highres.shape[-2:]
+    low = masks[:, mask_index].contiguous()                                      # [B, h4, w4]
+    up = ops.bilinear_upsample(low.view(Bn, 1, h4, w4), S_h, S_w)
+    loss, d_up = bce_with_logits(up.reshape(Bn, -1), target_highres.reshape(Bn, -1), pos_weight)
+    d_low = torch.empty(Bn, h4, w4, dtype=F32, device=masks.device)
+    check(lib().msam2_bilinear_upsample_bwd(_p(d_up), _p(d_low), Bn, h4, w4, S_h, S_w, _stream()))
+    d_masks = torch.zeros_like(masks, dtype=F32)
+    d_masks[:, mask_index] = d_low
+    return loss, d_masks
 
 
 class DecoderAdam:
@@ -84,17 +101,25 @@ class DecoderAdam:
 
 @torch.no_grad()
 def decoder_finetune_step(decoder, optimizer: DecoderAdam, src_tokens, pe_tokens, sparse, feat_s0, feat_s1, B: int, h: int, w: int,
-                          target_masks: torch.Tensor, pos_weight: float = 1.0, sync: bool = True, data_parallel: bool = False):
+                          target_masks: torch.Tensor, pos_weight: float = 1.0, sync: bool = True, data_parallel: bool = False,
+                          mask_index: int = None):
     """One optimisation step of the mask decoder.  Inputs as for `MaskDecoder.predict_masks_tokens`; target_masks [B, nm, 4h, 4w] in
-    {0, 1}.  Returns the loss value before the update (a Python float; with sync=False the 1-element device tensor, so that the whole
+    {0, 1} (one target per mask token), or -- with mask_index -- [B, 1, S, S] at the video resolution for that one mask (the
+    reference's loss, `upsampled_mask_loss`).  Returns the loss value before the update (a Python float; with sync=False the 1-element device tensor, so that the whole
     step -- ~3000 small launches -- can be captured in a hipGraph and replayed without host work).  data_parallel: one process per GPU,
     each on its own slices; the gradients are averaged with `parallel.allreduce_gradients` (one bucketed RCCL all-reduce) before Adam."""
     masks, _, _, _ = decoder.predict_masks_tokens(src_tokens, pe_tokens, sparse, feat_s0, feat_s1, B, h, w)
-    loss, d_masks = bce_with_logits(masks, target_masks, pos_weight)
+    if mask_index is None:
+        loss, d_masks = bce_with_logits(masks, target_masks, pos_weight)
+        n_loss = masks.numel()
+    else:   # the reference's loss: one mask, up-sampled to the target's (video) resolution -- target_masks [B, 1, S, S]
+        loss, d_masks = upsampled_mask_loss(masks, target_masks, mask_index, pos_weight)
+        n_loss = target_masks.numel()
     # Loss scale: |dloss/dlogit| <= max(pos_weight, 1) / n is ~1e-6 at 1024^2 -- below the 16-bit operand's normal range (fp16: 6e-5).
     # A fixed power of two (data independent, so the step stays capturable) brings the largest entry to 2^-4; the backward is linear
     # in d_masks, the update kernel multiplies the gradients by the inverse.
-    scale = 2.0 ** (math.floor(math.log2(masks.numel() / max(float(pos_weight), 1.0))) - 4)
+    # (n_loss elements share the mean; the up-sampling adjoint sums ~16 of them per low-res pixel: still <= 2^0)
+    scale = 2.0 ** (math.floor(math.log2(n_loss / max(float(pos_weight), 1.0))) - 4 - (0 if mask_index is None else 4))
     d_masks.mul_(scale)
     _, _, grads = bwd.mask_decoder_backward(decoder, src_tokens, pe_tokens, sparse, feat_s0, feat_s1, B, h, w, d_masks)
     inv_world = 1.0

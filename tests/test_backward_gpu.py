@@ -697,3 +697,84 @@ def test_memory_bank_loss_grads(mods):
     assert l2 < l1
     moved = {k.split(".")[0] for k, v in m.state_dict().items() if not torch.equal(v, before[k])}
     assert moved == {"sam_mask_decoder", "memory_attention", "memory_encoder", "obj_ptr_proj"}, moved
+
+
+@pytest.mark.parametrize("h,w,H,W", [(64, 64, 256, 256), (16, 24, 50, 97), (7, 5, 7, 5), (32, 32, 1024, 1024)])
+def test_bilinear_upsample_adjoint(mods, h, w, H, W):
+    """msam2_bilinear_upsample_bwd is the exact adjoint of the forward resize: <up(x), g> == <x, up^T(g)>, and equals autograd of
+    F.interpolate(mode="bilinear", align_corners=False)."""
+    B_, ops = mods
+    from medical_sam2_amd._lib import check, lib
+    from medical_sam2_amd.ops import _p, _stream
+    P = 3
+    x = rnd(P, 1, h, w, seed=180).requires_grad_(True)
+    g = rnd(P, 1, H, W, seed=181)
+    F.interpolate(x, size=(H, W), mode="bilinear", align_corners=False).backward(g)
+    gd = g.to(DEV).contiguous()
+    dx = torch.empty(P, h, w, device=DEV)
+    check(lib().msam2_bilinear_upsample_bwd(_p(gd), _p(dx), P, h, w, H, W, _stream()))
+    assert rel(dx, x.grad[:, 0]) < 1e-5
+    up = ops.bilinear_upsample(x.detach().to(DEV).contiguous(), H, W)
+    lhs, rhs = (up * gd).double().sum().item(), (x.detach()[:, 0].to(DEV) * dx).double().sum().item()
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+
+
+def test_upsampled_mask_loss_matches_reference_form(mods):
+    """The reference's training loss (BCE on the video-resolution logits of one mask) and its gradient w.r.t. all decoder mask logits."""
+    B_, ops = mods
+    import medical_sam2_amd.training as T
+    masks = rnd(2, 4, 64, 64, seed=182, scale=3.0).requires_grad_(True)
+    target = (rnd(2, 1, 256, 256, seed=183) > 0.2).float()
+    up = F.interpolate(masks[:, 1:2], size=(256, 256), mode="bilinear", align_corners=False)
+    ref = torch.nn.BCEWithLogitsLoss(pos_weight=torch.ones(1) * 2.0)(up, target)
+    ref.backward()
+    with torch.no_grad():
+        loss, dm = T.upsampled_mask_loss(masks.detach().to(DEV), target.to(DEV), mask_index=1, pos_weight=2.0)
+    assert abs(loss.item() - ref.item()) < 1e-5 and rel(dm, masks.grad) < 1e-5
+
+
+def test_decoder_finetune_step_reference_loss(mods):
+    """decoder_finetune_step with the reference's loss form (mask 0 up-sampled to the video resolution, BCE against the full-resolution
+    label): first loss equals oracle forward + F.interpolate + BCEWithLogitsLoss, the update direction of the mask-dependent parameters
+    follows autograd, the loss falls."""
+    B_, ops = mods
+    import medical_sam2_amd.build_sam as bs
+    import medical_sam2_amd.training as T
+    import medical_sam2_amd.weights as wts
+    m = bs.build_sam2("sam2_hiera_t", device="cpu", hydra_overrides_extra=["++model.image_size=256"])
+    sd = wts.init_weights("hiera_t", 0)
+    m.load_state_dict(sd, strict=True)
+    dec = m.sam_mask_decoder.to(DEV).eval()
+    pre = "sam_mask_decoder."
+    P = {k: v.clone().float().requires_grad_(k.startswith(pre)) for k, v in sd.items()}
+    B, E, C, S = 2, 16, 256, 256
+    q16 = lambda t: t.to(ops.OP16).float()
+    emb, pe, sparse = rnd(B, C, E, E, seed=190), rnd(1, C, E, E, seed=191), rnd(B, 2, C, seed=192)
+    f0, f1 = q16(rnd(B, 32, 4 * E, 4 * E, seed=193)), q16(rnd(B, 64, 2 * E, 2 * E, seed=194))
+    target = (rnd(B, 1, S, S, seed=195) > 0.3).float()
+    masks, _, _, _ = O.mask_decoder_predict(P, emb, pe, sparse, torch.zeros_like(emb), [f0, f1])
+    up = F.interpolate(masks[:, :1], size=(S, S), mode="bilinear", align_corners=False)
+    ref_loss = F.binary_cross_entropy_with_logits(up, target)
+    ref_loss.backward()
+    d = lambda t: t.detach().to(DEV)
+    tm = lambda t: d(t).permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()
+    before = {k: v.detach().clone() for k, v in dec.named_parameters()}
+    opt = T.DecoderAdam(dec, lr=1e-4)
+    args = (tm(emb), tm(pe), d(sparse), tm(f0).to(ops.OP16), tm(f1).to(ops.OP16), B, E, E, d(target))
+    with torch.no_grad():
+        l0 = T.decoder_finetune_step(dec, opt, *args, mask_index=0)
+        l1 = T.decoder_finetune_step(dec, opt, *args, mask_index=0)
+    assert abs(l0 - ref_loss.item()) < 2e-3 * abs(ref_loss.item()) and l1 < l0
+    cos_min, touched = 1.0, 0
+    for k, v in dec.named_parameters():
+        g = P[pre + k].grad
+        delta = (before[k] - v.detach()).cpu()            # after two Adam steps along (nearly) the same gradient: sign(g)-like
+        if g is None or g.abs().max() == 0:
+            assert delta.abs().max().item() == 0, k
+            continue
+        if k.endswith("k_proj.bias"):
+            continue
+        touched += 1
+        sig = g.abs() > 1e-3 * g.abs().max()
+        cos_min = min(cos_min, F.cosine_similarity(delta[sig].flatten(), torch.sign(g[sig]).flatten(), dim=0).item())
+    assert touched >= 40 and cos_min > 0.85, (touched, cos_min)
