@@ -132,11 +132,12 @@ def decoder_finetune_step(decoder, optimizer: DecoderAdam, src_tokens, pe_tokens
 @torch.no_grad()
 def memory_decoder_loss_grads(memory_attention, decoder, curr, curr_pos, memory, memory_pos, num_obj_ptr_tokens: int, pe_tokens, sparse,
                               feat_s0, feat_s1, B: int, h: int, w: int, target_masks: torch.Tensor, dense_tokens=None,
-                              pos_weight: float = 1.0, mem_scale: float = None, aux: dict = None):
+                              pos_weight: float = 1.0, mem_scale: float = None, aux: dict = None, mask_index: int = None):
     """Forward + backward of the memory-conditioned slice step (func_2d/function.py:70-191 / sam2_base.py:705-790 with a frozen image
     encoder and a detached memory bank, as func_2d/function.py:204-243 stores it): curr / curr_pos [L, B, C] current-slice features,
     memory / memory_pos [Nk, B, 64] the assembled bank -> memory attention -> (+ dense prompt embedding) -> mask decoder -> mean BCE with
-    logits on its mask logits.  Returns (loss 1-element tensor, decoder loss scale, memory loss scale, decoder gradients,
+    logits on its mask logits (all mask tokens against target_masks [B, nm, 4h, 4w], or with mask_index the reference's form: that one
+    mask up-sampled to target_masks [B, 1, S, S]).  Returns (loss 1-element tensor, decoder loss scale, memory loss scale, decoder gradients,
     memory-attention gradients, dcurr); each group's gradients (and dcurr) carry its loss scale (see `decoder_finetune_step`).
     The gradient that leaves the decoder towards the memory attention is orders of magnitude smaller than the one that entered it
     (it has crossed two attention blocks and two transposed convolutions), again below the fp16 operand range, so it is re-scaled by a
@@ -153,8 +154,13 @@ def memory_decoder_loss_grads(memory_attention, decoder, curr, curr_pos, memory,
     masks, _, _, _ = decoder.predict_masks_tokens(src, pe_tokens, sparse, feat_s0, feat_s1, B, h, w)
     if aux is not None:
         aux["masks"] = masks                                                     # [B, num_mask_tokens, 4h, 4w] logits of this forward
-    loss, d_masks = bce_with_logits(masks, target_masks, pos_weight)
-    scale = 2.0 ** (math.floor(math.log2(masks.numel() / max(float(pos_weight), 1.0))) - 4)
+    if mask_index is None:
+        loss, d_masks = bce_with_logits(masks, target_masks, pos_weight)
+        n_loss, extra = masks.numel(), 0
+    else:                                                                        # the reference's loss form (see upsampled_mask_loss)
+        loss, d_masks = upsampled_mask_loss(masks, target_masks, mask_index, pos_weight)
+        n_loss, extra = target_masks.numel(), 4
+    scale = 2.0 ** (math.floor(math.log2(n_loss / max(float(pos_weight), 1.0))) - 4 - extra)
     d_masks.mul_(scale)
     d_src, _, g_dec = bwd.mask_decoder_backward(decoder, src, pe_tokens, sparse, feat_s0, feat_s1, B, h, w, d_masks)
     if mem_scale is None:
@@ -173,10 +179,12 @@ def memory_decoder_finetune_step(memory_attention, decoder, opt_mem: DecoderAdam
     """One optimisation step of both parameter groups train_3d.py:34-54 builds around the frozen image encoder -- the mask decoder
     (`sam_layers`) and the memory attention (the bulk of `mem_layers`) -- on the loss of `memory_decoder_loss_grads` (same arguments).  The first call calibrates the memory group's loss scale (one host
     synchronisation) and stores it on `opt_mem`; later calls -- and a hipGraph captured after it -- reuse it."""
+    cal = getattr(opt_mem, "calibrated_loss_scales", {})                         # one calibration per loss form, made on its first (eager) step
     if kwargs.get("mem_scale") is None:
-        kwargs["mem_scale"] = getattr(opt_mem, "calibrated_loss_scale", None)     # calibrated on the first (eager) step, then reused
+        kwargs["mem_scale"] = cal.get(kwargs.get("mask_index"))
     loss, scale, scale_mem, g_dec, g_mem, _ = memory_decoder_loss_grads(memory_attention, decoder, *args, **kwargs)
-    opt_mem.calibrated_loss_scale = scale_mem / scale
+    cal[kwargs.get("mask_index")] = scale_mem / scale
+    opt_mem.calibrated_loss_scales = cal
     inv_world = 1.0
     if data_parallel:                                   # (ranks must share the calibrated loss scale: calibrate on rank 0's value or pass mem_scale)
         g_dec, inv_world = parallel.allreduce_gradients(g_dec)
@@ -187,13 +195,15 @@ def memory_decoder_finetune_step(memory_attention, decoder, opt_mem: DecoderAdam
 
 
 @torch.no_grad()
-def train_step_2d(model, opt_mem: DecoderAdam, opt_dec: DecoderAdam, imgs, pts, labels, memory, memory_pos, target_masks, sync: bool = True):
+def train_step_2d(model, opt_mem: DecoderAdam, opt_dec: DecoderAdam, imgs, pts, labels, memory, memory_pos, target_masks, sync: bool = True,
+                  mask_index: int = None):
     """One training iteration of the 2-D flow (func_2d/function.py:70-259) on the HIP path with the image and prompt encoders frozen
     (train_3d.py:34-37's choice of trainable groups): image encoder forward -> memory attention over the (detached) bank -> prompt
     encoder -> mask decoder -> BCE on the mask logits -> backward of decoder + memory attention -> Adam on both -> the new memory is
     encoded from the predicted mask for the bank (forward only, stored detached as func_2d/function.py:204-243 does).
     imgs [B,3,S,S] normalised, pts [B,P,2] / labels [B,P] clicks, memory / memory_pos [Nk,B,64] (bench.assemble_memory layout),
-    target_masks [B, num_mask_tokens, S/4, S/4].  Returns (loss, maskmem_features [B,64,S/16,S/16])."""
+    target_masks [B, num_mask_tokens, S/4, S/4], or with mask_index [B, 1, S, S] (the reference's loss on that up-sampled mask).
+    Returns (loss, maskmem_features [B,64,S/16,S/16])."""
     from .modeling.common import to_bf16, tokens_of
     B = imgs.shape[0]
     backbone_out = model.forward_image(imgs)
@@ -205,11 +215,13 @@ def train_step_2d(model, opt_mem: DecoderAdam, opt_dec: DecoderAdam, imgs, pts, 
     f0, f1 = to_bf16(tokens_of(hr[0])), to_bf16(tokens_of(hr[1]))
     dense = model.sam_prompt_encoder.no_mask_embed.weight.detach().reshape(1, -1)
     aux: dict = {}
-    kwargs = dict(dense_tokens=dense, aux=aux, mem_scale=getattr(opt_mem, "calibrated_loss_scale", None))
+    cal = getattr(opt_mem, "calibrated_loss_scales", {})                         # one calibration per loss form
+    kwargs = dict(dense_tokens=dense, aux=aux, mem_scale=cal.get(mask_index), mask_index=mask_index)
     loss, scale, scale_mem, g_dec, g_mem, _ = memory_decoder_loss_grads(
         model.memory_attention, model.sam_mask_decoder, vision_feats[-1], vision_pos_embeds[-1], memory, memory_pos, 0, pe, se.to(torch.float32),
         f0, f1, B, h, w, target_masks, **kwargs)
-    opt_mem.calibrated_loss_scale = scale_mem / scale
+    cal[mask_index] = scale_mem / scale
+    opt_mem.calibrated_loss_scales = cal
     opt_dec.step(g_dec, grad_scale=1.0 / scale)
     opt_mem.step(g_mem, grad_scale=1.0 / scale_mem)
     low_res = aux["masks"][:, :1].contiguous()                                   # single-mask output token (multimask_output=False)
@@ -222,7 +234,7 @@ def train_step_2d(model, opt_mem: DecoderAdam, opt_dec: DecoderAdam, imgs, pts, 
 @torch.no_grad()
 def memory_bank_loss_grads(model, curr, curr_pos, prev_pix_tokens, prev_mask_logits, prev_is_mask_from_pts: bool, memory_pos, pe_tokens, sparse,
                            feat_s0, feat_s1, B: int, h: int, w: int, target_masks: torch.Tensor, dense_tokens=None, pos_weight: float = 1.0,
-                           mem_scale: float = None, prev_sam_token: torch.Tensor = None):
+                           mem_scale: float = None, prev_sam_token: torch.Tensor = None, mask_index: int = None):
     """One level of back-propagation through the memory bank -- the path of the 3-D loop's `non_prompt_loss` (func_3d/function.py:160-184)
     that trains the memory ENCODER: the previous slice's memory is encoded here from its pixel features and predicted mask
     (`_encode_new_memory`, sam2_base.py:665-703), the current (unprompted) slice attends to it, and the mask loss of the current slice
@@ -253,7 +265,7 @@ def memory_bank_loss_grads(model, curr, curr_pos, prev_pix_tokens, prev_mask_log
     aux: dict = {}
     loss, scale, scale_mem, g_dec, g_mem, _ = memory_decoder_loss_grads(
         model.memory_attention, model.sam_mask_decoder, curr, curr_pos, memory, memory_pos, n_ptr, pe_tokens, sparse, feat_s0, feat_s1, B, h, w,
-        target_masks, dense_tokens=dense_tokens, pos_weight=pos_weight, mem_scale=mem_scale, aux=aux)
+        target_masks, dense_tokens=dense_tokens, pos_weight=pos_weight, mem_scale=mem_scale, aux=aux, mask_index=mask_index)
     dmem = aux["dmemory"]                                                                    # [L + n_ptr, B, 64], scaled by scale_mem
     d_mem = dmem[:L].transpose(0, 1).reshape(B * L, -1).contiguous()
     _, g_enc = bwd.memory_encoder_backward(enc, prev_pix_tokens, prev_mask_logits, mode, sc, bi, B, h, w, d_mem)
@@ -272,11 +284,14 @@ def memory_bank_finetune_step(model, optimizers: Dict[str, DecoderAdam], *args, 
     """Adam step of the three groups on `memory_bank_loss_grads` (same arguments).  `optimizers` maps "decoder" / "memory_attention" /
     "memory_encoder" to a DecoderAdam over `model.sam_mask_decoder` / `model.memory_attention` / `model.memory_encoder` (train_3d.py:50-54
     runs the first at lr 1e-4 and the memory groups at 1e-8); groups without an optimiser are left alone."""
-    if kwargs.get("mem_scale") is None and "memory_attention" in optimizers:
-        kwargs["mem_scale"] = getattr(optimizers["memory_attention"], "calibrated_loss_scale", None)
+    holder = optimizers.get("memory_attention")
+    cal = getattr(holder, "calibrated_loss_scales", {}) if holder is not None else {}
+    if kwargs.get("mem_scale") is None:
+        kwargs["mem_scale"] = cal.get(("bank", kwargs.get("mask_index")))
     loss, scales, grads = memory_bank_loss_grads(model, *args, **kwargs)
-    if "memory_attention" in optimizers:
-        optimizers["memory_attention"].calibrated_loss_scale = scales["memory_attention"] / scales["decoder"]
+    if holder is not None:
+        cal[("bank", kwargs.get("mask_index"))] = scales["memory_attention"] / scales["decoder"]
+        holder.calibrated_loss_scales = cal
     for grp, opt in optimizers.items():
         opt.step(grads[grp], grad_scale=1.0 / scales[grp])
     return float(loss.item()) if sync else loss

@@ -602,6 +602,16 @@ def test_train_step_2d(mods):
         assert losses[1] < losses[0] and losses[2] < losses[0], losses      # (Adam sign-like first steps: not necessarily monotone)
         moved = {k.split(".")[0] for k, v in m.state_dict().items() if not torch.equal(v, before[k])}
         assert moved == {"memory_attention", "sam_mask_decoder"}, moved
+    # the reference's loss form (mask 0 at the video resolution) through the same iteration, from fresh weights and optimisers
+    # (Adam's first sign-like steps may overshoot: the bar is on the loss after four iterations)
+    m2 = bs.build_sam2("sam2_hiera_t", device="cpu", hydra_overrides_extra=["++model.image_size=256"])
+    m2.load_state_dict(sd, strict=True)
+    m2 = m2.to(DEV).eval()
+    hi_target = (rnd(B, 1, S, S, seed=153) > 0.3).float()
+    om2, od2 = T.DecoderAdam(m2.memory_attention, lr=1e-5), T.DecoderAdam(m2.sam_mask_decoder, lr=1e-4)
+    with torch.no_grad():
+        hl = [T.train_step_2d(m2, om2, od2, d(imgs), d(pts), d(labels), d(memory), d(memory_pos), d(hi_target), mask_index=0)[0] for _ in range(4)]
+    assert hl[3] < 0.6 * hl[0], hl
     # the first loss against the oracle's forward (weights before any update)
     with torch.no_grad():
         P = {k: v.float() for k, v in sd.items()}
