@@ -14,6 +14,10 @@ RCCL is used for the barrier and the max-over-ranks time only.  scaling = "weak"
 
 Extra objects on the JSON line: "roofline" (dominant kernel = D=256 flash attention of memory attention, MFMA-bound; timed with
 HIP events on the launch stream) and "cpu_baseline" (the CPU oracle on a bounded sample, rank 0, N=1 only).
+
+Side figure (never part of `value`, `--no-train` skips it): `train_iteration` = one whole training iteration of the same configuration
+(frozen encoders forward, memory attention + mask decoder forward / backward / Adam, memory encoding) replayed as a hipGraph after the
+timed region, on a deep copy of the model; a failure there is reported inside that object and does not affect the line.
 """
 import argparse
 import ctypes
@@ -147,6 +151,44 @@ def pmc_traffic():
     return tot
 
 
+def train_iteration(m, imgs, pts, labels, memory, memory_pos, device):
+    """Side figure, never part of `value`: one whole training iteration of the same configuration (SURVEY.md 8(d) config 2 "time
+    forward (+backward when available)") -- frozen image / prompt encoders, forward + backward + Adam of memory attention and mask
+    decoder, memory encoding of the new prediction (`training.train_step_2d`) -- replayed as a hipGraph.  Reported as
+    {"ms": per iteration, "slices_per_s": ..}; None with the reason if anything in it fails (the headline line must not depend on it)."""
+    try:
+        import copy
+        import medical_sam2_amd.training as T
+        mt = copy.deepcopy(m)                              # the optimiser must not touch the benchmarked weights
+        B = imgs.shape[0]
+        g = torch.Generator().manual_seed(3)
+        target = (torch.randn(B, 4, 256, 256, generator=g) > 0.5).float().to(device)
+        om, od = T.DecoderAdam(mt.memory_attention, lr=1e-6), T.DecoderAdam(mt.sam_mask_decoder, lr=1e-4)
+        step = lambda sync: T.train_step_2d(mt, om, od, imgs, pts, labels, memory, memory_pos, target, sync=sync)
+        step(True)                                          # eager: calibrates the loss scale, packs weights
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            step(False)
+        torch.cuda.current_stream().wait_stream(st)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step(False)
+        graph.replay()
+        torch.cuda.synchronize()
+        n = 10
+        t0 = time.perf_counter()
+        for _ in range(n):
+            graph.replay()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        return {"ms": dt * 1e3, "slices_per_s": B / dt, "what": "train_step_2d: frozen encoders fwd + memory attention & mask decoder fwd/bwd + Adam "
+                "+ memory encoding, hipGraph replay"}
+    except Exception as e:  # noqa: BLE001 -- a side figure: report, do not fail the benchmark line
+        return {"ms": None, "error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def host_cpu_share() -> int:
     """CPUs this process may actually use: the cgroup quota when there is one (the GPU box gives 16 of its 256 hardware threads;
     running the oracle on all 256 is 3x SLOWER than on 16: tests/probes/cpu_threads_probe.py), else the affinity mask."""
@@ -207,6 +249,7 @@ def main():
     ap.add_argument("--streams", type=int, default=int(os.environ.get("MSAM2_BENCH_STREAMS", "1")),
                     help="process the step's slices as this many concurrent sub-batches on separate HIP streams (same work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the (untimed-in-value) training-iteration figure")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -303,6 +346,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_train:
+            line["train_iteration"] = train_iteration(m, imgs, pts, labels, memory, memory_pos, device)
         print(json.dumps(line), flush=True)
     if dist is not None:
         par.barrier(sync_dev)
