@@ -1,0 +1,92 @@
+"""Data-parallel fine-tuning on the HIP path: two ranks (gloo rendezvous on 127.0.0.1, both on the one GPU of the test box), each with
+half of the batch; the bucketed gradient all-reduce must reproduce the single-process full-batch gradients, and one Adam step must leave
+both ranks with identical parameters."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(B, E=16, C=256):
+    rnd = lambda *s, seed=0, scale=1.0: torch.randn(*s, generator=torch.Generator().manual_seed(seed)) * scale
+    emb, pe, sparse = rnd(B, C, E, E, seed=300), rnd(1, C, E, E, seed=301), rnd(B, 2, C, seed=302)
+    f0, f1 = rnd(B, 32, 4 * E, 4 * E, seed=303), rnd(B, 64, 2 * E, 2 * E, seed=304)
+    target = (rnd(B, 4, 4 * E, 4 * E, seed=305) > 0.4).float()
+    return emb, pe, sparse, f0, f1, target
+
+
+def _decoder():
+    import medical_sam2_amd.build_sam as bs
+    import medical_sam2_amd.weights as wts
+    m = bs.build_sam2("sam2_hiera_t", device="cpu", hydra_overrides_extra=["++model.image_size=256"])
+    m.load_state_dict(wts.init_weights("hiera_t", 0), strict=True)
+    return m.sam_mask_decoder.cuda().eval()
+
+
+def _grads(dec, sl, B_all):
+    import medical_sam2_amd.backward as bwd
+    import medical_sam2_amd.ops as ops
+    import medical_sam2_amd.training as T
+    emb, pe, sparse, f0, f1, target = _inputs(B_all)
+    E = emb.shape[-1]
+    d = lambda t: t[sl].cuda() if t.shape[0] == B_all else t.cuda()
+    tm = lambda t: d(t).permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()
+    n = d(emb).shape[0]
+    f0t, f1t = tm(f0).to(ops.OP16), tm(f1).to(ops.OP16)
+    masks, _, _, _ = dec.predict_masks_tokens(tm(emb), tm(pe), d(sparse), f0t, f1t, n, E, E)
+    loss, dm = T.bce_with_logits(masks, d(target), 1.0)
+    _, _, g = bwd.mask_decoder_backward(dec, tm(emb), tm(pe), d(sparse), f0t, f1t, n, E, E, dm * 4096.0)
+    return loss, {k: v / 4096.0 for k, v in g.items()}, (tm(emb), tm(pe), d(sparse), f0t, f1t, n, E, E, d(target))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.set_grad_enabled(False)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import medical_sam2_amd.parallel as par
+    import medical_sam2_amd.training as T
+    B_all = 4
+    per = B_all // world
+    dec = _decoder()
+    _, g_local, args = _grads(dec, slice(rank * per, (rank + 1) * per), B_all)
+    g_sum, inv = par.allreduce_gradients(g_local)
+    # reference on this rank: the full batch in one process (mean over 4 slices = mean of the two per-rank means)
+    _, g_full, _ = _grads(dec, slice(0, B_all), B_all)
+    num = sum(((g_sum[k] * inv).double() - g_full[k].double()).pow(2).sum().item() for k in g_full if not k.endswith("k_proj.bias"))
+    den = sum(g_full[k].double().pow(2).sum().item() for k in g_full if not k.endswith("k_proj.bias"))
+    rel = (num / den) ** 0.5
+    # one data-parallel Adam step, then compare the parameters of the two ranks
+    opt = T.DecoderAdam(dec, lr=1e-4)
+    T.decoder_finetune_step(dec, opt, *args, data_parallel=True)
+    flat = torch.cat([p.detach().reshape(-1) for p in dec.parameters()]).cpu()
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    same = all(torch.equal(gathered[0], t) for t in gathered[1:])
+    q.put((rank, rel, bool(same)))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_decoder_step_two_ranks():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 200)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(2))
+    for rank, rel, same in res:
+        assert rel < 1e-2, (rank, rel)          # all-reduced half-batch gradients == full-batch gradients (16-bit operand noise)
+        assert same, rank                       # identical parameters on both ranks after the step
