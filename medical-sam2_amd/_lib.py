@@ -70,7 +70,7 @@ SIGNATURES = {
     "msam2_gemm_tt": (c_i, [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_l, c_p]),
     "msam2_bilinear_upsample_bwd": (c_i, [c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_p]),
     "msam2_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_l, c_p]),
-    "msam2_adam_step_multi": (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_l, c_f, c_p]),
+    "msam2_adam_step_multi": (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_l, c_f, c_f, c_p]),
     "msam2_attention_small_bwd": (c_i, [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_f, c_p]),
     "msam2_seg_counts": (c_i, [c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_p]),
     "msam2_non_overlap": (c_i, [c_p, c_p, c_l, c_l, c_p]),

@@ -689,7 +689,7 @@ struct AdamTable {
 };
 
 __global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable tb, float lr, float b1, float b2, float eps, float bc1, float bc2,
-                                                         float gscale) {
+                                                         float gscale, float decay) {
   const int t = blockIdx.y;
   float* __restrict__ p = tb.p[t];
   const float* __restrict__ g = tb.g[t];
@@ -702,13 +702,13 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable tb, float lr,
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi;
     v[i] = vi;
-    p[i] -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+    p[i] = p[i] * decay - lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);          // decay = 1 - lr * weight_decay (AdamW, decoupled)
   }
 }
 
 extern "C" int msam2_adam_step_multi(void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
                                      const int64_t* numel, int64_t count, float lr, float beta1, float beta2, float eps, int64_t step,
-                                     float grad_scale, void* stream) {
+                                     float grad_scale, float weight_decay, void* stream) {
   MSAM2_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel && count > 0 && step >= 1, "adam_step_multi: bad arguments");
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   for (int64_t c0 = 0; c0 < count; c0 += ADAM_CHUNK) {
@@ -723,7 +723,8 @@ extern "C" int msam2_adam_step_multi(void* const* params, const void* const* gra
       nmax = max(nmax, numel[j]);
     }
     dim3 grid((unsigned)min((int64_t)128, cdiv(nmax, 256)), (unsigned)nt);
-    hipLaunchKernelGGL(adam_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, tb, lr, beta1, beta2, eps, bc1, bc2, grad_scale);
+    hipLaunchKernelGGL(adam_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, tb, lr, beta1, beta2, eps, bc1, bc2, grad_scale,
+                       1.f - lr * weight_decay);
   }
   return msam2_check_launch("adam_step_multi");
 }

@@ -63,8 +63,9 @@ class DecoderAdam:
     """torch.optim.Adam(params, lr, betas, eps) semantics for the parameters of one module (the mask decoder, the memory attention, ...:
     gradient names are relative to it), state kept as flat fp32 tensors."""
 
-    def __init__(self, decoder, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8):
-        self.decoder, self.lr, self.betas, self.eps, self.t = decoder, lr, betas, eps, 0
+    def __init__(self, decoder, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        """weight_decay = 0: torch.optim.Adam as train_3d.py:50-54 builds it; > 0: torch.optim.AdamW's decoupled decay (train_2d.py:43-47)."""
+        self.decoder, self.lr, self.betas, self.eps, self.t, self.weight_decay = decoder, lr, betas, eps, 0, weight_decay
         self.state: Dict[str, tuple] = {}
 
     @torch.no_grad()
@@ -93,7 +94,7 @@ class DecoderAdam:
         n = len(names)
         arr = [(ctypes.c_void_p * n)(*tab) for tab in tabs]
         check(lib().msam2_adam_step_multi(arr[0], arr[1], arr[2], arr[3], (ctypes.c_int64 * n)(*numel), n, self.lr, self.betas[0],
-                                          self.betas[1], self.eps, self.t, float(grad_scale), _stream()))
+                                          self.betas[1], self.eps, self.t, float(grad_scale), float(self.weight_decay), _stream()))
         # the update went through raw pointers: bump the tensor versions (no kernel) so cached kernel-ready weights are rebuilt
         ps = tuple(params[name] for name in names)
         torch._C._autograd._unsafe_set_version_counter(ps, tuple(p._version + 1 for p in ps))

@@ -788,3 +788,25 @@ def test_decoder_finetune_step_reference_loss(mods):
         sig = g.abs() > 1e-3 * g.abs().max()
         cos_min = min(cos_min, F.cosine_similarity(delta[sig].flatten(), torch.sign(g[sig]).flatten(), dim=0).item())
     assert touched >= 40 and cos_min > 0.85, (touched, cos_min)
+
+
+def test_adamw_multi_tensor_matches_torch(mods):
+    """DecoderAdam (one multi-tensor launch per 24 parameters) against torch.optim.Adam / AdamW over several steps on ragged parameter
+    shapes, with a loss scale folded into grad_scale."""
+    B_, ops = mods
+    import medical_sam2_amd.training as T
+    shapes = [(7,), (33, 5), (256, 256), (1, 1, 3), (2048,)] * 7                  # 35 parameters: two launches
+    for wd in (0.0, 0.05):
+        mod = torch.nn.ParameterList([torch.nn.Parameter(rnd(*sh, seed=400 + i)) for i, sh in enumerate(shapes)]).to(DEV)
+        ref = [torch.nn.Parameter(p.detach().cpu().clone()) for p in mod]
+        opt_ref = (torch.optim.AdamW(ref, lr=1e-3, weight_decay=wd) if wd else torch.optim.Adam(ref, lr=1e-3))
+        opt = T.DecoderAdam(mod, lr=1e-3, weight_decay=wd)
+        for step in range(3):
+            gs = [rnd(*sh, seed=500 + 10 * step + i) for i, sh in enumerate(shapes)]
+            for p, g in zip(ref, gs):
+                p.grad = g.clone()
+            opt_ref.step()
+            with torch.no_grad():
+                opt.step({str(i): (g * 64.0).to(DEV) for i, g in enumerate(gs)}, grad_scale=1.0 / 64.0)
+        for i, (p, r) in enumerate(zip(mod, ref)):
+            assert torch.allclose(p.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-6), (wd, i)
