@@ -34,6 +34,9 @@ class WeightCache:
 
 def w_bf16(cache: WeightCache, key: str, *weights: torch.Tensor) -> torch.Tensor:
     """bf16 [sum(out_i), in] matrix from one or more nn.Linear / 1x1-conv weights stacked along the output dim."""
+    if len(weights) == 1:                                  # one conversion pass, no concatenation copy (re-done after every optimiser step)
+        w0 = weights[0]
+        return cache.get(key, weights, lambda: w0.detach().reshape(w0.shape[0], -1).to(OP16).contiguous())
     return cache.get(key, weights, lambda: torch.cat([w.detach().reshape(w.shape[0], -1) for w in weights], 0).to(OP16).contiguous())
 
 
