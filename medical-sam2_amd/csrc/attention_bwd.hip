@@ -488,6 +488,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dma_kernel(AttnBwdParams 
     issue(t_begin, 0);
     stat_load(t_begin);
     stat_store(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the bare s_barrier below does not wait for this LDS write
   }
   for (int tile = t_begin; tile < t_full_end; ++tile) {
     const int st_i = (tile - t_begin) & 1;
