@@ -15,6 +15,8 @@ RCCL is used for the barrier and the max-over-ranks time only.  scaling = "weak"
 Extra objects on the JSON line: "roofline" (dominant kernel = D=256 flash attention of memory attention, MFMA-bound; timed with
 HIP events on the launch stream) and "cpu_baseline" (the CPU oracle on a bounded sample, rank 0, N=1 only).
 
+`cpu_baseline.parity_slice0`: the oracle sample IS slice 0 of the timed step (same image, click and memory bank), so its mask is compared
+with the HIP path's -- mask IoU and max / mean |delta logit| at the full 1024^2 size.
 Side figure (never part of `value`, `--no-train` skips it): `train_iteration` = one whole training iteration of the same configuration
 (frozen encoders forward, memory attention + mask decoder forward / backward / Adam, memory encoding) replayed as a hipGraph after the
 timed region, on a deep copy of the model; a failure there is reported inside that object and does not affect the line.
@@ -202,9 +204,12 @@ def host_cpu_share() -> int:
     return n
 
 
-def cpu_baseline():
+def cpu_baseline(sample=None):
     """The CPU oracle (fp32 torch restatement, "port") on ONE slice of the same workload (1 memory of the 4 -> scaled
-    honestly: the sample is one slice with its full 4-memory bank), 1 warm-up + 2 timed repetitions, on the host's CPU share."""
+    honestly: the sample is one slice with its full 4-memory bank), 1 warm-up + 2 timed repetitions, on the host's CPU share.
+    sample = (img [1,3,S,S], pts, labels, memory [Nk,1,64], memory_pos [Nk,1,64], hip_low_res [1,1,256,256]) on the CPU: slice 0 of the
+    timed step with the HIP path's mask logits for it -- the oracle then runs on exactly these inputs and the returned object also
+    carries the parity of the two masks (the second half of BASELINE.json's metric: mask IoU vs reference)."""
     from oracle import sam2_oracle as O
     torch.set_num_threads(host_cpu_share())
     import medical_sam2_amd.synthetic as syn
@@ -212,10 +217,15 @@ def cpu_baseline():
     torch.set_grad_enabled(False)
     P = wts.init_weights("hiera_s", 0)
     cfg = O.model_config("hiera_s", 1024)
-    img, pts, labels = syn.image_batch([0], 1024)
-    g = torch.Generator().manual_seed(1234)
-    memory = torch.randn(4 * 4096, 1, 64, generator=g) * 0.5
-    memory_pos = O.sine_pos_2d(64, 64, 64).flatten(1).t()[:, None, :].repeat(4, 1, 1)
+    hip_low = None
+    if sample is not None:
+        img, pts, labels, memory, memory_pos, hip_low = sample
+    else:
+        img, pts, labels = syn.image_batch([0], 1024)
+        g = torch.Generator().manual_seed(1234)
+        memory = torch.randn(4 * 4096, 1, 64, generator=g) * 0.5
+        memory_pos = O.sine_pos_2d(64, 64, 64).flatten(1).t()[:, None, :].repeat(4, 1, 1)
+    last = {}
 
     def one():
         bo = O.forward_image(P, cfg, img)
@@ -226,6 +236,7 @@ def cpu_baseline():
         sp, de = O.prompt_encoder(P, cfg, (pts, labels), None, None)
         masks, iou, toks, obj = O.mask_decoder(P, cfg, emb, O.dense_pe(P, 64, 64), sp, de, False, hr)
         high = torch.nn.functional.interpolate(masks, size=(1024, 1024), mode="bilinear", align_corners=False)
+        last["masks"] = masks
         return O.encode_new_memory(P, cfg, top, (64, 64), high, True)
 
     one()
@@ -234,9 +245,17 @@ def cpu_baseline():
     for _ in range(reps):
         one()
     dt = (time.perf_counter() - t0) / reps
-    return {"value": 1.0 / dt, "unit": "slices/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 slice (of the 4-slice step) through oracle/sam2_oracle.py fp32, its 4x4096-token memory bank, "
-                      f"1 warm-up + {reps} timed reps, {dt:.2f} s per slice"}
+    res = {"value": 1.0 / dt, "unit": "slices/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"1 slice (of the 4-slice step) through oracle/sam2_oracle.py fp32, its 4x4096-token memory bank, "
+                     f"1 warm-up + {reps} timed reps, {dt:.2f} s per slice"}
+    if hip_low is not None:
+        a, b = hip_low.float() > 0, last["masks"] > 0
+        union = (a | b).sum().item()
+        res["parity_slice0"] = {"mask_iou_vs_oracle": (a & b).sum().item() / union if union else 1.0,
+                                "max_abs_dlogit": (hip_low.float() - last["masks"]).abs().max().item(),
+                                "mean_abs_dlogit": (hip_low.float() - last["masks"]).abs().mean().item(),
+                                "foreground_pixels": int(b.sum().item())}
+    return res
 
 
 def main():
@@ -345,7 +364,9 @@ def main():
                          "hbm_GBs_on_algorithmic_bytes": k_bytes / k_s / 1e9, "hbm_frac_of_peak": k_bytes / k_s / 1e9 / HBM_PEAK_GBS},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            c = lambda t: t.detach().float().cpu()
+            sample = (c(imgs[:1]), c(pts[:1]), labels[:1].cpu(), c(memory[:, :1]), c(memory_pos[:, :1]), c(out[0][:1]))
+            line["cpu_baseline"] = cpu_baseline(sample)
         if world == 1 and not args.no_train:
             line["train_iteration"] = train_iteration(m, imgs, pts, labels, memory, memory_pos, device)
         print(json.dumps(line), flush=True)
