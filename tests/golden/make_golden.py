@@ -132,15 +132,17 @@ def sub(t: torch.Tensor, n: int = 4096) -> np.ndarray:
     return f[::step][:n].numpy().copy()
 
 
-def run_slice_chain(model: str, image_size: int, n_slices: int, tag: str, store_full: bool):
+def run_slice_chain(model: str, image_size: int, n_slices: int, tag: str, store_full: bool, weights_seed: int = 0,
+                    image_seed_base: int = 10):
     """cond slice 0 (point prompt) then n_slices-1 propagated slices through the reference's forward_image/track_step."""
-    m = build_reference(model, image_size)
+    m = build_reference(model, image_size, seed=weights_seed)
     out = {}
-    meta = {"model": model, "image_size": image_size, "n_slices": n_slices, "weights_seed": 0}
+    meta = {"model": model, "image_size": image_size, "n_slices": n_slices, "weights_seed": weights_seed,
+            "image_seed_base": image_seed_base}
     output_dict = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
     with torch.no_grad():
         for t in range(n_slices):
-            img, pts, labels = syn.image_batch([10 + t], image_size)
+            img, pts, labels = syn.image_batch([image_seed_base + t], image_size)
             # keep the click inside the same blob layout for every slice: reuse slice-0 click on slice 0 only
             bo = m.forward_image(img)
             _, feats, pos, sizes = m._prepare_backbone_features(bo)
@@ -174,6 +176,70 @@ def run_slice_chain(model: str, image_size: int, n_slices: int, tag: str, store_
             out[f"{tag}_t{t}_maskmem_pos_sub"] = sub(cur["maskmem_pos_enc"][0])
             meta[f"t{t}"] = {"pred_masks": stats(cur["pred_masks"]), "fg_frac": float((cur["pred_masks"] > 0).float().mean()),
                              "maskmem_features": stats(cur["maskmem_features"])}
+    return out, meta
+
+
+def find_bplus_seed(image_size: int = 256, n_slices: int = 2, tries: int = 24):
+    """First weight seed whose hiera_b+ chain has an object score > 0 and a non-trivial foreground on every slice (seed 0's
+    masks are the constant NO_OBJ_SCORE fill, which pins nothing about the mask path)."""
+    for seed in range(1, tries):
+        o, meta = run_slice_chain("hiera_b+", image_size, n_slices, "b256", store_full=False, weights_seed=seed)
+        fg = [meta[f"t{t}"]["fg_frac"] for t in range(n_slices)]
+        lo = [float(np.abs(o[f"b256_t{t}_pred_masks"]).max()) for t in range(n_slices)]
+        print("hiera_b+ weight seed", seed, "fg", fg, "max|logit|", lo)
+        if all(0.01 < f < 0.95 for f in fg) and all(v < 1000 for v in lo):
+            return o, meta
+    raise RuntimeError("no hiera_b+ seed with foreground masks found")
+
+
+def run_long_chain(model: str, image_size: int, n_slices: int, cond_frames, tag: str):
+    """Steady-state memory bank (sam2_base.py:494-663): `cond_frames` get a click and are processed first (as the predictor /
+    train_3d do), then every other slice is propagated in order.  With 28 slices and 4 conditioning frames the propagated slices
+    see every selected conditioning memory (t_pos 0) + the t-1..t-6 window (7-entry bank wrap), and from slice 17 on the
+    16-pointer cap (past conditioning pointers + at most 15 preceding non-conditioning ones).  The memory / pointer-token
+    counts the reference hands to memory_attention are recorded per slice."""
+    m = build_reference(model, image_size)
+    out, meta = {}, {"model": model, "image_size": image_size, "n_slices": n_slices, "cond_frames": list(cond_frames),
+                     "weights_seed": 0, "image_seed_base": 300}
+    seen = {}
+    real = m.memory_attention.forward
+
+    def spy(curr, memory, curr_pos=None, memory_pos=None, num_obj_ptr_tokens=0):
+        seen["n"] = (int(memory.shape[0]), int(num_obj_ptr_tokens))
+        return real(curr=curr, memory=memory, curr_pos=curr_pos, memory_pos=memory_pos, num_obj_ptr_tokens=num_obj_ptr_tokens)
+
+    m.memory_attention.forward = spy
+    od = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
+    feats_cache = {}
+    counts = {}
+    with torch.no_grad():
+        def enc(t):
+            img, pts, labels = syn.image_batch([300 + t], image_size)
+            bo = m.forward_image(img)
+            _, feats, pos, sizes = m._prepare_backbone_features(bo)
+            return feats, pos, sizes, pts, labels
+        for t in cond_frames:
+            feats, pos, sizes, pts, labels = enc(t)
+            cur = m.track_step(frame_idx=t, is_init_cond_frame=True, current_vision_feats=feats, current_vision_pos_embeds=pos,
+                               feat_sizes=sizes, point_inputs={"point_coords": pts, "point_labels": labels}, mask_inputs=None,
+                               output_dict=od, num_frames=n_slices, run_mem_encoder=True)
+            od["cond_frame_outputs"][t] = cur
+        for t in range(n_slices):
+            if t in od["cond_frame_outputs"]:
+                cur = od["cond_frame_outputs"][t]
+            else:
+                feats, pos, sizes, _, _ = enc(t)
+                seen.clear()
+                cur = m.track_step(frame_idx=t, is_init_cond_frame=False, current_vision_feats=feats, current_vision_pos_embeds=pos,
+                                   feat_sizes=sizes, point_inputs=None, mask_inputs=None, output_dict=od, num_frames=n_slices,
+                                   run_mem_encoder=True)
+                od["non_cond_frame_outputs"][t] = cur
+                counts[t] = list(seen["n"])
+            out[f"{tag}_t{t}_pred_masks"] = cur["pred_masks"].numpy().copy()
+            out[f"{tag}_t{t}_obj_ptr"] = cur["obj_ptr"].numpy().copy()
+            out[f"{tag}_t{t}_maskmem_features_sub"] = sub(cur["maskmem_features"])
+            meta[f"t{t}"] = {"fg_frac": float((cur["pred_masks"] > 0).float().mean())}
+    meta["memory_tokens"] = {str(k): v for k, v in counts.items()}
     return out, meta
 
 
@@ -485,6 +551,19 @@ def main():
         json.dump(allmeta, open(os.path.join(OUT, "meta.json"), "w"), indent=1)
         print({k: v.tolist() for k, v in o.items()})
         return
+    if len(sys.argv) > 1 and sys.argv[1] in ("long", "bplus"):
+        allmeta = json.load(open(os.path.join(OUT, "meta.json")))
+        if sys.argv[1] == "long":
+            o, meta = run_long_chain("hiera_s", 256, 28, (0, 8, 16, 22), "long256")
+            name = "chain_long_hiera_s_256"
+        else:
+            o, meta = find_bplus_seed()
+            name = "chain_hiera_bplus_256"
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **o)
+        allmeta[name] = meta
+        json.dump(allmeta, open(os.path.join(OUT, "meta.json"), "w"), indent=1)
+        print(name, os.path.getsize(os.path.join(OUT, name + ".npz")), {k: v for k, v in meta.items() if k in ("memory_tokens", "weights_seed")})
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "video":
         o, meta = run_video_predictor_case()
         np.savez_compressed(os.path.join(OUT, "video_predictor_t256.npz"), **o)
@@ -509,9 +588,12 @@ def main():
     o, meta = run_slice_chain("hiera_s", 1024, 3, "s1024", store_full=False)
     np.savez_compressed(os.path.join(OUT, "chain_hiera_s_1024.npz"), **o)
     allmeta["chain_hiera_s_1024"] = meta
-    o, meta = run_slice_chain("hiera_b+", 256, 2, "b256", store_full=False)
+    o, meta = find_bplus_seed()
     np.savez_compressed(os.path.join(OUT, "chain_hiera_bplus_256.npz"), **o)
     allmeta["chain_hiera_bplus_256"] = meta
+    o, meta = run_long_chain("hiera_s", 256, 28, (0, 8, 16, 22), "long256")
+    np.savez_compressed(os.path.join(OUT, "chain_long_hiera_s_256.npz"), **o)
+    allmeta["chain_long_hiera_s_256"] = meta
     o, meta = run_image_predictor_case()
     np.savez_compressed(os.path.join(OUT, "config1_image_predictor.npz"), **o)
     allmeta["config1_image_predictor"] = meta

@@ -126,11 +126,12 @@ def test_memory_encoder_vs_reference(P):
 
 
 def _run_chain(model, image_size, n_slices, tag, gold, meta):
-    P = wts.init_weights(model, 0)
+    P = wts.init_weights(model, meta.get("weights_seed", 0))
+    seed0 = meta.get("image_seed_base", 10)
     cfg = O.model_config(model, image_size)
     od = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
     for t in range(n_slices):
-        img, pts, labels = syn.image_batch([10 + t], image_size)
+        img, pts, labels = syn.image_batch([seed0 + t], image_size)
         collect = {} if t == 0 else None
         bo = O.forward_image(P, cfg, img, collect=collect)
         if t == 0:
@@ -164,8 +165,47 @@ def test_slice_chain_hiera_t_256():
 
 
 def test_slice_chain_hiera_bplus_256():
-    """Hiera-B+ trunk (class defaults of hieradet.py:176-201 with the upstream embed_dim 112 / 2 heads: head dim 56)."""
-    _run_chain("hiera_b+", 256, 2, "b256", load_npz("chain_hiera_bplus_256.npz"), load_meta()["chain_hiera_bplus_256"])
+    """Hiera-B+ trunk (class defaults of hieradet.py:176-201 with the upstream embed_dim 112 / 2 heads: head dim 56).  The weight
+    seed is the first one whose reference masks have foreground on both slices (seed 0's object score is <= 0: constant fill)."""
+    gold, meta = load_npz("chain_hiera_bplus_256.npz"), load_meta()["chain_hiera_bplus_256"]
+    for t in range(2):
+        assert 0.01 < meta[f"t{t}"]["fg_frac"] < 0.95 and np.abs(gold[f"b256_t{t}_pred_masks"]).max() < 1000
+    _run_chain("hiera_b+", 256, 2, "b256", gold, meta)
+
+
+def test_long_chain_steady_state_memory_bank():
+    """28 slices, conditioning frames 0/8/16/22 processed first (sam2_base.py:494-663 in its steady state): every propagated slice
+    must hand memory_attention the same number of memory tokens / pointer tokens as the reference did (all conditioning memories +
+    the t-1..t-6 window; past conditioning pointers + the capped run of preceding non-conditioning pointers), and reproduce its
+    masks and pointers."""
+    gold, meta = load_npz("chain_long_hiera_s_256.npz"), load_meta()["chain_long_hiera_s_256"]
+    T, cond = meta["n_slices"], meta["cond_frames"]
+    P = wts.init_weights("hiera_s", meta["weights_seed"])
+    cfg = O.model_config("hiera_s", 256)
+    od = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
+
+    def enc(t):
+        img, pts, labels = syn.image_batch([meta["image_seed_base"] + t], 256)
+        feats, pos, sizes = O.prepare_backbone_features(O.forward_image(P, cfg, img))
+        return feats, pos, sizes, {"point_coords": pts, "point_labels": labels}
+
+    for t in cond:
+        feats, pos, sizes, pin = enc(t)
+        od["cond_frame_outputs"][t] = O.track_step(P, cfg, t, True, feats, pos, sizes, pin, None, od, T)
+    assert max(int(v[1]) for v in meta["memory_tokens"].values()) >= 64 and len(cond) > 3      # the fixture reaches the caps
+    for t in range(T):
+        if t in cond:
+            cur = od["cond_frame_outputs"][t]
+        else:
+            feats, pos, sizes, _ = enc(t)
+            col = {}
+            cur = od["non_cond_frame_outputs"][t] = O.track_step(P, cfg, t, False, feats, pos, sizes, None, None, od, T, collect=col)
+            assert [col["memory_shape"][0], col["num_obj_ptr_tokens"]] == meta["memory_tokens"][str(t)], t
+        ref = gold[f"long256_t{t}_pred_masks"]
+        assert mask_iou(cur["pred_masks"], ref) >= 0.999, (t, mask_iou(cur["pred_masks"], ref))
+        assert max_abs(cur["pred_masks"], ref) < 5e-3
+        assert rel_err(cur["obj_ptr"], gold[f"long256_t{t}_obj_ptr"]) < 5e-4
+        assert rel_err(sub(cur["maskmem_features"]), gold[f"long256_t{t}_maskmem_features_sub"]) < 5e-4
 
 
 def test_slice_chain_hiera_s_1024():
