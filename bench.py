@@ -12,7 +12,7 @@ N>1 (launched by torch.distributed.run, one rank per GPU): every rank runs the s
 its own memory bank -- the 2D path shares nothing between replicas (SURVEY.md 8(e)) -- so there is no data-path collective;
 RCCL is used for the barrier and the max-over-ranks time only.  scaling = "weak".
 
-Extra objects on the JSON line: "roofline" (dominant kernel = D=256 flash attention of memory attention, MFMA-bound; timed with
+Extra objects on the JSON line: "roofline" (dominant kernel = the memory cross-attention, attn_kv64_kernel, MFMA-bound; timed with
 HIP events on the launch stream) and "cpu_baseline" (the CPU oracle on a bounded sample, rank 0, N=1 only).
 
 `cpu_baseline.parity_slice0`: the oracle sample IS slice 0 of the timed step (same image, click and memory bank), so its mask is compared
@@ -87,11 +87,14 @@ def assemble_memory(m, bank_feats, sampled):
 
 
 def time_dominant_kernel(device, batch):
-    """HIP-event timing (on the launch stream) of the dominant kernel -- the D=256 single-head flash attention (split-KV pass,
-    attn_glds_kernel<256,256,4,2>) at the cross-attention shape of this workload: Lq = 4096, Lk = batch*4096 per slice.
-    The split pass is launched alone (negative split count, partials stay in a caller-owned workspace) so the figure is that
-    kernel's own average duration, comparable with rocprofv3's kernel trace; the fwd+merge pair is timed as well.
-    Returns (avg seconds per launch of the kernel, flops, algorithmic bytes, splits, avg seconds of the fwd+merge pair)."""
+    """HIP-event timing (on the launch stream) of the dominant kernel -- the memory cross-attention (RoPEAttention with kv_in_dim 64,
+    transformer.py:288-331) as the model runs it: attn_kv64_kernel, 256-wide rotated q / k rows, the value product contracted in the
+    64-channel memory space (v_proj folded into out_proj) -- at the cross-attention shape of this workload: Lq = 4096,
+    Lk = batch*4096 per slice.  The split pass is launched alone (negative split count, partials stay in a caller-owned workspace)
+    so the figure is that kernel's own average duration, comparable with rocprofv3's kernel trace; the fwd+merge pair is timed too.
+    `flops` is the ALGORITHMIC figure of SURVEY.md 8(d) (4 Lq Lk 256 per object: the reference's 256-wide formulation);
+    `executed` = 2 Lq Lk (256 + 64) is what the kernel's MFMAs actually do after the fold.
+    Returns (avg seconds per launch, algorithmic flops, executed flops, algorithmic bytes, splits, avg seconds of the fwd+merge pair)."""
     import medical_sam2_amd.ops as ops
     from medical_sam2_amd._lib import lib, check
     from medical_sam2_amd.modeling.common import attn_splits
@@ -99,10 +102,9 @@ def time_dominant_kernel(device, batch):
     g = torch.Generator().manual_seed(5)
     q = (torch.randn(B, 1, Lq, D, generator=g)).to(ops.OP16).to(device)
     k = (torch.randn(B, 1, Lk, D, generator=g)).to(ops.OP16).to(device)
-    v = (torch.randn(B, 1, Lk, D, generator=g)).to(ops.OP16).to(device)
+    v = (torch.randn(B, 1, Lk, 64, generator=g)).to(ops.OP16).to(device)
     splits = attn_splits(B, 1, Lq, Lk)
-    out = torch.empty(B, Lq, 1, D, dtype=ops.OP16, device=device).permute(0, 2, 1, 3)
-    ws = ops.attention_workspace(B, 1, Lq, D, splits, device)
+    ws = ops.attention_workspace(B, 1, Lq, 64, splits, device)
     stream = torch.cuda.current_stream().cuda_stream
     e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
     check(lib().msam2_event_create(ctypes.byref(e0)))
@@ -122,31 +124,32 @@ def time_dominant_kernel(device, batch):
         return ms.value / 1e3 / n
 
     defer = splits > 1
-    run_kernel = lambda: ops.attention(q, k, v, splits=splits, out=out, workspace=ws, defer_merge=defer)
-    run_pair = lambda: ops.attention(q, k, v, splits=splits, out=out, workspace=ws)
+    run_kernel = lambda: ops.attention_kv64(q, k, v, splits=splits, workspace=ws, defer_merge=defer)
+    run_pair = lambda: ops.attention_kv64(q, k, v, splits=splits, workspace=ws)
     # alternate the two measurements (the chip's clock moves with load) and average
     tp1, tk1, tp2, tk2 = timed(run_pair), timed(run_kernel), timed(run_pair), timed(run_kernel)
     t_kernel, t_pair = 0.5 * (tk1 + tk2), 0.5 * (tp1 + tp2)
     lib().msam2_event_destroy(e0)
     lib().msam2_event_destroy(e1)
     flops = 4.0 * B * Lq * Lk * D
-    bytes_ = 2.0 * B * (2 * Lq * D + 2 * Lk * D)
-    return t_kernel, flops, bytes_, splits, t_pair
+    executed = 2.0 * B * Lq * Lk * (D + 64)
+    bytes_ = 2.0 * B * (Lq * D + Lk * D + Lk * 64 + Lq * 64)
+    return t_kernel, flops, executed, bytes_, splits, t_pair
 
 
 def pmc_traffic():
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/, collected with
-    `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on tools/one_attn.py at this exact shape): counter units of 1 KiB, FETCH_SIZE doubled on
-    gfx950 (MI355X_MICROARCH.md, HBM/rocprofv3 section).  None when the files are absent."""
+    `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on `tools/one_attn.py 4 1 4096 16384 kv64 <splits>` at this exact shape): counter units of
+    1 KiB, FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md, HBM/rocprofv3 section).  None when the files are absent."""
     import csv
     here = os.path.dirname(os.path.abspath(__file__))
     tot = 0.0
     for name, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
-        path = os.path.join(here, "profiles", f"r01_attn256_pmc_{name}.csv")
+        path = os.path.join(here, "profiles", f"r02_attnkv64_pmc_{name}.csv")
         if not os.path.exists(path):
             return None
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-                if r.get("Counter_Name") == name and "attn_glds_kernel" in r.get("Kernel_Name", "")]
+                if r.get("Counter_Name") == name and "attn_kv64_kernel" in r.get("Kernel_Name", "")]
         if not vals:
             return None
         tot += mult * 1024.0 * sum(vals) / len(vals)
@@ -346,7 +349,7 @@ def main():
     import medical_sam2_amd.ops as ops
     if rank == 0:
         slices = args.batch * args.steps * world
-        k_s, k_flops, k_bytes, splits, pair_s = time_dominant_kernel(device, args.batch)
+        k_s, k_flops, k_exec, k_bytes, splits, pair_s = time_dominant_kernel(device, args.batch)
         achieved = k_flops / k_s / 1e12
         line = {
             "metric": "slices/sec @1024^2 (Hiera-S)", "value": slices / dt, "unit": "slices/s", "n_gpus": world,
@@ -358,8 +361,11 @@ def main():
                        "slices_per_step_per_gpu": args.batch, "hip_graph": graph is not None, "weights": "random name-keyed init"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(),
-                         "kernel": f"attn_glds_kernel<256,256,4,2> (split-KV pass, {splits} splits) at B={args.batch} Lq=4096 Lk={args.batch * 4096}",
+                         "kernel": f"attn_kv64_kernel<4,3> (memory cross-attention, value product folded to the 64-channel memory space; "
+                                   f"split-KV pass, {splits} splits) at B={args.batch} Lq=4096 Lk={args.batch * 4096}",
                          "avg_launch_us": k_s * 1e6, "with_merge_us": pair_s * 1e6, "flops_per_launch": k_flops,
+                         "flops_definition": "algorithmic, SURVEY 8(d): 4*Lq*Lk*256 per object (the reference's 256-wide SDPA)",
+                         "executed_flops_per_launch": k_exec, "frac_on_executed_flops": k_exec / k_s / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                          "algorithmic_bytes_per_launch": k_bytes,
                          "hbm_GBs_on_algorithmic_bytes": k_bytes / k_s / 1e9, "hbm_frac_of_peak": k_bytes / k_s / 1e9 / HBM_PEAK_GBS},
         }

@@ -15,6 +15,7 @@
 #ifdef MSAM2_STAMP
 // diagnostic build only (tools/attn_probe.hip): per-section cycle sums of one wave, never compiled into the product library
 __device__ unsigned long long g_stamp[16];
+__device__ unsigned long long g_wgtime[4096][4];   // per workgroup: realtime at entry, loop start, loop end, exit (100 MHz ticks)
 #define STAMP(var)                                                                     \
   do {                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                 \
@@ -623,6 +624,293 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_glds_kernel(AttnParams p) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Memory cross-attention with the value product contracted in the 64-channel memory space (attn_kv64_kernel).
+// RoPEAttention (transformer.py:288-331) with kv_in_dim = 64 computes softmax(q k^T) (M W_v^T + b_v): the values carry no rotary
+// encoding and every softmax row sums to one, so  P (M W_v^T + b_v) = (P M) W_v^T + b_v  exactly.  The kernel therefore streams the
+// 64-channel memory rows M as "values" (O' = P M, [Lq, 64]) and the caller folds W_v into the out-projection: 5/8 of the MFMA work of
+// the 256-wide formulation, a 4 KB instead of a 16 KB value tile per 32 keys, and a 32-register instead of a 128-register O
+// accumulator -- which is what lets three workgroups (12 waves) share a CU and leaves room to keep K fragments in flight.
+//   K image [32 keys][512 B]: 16-byte chunk c of key r at (c & ~15) | ((c & 15) ^ (r & 15))   (ds_read_b128 rows, as above)
+//   V image [32 keys][128 B]: chunk c of key r at c ^ (((r >> 1) & 1) << 2): the four rows a transposed read touches (r, r+1, r+2,
+//   r+3 of an aligned group) land on the four 64-byte quarters of the 256-byte bank row.
+// ------------------------------------------------------------------------------------------------------------------
+template <int NW, int OCC>
+__global__ __launch_bounds__(NW * 64, OCC) void attn_kv64_kernel(AttnParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int D = 256, DV = 64, BK = 32;
+  constexpr int RB = D * 2, CPR = D / 8;        // K image: row bytes, 16-byte chunks per row
+  constexpr int RBV = DV * 2, CPRV = DV / 8;    // V image
+  constexpr int TILE_K = BK * RB, TILE_V = BK * RBV, STAGE = TILE_K + TILE_V;
+  constexpr int PWK = TILE_K / 1024 / NW, PWV = TILE_V / 1024 / NW;   // DMA pieces (1 KiB per wave-instruction) per wave
+  constexpr int DSTEPS = D / 16, DBLK = DV / 32;
+  static_assert(TILE_K % (1024 * NW) == 0 && TILE_V % (1024 * NW) == 0, "tiles must split evenly over the waves");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+
+#ifdef MSAM2_STAMP
+  const unsigned long long wg_t0_ = __builtin_amdgcn_s_memrealtime();
+#endif
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  // XCD-aware work mapping (see attn_glds_kernel): the query tiles of one (batch, head, split) share an XCD's L2
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int nwg = gx * gy * gridDim.z;
+  int lid = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  {
+    const int q8 = nwg / 8, rem = nwg % 8, xcd = lid % 8;
+    lid = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + lid / 8;
+  }
+  const int qtile = lid % gx;
+  const int head = (lid / gx) % gy;
+  const int zz = lid / (gx * gy);
+  const int split = zz % p.splits, z = zz / p.splits;
+  const op16* qb = p.q + (int64_t)z * p.q_bs + (int64_t)head * p.q_hs;
+  const op16* kb = p.k + (int64_t)z * p.k_bs + (int64_t)head * p.k_hs;
+  const op16* vb = p.v + (int64_t)z * p.v_bs + (int64_t)head * p.v_hs;
+
+  const int qi = qtile * (NW * 32) + wave * 32 + r;
+  const bool qvalid = qi < p.Lq;
+  op16x8 qf[DSTEPS];
+#pragma unroll
+  for (int s = 0; s < DSTEPS; ++s) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (qvalid) v = *reinterpret_cast<const uint4*>(qb + (int64_t)qi * p.q_ts + s * 16 + h * 8);
+    qf[s] = __builtin_bit_cast(op16x8, v);
+  }
+
+  const int tiles_total = (p.Lk + BK - 1) / BK;
+  const int tiles_per = (tiles_total + p.splits - 1) / p.splits;
+  const int t_begin = split * tiles_per;
+  const int t_end = min(tiles_total, t_begin + tiles_per);
+  const int t_full_end = min(t_end, p.Lk / BK);
+
+  const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, 0x7fffffff, 0x00020000);
+  const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, 0x7fffffff, 0x00020000);
+  const int k_rb = (int)p.k_ts * 2, v_rb = (int)p.v_ts * 2;   // global row pitch in bytes
+  unsigned koff[PWK], voff[PWV];
+#pragma unroll
+  for (int j = 0; j < PWK; ++j) {
+    const int f = (wave * PWK + j) * 64 + lane;
+    const int row = f / CPR, c = f % CPR;
+    koff[j] = (unsigned)(row * k_rb + (((c & ~15) | ((c & 15) ^ (row & 15))) << 4));
+  }
+#pragma unroll
+  for (int j = 0; j < PWV; ++j) {
+    const int f = (wave * PWV + j) * 64 + lane;
+    const int row = f / CPRV, c = f % CPRV;
+    voff[j] = (unsigned)(row * v_rb + ((c ^ (((row >> 1) & 1) << 2)) << 4));
+  }
+  auto issue = [&](int tile, int stage) {
+    unsigned char* kdst = smem + stage * STAGE + wave * PWK * 1024;
+    unsigned char* vdst = smem + stage * STAGE + TILE_K + wave * PWV * 1024;
+    const unsigned ks = (unsigned)(tile * BK) * (unsigned)k_rb, vs = (unsigned)(tile * BK) * (unsigned)v_rb;
+#pragma unroll
+    for (int j = 0; j < PWK; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(kdst + j * 1024), 16, koff[j], ks, 0, 0);
+#pragma unroll
+    for (int j = 0; j < PWV; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(vdst + j * 1024), 16, voff[j], vs, 0, 0);
+  };
+
+  f32x16 o[DBLK];
+#pragma unroll
+  for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  STAMP_DECL;
+
+  // fragment read offsets.  K: key row r, chunk 2*st + h.  V (transposed read): lane supplies key 4h + q (+16 st, +8 u),
+  // elements d0 + 16*cgrp + 4p .. +3 with q = li>>2, p = li&3.
+  const int k_row = r * RB, k_x = r & 15;
+  const int li = lane & 15, vq = li >> 2, vp = li & 3, cgrp = (lane >> 4) & 1;
+  const int v_row = (4 * h + vq) * RBV + ((vp & 1) << 3);
+  const int v_sw = ((vq >> 1) & 1) << 2, v_c0 = 2 * cgrp + (vp >> 1);
+
+  auto compute = [&](int stage, int key0, const bool masked) __attribute__((always_inline)) {
+    const unsigned char* kbase = smem + stage * STAGE;
+    const unsigned char* vbase = kbase + TILE_K;
+    typedef __attribute__((ext_vector_type(8))) short short8_t;
+    auto kread = [&](int st) {
+      const int c = 2 * st + h;
+      return *reinterpret_cast<const op16x8*>(kbase + k_row + (((c & ~15) | ((c & 15) ^ k_x)) << 4));
+    };
+    auto vread = [&](int d, int st) {
+      const int cch = (d * 4 + v_c0) ^ v_sw;
+      const unsigned char* a0 = vbase + v_row + (16 * st) * RBV + (cch << 4);
+      const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0));
+      const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0 + 8 * RBV));
+      short8_t vv8;
+      vv8[0] = lo[0]; vv8[1] = lo[1]; vv8[2] = lo[2]; vv8[3] = lo[3];
+      vv8[4] = hi[0]; vv8[5] = hi[1]; vv8[6] = hi[2]; vv8[7] = hi[3];
+      return __builtin_bit_cast(op16x8, vv8);
+    };
+    // S^T = K Q^T: a rolling window of KPF K fragments stays in flight ahead of the MFMA that consumes the oldest one
+#ifndef MSAM2_KV64_KPF
+#define MSAM2_KV64_KPF 4
+#endif
+    constexpr int KPF = MSAM2_KV64_KPF;
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+    op16x8 kf[KPF];
+#pragma unroll
+    for (int g = 0; g < KPF; ++g) kf[g] = kread(g);
+#pragma unroll
+    for (int g = 0; g < DSTEPS; ++g) {
+      s = MSAM2_MFMA_32x32x16(kf[g % KPF], qf[g], s, 0, 0, 0);
+      if (g + KPF < DSTEPS) kf[g % KPF] = kread(g + KPF);
+    }
+    STAMP(t2_);
+    // the four V^T fragments of the tile (16 registers) are fetched under the softmax
+    op16x8 vf[DBLK][2];
+#pragma unroll
+    for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) vf[d][st] = vread(d, st);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      if (masked) {
+        const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (key >= p.Lk) s[e] = -INFINITY;
+      }
+      mx = fmaxf(mx, s[e]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;   // scale > 0: max commutes with it
+    const float m_new = fmaxf(m_run, mx);
+    if (__any(m_new > m_run)) {
+      const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+      m_run = m_new;
+    }
+    op16x8 pf[2];
+    float psum = 0.f;
+    const float nm = -m_run;   // finite: every tile holds >= 1 valid key
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], p.scale_log2, nm));
+      psum += pe;
+      pf[e >> 3][e & 7] = f2op(pe);
+    }
+    l_run += psum;
+    STAMP(t3_);
+#pragma unroll
+    for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) o[d] = MSAM2_MFMA_32x32x16(vf[d][st], pf[st], o[d], 0, 0, 0);
+  };
+
+  // ONE barrier per tile (see attn_glds_kernel): tile t's pieces were issued a whole compute phase earlier
+#ifdef MSAM2_STAMP
+  const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime(), ct0_ = __builtin_amdgcn_s_memtime();
+#endif
+  if (t_begin < t_full_end) issue(t_begin, 0);
+  for (int tile = t_begin; tile < t_full_end; ++tile) {
+    const int st_i = (tile - t_begin) & 1;
+    STAMP(t0_);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tile + 1 < t_full_end) issue(tile + 1, st_i ^ 1);
+    STAMP(t1_);
+    compute(st_i, tile * BK, false);
+    STAMP(t4_);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    STAMP(t5_);
+#ifdef MSAM2_STAMP
+    acc_[0] += t1_ - t0_; acc_[1] += t2_ - t1_; acc_[2] += t3_ - t2_; acc_[3] += t4_ - t3_; acc_[4] += t5_ - t4_;
+#endif
+  }
+#ifdef MSAM2_STAMP
+  if (blockIdx.x == 3 && blockIdx.y == 0 && blockIdx.z == 1 && threadIdx.x == 64) {
+    for (int i = 0; i < 5; ++i) g_stamp[8 + i] = acc_[i];
+    g_stamp[13] = (unsigned long long)(t_full_end - t_begin);
+    g_stamp[14] = __builtin_amdgcn_s_memrealtime() - rt0_;      // 100 MHz ticks over the loop
+    g_stamp[15] = __builtin_amdgcn_s_memtime() - ct0_;          // shader cycles over the loop
+  }
+#endif
+  if (t_full_end < t_end) {
+    // partial last tile: rows past Lk re-read the last valid key (their scores are masked to -inf)
+    const int key0 = t_full_end * BK, last = p.Lk - 1 - key0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                             // every wave is done with the last full tile's stage
+#pragma unroll
+    for (int j = 0; j < PWK; ++j) {
+      const int f = (wave * PWK + j) * 64 + lane;
+      const int row = f / CPR, c = f % CPR, rr = min(row, last);
+      const unsigned ko = (unsigned)((key0 + rr) * k_rb + (((c & ~15) | ((c & 15) ^ (row & 15))) << 4));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(smem + (wave * PWK + j) * 1024), 16, ko, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < PWV; ++j) {
+      const int f = (wave * PWV + j) * 64 + lane;
+      const int row = f / CPRV, c = f % CPRV, rr = min(row, last);
+      const unsigned vo = (unsigned)((key0 + rr) * v_rb + ((c ^ (((row >> 1) & 1) << 2)) << 4));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(smem + TILE_K + (wave * PWV + j) * 1024), 16, vo, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    compute(0, key0, true);
+  }
+
+#ifdef MSAM2_STAMP
+  const unsigned long long wg_t2_ = __builtin_amdgcn_s_memrealtime();
+#endif
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (!qvalid) return;
+  const float inv = 1.f / l_tot;   // > 0: every split owns at least one valid key
+  op16* dst;
+  if (p.splits == 1) {
+    dst = p.o + (int64_t)z * p.o_bs + (int64_t)head * p.o_hs + (int64_t)qi * p.o_ts;
+  } else {
+    const int64_t Bz = gridDim.z / p.splits;
+    const int64_t row = (((int64_t)split * Bz + z) * p.H + head) * p.Lq + qi;
+    dst = p.o_part + row * DV;
+    if (h == 0) {
+      p.ml_part[row * 2 + 0] = m_run;
+      p.ml_part[row * 2 + 1] = l_tot;
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      op16x4 w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = f2op(o[d][4 * g + e] * inv);
+      *reinterpret_cast<op16x4*>(dst + d * 32 + 8 * g + 4 * h) = w;
+    }
+#ifdef MSAM2_STAMP
+  if (threadIdx.x == 0) {
+    const int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (wg < 4096) {
+      g_wgtime[wg][0] = wg_t0_; g_wgtime[wg][1] = rt0_; g_wgtime[wg][2] = wg_t2_;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      g_wgtime[wg][3] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
+#endif
+#endif
+}
+
+#ifndef MSAM2_KV64_OCC
+#define MSAM2_KV64_OCC 3
+#endif
+static int launch_attn_kv64(const AttnParams& p, int Bz, hipStream_t s) {
+  dim3 grid(cdiv(p.Lq, 128), p.H, Bz * p.splits);
+  hipLaunchKernelGGL((attn_kv64_kernel<4, MSAM2_KV64_OCC>), grid, dim3(256), 0, s, p);
+  if (p.splits > 1 && !p.defer_merge) {
+    const int64_t rows = (int64_t)Bz * p.H * p.Lq;
+    hipLaunchKernelGGL((attn_merge_kernel<64>), dim3(cdiv(rows * 64, 256)), dim3(256), 0, s, p, Bz);
+  }
+  return msam2_check_launch("attention_kv64_fwd");
+}
+
 template <int D>
 static int launch_attn_glds(const AttnParams& p, int Bz, hipStream_t s) {
   dim3 grid(cdiv(p.Lq, 128), p.H, Bz * p.splits);
@@ -765,6 +1053,41 @@ extern "C" int msam2_attention_fwd_lse(const void* q, const int64_t* q_strides, 
   MSAM2_REQUIRE(lse, "attention_fwd_lse: null lse");
   return attention_fwd_impl(q, q_strides, k, k_strides, v, v_strides, o, o_strides, B, H, Lq, Lk, D, scale, splits, workspace, workspace_bytes,
                             lse, stream);
+}
+
+// softmax(Q K^T * scale) V with 256-wide q / k rows and 64-wide value rows (attn_kv64_kernel): the memory cross-attention with the
+// value projection folded out of the attention (O' = P M; the caller applies W_v and b_v behind it).  o: [.., 64] rows; workspace and
+// merge as msam2_attention_fwd with D = 64 (msam2_attention_workspace_bytes(B, H, Lq, 64, splits), msam2_attention_merge(.., D = 64, ..)).
+extern "C" int msam2_attention_kv64_fwd(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
+                                        const void* v, const int64_t* v_strides, void* o, const int64_t* o_strides, int64_t B,
+                                        int64_t H, int64_t Lq, int64_t Lk, float scale, int splits, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  MSAM2_REQUIRE(q && k && v && o, "attention_kv64: null tensor");
+  MSAM2_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attention_kv64: empty problem");
+  const bool defer = splits < 0;
+  if (defer) splits = -splits;
+  MSAM2_REQUIRE(splits >= 1 && splits <= 64, "attention_kv64: bad split count %d", splits);
+  for (int i = 0; i < 3; ++i)
+    MSAM2_REQUIRE(q_strides[i] % 8 == 0 && k_strides[i] % 8 == 0 && v_strides[i] % 8 == 0 && o_strides[i] % 4 == 0,
+                  "attention_kv64: strides must keep 16-byte row alignment");
+  MSAM2_REQUIRE(Lk * k_strides[2] * 2 < (1ll << 31) && Lk * v_strides[2] * 2 < (1ll << 31), "attention_kv64: key range beyond the 2 GiB buffer window");
+  splits = attn_effective_splits(Lk, splits);
+  MSAM2_REQUIRE(workspace_bytes >= msam2_attention_workspace_bytes(B, H, Lq, 64, splits), "attention_kv64: workspace too small");
+  MSAM2_REQUIRE(!defer || splits > 1, "attention_kv64: a deferred merge needs an effective split count > 1");
+  MSAM2_REQUIRE(splits == 1 || workspace, "attention_kv64: split-KV needs a workspace");
+  AttnParams p = {};
+  p.q = (const op16*)q; p.k = (const op16*)k; p.v = (const op16*)v; p.o = (op16*)o;
+  p.q_bs = q_strides[0]; p.q_hs = q_strides[1]; p.q_ts = q_strides[2];
+  p.k_bs = k_strides[0]; p.k_hs = k_strides[1]; p.k_ts = k_strides[2];
+  p.v_bs = v_strides[0]; p.v_hs = v_strides[1]; p.v_ts = v_strides[2];
+  p.o_bs = o_strides[0]; p.o_hs = o_strides[1]; p.o_ts = o_strides[2];
+  p.B = (int)B; p.H = (int)H; p.Lq = (int)Lq; p.Lk = (int)Lk;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  p.splits = splits;
+  p.defer_merge = defer ? 1 : 0;
+  p.o_part = (op16*)workspace;
+  p.ml_part = workspace ? reinterpret_cast<float*>(p.o_part + (size_t)splits * B * H * Lq * 64) : nullptr;
+  return launch_attn_kv64(p, (int)B, (hipStream_t)stream);
 }
 
 // Windowed attention straight from the un-partitioned token image (replaces window_partition + SDPA +

@@ -21,6 +21,7 @@ from .encoder import MLP  # noqa: F401  (re-export for the registry)
 
 import os as _os
 _FUSED_ROPE = _os.environ.get("MSAM2_NO_FUSED_ROPE") is None   # experiment switch: rotate in a separate in-place kernel instead
+_FOLD_V = _os.environ.get("MSAM2_NO_VALUE_FOLD") is None       # experiment switch: 256-wide values through v_proj instead
 
 
 class LayerNorm2d(nn.Module):
@@ -115,6 +116,29 @@ class RoPEAttention(Attention):
         ops.rope_(y, n_rope, tab)
         return y
 
+    def folds_values(self) -> bool:
+        """True when the value projection can be folded out of the attention: P (M W_v^T + b_v) = (P M) W_v^T + b_v because the
+        values carry no rotary encoding (transformer.py:318 sees v untouched) and softmax rows sum to one.  Built for the memory
+        cross-attention's shape (kv_in_dim 64 -> one 256-wide head): the attention then runs on the 64-channel memory rows
+        themselves (ops.attention_kv64) and v_proj rides in the out-projection (out_folded)."""
+        return _FOLD_V and self.kv_in_dim == 64 and self.internal_dim == 256 and self.num_heads == 1
+
+    def out_folded(self, o64: torch.Tensor, residual: Optional[torch.Tensor], out_dtype=F32) -> torch.Tensor:
+        """out_proj(o64 W_v^T + b_v) as ONE K = 64 GEMM: weight W_o W_v and bias W_o b_v + b_o composed in fp32."""
+        ps = [self.out_proj.weight, self.out_proj.bias, self.v_proj.weight, self.v_proj.bias]
+        w = self._wc.get("ovw", ps, lambda: (self.out_proj.weight.detach().float() @ self.v_proj.weight.detach().float()).to(OP16).contiguous())
+        b = self._wc.get("ovb", ps, lambda: (self.out_proj.weight.detach().float() @ self.v_proj.bias.detach().float()
+                                             + self.out_proj.bias.detach().float()).contiguous())
+        return ops.gemm(o64, w, b, residual=residual, out_dtype=out_dtype)
+
+    def core_folded(self, q: torch.Tensor, k: torch.Tensor, mem_v: torch.Tensor) -> torch.Tensor:
+        """rotated q [B, Lq, 256], rotated k [B, Lk, 256], un-projected values mem_v [B, Lk, 64] -> 16-bit [B*Lq, 64]"""
+        B, Lq, C = q.shape
+        Lk = k.shape[1]
+        o = ops.attention_kv64(q.view(B, Lq, 1, C).permute(0, 2, 1, 3), k.view(B, Lk, 1, C).permute(0, 2, 1, 3),
+                               mem_v.reshape(B, Lk, 1, 64).permute(0, 2, 1, 3), splits=attn_splits(B, 1, Lq, Lk))
+        return o.permute(0, 2, 1, 3).reshape(B * Lq, 64)
+
     def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_k_exclude_rope: int = 0) -> torch.Tensor:
         assert not (self.training and self.dropout_p > 0.0), "attention dropout (train mode) is outside the forward hot path"
         B, Lq, _ = q.shape
@@ -180,8 +204,12 @@ class MemoryAttentionLayer(nn.Module):
         t = self._ln("norm2", x)
         q = ca.proj_rope("q", t, B, L, L, tab)
         kk = ca.proj_rope("k", mem_k.reshape(B * Nk, -1), B, Nk, Nk - n_ptr_tokens, tab)
-        vv = ca.proj("v", mem_v.reshape(B * Nk, -1)).view(B, Nk, C)
-        x = ca.out(ca.core(q, kk, vv), x)
+        if ca.folds_values():
+            # O' = softmax(q k^T) M on the 64-channel memory rows; v_proj is folded into the out-projection (5/8 of the MFMA work)
+            x = ca.out_folded(ca.core_folded(q, kk, mem_v), x)
+        else:
+            vv = ca.proj("v", mem_v.reshape(B * Nk, -1)).view(B, Nk, C)
+            x = ca.out(ca.core(q, kk, vv), x)
         # FFN
         t = self._ln("norm3", x)
         h = ops.gemm(t, w_bf16(wc, "f1", self.linear1.weight), v_f32(wc, "f1b", self.linear1.bias), act=ops.ACT_RELU)

@@ -172,6 +172,27 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, splits: int 
     return out
 
 
+def attention_kv64(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, splits: int = 1, scale: Optional[float] = None,
+                   workspace: Optional[torch.Tensor] = None, defer_merge: bool = False) -> torch.Tensor:
+    """softmax(q k^T / sqrt(256)) v for q [B,H,Lq,256], k [B,H,Lk,256] and 64-wide value rows v [B,H,Lk,64] (the memory bank itself:
+    the memory cross-attention with v_proj folded into out_proj).  Returns the [B,H,Lq,64] view of a [B,Lq,H,64] buffer.
+    defer_merge: the split pass only (finish with attention_merge on the returned view)."""
+    B, H, Lq, D = q.shape
+    Lk = k.shape[2]
+    _req(D == 256 and k.shape[3] == 256 and v.shape[3] == 64 and v.shape[2] == Lk, "attention_kv64: q/k rows of 256, v rows of 64")
+    for t in (q, k, v):
+        _req(t.dtype == OP16 and t.stride(3) == 1, "attention tensors must be 16-bit (ops.OP16) with contiguous head dim")
+    out = torch.empty(B, Lq, H, 64, dtype=OP16, device=q.device).permute(0, 2, 1, 3)
+    ws_bytes = lib().msam2_attention_workspace_bytes(B, H, Lq, 64, splits)
+    ws = workspace if workspace is not None else (torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=q.device) if splits > 1 else None)
+    _req(not defer_merge or (workspace is not None and splits > 1), "defer_merge needs splits > 1 and a caller-owned workspace")
+    _req(ws is None or ws.numel() * ws.element_size() >= ws_bytes, "attention workspace too small")
+    sc = scale if scale is not None else 1.0 / math.sqrt(D)
+    check(lib().msam2_attention_kv64_fwd(_p(q), _strides3(q), _p(k), _strides3(k), _p(v), _strides3(v), _p(out), _strides3(out),
+                                         B, H, Lq, Lk, sc, -splits if defer_merge else splits, _p(ws), ws_bytes if ws is not None else 0, _stream()))
+    return out
+
+
 def attention_workspace(B: int, H: int, Lq: int, D: int, splits: int, device) -> torch.Tensor:
     return torch.empty(max(lib().msam2_attention_workspace_bytes(B, H, Lq, D, splits), 1), dtype=torch.uint8, device=device)
 

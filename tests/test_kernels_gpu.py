@@ -222,6 +222,54 @@ def test_attention_vs_oracle(ops, B, H, Lq, Lk, D, splits):
     close(out, ref, 0.02, 0.01, "attention")
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,splits", [(1, 1, 32, 32, 1), (2, 1, 200, 520, 1), (1, 1, 130, 2100, 4), (2, 1, 64, 4096 + 8, 8),
+                                              (1, 2, 256, 1000, 3), (1, 1, 1024, 33, 1)])
+def test_attention_kv64_vs_oracle(ops, B, H, Lq, Lk, splits):
+    """memory cross-attention with 64-wide value rows (msam2_attention_kv64_fwd): partial tiles, ragged query tiles, splits"""
+    q, k, v = bf(rnd(B, H, Lq, 256, seed=1)), bf(rnd(B, H, Lk, 256, seed=2)), bf(rnd(B, H, Lk, 64, seed=3))
+    v = bf(v.float() + torch.arange(Lk).float()[None, None, :, None] / Lk)       # row-distinct values: a key permutation would show
+    ref = _attn_ref(q.float(), k.float(), v.float())
+    out = ops.attention_kv64(q.to(DEV), k.to(DEV), v.to(DEV), splits=splits)
+    assert out.shape == (B, H, Lq, 64) and out.permute(0, 2, 1, 3).is_contiguous()
+    close(out, ref, 0.02, 0.01, "attention kv64")
+
+
+def test_attention_kv64_strided_and_rescale(ops):
+    """k / v as strided views (the [B, Nk, C] layouts of the memory bank), a peaked key in a late tile (running-max rescale), and
+    the deferred merge == the fused call bit for bit"""
+    B, Lq, Lk = 2, 96, 700
+    q = bf(rnd(B, 1, Lq, 256, seed=1))
+    kbig, vbig = bf(rnd(B, Lk, 320, seed=2) * 0.2), bf(rnd(B, Lk, 128, seed=3))
+    kbig[0, 610, 64:] = bf(q[0, 0, 7].float() * 3)
+    k = kbig[:, :, 64:].unsqueeze(1)            # [B,1,Lk,256], row pitch 320
+    v = vbig[:, :, 64:].unsqueeze(1)            # [B,1,Lk,64], row pitch 128
+    ref = _attn_ref(q.float(), k.float(), v.float())
+    dq, dk, dv = q.to(DEV), kbig.to(DEV)[:, :, 64:].unsqueeze(1), vbig.to(DEV)[:, :, 64:].unsqueeze(1)
+    one = ops.attention_kv64(dq, dk, dv)
+    close(one, ref, 0.02, 0.01, "kv64 strided")
+    fused = ops.attention_kv64(dq, dk, dv, splits=5)
+    close(fused, ref, 0.02, 0.01, "kv64 strided split")
+    ws = ops.attention_workspace(B, 1, Lq, 64, 5, DEV)
+    part = ops.attention_kv64(dq, dk, dv, splits=5, workspace=ws, defer_merge=True)
+    ops.attention_merge(part, Lk, 5, ws)
+    assert torch.equal(part, fused)
+
+
+def test_attention_long_key_range_vs_fp64(ops):
+    """Lk = 155 648 + 64 (BASELINE config 3's steady state: 38 memories of 4096 tokens + pointer tokens): both D = 256 kernels against
+    an fp64 softmax on 256 query rows, through the split counts the model uses."""
+    from medical_sam2_amd.modeling.common import attn_splits
+    Lq, Lk = 256, 38 * 4096 + 64
+    q, k = bf(rnd(1, 1, Lq, 256, seed=1) * 0.5), bf(rnd(1, 1, Lk, 256, seed=2) * 0.5)
+    v, m = bf(rnd(1, 1, Lk, 256, seed=3)), bf(rnd(1, 1, Lk, 64, seed=4))
+    sp = max(attn_splits(1, 1, 4096, Lk), 2)
+    for name, vals, fn in (("d256", v, ops.attention), ("kv64", m, ops.attention_kv64)):
+        ref = _attn_ref(q.float(), k.float(), vals.float())
+        out = fn(q.to(DEV), k.to(DEV), vals.to(DEV), splits=sp)
+        # 155 k-term convex combinations of N(0,1) values: |ref| ~ 0.02; the bound is the 16-bit rounding of p and of the partials
+        close(out, ref, 2e-3, 0.01, f"long key range {name} (splits {sp})")
+
+
 def test_attention_deferred_merge(ops):
     """split pass alone (negative split count through the C ABI) + msam2_attention_merge == the fused call, bit for bit"""
     B, H, Lq, Lk, D, splits = 2, 1, 200, 1000, 256, 4

@@ -20,6 +20,7 @@ DOC = {
     "msam2_attention_workspace_bytes": "Scratch needed by msam2_attention_fwd when splits > 1 (fp32 partial O, running max, partial sum).",
     "msam2_attention_merge": "Second half of a split-KV attention call issued with a NEGATIVE split count (the split pass alone, partials left in the\nworkspace): combines the per-split (max, sum, O) triples into o.  Lets a host time / overlap the two kernels separately.",
     "msam2_attention_fwd": "softmax(Q K^T * scale) V, non-causal, 16-bit in/out, fp32 softmax/accumulate; head dim 64/96/128/256; q/k/v/o given by\nelement strides {batch, head, token}.  splits > 1 = split-KV (flash-decoding) with an in-library merge; splits < 0 = the split pass only\n(finish with msam2_attention_merge).\nReplaces F.scaled_dot_product_attention at hieradet.py:72-76 (global blocks) and transformer.py:318 (RoPEAttention,\nmemory attention self/cross).",
+    "msam2_attention_kv64_fwd": "Memory cross-attention of RoPEAttention with kv_in_dim = 64 (transformer.py:288-331 as called at memory_attention.py:76-85) with\nthe value product contracted in the 64-channel memory space: O' = softmax(Q K^T * scale) M for 256-wide rotated q / k rows and the\n64-wide memory rows M.  Because the values carry no rotary encoding and softmax rows sum to one, P (M W_v^T + b_v) = O' W_v^T + b_v:\nthe caller folds v_proj into out_proj (one K = 64 GEMM).  Strides / splits / workspace / merge as msam2_attention_fwd with D = 64.",
     "msam2_window_attention_fwd": "Windowed Hiera attention straight from un-partitioned qkv tokens: replaces window_partition -> SDPA ->\nwindow_unpartition (backbones/utils.py:16-62 + hieradet.py:138-158,72-76).  Zero-padded window tokens are unmasked keys\nwhose K/V rows are kpad/vpad (= qkv bias), exactly what the reference computes; q may come from a 2x2 max-pooled image\n(q-pool at stage changes, hieradet.py:65-69).",
     "msam2_attention_small_fwd": "Attention with head dim 16/32 (two-way decoder: transformer.py:239-263 via 165-196, 74-118): tokens->image,\nimage->tokens and token self-attention.  q/k/v/o: 16-bit [B, L, heads*D].",
     "msam2_add_cast": "out = a + alpha * b on a logical [D0,D1,C] volume with arbitrary outer strides (0 = broadcast) and dtype conversion:\nmemory_attention.py:139-147 (+0.1*pos, seq-first -> batch-first), 74-76 (memory + pos), transformer.py:175-190 (q + pe,\nk + pe), mask_decoder.py:231 (src + dense), sam2_base.py:642 (+ no_mem_embed), 571-580,626-635 (memory-bank assembly).",
