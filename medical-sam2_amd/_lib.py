@@ -30,6 +30,8 @@ SIGNATURES = {
     "msam2_attention_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_f, c_i, c_p, c_z, c_p]),
     "msam2_attention_fwd_lse": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_f, c_i, c_p, c_z, c_p, c_p]),
     "msam2_attention_kv64_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_f, c_i, c_p, c_z, c_p]),
+    "msam2_attention_kv64_partial": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_f, c_i, c_i, c_i, c_p, c_z, c_p]),
+    "msam2_attention_effective_splits": (c_i, [c_l, c_i]),
     "msam2_attention_merge": (c_i, [c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_i, c_p, c_z, c_p]),
     "msam2_window_attention_fwd": (c_i, [c_p, c_l, c_l, c_l, c_l, c_l, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_p, c_p, c_p, c_l, c_l,
                                          c_l, c_l, c_l, c_f, c_p]),
@@ -71,7 +73,7 @@ SIGNATURES = {
     "msam2_gemm_tt": (c_i, [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_l, c_p]),
     "msam2_bilinear_upsample_bwd": (c_i, [c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_p]),
     "msam2_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_l, c_p]),
-    "msam2_adam_step_multi": (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_l, c_f, c_f, c_p]),
+    "msam2_adam_step_multi": (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_l, c_f, c_f, c_p, c_p]),
     "msam2_attention_small_bwd": (c_i, [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_f, c_p]),
     "msam2_seg_counts": (c_i, [c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_p]),
     "msam2_non_overlap": (c_i, [c_p, c_p, c_l, c_l, c_p]),

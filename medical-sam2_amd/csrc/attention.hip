@@ -41,6 +41,7 @@ struct AttnParams {
   // split-KV
   int splits;
   int defer_merge;  // split-KV partials stay in the workspace; msam2_attention_merge finishes (benchmark / overlap use)
+  int split_begin, split_cnt;  // attn_kv64_kernel only: this launch computes splits [split_begin, split_begin + split_cnt) of `splits`
   op16* o_part;    // [splits][Bz][H][Lq][D] 16-bit, each split's own softmax-normalised output
   float* ml_part;  // [splits][Bz][H][Lq][2]  (running max in log2 domain, partial sum)
   // log-sum-exp rows [Bz][H][Lq] (log2 domain) for the backward; written by the merge kernel (split path) or by the
@@ -664,7 +665,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kv64_kernel(AttnParams p) {
   const int qtile = lid % gx;
   const int head = (lid / gx) % gy;
   const int zz = lid / (gx * gy);
-  const int split = zz % p.splits, z = zz / p.splits;
+  const int split = p.split_begin + zz % p.split_cnt, z = zz / p.split_cnt;
   const op16* qb = p.q + (int64_t)z * p.q_bs + (int64_t)head * p.q_hs;
   const op16* kb = p.k + (int64_t)z * p.k_bs + (int64_t)head * p.k_hs;
   const op16* vb = p.v + (int64_t)z * p.v_bs + (int64_t)head * p.v_hs;
@@ -868,7 +869,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kv64_kernel(AttnParams p) {
   if (p.splits == 1) {
     dst = p.o + (int64_t)z * p.o_bs + (int64_t)head * p.o_hs + (int64_t)qi * p.o_ts;
   } else {
-    const int64_t Bz = gridDim.z / p.splits;
+    const int64_t Bz = gridDim.z / p.split_cnt;
     const int64_t row = (((int64_t)split * Bz + z) * p.H + head) * p.Lq + qi;
     dst = p.o_part + row * DV;
     if (h == 0) {
@@ -902,7 +903,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kv64_kernel(AttnParams p) {
 #define MSAM2_KV64_OCC 3
 #endif
 static int launch_attn_kv64(const AttnParams& p, int Bz, hipStream_t s) {
-  dim3 grid(cdiv(p.Lq, 128), p.H, Bz * p.splits);
+  dim3 grid(cdiv(p.Lq, 128), p.H, Bz * p.split_cnt);
   hipLaunchKernelGGL((attn_kv64_kernel<4, MSAM2_KV64_OCC>), grid, dim3(256), 0, s, p);
   if (p.splits > 1 && !p.defer_merge) {
     const int64_t rows = (int64_t)Bz * p.H * p.Lq;
@@ -1058,20 +1059,30 @@ extern "C" int msam2_attention_fwd_lse(const void* q, const int64_t* q_strides, 
 // softmax(Q K^T * scale) V with 256-wide q / k rows and 64-wide value rows (attn_kv64_kernel): the memory cross-attention with the
 // value projection folded out of the attention (O' = P M; the caller applies W_v and b_v behind it).  o: [.., 64] rows; workspace and
 // merge as msam2_attention_fwd with D = 64 (msam2_attention_workspace_bytes(B, H, Lq, 64, splits), msam2_attention_merge(.., D = 64, ..)).
-extern "C" int msam2_attention_kv64_fwd(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
-                                        const void* v, const int64_t* v_strides, void* o, const int64_t* o_strides, int64_t B,
-                                        int64_t H, int64_t Lq, int64_t Lk, float scale, int splits, void* workspace,
-                                        size_t workspace_bytes, void* stream) {
-  MSAM2_REQUIRE(q && k && v && o, "attention_kv64: null tensor");
+static int attention_kv64_impl(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides, const void* v,
+                               const int64_t* v_strides, void* o, const int64_t* o_strides, int64_t B, int64_t H, int64_t Lq,
+                               int64_t Lk, float scale, int splits, int split_begin, int split_cnt, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  MSAM2_REQUIRE(q && k && v && (o || split_cnt >= 0), "attention_kv64: null tensor");
   MSAM2_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attention_kv64: empty problem");
-  const bool defer = splits < 0;
+  bool defer = splits < 0;
   if (defer) splits = -splits;
   MSAM2_REQUIRE(splits >= 1 && splits <= 64, "attention_kv64: bad split count %d", splits);
   for (int i = 0; i < 3; ++i)
-    MSAM2_REQUIRE(q_strides[i] % 8 == 0 && k_strides[i] % 8 == 0 && v_strides[i] % 8 == 0 && o_strides[i] % 4 == 0,
+    MSAM2_REQUIRE(q_strides[i] % 8 == 0 && k_strides[i] % 8 == 0 && v_strides[i] % 8 == 0 && (!o || o_strides[i] % 4 == 0),
                   "attention_kv64: strides must keep 16-byte row alignment");
   MSAM2_REQUIRE(Lk * k_strides[2] * 2 < (1ll << 31) && Lk * v_strides[2] * 2 < (1ll << 31), "attention_kv64: key range beyond the 2 GiB buffer window");
-  splits = attn_effective_splits(Lk, splits);
+  const int eff = attn_effective_splits(Lk, splits);
+  if (split_cnt >= 0) {   // partial launch: the caller passes the EFFECTIVE split count and a sub-range of it
+    MSAM2_REQUIRE(eff == splits && eff > 1, "attention_kv64_partial: pass msam2_attention_effective_splits(Lk, splits) (> 1) as the split count");
+    MSAM2_REQUIRE(split_begin >= 0 && split_cnt >= 0 && split_begin + split_cnt <= eff, "attention_kv64_partial: bad split range");
+    defer = true;
+    if (split_cnt == 0) return MSAM2_OK;
+  } else {
+    split_begin = 0;
+    split_cnt = eff;
+  }
+  splits = eff;
   MSAM2_REQUIRE(workspace_bytes >= msam2_attention_workspace_bytes(B, H, Lq, 64, splits), "attention_kv64: workspace too small");
   MSAM2_REQUIRE(!defer || splits > 1, "attention_kv64: a deferred merge needs an effective split count > 1");
   MSAM2_REQUIRE(splits == 1 || workspace, "attention_kv64: split-KV needs a workspace");
@@ -1080,14 +1091,40 @@ extern "C" int msam2_attention_kv64_fwd(const void* q, const int64_t* q_strides,
   p.q_bs = q_strides[0]; p.q_hs = q_strides[1]; p.q_ts = q_strides[2];
   p.k_bs = k_strides[0]; p.k_hs = k_strides[1]; p.k_ts = k_strides[2];
   p.v_bs = v_strides[0]; p.v_hs = v_strides[1]; p.v_ts = v_strides[2];
-  p.o_bs = o_strides[0]; p.o_hs = o_strides[1]; p.o_ts = o_strides[2];
+  if (o) { p.o_bs = o_strides[0]; p.o_hs = o_strides[1]; p.o_ts = o_strides[2]; }
   p.B = (int)B; p.H = (int)H; p.Lq = (int)Lq; p.Lk = (int)Lk;
   p.scale_log2 = scale * 1.4426950408889634f;
   p.splits = splits;
+  p.split_begin = split_begin;
+  p.split_cnt = split_cnt;
   p.defer_merge = defer ? 1 : 0;
   p.o_part = (op16*)workspace;
   p.ml_part = workspace ? reinterpret_cast<float*>(p.o_part + (size_t)splits * B * H * Lq * 64) : nullptr;
   return launch_attn_kv64(p, (int)B, (hipStream_t)stream);
+}
+
+extern "C" int msam2_attention_kv64_fwd(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
+                                        const void* v, const int64_t* v_strides, void* o, const int64_t* o_strides, int64_t B,
+                                        int64_t H, int64_t Lq, int64_t Lk, float scale, int splits, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  MSAM2_REQUIRE(o, "attention_kv64: null output");
+  return attention_kv64_impl(q, q_strides, k, k_strides, v, v_strides, o, o_strides, B, H, Lq, Lk, scale, splits, 0, -1, workspace, workspace_bytes, stream);
+}
+
+// The split count msam2_attention_fwd / _kv64_fwd actually run with for a requested one (every split owns >= one 32-key tile).
+extern "C" int msam2_attention_effective_splits(int64_t Lk, int splits) { return attn_effective_splits(Lk, splits < 0 ? -splits : splits); }
+
+// Splits [split_begin, split_begin + split_count) of a `splits`-way msam2_attention_kv64_fwd (splits = the EFFECTIVE count): their
+// partial (max, sum, O') triples land in the same workspace slots as in the full call; nothing is merged.  The cross-GPU key split of
+// the propagation chain: every rank computes its share, the slots are all-gathered, msam2_attention_merge
+// (D = 64) finishes -- bit-identical to one rank computing all splits.
+extern "C" int msam2_attention_kv64_partial(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
+                                            const void* v, const int64_t* v_strides, int64_t B, int64_t H, int64_t Lq, int64_t Lk,
+                                            float scale, int splits, int split_begin, int split_count, void* workspace,
+                                            size_t workspace_bytes, void* stream) {
+  MSAM2_REQUIRE(split_count >= 0, "attention_kv64_partial: negative split count");
+  return attention_kv64_impl(q, q_strides, k, k_strides, v, v_strides, nullptr, nullptr, B, H, Lq, Lk, scale, splits, split_begin, split_count,
+                             workspace, workspace_bytes, stream);
 }
 
 // Windowed attention straight from the un-partitioned token image (replaces window_partition + SDPA +

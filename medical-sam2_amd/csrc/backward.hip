@@ -688,16 +688,30 @@ struct AdamTable {
   int64_t n[ADAM_CHUNK];
 };
 
+// `step` (device, optional): the optimiser's step count t >= 1 kept in device memory so that a captured hipGraph advances it on every
+// replay (adam_tick_kernel increments it at the head of each step) -- the bias corrections 1 - beta^t are then those of
+// torch.optim.Adam on every replay, not the ones of the step the graph was captured at.  Non-finite gradient entries leave their
+// parameter and moments untouched (an fp16 overflow upstream must not poison the optimiser state).
+__global__ void adam_tick_kernel(int* step) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1;
+}
+
 __global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable tb, float lr, float b1, float b2, float eps, float bc1, float bc2,
-                                                         float gscale, float decay) {
+                                                         float gscale, float decay, const int* __restrict__ step) {
   const int t = blockIdx.y;
   float* __restrict__ p = tb.p[t];
   const float* __restrict__ g = tb.g[t];
   float* __restrict__ m = tb.m[t];
   float* __restrict__ v = tb.v[t];
   const int64_t n = tb.n[t];
+  if (step) {
+    const float ts = (float)*step;
+    bc1 = 1.f - __powf(b1, ts);
+    bc2 = 1.f - __powf(b2, ts);
+  }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float gi = g[i] * gscale;
+    if (!isfinite(gi)) continue;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi;
@@ -706,11 +720,14 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable tb, float lr,
   }
 }
 
+// step_counter (int32 on the device, may be null): when given, the library increments it once (a kernel, so that it is part of a
+// captured graph) and the update reads t from it; the host `step` is then ignored.
 extern "C" int msam2_adam_step_multi(void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
                                      const int64_t* numel, int64_t count, float lr, float beta1, float beta2, float eps, int64_t step,
-                                     float grad_scale, float weight_decay, void* stream) {
-  MSAM2_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel && count > 0 && step >= 1, "adam_step_multi: bad arguments");
-  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+                                     float grad_scale, float weight_decay, void* step_counter, void* stream) {
+  MSAM2_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel && count > 0 && (step >= 1 || step_counter), "adam_step_multi: bad arguments");
+  const float bc1 = 1.f - powf(beta1, (float)(step >= 1 ? step : 1)), bc2 = 1.f - powf(beta2, (float)(step >= 1 ? step : 1));
+  if (step_counter) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (int*)step_counter);
   for (int64_t c0 = 0; c0 < count; c0 += ADAM_CHUNK) {
     const int nt = (int)min((int64_t)ADAM_CHUNK, count - c0);
     AdamTable tb;
@@ -724,7 +741,7 @@ extern "C" int msam2_adam_step_multi(void* const* params, const void* const* gra
     }
     dim3 grid((unsigned)min((int64_t)128, cdiv(nmax, 256)), (unsigned)nt);
     hipLaunchKernelGGL(adam_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, tb, lr, beta1, beta2, eps, bc1, bc2, grad_scale,
-                       1.f - lr * weight_decay);
+                       1.f - lr * weight_decay, (const int*)step_counter);
   }
   return msam2_check_launch("adam_step_multi");
 }

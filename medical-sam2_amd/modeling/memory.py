@@ -133,10 +133,25 @@ class RoPEAttention(Attention):
 
     def core_folded(self, q: torch.Tensor, k: torch.Tensor, mem_v: torch.Tensor) -> torch.Tensor:
         """rotated q [B, Lq, 256], rotated k [B, Lk, 256], un-projected values mem_v [B, Lk, 64] -> 16-bit [B*Lq, 64]"""
+        from .. import parallel
         B, Lq, C = q.shape
         Lk = k.shape[1]
-        o = ops.attention_kv64(q.view(B, Lq, 1, C).permute(0, 2, 1, 3), k.view(B, Lk, 1, C).permute(0, 2, 1, 3),
-                               mem_v.reshape(B, Lk, 1, 64).permute(0, 2, 1, 3), splits=attn_splits(B, 1, Lq, Lk))
+        q4, k4, v4 = (q.view(B, Lq, 1, C).permute(0, 2, 1, 3), k.view(B, Lk, 1, C).permute(0, 2, 1, 3),
+                      mem_v.reshape(B, Lk, 1, 64).permute(0, 2, 1, 3))
+        splits = attn_splits(B, 1, Lq, Lk)
+        kvs = parallel.current_kv_split()
+        eff = ops.attention_effective_splits(Lk, splits) if kvs is not None else 1
+        if eff > 1:
+            # cross-GPU key split (parallel.KVSplit): this rank's share of the SAME partials one rank would compute, all-gather of the
+            # (max, sum, O') slots, then the library's merge -- bit-identical to the single-rank call below
+            ws = ops.attention_workspace(B, 1, Lq, 64, eff, q.device)
+            s0, s1 = kvs.share(eff)
+            ops.attention_kv64_partial(q4, k4, v4, splits=eff, split_begin=s0, split_count=s1 - s0, workspace=ws)
+            kvs.exchange(ws, eff, B * Lq)
+            o = torch.empty(B, Lq, 1, 64, dtype=OP16, device=q.device).permute(0, 2, 1, 3)
+            ops.attention_merge(o, Lk, eff, ws)
+        else:
+            o = ops.attention_kv64(q4, k4, v4, splits=splits)
         return o.permute(0, 2, 1, 3).reshape(B * Lq, 64)
 
     def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_k_exclude_rope: int = 0) -> torch.Tensor:

@@ -193,6 +193,23 @@ def attention_kv64(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, splits:
     return out
 
 
+def attention_effective_splits(Lk: int, splits: int) -> int:
+    return int(lib().msam2_attention_effective_splits(Lk, splits))
+
+
+def attention_kv64_partial(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, splits: int, split_begin: int, split_count: int,
+                           workspace: torch.Tensor, scale: Optional[float] = None) -> None:
+    """Splits [split_begin, split_begin + split_count) of a `splits`-way attention_kv64 (effective count) into `workspace`; finish with
+    attention_merge on a [B,H,Lq,64] output view once every slot is filled (parallel.KVSplit all-gathers the other ranks' slots)."""
+    B, H, Lq, D = q.shape
+    Lk = k.shape[2]
+    for t in (q, k, v):
+        _req(t.dtype == OP16 and t.stride(3) == 1, "attention tensors must be 16-bit (ops.OP16) with contiguous head dim")
+    sc = scale if scale is not None else 1.0 / math.sqrt(D)
+    check(lib().msam2_attention_kv64_partial(_p(q), _strides3(q), _p(k), _strides3(k), _p(v), _strides3(v), B, H, Lq, Lk, sc, splits,
+                                             split_begin, split_count, _p(workspace), workspace.numel() * workspace.element_size(), _stream()))
+
+
 def attention_workspace(B: int, H: int, Lq: int, D: int, splits: int, device) -> torch.Tensor:
     return torch.empty(max(lib().msam2_attention_workspace_bytes(B, H, Lq, D, splits), 1), dtype=torch.uint8, device=device)
 

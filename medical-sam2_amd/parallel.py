@@ -58,43 +58,183 @@ def barrier(device: Optional[torch.device] = None, group=None):
             dist.barrier(group=group)
 
 
-def gather_cond_memories(local: Dict[int, dict], frame_ids: List[int], group=None) -> Dict[int, dict]:
-    """All-gather the conditioning-slice memories.
+def _is_dist(group=None) -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
-    `frame_ids` is the global, ordered list of conditioning slice indices; rank r owns the contiguous share
-    `shard_range(len(frame_ids), r, world)` of it and passes its outputs in `local` ({frame_idx: track_step output with
-    "maskmem_features", "maskmem_pos_enc", "obj_ptr", "pred_masks"}).  Every rank returns the full {frame_idx: output} map.
-    Two collectives in total (features, pointers), each moving one fixed-size slab per rank (shares are padded to the largest
-    share), i.e. a few large messages instead of one per slice."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+
+def _gather_slabs(mine: List[torch.Tensor], counts: List[int], item_shape, dtype, device, group=None) -> List[List[torch.Tensor]]:
+    """One all-gather of a fixed-size slab per rank: rank r contributes counts[r] items of `item_shape` (its `mine` list; may be empty),
+    slabs are padded to max(counts).  Returns per rank the list of its items (views into the gathered slabs)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    cap = max(max(counts), 1)
+    slab = torch.zeros((cap,) + tuple(item_shape), dtype=dtype, device=device)
+    assert len(mine) == counts[rank]
+    for i, t in enumerate(mine):
+        slab[i].copy_(t.reshape(item_shape))
+    out = [torch.empty_like(slab) for _ in range(world)]
+    dist.all_gather(out, slab, group=group)
+    return [[out[r][i] for i in range(counts[r])] for r in range(world)]
+
+
+def gather_cond_memories(local: Dict[int, dict], frame_ids: List[int], group=None, owners: Optional[List[int]] = None,
+                         like: Optional[tuple] = None) -> Dict[int, dict]:
+    """All-gather the conditioning-slice outputs the propagation chain needs.
+
+    `frame_ids` is the global, ordered list of conditioning slice indices and `owners[i]` the rank that processed frame_ids[i]
+    (default: contiguous shares `shard_range(len(frame_ids), r, world)`); a rank passes its own outputs in `local` ({frame_idx:
+    track_step output with "maskmem_features", "maskmem_pos_enc", "obj_ptr", "pred_masks"}) -- possibly none at all: it then joins
+    the collectives with an empty slab and needs `like` = (n_obj, mem_dim, embedding side, hidden_dim, device) for the shapes.
+    Every rank returns the full {frame_idx: output} map.  Three collectives in total (memory features, pointers, low-res masks),
+    each moving one fixed-size slab per rank (padded to the largest share), i.e. a few large messages instead of one per slice.
+    `maskmem_pos_enc` is an input-independent table: never sent; remote entries take the first local one or, on a rank that owns no
+    conditioning slice, None (the caller fills it in: `volume.segment_volume`)."""
+    if not _is_dist(group):
         return dict(local)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    shares = [shard_range(len(frame_ids), r, world) for r in range(world)]
-    cap = max(e - b for b, e in shares)
-    b0, e0 = shares[rank]
-    mine = [local[frame_ids[i]] for i in range(b0, e0)]
-    assert mine, "every rank must own at least one conditioning slice"
-    f0, p0 = mine[0]["maskmem_features"], mine[0]["obj_ptr"]
-    feats = torch.zeros((cap,) + tuple(f0.shape), dtype=f0.dtype, device=f0.device)
-    ptrs = torch.zeros((cap,) + tuple(p0.shape), dtype=p0.dtype, device=p0.device)
-    for i, o in enumerate(mine):
-        feats[i].copy_(o["maskmem_features"])
-        ptrs[i].copy_(o["obj_ptr"])
-    all_f = [torch.empty_like(feats) for _ in range(world)]
-    all_p = [torch.empty_like(ptrs) for _ in range(world)]
-    dist.all_gather(all_f, feats, group=group)
-    dist.all_gather(all_p, ptrs, group=group)
-    pos = mine[0]["maskmem_pos_enc"]  # constant table, identical on every rank
+    if owners is None:
+        owners = []
+        for r in range(world):
+            b, e = shard_range(len(frame_ids), r, world)
+            owners += [r] * (e - b)
+    assert len(owners) == len(frame_ids)
+    counts = [sum(1 for o in owners if o == r) for r in range(world)]
+    my_ids = [f for f, o in zip(frame_ids, owners) if o == rank]
+    assert sorted(my_ids) == sorted(local), "a rank must pass exactly the conditioning slices it owns"
+    mine = [local[f] for f in my_ids]
+    if mine:
+        f0, p0, m0 = mine[0]["maskmem_features"], mine[0]["obj_ptr"], mine[0]["pred_masks"]
+        shapes = (tuple(f0.shape), tuple(p0.shape), tuple(m0.shape))
+        dts, device = (f0.dtype, p0.dtype, m0.dtype), f0.device
+    else:
+        assert like is not None, "a rank without conditioning slices needs `like` to join the exchange"
+        n_obj, mem_dim, E, hidden, device = like
+        shapes = ((n_obj, mem_dim, E, E), (n_obj, hidden), (n_obj, 1, 4 * E, 4 * E))
+        dts = (torch.float32,) * 3
+    all_f = _gather_slabs([o["maskmem_features"] for o in mine], counts, shapes[0], dts[0], device, group)
+    all_p = _gather_slabs([o["obj_ptr"] for o in mine], counts, shapes[1], dts[1], device, group)
+    all_m = _gather_slabs([o["pred_masks"] for o in mine], counts, shapes[2], dts[2], device, group)
+    pos = mine[0]["maskmem_pos_enc"] if mine else None
     out: Dict[int, dict] = {}
-    for r, (b, e) in enumerate(shares):
-        for i in range(b, e):
-            fid = frame_ids[i]
-            if r == rank:
-                out[fid] = local[fid]
-            else:
-                out[fid] = {"maskmem_features": all_f[r][i - b], "maskmem_pos_enc": pos, "obj_ptr": all_p[r][i - b],
-                            "pred_masks": None, "pred_masks_high_res": None, "point_inputs": None, "mask_inputs": None}
+    seen = [0] * world
+    for fid, r in zip(frame_ids, owners):
+        i = seen[r]
+        seen[r] += 1
+        if r == rank:
+            out[fid] = local[fid]
+        else:
+            out[fid] = {"maskmem_features": all_f[r][i], "maskmem_pos_enc": pos, "obj_ptr": all_p[r][i], "pred_masks": all_m[r][i],
+                        "pred_masks_high_res": None, "point_inputs": None, "mask_inputs": None}
     return out
+
+
+def gather_slice_features(local: Dict[int, dict], slice_ids: List[int], owners: List[int], group=None) -> Dict[int, dict]:
+    """All-gather the backbone features of the slices in `slice_ids` (owners[i] = rank that encoded slice_ids[i]; `local` = this
+    rank's {slice: {"backbone_fpn": [levels x [1,C,h,w]], "vision_pos_enc": [...]}}): one collective per feature level, one padded slab
+    per rank.  The position tables are input-independent and stay local (every returned entry shares this rank's own, or None when
+    the rank encoded nothing -- the caller then supplies them)."""
+    if not _is_dist(group):
+        return dict(local)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    counts = [sum(1 for o in owners if o == r) for r in range(world)]
+    my_ids = [t for t, o in zip(slice_ids, owners) if o == rank]
+    assert sorted(my_ids) == sorted(local), "a rank must pass exactly the slices it encoded"
+    # level shapes: from a local sample, else from the first owner (one small broadcast of the shape table)
+    meta = None
+    if my_ids:
+        one = local[my_ids[0]]["backbone_fpn"]
+        meta = [list(f.shape[1:]) for f in one]
+    objs = [None] * world
+    dist.all_gather_object(objs, meta, group=group)
+    meta = next(m for m in objs if m is not None)
+    sample = next(iter(local.values())) if local else None
+    device = sample["backbone_fpn"][0].device if sample else torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    levels = []
+    for lvl, shp in enumerate(meta):
+        levels.append(_gather_slabs([local[t]["backbone_fpn"][lvl] for t in my_ids], counts, (1,) + tuple(shp), torch.float32, device, group))
+    pos = sample["vision_pos_enc"] if sample else None
+    out: Dict[int, dict] = {}
+    seen = [0] * world
+    for t, r in zip(slice_ids, owners):
+        i = seen[r]
+        seen[r] += 1
+        out[t] = local[t] if r == rank else {"backbone_fpn": [levels[lvl][r][i] for lvl in range(len(meta))], "vision_pos_enc": pos}
+    return out
+
+
+def gather_object_shards(masks: Dict[int, torch.Tensor], slice_ids: List[int], n_obj: int, group=None) -> Dict[int, torch.Tensor]:
+    """Object-sharded chain -> full object batch on every rank: masks[t] is this rank's [n_local, 1, h, w] share
+    (`shard_range(n_obj, rank, world)`) for every t in slice_ids; one all-gather of a [len(slice_ids), cap, 1, h, w] slab."""
+    if not _is_dist(group):
+        return dict(masks)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    shares = [shard_range(n_obj, r, world) for r in range(world)]
+    cap = max(e - b for b, e in shares)
+    if not slice_ids:
+        return {}
+    m0 = masks[slice_ids[0]]
+    slab = torch.zeros((len(slice_ids), cap) + tuple(m0.shape[1:]), dtype=m0.dtype, device=m0.device)
+    for i, t in enumerate(slice_ids):
+        slab[i, : masks[t].shape[0]].copy_(masks[t])
+    out = [torch.empty_like(slab) for _ in range(world)]
+    dist.all_gather(out, slab, group=group)
+    return {t: torch.cat([out[r][i, : e - b] for r, (b, e) in enumerate(shares)], dim=0) for i, t in enumerate(slice_ids)}
+
+
+_KV_SPLIT = None
+
+
+def current_kv_split():
+    """The active `KVSplit` context (None outside one): consulted by the memory cross-attention."""
+    return _KV_SPLIT
+
+
+class KVSplit:
+    """Cross-GPU split of the memory cross-attention's KEY range (the n_obj < ranks case): while active, every
+    rank computes only its share of the split-KV partials -- the SAME partials, over the same key ranges and in the same workspace
+    slots, that one rank computes for all splits -- then one all-gather per layer moves the (max, sum, O') triples (64-wide O':
+    136 B per query row and split) and the library's merge kernel finishes, so the result is bit-identical to the single-rank run.
+    Everything else of the chain (self-attention, heads, memory encoder) is replicated."""
+
+    def __init__(self, model=None, group=None):
+        global _KV_SPLIT
+        assert _is_dist(group), "KVSplit needs an initialised process group with more than one rank"
+        self.group, self.world, self.rank = group, dist.get_world_size(group), dist.get_rank(group)
+        self.calls = 0
+        self._prev = _KV_SPLIT
+        _KV_SPLIT = self
+
+    def close(self):
+        global _KV_SPLIT
+        _KV_SPLIT = self._prev
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+        return False
+
+    def share(self, splits: int) -> Tuple[int, int]:
+        return shard_range(splits, self.rank, self.world)
+
+    def exchange(self, workspace: torch.Tensor, splits: int, rows: int, width: int = 64):
+        """workspace (uint8) holds o_part [splits, rows, width] 16-bit then ml_part [splits, rows, 2] fp32 (msam2_attention_fwd's
+        layout); this rank has filled the slots of its share.  All-gather the other ranks' slots in place."""
+        self.calls += 1
+        o_bytes = splits * rows * width * 2
+        o = workspace[:o_bytes].view(splits, rows * width * 2)                    # raw bytes: every backend moves uint8
+        ml = workspace[o_bytes: o_bytes + splits * rows * 8].view(splits, rows * 8)
+        shares = [shard_range(splits, r, self.world) for r in range(self.world)]
+        cap = max(e - b for b, e in shares)
+        b0, e0 = shares[self.rank]
+        for buf in (o, ml):
+            send = torch.zeros((cap, buf.shape[1]), dtype=buf.dtype, device=buf.device)
+            send[: e0 - b0].copy_(buf[b0:e0])
+            recv = [torch.empty_like(send) for _ in range(self.world)]
+            dist.all_gather(recv, send, group=self.group)
+            for r, (b, e) in enumerate(shares):
+                if r != self.rank and e > b:
+                    buf[b:e].copy_(recv[r][: e - b])
 
 
 def allreduce_gradients(grads: Dict[str, torch.Tensor], group=None, bucket_bytes: int = 64 << 20) -> Tuple[Dict[str, torch.Tensor], float]:

@@ -6,9 +6,17 @@ the remaining slices with the memory bank -- the work `func_3d/function.py:226-2
 Differences from the reference flow that do not change results: every slice is encoded once (the reference encodes conditioning
 slices twice, sam2_video_predictor.py:1378-1380), and conditioning slices run the memory encoder in the same `track_step` call.
 
-Multi-GPU (one process per GPU): conditioning slices are independent -> sharded contiguously over the ranks, then ONE RCCL
-all-gather of their memories (`parallel.gather_cond_memories`); the propagation chain is sequential in the slice index and is
-replicated, or sharded over objects when there are at least as many objects as ranks.
+Multi-GPU (one process per GPU):
+  1. image encoder of ALL slices + conditioning-slice heads / memory encoding: independent per slice -> every rank takes a contiguous
+     share of the slices (`parallel.shard_range`), conditioning or not;
+  2. ONE exchange step: all-gather of the conditioning memories / pointers (`parallel.gather_cond_memories`; ranks without a
+     conditioning slice join with an empty slab) and of the non-conditioning slices' backbone features
+     (`parallel.gather_slice_features`: 16.8 MB per slice at 1024^2, a few large messages);
+  3. the propagation chain is sequential in the slice index: it is sharded over OBJECTS when there are at least as many objects as
+     ranks (objects never interact: non_overlap_masks is off), otherwise every rank runs it with the memory cross-attention's KEY
+     range split over the ranks (`parallel.KVSplit`: each rank's share of the split-KV partials, one all-gather of the (max, sum, O')
+     triples per layer, then the same merge kernel) -- both bit-identical to the single-rank result;
+  4. every rank returns ALL slices' masks for ALL objects (one all-gather over the object shards).
 """
 from __future__ import annotations
 
@@ -18,7 +26,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .parallel import gather_cond_memories, shard_range
+from .parallel import KVSplit, gather_cond_memories, gather_object_shards, gather_slice_features, shard_range
 
 
 class _SliceEncoder:
@@ -31,8 +39,8 @@ class _SliceEncoder:
         self.pos = 0
         self.cache: Dict[int, dict] = {}
 
-    def get(self, t: int, n_obj: int):
-        """features of slice t expanded (views) over the objects like sam2_video_predictor.py:1284-1296"""
+    def raw(self, t: int) -> dict:
+        """{"backbone_fpn": [3 x [1,C,h,w]], "vision_pos_enc": [3 x [1,C,h,w]]} of slice t"""
         if t not in self.cache:
             assert self.pos < len(self.order) and self.order[self.pos] == t, "slices must be consumed in the announced order"
             ids = self.order[self.pos: self.pos + self.batch]
@@ -41,11 +49,15 @@ class _SliceEncoder:
             for j, u in enumerate(ids):
                 self.cache[u] = {"backbone_fpn": [f[j: j + 1] for f in bo["backbone_fpn"]],
                                  "vision_pos_enc": [p[:1] for p in bo["vision_pos_enc"]]}
-        one = self.cache.pop(t)
-        bo = {"backbone_fpn": [f.expand(n_obj, -1, -1, -1) for f in one["backbone_fpn"]],
-              "vision_pos_enc": [p.expand(n_obj, -1, -1, -1) for p in one["vision_pos_enc"]]}
-        _, feats, pos, sizes = self.model._prepare_backbone_features(bo)
-        return feats, pos, sizes
+        return self.cache.pop(t)
+
+
+def _expand(model, one: dict, n_obj: int):
+    """features of one slice expanded (views) over the objects like sam2_video_predictor.py:1284-1296"""
+    bo = {"backbone_fpn": [f.expand(n_obj, -1, -1, -1) for f in one["backbone_fpn"]],
+          "vision_pos_enc": [p.expand(n_obj, -1, -1, -1) for p in one["vision_pos_enc"]]}
+    _, feats, pos, sizes = model._prepare_backbone_features(bo)
+    return feats, pos, sizes
 
 
 def box_point_inputs(boxes: torch.Tensor) -> dict:
@@ -57,10 +69,11 @@ def box_point_inputs(boxes: torch.Tensor) -> dict:
 
 @torch.no_grad()
 def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_hole_area: int = 0, group=None,
-                   shard_objects: bool = True, encode_batch: int = 8) -> Dict[int, torch.Tensor]:
+                   shard_objects: bool = True, encode_batch: int = 8, kv_split: bool = True) -> Dict[int, torch.Tensor]:
     """volume: [T,3,S,S] normalised slices on the GPU; prompts: {slice_idx: {"boxes": [n,4]} | {"point_coords", "point_labels"}}
-    for the conditioning slices (same n objects everywhere).  Returns {slice_idx: low-res mask logits [n,1,S/4,S/4]}.
-    encode_batch: slices per image-encoder call (results do not depend on it)."""
+    for the conditioning slices (same n objects everywhere).  Returns {slice_idx: low-res mask logits [n,1,S/4,S/4]} for ALL slices
+    and ALL objects on every rank.  encode_batch: slices per image-encoder call (results do not depend on it).  shard_objects /
+    kv_split: the two ways the propagation chain uses several ranks (module docstring); with both off it is replicated."""
     T = volume.shape[0]
     cond_ids = sorted(prompts)
     assert cond_ids, "at least one conditioning slice is needed"
@@ -69,43 +82,81 @@ def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_h
     distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     rank = dist.get_rank(group) if distributed else 0
     world = dist.get_world_size(group) if distributed else 1
+    cond_set = set(cond_ids)
 
-    # 1. conditioning slices: independent -> this rank's contiguous share
-    b, e = shard_range(len(cond_ids), rank, world)
+    # 1. this rank's contiguous share of ALL slices: image encoder; conditioning slices also run their heads + memory encoder
+    b, e = shard_range(T, rank, world)
+    mine = list(range(b, e))
+    # conditioning slices first (their memories go into the exchange), then the rest of the share in slice order
+    order = [t for t in mine if t in cond_set] + [t for t in mine if t not in cond_set]
+    enc = _SliceEncoder(model, volume, order, encode_batch)
     empty = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
-    local = {}
-    enc = _SliceEncoder(model, volume, [cond_ids[i] for i in range(b, e)], encode_batch)
-    for i in range(b, e):
-        t = cond_ids[i]
+    local_cond: Dict[int, dict] = {}
+    for t in order:
+        if t not in cond_set:
+            break
         pr = prompts[t]
         pin = box_point_inputs(pr["boxes"]) if "boxes" in pr else {"point_coords": pr["point_coords"], "point_labels": pr["point_labels"]}
-        feats, pos, sizes = enc.get(t, n_obj)
-        local[t] = model.track_step(frame_idx=t, is_init_cond_frame=True, current_vision_feats=feats, current_vision_pos_embeds=pos,
-                                    feat_sizes=sizes, point_inputs=pin, mask_inputs=None, output_dict=empty, num_frames=T)
-    # 2. the one exchange step
-    cond = gather_cond_memories(local, cond_ids, group) if distributed else local
-    masks: Dict[int, torch.Tensor] = {t: o["pred_masks"] for t, o in local.items()}
+        feats, pos, sizes = _expand(model, enc.raw(t), n_obj)
+        local_cond[t] = model.track_step(frame_idx=t, is_init_cond_frame=True, current_vision_feats=feats, current_vision_pos_embeds=pos,
+                                         feat_sizes=sizes, point_inputs=pin, mask_inputs=None, output_dict=empty, num_frames=T)
+    local_feats: Dict[int, dict] = {t: enc.raw(t) for t in order if t not in cond_set}
+    # input-independent position tables of the three feature levels: from any slice this rank encoded
+    if local_feats:
+        pos_tables = next(iter(local_feats.values()))["vision_pos_enc"]
+    else:
+        pos_tables = model.forward_image(volume[:1])["vision_pos_enc"]
+        pos_tables = [p[:1] for p in pos_tables[-model.num_feature_levels:]]
 
-    # 3. propagation (sequential in t).  Objects never interact (non_overlap_masks off), so with enough objects each rank
-    # carries a slice of the object batch through the chain; otherwise the chain is replicated.
-    ob, oe = (shard_range(n_obj, rank, world) if (distributed and shard_objects and n_obj >= world) else (0, n_obj))
+    # 2. the one exchange step
+    if distributed:
+        owner = lambda t: next(r for r in range(world) if shard_range(T, r, world)[0] <= t < shard_range(T, r, world)[1])
+        like = (n_obj, model.mem_dim, model.sam_image_embedding_size, model.hidden_dim, volume.device)
+        cond = gather_cond_memories(local_cond, cond_ids, group, owners=[owner(t) for t in cond_ids], like=like)
+        non_cond_ids = [t for t in range(T) if t not in cond_set]
+        feats_all = gather_slice_features(local_feats, non_cond_ids, [owner(t) for t in non_cond_ids], group)
+        for o in cond.values():                       # remote entries: the position table of the memory encoder is a constant
+            if o["maskmem_pos_enc"] is None:
+                o["maskmem_pos_enc"] = [model.memory_encoder.position_encoding(o["maskmem_features"]).to(o["maskmem_features"].dtype)]
+        for o in feats_all.values():
+            if o["vision_pos_enc"] is None:
+                o["vision_pos_enc"] = pos_tables
+    else:
+        cond, feats_all = local_cond, local_feats
+
+    # 3. propagation (sequential in t): object-sharded, key-split or replicated
+    obj_shard = distributed and shard_objects and n_obj >= world
+    ob, oe = shard_range(n_obj, rank, world) if obj_shard else (0, n_obj)
     sl = slice(ob, oe)
-    if (ob, oe) != (0, n_obj):
-        cond = {t: _slice_objects(o, sl) for t, o in cond.items()}
-    output_dict = {"cond_frame_outputs": cond, "non_cond_frame_outputs": {}}
-    enc = _SliceEncoder(model, volume, [t for t in range(T) if t not in cond], encode_batch)
-    for t in range(T):
-        if t in cond:
-            continue
-        feats, pos, sizes = enc.get(t, oe - ob)
-        cur = model.track_step(frame_idx=t, is_init_cond_frame=False, current_vision_feats=feats, current_vision_pos_embeds=pos,
-                               feat_sizes=sizes, point_inputs=None, mask_inputs=None, output_dict=output_dict, num_frames=T)
-        output_dict["non_cond_frame_outputs"][t] = cur
-        masks[t] = cur["pred_masks"]
+    chain_cond = {t: _slice_objects(o, sl) for t, o in cond.items()} if obj_shard else cond
+    output_dict = {"cond_frame_outputs": chain_cond, "non_cond_frame_outputs": {}}
+    masks: Dict[int, torch.Tensor] = {}
+    split_ctx = KVSplit(model, group) if (distributed and kv_split and not obj_shard) else None
+    try:
+        for t in range(T):
+            if t in cond_set:
+                continue
+            feats, pos, sizes = _expand(model, feats_all.pop(t), oe - ob)
+            cur = model.track_step(frame_idx=t, is_init_cond_frame=False, current_vision_feats=feats, current_vision_pos_embeds=pos,
+                                   feat_sizes=sizes, point_inputs=None, mask_inputs=None, output_dict=output_dict, num_frames=T)
+            output_dict["non_cond_frame_outputs"][t] = cur
+            masks[t] = cur["pred_masks"]
+    finally:
+        if split_ctx is not None:
+            split_ctx.close()
+
+    # 4. everything everywhere: conditioning masks from their owners, propagated masks from the object shards
+    if distributed:
+        cond_masks = {t: o["pred_masks"] for t, o in cond.items()}            # gathered with the memories (full object batch)
+        if obj_shard:
+            masks = gather_object_shards(masks, [t for t in range(T) if t not in cond_set], n_obj, group)
+    else:
+        cond_masks = {t: o["pred_masks"] for t, o in local_cond.items()}
+    masks.update(cond_masks)
     if fill_hole_area > 0:
         for t in masks:
             masks[t] = ops.fill_holes_(masks[t].contiguous().clone(), fill_hole_area)
-    return masks
+    return {t: masks[t] for t in sorted(masks)}
 
 
 def _slice_objects(o: dict, sl: slice) -> dict:

@@ -43,13 +43,47 @@ def _worker(rank, world, port, q):
         g = torch.Generator().manual_seed(f)
         local[f] = {"maskmem_features": torch.randn(2, 64, 4, 4, generator=g), "maskmem_pos_enc": pos,
                     "obj_ptr": torch.randn(2, 256, generator=g), "pred_masks": torch.zeros(2, 1, 16, 16)}
+    for f in local:
+        local[f]["pred_masks"] = torch.full((2, 1, 16, 16), float(f))
     full = par.gather_cond_memories(local, frame_ids)
     assert sorted(full) == frame_ids
+    ok_masks = all(torch.equal(full[f]["pred_masks"], torch.full((2, 1, 16, 16), float(f))) for f in frame_ids)
     ok = True
     for f in frame_ids:
         g = torch.Generator().manual_seed(f)
         ok &= torch.equal(full[f]["maskmem_features"], torch.randn(2, 64, 4, 4, generator=g))
         ok &= torch.equal(full[f]["obj_ptr"], torch.randn(2, 256, generator=g))
+    ok &= ok_masks
+    # explicit owners with an EMPTY rank (more ranks than conditioning slices): rank 1 owns nothing and joins with `like`
+    one = {7: {"maskmem_features": torch.full((2, 64, 4, 4), 7.0), "maskmem_pos_enc": pos, "obj_ptr": torch.full((2, 256), 7.0),
+               "pred_masks": torch.full((2, 1, 16, 16), 7.0)}} if rank == 0 else {}
+    got = par.gather_cond_memories(one, [7], owners=[0], like=(2, 64, 4, 256, dev))
+    ok &= sorted(got) == [7] and bool((got[7]["maskmem_features"] == 7).all()) and bool((got[7]["pred_masks"] == 7).all())
+    ok &= (got[7]["maskmem_pos_enc"] is None) == (rank == 1)
+    # backbone features of the non-conditioning slices: 3 slices, rank 0 encoded two of them
+    sl_ids, owners = [1, 3, 5], [0, 0, 1]
+    mk = lambda t: {"backbone_fpn": [torch.full((1, 4, 8, 8), float(t)), torch.full((1, 8, 4, 4), 10.0 + t)], "vision_pos_enc": ["pos"]}
+    feats = par.gather_slice_features({t: mk(t) for t, o in zip(sl_ids, owners) if o == rank}, sl_ids, owners)
+    ok &= sorted(feats) == sl_ids and all(bool((feats[t]["backbone_fpn"][0] == t).all()) and bool((feats[t]["backbone_fpn"][1] == 10.0 + t).all())
+                                          and feats[t]["backbone_fpn"][0].shape == (1, 4, 8, 8) for t in sl_ids)
+    # object shards -> full object batch (3 objects over 2 ranks: 2 + 1)
+    ob, oe = par.shard_range(3, rank, world)
+    sh = {t: torch.arange(ob, oe, dtype=torch.float32).reshape(-1, 1, 1, 1).expand(-1, 1, 2, 2).contiguous() + 10 * t for t in (0, 1)}
+    fullm = par.gather_object_shards(sh, [0, 1], 3)
+    ok &= all(torch.equal(fullm[t][:, 0, 0, 0], torch.arange(3.0) + 10 * t) for t in (0, 1))
+    # key-split exchange: 5 splits over 2 ranks (3 + 2) of a [splits, rows, 64] 16-bit + [splits, rows, 2] fp32 workspace
+    S, rows = 5, 6
+    ref_o = torch.arange(S * rows * 64, dtype=torch.int16).reshape(S, rows * 64)
+    ref_ml = torch.arange(S * rows * 2, dtype=torch.float32).reshape(S, rows * 2)
+    ws = torch.zeros(S * rows * 64 * 2 + S * rows * 8, dtype=torch.uint8)
+    with par.KVSplit() as kvs:
+        b0, e0 = kvs.share(S)
+        ws[: S * rows * 128].view(torch.int16).view(S, -1)[b0:e0] = ref_o[b0:e0]
+        ws[S * rows * 128:].view(torch.float32).view(S, -1)[b0:e0] = ref_ml[b0:e0]
+        kvs.exchange(ws, S, rows)
+        ok &= par.current_kv_split() is kvs
+    ok &= par.current_kv_split() is None
+    ok &= torch.equal(ws[: S * rows * 128].view(torch.int16).view(S, -1), ref_o) and torch.equal(ws[S * rows * 128:].view(torch.float32).view(S, -1), ref_ml)
     # data-parallel gradient reduction: ragged shapes, two buckets forced by a small bucket size
     gen = lambda r, n, shape: torch.randn(*shape, generator=torch.Generator().manual_seed(100 * r + n))
     shapes = {"b.weight": (7, 5), "a.bias": (3,), "c.gamma": (1, 2, 3), "d.w": (40, 10)}

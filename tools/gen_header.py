@@ -21,6 +21,8 @@ DOC = {
     "msam2_attention_merge": "Second half of a split-KV attention call issued with a NEGATIVE split count (the split pass alone, partials left in the\nworkspace): combines the per-split (max, sum, O) triples into o.  Lets a host time / overlap the two kernels separately.",
     "msam2_attention_fwd": "softmax(Q K^T * scale) V, non-causal, 16-bit in/out, fp32 softmax/accumulate; head dim 64/96/128/256; q/k/v/o given by\nelement strides {batch, head, token}.  splits > 1 = split-KV (flash-decoding) with an in-library merge; splits < 0 = the split pass only\n(finish with msam2_attention_merge).\nReplaces F.scaled_dot_product_attention at hieradet.py:72-76 (global blocks) and transformer.py:318 (RoPEAttention,\nmemory attention self/cross).",
     "msam2_attention_kv64_fwd": "Memory cross-attention of RoPEAttention with kv_in_dim = 64 (transformer.py:288-331 as called at memory_attention.py:76-85) with\nthe value product contracted in the 64-channel memory space: O' = softmax(Q K^T * scale) M for 256-wide rotated q / k rows and the\n64-wide memory rows M.  Because the values carry no rotary encoding and softmax rows sum to one, P (M W_v^T + b_v) = O' W_v^T + b_v:\nthe caller folds v_proj into out_proj (one K = 64 GEMM).  Strides / splits / workspace / merge as msam2_attention_fwd with D = 64.",
+    "msam2_attention_effective_splits": "The split count msam2_attention_fwd / msam2_attention_kv64_fwd actually run with for a requested one (every split owns at least one\n32-key tile); what msam2_attention_kv64_partial expects as `splits`.",
+    "msam2_attention_kv64_partial": "Splits [split_begin, split_begin + split_count) of a `splits`-way msam2_attention_kv64_fwd: the partial (max, sum, O') triples land in\nthe workspace slots the full call would use, nothing is merged.  Cross-GPU key split of the 3-D propagation chain (the reference has no\ncounterpart: sam2_base.py:494-663 attends to the whole bank on one device): every rank computes its share of the splits, the slots are\nall-gathered, msam2_attention_merge (D = 64) finishes -- bit-identical to one rank computing all splits.",
     "msam2_window_attention_fwd": "Windowed Hiera attention straight from un-partitioned qkv tokens: replaces window_partition -> SDPA ->\nwindow_unpartition (backbones/utils.py:16-62 + hieradet.py:138-158,72-76).  Zero-padded window tokens are unmasked keys\nwhose K/V rows are kpad/vpad (= qkv bias), exactly what the reference computes; q may come from a 2x2 max-pooled image\n(q-pool at stage changes, hieradet.py:65-69).",
     "msam2_attention_small_fwd": "Attention with head dim 16/32 (two-way decoder: transformer.py:239-263 via 165-196, 74-118): tokens->image,\nimage->tokens and token self-attention.  q/k/v/o: 16-bit [B, L, heads*D].",
     "msam2_add_cast": "out = a + alpha * b on a logical [D0,D1,C] volume with arbitrary outer strides (0 = broadcast) and dtype conversion:\nmemory_attention.py:139-147 (+0.1*pos, seq-first -> batch-first), 74-76 (memory + pos), transformer.py:175-190 (q + pe,\nk + pe), mask_decoder.py:231 (src + dense), sam2_base.py:642 (+ no_mem_embed), 571-580,626-635 (memory-bank assembly).",
@@ -51,7 +53,7 @@ DOC = {
     "msam2_gemm_tt": "Weight-gradient GEMM C[M,N] (fp32) = sum_k A[k][m] B[k][n] on k-major 16-bit operands: dW = dY^T X of nn.Linear under autograd\n(sam2_utils.py:127-131, memory_attention.py:96, transformer.py:241-261) straight from the token-major dY and X -- no transposed copies;\nthe token reduction is split over workgroups (fp32 atomics into the zeroed output).  a_colsum (optional, [M]) receives sum_k A[k][m]:\nthe bias gradient in the same pass over dY.",
     "msam2_bilinear_upsample_bwd": "Adjoint of msam2_bilinear_upsample: gradient of the video-resolution mask logits (sam2_video_predictor.py:724-744, the tensor the\ntraining loss of func_3d/function.py:137-170 is taken on) back to the decoder's low-resolution logits.",
     "msam2_adam_step": "One torch.optim.Adam step (no weight decay / amsgrad) on a flat fp32 parameter (train_3d.py:50).",
-    "msam2_adam_step_multi": "The same Adam step over `count` parameters (host arrays of device pointers and element counts), 24 per launch;\ngradients are multiplied by grad_scale first (1 / loss scale);\nweight_decay > 0 gives torch.optim.AdamW's decoupled decay (train_2d.py:43-47), 0 plain Adam (train_3d.py:50-54).",
+    "msam2_adam_step_multi": "The same Adam step over `count` parameters (host arrays of device pointers and element counts), 24 per launch;\ngradients are multiplied by grad_scale first (1 / loss scale);\nstep_counter (device int32, optional): the step count lives on the device and is incremented by the call (a kernel), so a captured\nhipGraph advances the bias corrections on every replay; non-finite gradient entries are skipped;\nweight_decay > 0 gives torch.optim.AdamW's decoupled decay (train_2d.py:43-47), 0 plain Adam (train_3d.py:50-54).",
     "msam2_attention_small_bwd": "Backward of the two-way decoder's attention (transformer.py:239-263 under autograd; 8 heads of 16 / 32 channels) when one side has\n<= 32 tokens: dq / dk / dv (fp32, token-major) from 16-bit q / k / v and the fp32 upstream gradient, one workgroup per (batch, head).",
     "msam2_seg_counts": "Counts behind eval_seg (func_3d/utils.py:139-214, func_2d/utils.py:505-580): per threshold, batch element and class the\ninteger |pred>t & gt>t|, |pred>t|, |gt>t| in one pass; IoU / Dice follow on the host.",
     "msam2_non_overlap": "SAM2Base._apply_non_overlapping_constraints (sam2_base.py:812-830): keep the arg-max object per pixel, clamp the\nothers to <= -10.",
