@@ -171,15 +171,7 @@ def train_iteration(m, imgs, pts, labels, memory, memory_pos, device):
         om, od = T.DecoderAdam(mt.memory_attention, lr=1e-6), T.DecoderAdam(mt.sam_mask_decoder, lr=1e-4)
         step = lambda sync: T.train_step_2d(mt, om, od, imgs, pts, labels, memory, memory_pos, target, sync=sync)
         step(True)                                          # eager: calibrates the loss scale, packs weights
-        st = torch.cuda.Stream()
-        st.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(st):
-            step(False)
-        torch.cuda.current_stream().wait_stream(st)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step(False)
+        graph = T.GraphedStep(lambda: step(False), [om, od])   # capture; replays advance Adam's device-side step count
         graph.replay()
         torch.cuda.synchronize()
         n = 10

@@ -65,17 +65,32 @@ class DecoderAdam:
 
     def __init__(self, decoder, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
         """weight_decay = 0: torch.optim.Adam as train_3d.py:50-54 builds it; > 0: torch.optim.AdamW's decoupled decay (train_2d.py:43-47)."""
-        self.decoder, self.lr, self.betas, self.eps, self.t, self.weight_decay = decoder, lr, betas, eps, 0, weight_decay
+        self.decoder, self.lr, self.betas, self.eps, self.weight_decay = decoder, lr, betas, eps, weight_decay
         self.state: Dict[str, tuple] = {}
+        self._t_dev = None          # int32 [1] on the parameters' device: the step count t (advanced by a kernel inside every step)
+
+    @property
+    def t(self) -> int:
+        """number of steps taken so far, eager and replayed (one device -> host read)"""
+        return 0 if self._t_dev is None else int(self._t_dev.item())
+
+    def mark_updated(self):
+        """Bump the version counters of the parameters (no kernel).  `step` does it itself; a hipGraph REPLAY of a captured step
+        updates the parameters through raw pointers without running this host code, so whoever replays calls it afterwards
+        (`GraphedStep.replay` does) -- otherwise the kernel-ready 16-bit weight copies of `WeightCache` that EAGER code reads would
+        go stale after the first post-capture rebuild."""
+        ps = tuple(self.decoder.parameters())
+        torch._C._autograd._unsafe_set_version_counter(ps, tuple(p._version + 1 for p in ps))
 
     @torch.no_grad()
     def step(self, grads: Dict[str, torch.Tensor], grad_scale: float = 1.0):
         """`grads` may carry a loss scale: they are multiplied by `grad_scale` (its inverse) inside the update kernel.
-        (The bias corrections 1 - beta^t are host scalars baked into the launch: a captured graph replays the step count it was
-        captured with -- exact for t -> infinity, i.e. use eager steps while t is small if the warm-up matters.)"""
+        The step count t lives on the device and is incremented by a kernel of the same call, so a captured graph advances the bias
+        corrections 1 - beta^t on every replay exactly like torch.optim.Adam (tests/test_backward_gpu.py::test_adam_graph_replays)."""
         import ctypes
-        self.t += 1
         params = dict(self.decoder.named_parameters())
+        if self._t_dev is None:
+            self._t_dev = torch.zeros(1, dtype=torch.int32, device=next(iter(params.values())).device)
         names = list(grads.keys())
         keep = []                                      # fp32 contiguous gradient copies stay alive until the launches are queued
         tabs = [[], [], [], []]
@@ -94,10 +109,54 @@ class DecoderAdam:
         n = len(names)
         arr = [(ctypes.c_void_p * n)(*tab) for tab in tabs]
         check(lib().msam2_adam_step_multi(arr[0], arr[1], arr[2], arr[3], (ctypes.c_int64 * n)(*numel), n, self.lr, self.betas[0],
-                                          self.betas[1], self.eps, self.t, float(grad_scale), float(self.weight_decay), _stream()))
+                                          self.betas[1], self.eps, 0, float(grad_scale), float(self.weight_decay), _p(self._t_dev), _stream()))
         # the update went through raw pointers: bump the tensor versions (no kernel) so cached kernel-ready weights are rebuilt
         ps = tuple(params[name] for name in names)
         torch._C._autograd._unsafe_set_version_counter(ps, tuple(p._version + 1 for p in ps))
+
+
+class GraphedStep:
+    """A training step captured into a hipGraph together with what a replay needs on the host side: `replay()` relaunches the graph and
+    then bumps the version counters of every parameter the captured optimisers update (`DecoderAdam.mark_updated`), so that eager code
+    running between replays (validation, the predictor, `_encode_new_memory`) rebuilds its 16-bit weight copies instead of reading
+    stale ones.  The step function must be capturable (sync=False: no host reads) and already calibrated by one eager call."""
+
+    def __init__(self, step_fn, optimizers):
+        self.optimizers = list(optimizers)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step_fn()                                   # warm-up on a side stream (allocator, lazy module loads)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = step_fn()
+
+    def replay(self):
+        self.graph.replay()
+        for o in self.optimizers:
+            o.mark_updated()
+        return self.out
+
+
+def _shared_pow2_scale(amax: torch.Tensor, data_parallel: bool, group=None) -> float:
+    """Power-of-two loss scale from max|gradient| (a 1-element device tensor).  Data parallel: the maximum is taken over ALL ranks first
+    (one MAX all-reduce), so every rank scales -- and later un-scales -- by the same factor; summing gradients that carry different
+    scales would be wrong."""
+    if data_parallel and parallel._is_dist(group):
+        import torch.distributed as dist
+        dist.all_reduce(amax, op=dist.ReduceOp.MAX, group=group)
+    a = float(amax.item())
+    return 2.0 ** (-3 - math.ceil(math.log2(a))) if a > 0 and math.isfinite(a) else 1.0
+
+
+def _assert_same_on_all_ranks(value: float, what: str, group=None):
+    if parallel._is_dist(group):
+        import torch.distributed as dist
+        vals = [None] * dist.get_world_size(group)
+        dist.all_gather_object(vals, float(value), group=group)
+        assert all(v == vals[0] for v in vals), f"{what} differs across the data-parallel ranks: {vals}"
 
 
 @torch.no_grad()
@@ -133,7 +192,8 @@ def decoder_finetune_step(decoder, optimizer: DecoderAdam, src_tokens, pe_tokens
 @torch.no_grad()
 def memory_decoder_loss_grads(memory_attention, decoder, curr, curr_pos, memory, memory_pos, num_obj_ptr_tokens: int, pe_tokens, sparse,
                               feat_s0, feat_s1, B: int, h: int, w: int, target_masks: torch.Tensor, dense_tokens=None,
-                              pos_weight: float = 1.0, mem_scale: float = None, aux: dict = None, mask_index: int = None):
+                              pos_weight: float = 1.0, mem_scale: float = None, aux: dict = None, mask_index: int = None,
+                              data_parallel: bool = False):
     """Forward + backward of the memory-conditioned slice step (func_2d/function.py:70-191 / sam2_base.py:705-790 with a frozen image
     encoder and a detached memory bank, as func_2d/function.py:204-243 stores it): curr / curr_pos [L, B, C] current-slice features,
     memory / memory_pos [Nk, B, 64] the assembled bank -> memory attention -> (+ dense prompt embedding) -> mask decoder -> mean BCE with
@@ -143,7 +203,8 @@ def memory_decoder_loss_grads(memory_attention, decoder, curr, curr_pos, memory,
     The gradient that leaves the decoder towards the memory attention is orders of magnitude smaller than the one that entered it
     (it has crossed two attention blocks and two transposed convolutions), again below the fp16 operand range, so it is re-scaled by a
     second power of two: `mem_scale` if given (a captured graph must pass the value calibrated on an eager step), else chosen from
-    max|d_src| -- one host synchronisation."""
+    max|d_src| -- one host synchronisation; with data_parallel the maximum is taken over all ranks (one MAX all-reduce), because the
+    ranks' gradients are summed afterwards and must carry the same scale."""
     L, _, C = curr.shape
     y, state = bwd.memory_attention_forward_saved(memory_attention, curr, curr_pos, memory, memory_pos, num_obj_ptr_tokens)
     src = y.transpose(0, 1).reshape(B * L, C)
@@ -165,8 +226,7 @@ def memory_decoder_loss_grads(memory_attention, decoder, curr, curr_pos, memory,
     d_masks.mul_(scale)
     d_src, _, g_dec = bwd.mask_decoder_backward(decoder, src, pe_tokens, sparse, feat_s0, feat_s1, B, h, w, d_masks)
     if mem_scale is None:
-        amax = float(d_src.abs().max().item())
-        mem_scale = 2.0 ** (-3 - math.ceil(math.log2(amax))) if amax > 0 and math.isfinite(amax) else 1.0
+        mem_scale = _shared_pow2_scale(d_src.abs().max().reshape(1), data_parallel)
     d_src = d_src * mem_scale
     dcurr, dmemory, dmemory_pos, g_mem = bwd.memory_attention_backward_saved(memory_attention, state, d_src.view(B, L, C).transpose(0, 1))
     if aux is not None:
@@ -183,11 +243,14 @@ def memory_decoder_finetune_step(memory_attention, decoder, opt_mem: DecoderAdam
     cal = getattr(opt_mem, "calibrated_loss_scales", {})                         # one calibration per loss form, made on its first (eager) step
     if kwargs.get("mem_scale") is None:
         kwargs["mem_scale"] = cal.get(kwargs.get("mask_index"))
-    loss, scale, scale_mem, g_dec, g_mem, _ = memory_decoder_loss_grads(memory_attention, decoder, *args, **kwargs)
+    calibrating = kwargs.get("mem_scale") is None
+    loss, scale, scale_mem, g_dec, g_mem, _ = memory_decoder_loss_grads(memory_attention, decoder, *args, data_parallel=data_parallel, **kwargs)
     cal[kwargs.get("mask_index")] = scale_mem / scale
     opt_mem.calibrated_loss_scales = cal
     inv_world = 1.0
-    if data_parallel:                                   # (ranks must share the calibrated loss scale: calibrate on rank 0's value or pass mem_scale)
+    if data_parallel:
+        if calibrating:                                 # the calibration was collective (MAX over ranks): every rank must hold the same scale
+            _assert_same_on_all_ranks(scale_mem / scale, "memory-attention loss scale")
         g_dec, inv_world = parallel.allreduce_gradients(g_dec)
         g_mem, _ = parallel.allreduce_gradients(g_mem)
     opt_dec.step(g_dec, grad_scale=inv_world / scale)

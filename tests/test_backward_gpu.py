@@ -810,3 +810,58 @@ def test_adamw_multi_tensor_matches_torch(mods):
                 opt.step({str(i): (g * 64.0).to(DEV) for i, g in enumerate(gs)}, grad_scale=1.0 / 64.0)
         for i, (p, r) in enumerate(zip(mod, ref)):
             assert torch.allclose(p.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-6), (wd, i)
+
+
+def test_adam_graph_replays_match_eager_and_torch(mods):
+    """A hipGraph captured around DecoderAdam.step must advance the step count on every replay (device-side counter): N replays ==
+    N eager steps == torch.optim.Adam's bias corrections.  Captured at t = 3, as bench.py's training figure does."""
+    B_, ops = mods
+    import medical_sam2_amd.training as T
+    shapes = [(7,), (33, 5), (256, 64)]
+    g_host = [rnd(*sh, seed=900 + i) for i, sh in enumerate(shapes)]
+    ref = [torch.nn.Parameter(rnd(*sh, seed=800 + i)) for i, sh in enumerate(shapes)]
+    opt_ref = torch.optim.Adam(ref, lr=1e-2)
+    mod = torch.nn.ParameterList([torch.nn.Parameter(p.detach().clone()) for p in ref]).to(DEV)
+    grads = {str(i): g.to(DEV) for i, g in enumerate(g_host)}          # static gradient buffers: the graph re-reads them
+    opt = T.DecoderAdam(mod, lr=1e-2)
+    n_eager, n_replay = 2, 6
+    with torch.no_grad():
+        for _ in range(n_eager):
+            opt.step(grads)
+        gs = T.GraphedStep(lambda: opt.step(grads), [opt])              # warm-up call + captured call: 2 more steps, then replays
+        v0 = [p._version for p in mod]
+        for _ in range(n_replay):
+            gs.replay()
+    total = n_eager + 2 + n_replay
+    assert opt.t == total
+    assert all(p._version == v + n_replay for p, v in zip(mod, v0))     # replays bump the versions (WeightCache signatures move)
+    for _ in range(total):
+        for p, g in zip(ref, g_host):
+            p.grad = g.clone()
+        opt_ref.step()
+    for i, (p, r) in enumerate(zip(mod, ref)):
+        assert torch.allclose(p.detach().cpu(), r.detach(), rtol=2e-5, atol=2e-6), i
+
+
+def test_eager_forward_after_graph_replays_sees_fresh_weights(mods):
+    """WeightCache staleness (the 16-bit weight copies are keyed on (data_ptr, version)): after replays of a captured optimiser step an
+    eager GEMM through the module's cached weight must use the UPDATED parameter."""
+    B_, ops = mods
+    import medical_sam2_amd.training as T
+    from medical_sam2_amd.modeling.common import WeightCache, w_bf16
+    lin = torch.nn.Linear(64, 32).to(DEV)
+    wc = WeightCache()
+    x = rnd(16, 64, seed=5).to(ops.OP16).to(DEV)
+    grads = {"weight": torch.ones(32, 64, device=DEV), "bias": torch.ones(32, device=DEV)}
+    opt = T.DecoderAdam(lin, lr=1e-1)
+    fwd = lambda: ops.gemm(x, w_bf16(wc, "w", lin.weight), lin.bias.detach(), out_dtype=torch.float32)
+    with torch.no_grad():
+        opt.step(grads)
+        gs = T.GraphedStep(lambda: opt.step(grads), [opt])
+        y0 = fwd()                                                       # eager forward after the capture: rebuilds the cached copy
+        for _ in range(3):
+            gs.replay()
+        y1 = fwd()
+        want = x.float() @ lin.weight.detach().to(ops.OP16).float().t() + lin.bias.detach()
+    assert (y1 - y0).abs().max().item() > 1e-2                           # the parameters moved (lr 0.1, constant gradient)
+    assert torch.allclose(y1, want, rtol=1e-3, atol=1e-3)                # and the eager path used the moved ones

@@ -74,6 +74,77 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _joint_inputs(B, E=16, C=256, L=256):
+    rnd = lambda *s, seed=0, scale=1.0: torch.randn(*s, generator=torch.Generator().manual_seed(seed)) * scale
+    d = dict(curr=rnd(L, B, C, seed=400), curr_pos=rnd(L, B, C, seed=401), memory=rnd(2 * L + 4, B, 64, seed=402),
+             memory_pos=rnd(2 * L + 4, B, 64, seed=403), pe=rnd(L, C, seed=404), sparse=rnd(B, 2, C, seed=405),
+             f0=rnd(B * 16 * L, 32, seed=406), f1=rnd(B * 4 * L, 64, seed=407),
+             target=(rnd(B, 4, 4 * E, 4 * E, seed=408) > 0.4).float())
+    # very different gradient magnitudes on the two halves of the batch, so that a per-rank calibration WOULD pick different powers of two
+    d["target"][B // 2:] = 1.0
+    d["curr"][:, B // 2:] *= 8.0
+    return d
+
+
+def _joint_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.set_grad_enabled(False)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import medical_sam2_amd.build_sam as bs
+    import medical_sam2_amd.ops as ops
+    import medical_sam2_amd.training as T
+    import medical_sam2_amd.weights as wts
+    m = bs.build_sam2("sam2_hiera_t", device="cpu", hydra_overrides_extra=["++model.image_size=256"])
+    m.load_state_dict(wts.init_weights("hiera_t", 0), strict=True)
+    m = m.cuda().eval()
+    B_all, E = 4, 16
+    per = B_all // world
+    d = _joint_inputs(B_all)
+    sl = slice(rank * per, (rank + 1) * per)
+    c = lambda t: t.cuda().contiguous()
+    L = E * E
+    f0 = d["f0"].view(B_all, 16 * L, 32)[sl].reshape(-1, 32)
+    f1 = d["f1"].view(B_all, 4 * L, 64)[sl].reshape(-1, 64)
+    args = (c(d["curr"][:, sl]), c(d["curr_pos"][:, sl]), c(d["memory"][:, sl]), c(d["memory_pos"][:, sl]), 4, c(d["pe"]), c(d["sparse"][sl]),
+            c(f0).to(ops.OP16), c(f1).to(ops.OP16), per, E, E, c(d["target"][sl]))
+    # what a per-rank (non-collective) calibration would have chosen on this rank
+    _, sc, sc_mem_local, _, _, _ = T.memory_decoder_loss_grads(m.memory_attention, m.sam_mask_decoder, *args)
+    om, od = T.DecoderAdam(m.memory_attention, lr=1e-5), T.DecoderAdam(m.sam_mask_decoder, lr=1e-4)
+    T.memory_decoder_finetune_step(m.memory_attention, m.sam_mask_decoder, om, od, *args, data_parallel=True)
+    shared = om.calibrated_loss_scales[None]
+    flat = torch.cat([p.detach().reshape(-1) for mod in (m.memory_attention, m.sam_mask_decoder) for p in mod.parameters()]).cpu()
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    same = all(torch.equal(gathered[0], t) for t in gathered[1:])
+    q.put((rank, float(sc_mem_local / sc), float(shared), bool(same), bool(torch.isfinite(flat).all())))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_joint_step_shares_the_loss_scale():
+    """memory_decoder_finetune_step(data_parallel=True): the memory group's loss scale is calibrated COLLECTIVELY (MAX of max|d_src|
+    over the ranks) -- with per-rank calibration the two halves of this batch pick different powers of two and the summed gradients
+    would be wrong; afterwards both ranks hold the same scale and bit-identical parameters."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_joint_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(2))
+    (_, loc0, sh0, same0, fin0), (_, loc1, sh1, same1, fin1) = res
+    assert sh0 == sh1 and sh0 == min(loc0, loc1)          # the shared scale is the one of the larger gradient (MAX of amax)
+    assert loc0 != loc1, "the test inputs must make a per-rank calibration disagree"
+    assert same0 and same1 and fin0 and fin1
+
+
 def test_data_parallel_decoder_step_two_ranks():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
