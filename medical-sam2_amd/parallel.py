@@ -62,6 +62,16 @@ def _is_dist(group=None) -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
 
+def _to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """[n,C,h,w] -> channels-last MEMORY [n,h,w,C] (free for this package's feature maps, which are NCHW views of token-major buffers)"""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _from_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """[n,h,w,C] memory -> the [n,C,h,w] view the modules hand around (token-major underneath, as every kernel expects)"""
+    return x.permute(0, 3, 1, 2)
+
+
 def _gather_slabs(mine: List[torch.Tensor], counts: List[int], item_shape, dtype, device, group=None) -> List[List[torch.Tensor]]:
     """One all-gather of a fixed-size slab per rank: rank r contributes counts[r] items of `item_shape` (its `mine` list; may be empty),
     slabs are padded to max(counts).  Returns per rank the list of its items (views into the gathered slabs)."""
@@ -103,14 +113,15 @@ def gather_cond_memories(local: Dict[int, dict], frame_ids: List[int], group=Non
     mine = [local[f] for f in my_ids]
     if mine:
         f0, p0, m0 = mine[0]["maskmem_features"], mine[0]["obj_ptr"], mine[0]["pred_masks"]
-        shapes = (tuple(f0.shape), tuple(p0.shape), tuple(m0.shape))
+        n_, c_, h_, w_ = f0.shape
+        shapes = ((n_, h_, w_, c_), tuple(p0.shape), tuple(m0.shape))            # memory features travel channels-last
         dts, device = (f0.dtype, p0.dtype, m0.dtype), f0.device
     else:
         assert like is not None, "a rank without conditioning slices needs `like` to join the exchange"
         n_obj, mem_dim, E, hidden, device = like
-        shapes = ((n_obj, mem_dim, E, E), (n_obj, hidden), (n_obj, 1, 4 * E, 4 * E))
+        shapes = ((n_obj, E, E, mem_dim), (n_obj, hidden), (n_obj, 1, 4 * E, 4 * E))
         dts = (torch.float32,) * 3
-    all_f = _gather_slabs([o["maskmem_features"] for o in mine], counts, shapes[0], dts[0], device, group)
+    all_f = _gather_slabs([_to_nhwc(o["maskmem_features"]) for o in mine], counts, shapes[0], dts[0], device, group)
     all_p = _gather_slabs([o["obj_ptr"] for o in mine], counts, shapes[1], dts[1], device, group)
     all_m = _gather_slabs([o["pred_masks"] for o in mine], counts, shapes[2], dts[2], device, group)
     pos = mine[0]["maskmem_pos_enc"] if mine else None
@@ -122,7 +133,7 @@ def gather_cond_memories(local: Dict[int, dict], frame_ids: List[int], group=Non
         if r == rank:
             out[fid] = local[fid]
         else:
-            out[fid] = {"maskmem_features": all_f[r][i], "maskmem_pos_enc": pos, "obj_ptr": all_p[r][i], "pred_masks": all_m[r][i],
+            out[fid] = {"maskmem_features": _from_nhwc(all_f[r][i]), "maskmem_pos_enc": pos, "obj_ptr": all_p[r][i], "pred_masks": all_m[r][i],
                         "pred_masks_high_res": None, "point_inputs": None, "mask_inputs": None}
     return out
 
@@ -142,7 +153,7 @@ def gather_slice_features(local: Dict[int, dict], slice_ids: List[int], owners: 
     meta = None
     if my_ids:
         one = local[my_ids[0]]["backbone_fpn"]
-        meta = [list(f.shape[1:]) for f in one]
+        meta = [[f.shape[2], f.shape[3], f.shape[1]] for f in one]              # (h, w, C): features travel channels-last
     objs = [None] * world
     dist.all_gather_object(objs, meta, group=group)
     meta = next(m for m in objs if m is not None)
@@ -150,14 +161,14 @@ def gather_slice_features(local: Dict[int, dict], slice_ids: List[int], owners: 
     device = sample["backbone_fpn"][0].device if sample else torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     levels = []
     for lvl, shp in enumerate(meta):
-        levels.append(_gather_slabs([local[t]["backbone_fpn"][lvl] for t in my_ids], counts, (1,) + tuple(shp), torch.float32, device, group))
+        levels.append(_gather_slabs([_to_nhwc(local[t]["backbone_fpn"][lvl]) for t in my_ids], counts, (1,) + tuple(shp), torch.float32, device, group))
     pos = sample["vision_pos_enc"] if sample else None
     out: Dict[int, dict] = {}
     seen = [0] * world
     for t, r in zip(slice_ids, owners):
         i = seen[r]
         seen[r] += 1
-        out[t] = local[t] if r == rank else {"backbone_fpn": [levels[lvl][r][i] for lvl in range(len(meta))], "vision_pos_enc": pos}
+        out[t] = local[t] if r == rank else {"backbone_fpn": [_from_nhwc(levels[lvl][r][i]) for lvl in range(len(meta))], "vision_pos_enc": pos}
     return out
 
 

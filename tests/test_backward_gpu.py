@@ -832,7 +832,7 @@ def test_adam_graph_replays_match_eager_and_torch(mods):
         v0 = [p._version for p in mod]
         for _ in range(n_replay):
             gs.replay()
-    total = n_eager + 2 + n_replay
+    total = n_eager + 1 + n_replay
     assert opt.t == total
     assert all(p._version == v + n_replay for p, v in zip(mod, v0))     # replays bump the versions (WeightCache signatures move)
     for _ in range(total):

@@ -58,6 +58,7 @@ def _worker(rank, world, port, q):
     one = {7: {"maskmem_features": torch.full((2, 64, 4, 4), 7.0), "maskmem_pos_enc": pos, "obj_ptr": torch.full((2, 256), 7.0),
                "pred_masks": torch.full((2, 1, 16, 16), 7.0)}} if rank == 0 else {}
     got = par.gather_cond_memories(one, [7], owners=[0], like=(2, 64, 4, 256, dev))
+    ok &= got[7]["maskmem_features"].shape == (2, 64, 4, 4) and got[7]["maskmem_features"].permute(0, 2, 3, 1).is_contiguous() == (rank == 1)
     ok &= sorted(got) == [7] and bool((got[7]["maskmem_features"] == 7).all()) and bool((got[7]["pred_masks"] == 7).all())
     ok &= (got[7]["maskmem_pos_enc"] is None) == (rank == 1)
     # backbone features of the non-conditioning slices: 3 slices, rank 0 encoded two of them
