@@ -69,11 +69,13 @@ def box_point_inputs(boxes: torch.Tensor) -> dict:
 
 @torch.no_grad()
 def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_hole_area: int = 0, group=None,
-                   shard_objects: bool = True, encode_batch: int = 8, kv_split: bool = True) -> Dict[int, torch.Tensor]:
+                   shard_objects: bool = True, encode_batch: int = 8, kv_split: bool = True, return_state: bool = False):
     """volume: [T,3,S,S] normalised slices on the GPU; prompts: {slice_idx: {"boxes": [n,4]} | {"point_coords", "point_labels"}}
     for the conditioning slices (same n objects everywhere).  Returns {slice_idx: low-res mask logits [n,1,S/4,S/4]} for ALL slices
     and ALL objects on every rank.  encode_batch: slices per image-encoder call (results do not depend on it).  shard_objects /
-    kv_split: the two ways the propagation chain uses several ranks (module docstring); with both off it is replicated."""
+    kv_split: the two ways the propagation chain uses several ranks (module docstring); with both off it is replicated.
+    return_state: also return the chain's `output_dict` ({"cond_frame_outputs", "non_cond_frame_outputs"}: per slice the track_step
+    outputs with memories and pointers, this rank's object share) -- what a caller needs to continue or to audit the propagation."""
     T = volume.shape[0]
     cond_ids = sorted(prompts)
     assert cond_ids, "at least one conditioning slice is needed"
@@ -156,7 +158,8 @@ def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_h
     if fill_hole_area > 0:
         for t in masks:
             masks[t] = ops.fill_holes_(masks[t].contiguous().clone(), fill_hole_area)
-    return {t: masks[t] for t in sorted(masks)}
+    out = {t: masks[t] for t in sorted(masks)}
+    return (out, output_dict) if return_state else out
 
 
 def _slice_objects(o: dict, sl: slice) -> dict:
