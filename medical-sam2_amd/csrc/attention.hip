@@ -215,7 +215,7 @@ __global__ __launch_bounds__(NW * 64, (WIN && NW == 4) ? 3 : 1) void attn_fwd_ke
     for (int e = 0; e < 16; ++e) {
       const float pe = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(s[e] - m_run);
       psum += pe;
-      pf[e >> 3][e & 7] = f2op(pe);
+      pf[e >> 3][e & 7] = f2op_fast(pe);
     }
     l_run += psum;
     // O^T[d][query] += V^T[d][key] P^T[key][query]
@@ -494,8 +494,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_glds_kernel(AttnParams p) {
       const f32x2_t t = __builtin_elementwise_fma(sv, sc2, nm2);
       const f32x2_t pe = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
       psum2 += pe;
-      pf[e >> 3][e & 7] = f2op(pe[0]);
-      pf[e >> 3][(e & 7) + 1] = f2op(pe[1]);
+      pf[e >> 3][e & 7] = f2op_fast(pe[0]);
+      pf[e >> 3][(e & 7) + 1] = f2op_fast(pe[1]);
     }
     l_run += psum2[0] + psum2[1];
     STAMP(t3_);
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kv64_kernel(AttnParams p) {
     for (int e = 0; e < 16; ++e) {
       const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], p.scale_log2, nm));
       psum += pe;
-      pf[e >> 3][e & 7] = f2op(pe);
+      pf[e >> 3][e & 7] = f2op_fast(pe);
     }
     l_run += psum;
     STAMP(t3_);

@@ -39,7 +39,15 @@ int msam2_check_launch(const char* what);
   } while (0)
 
 __device__ __forceinline__ float op2f(op16 x) { return (float)x; }
+// fp32 -> operand.  The fp16 build SATURATES at +-65504 (one v_med3_f32): a value beyond the fp16 range -- a real checkpoint's large
+// MLP / qkv activation, an un-scaled gradient -- must not become inf and travel through softmax / LayerNorm / the optimiser state.
+// NaN stays NaN.  f2op_fast is the plain conversion for values known to be bounded (softmax probabilities in [0, 1]).
+__device__ __forceinline__ op16 f2op_fast(float x) { return (op16)x; }
+#if MSAM2_OPERAND_IS_FP16
+__device__ __forceinline__ op16 f2op(float x) { return (op16)__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f); }
+#else
 __device__ __forceinline__ op16 f2op(float x) { return (op16)x; }
+#endif
 
 // exact-erf GELU (nn.GELU default).  erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. at fp32 round-off of the
 // surrounding arithmetic and far below the op16 rounding of every consumer) -- ~4x fewer VALU operations than erff().

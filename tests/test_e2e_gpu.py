@@ -180,8 +180,10 @@ def test_long_chain_steady_state_memory_bank(build):
                 got = cur["pred_masks"].float().cpu().numpy()
                 iou, mx, mean = mask_iou(got, ref), max_abs(got, ref), _mean_abs(got, ref)
                 REPORT[f"long256_t{t}"] = dict(iou=iou, max_abs=mx, mean_abs=mean)
+                flips = int(((got > 0) != (ref > 0)).sum())
                 worst = dict(iou=min(worst["iou"], iou), max=max(worst["max"], mx), mean=max(worst["mean"], mean),
-                             ptr=max(worst["ptr"], rel_err(cur["obj_ptr"].cpu(), gold[f"long256_t{t}_obj_ptr"])))
+                             ptr=max(worst["ptr"], rel_err(cur["obj_ptr"].cpu(), gold[f"long256_t{t}_obj_ptr"])),
+                             flips=max(worst.get("flips", 0), flips))
                 inter += float(((got > 0) & (ref > 0)).sum())
                 union += float(((got > 0) | (ref > 0)).sum())
     finally:
@@ -189,8 +191,11 @@ def test_long_chain_steady_state_memory_bank(build):
     REPORT["long256_worst"] = worst
     REPORT["long256_pooled_iou"] = inter / union
     _dump()
-    # errors do not accumulate along the chain: every slice keeps the propagated-slice bounds of the short chains
-    assert worst["iou"] >= TOL_IOU - 0.02 and worst["max"] <= 3 * TOL_MAX and worst["mean"] <= 3 * TOL_MEAN and worst["ptr"] < 4 * TOL_PTR, worst
+    # errors do not accumulate along the chain: every slice keeps the propagated-slice logit bounds of the short chains.  The
+    # propagated masks of this fixture cover 50-170 of the 4096 low-res pixels, where ONE flipped border pixel is 1-2 % of IoU, so the
+    # per-slice mask bar is on the flipped-pixel count (<= 0.1 % of the map with fp16 operands, <= 0.5 % with bf16) and IoU is pooled
+    max_flips = 4 if _fp16() else 20
+    assert worst["flips"] <= max_flips and worst["max"] <= 3 * TOL_MAX and worst["mean"] <= 3 * TOL_MEAN and worst["ptr"] < 4 * TOL_PTR, worst
     assert inter / union >= TOL_IOU_POOLED, inter / union
 
 

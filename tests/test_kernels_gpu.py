@@ -185,6 +185,26 @@ def test_gemm_qkv_pool2x2_fused(ops, B, H, W, width, K):
     assert torch.equal(q2, ref_q)
 
 
+def test_fp16_operands_saturate_instead_of_overflowing(ops):
+    """fp16 build: a 16-bit GEMM / LayerNorm output beyond +-65504 saturates (common.h f2op) instead of becoming inf -- with a real
+    checkpoint a large MLP / qkv activation must not poison softmax, LayerNorm or the optimiser state.  bf16 build: in range anyway."""
+    a = torch.full((128, 512), 300.0).to(OP16()).to(DEV)
+    w = torch.ones(64, 512).to(OP16()).to(DEV)
+    w[1::2] = -1.0
+    out = ops.gemm(a, w, None)                                   # |a w^T| = 153600
+    assert torch.isfinite(out.float()).all()
+    if OP16() == torch.float16:
+        assert out[:, 0].float().min().item() == 65504.0 and out[:, 1].float().max().item() == -65504.0
+    else:
+        assert abs(out[0, 0].float().item() - 153600.0) < 1200.0
+    big = torch.zeros(4, 256)
+    big[:, 0] = 3.0e6                                            # LayerNorm output ~ 16 * gamma: gamma 1e4 -> 1.6e5 > fp16 max
+    y = ops.layernorm(big.to(DEV), torch.full((256,), 1.0e4, device=DEV), torch.zeros(256, device=DEV), 1e-6)
+    assert torch.isfinite(y.float()).all() and y.float().abs().max().item() >= 65504.0 * (1.0 if OP16() == torch.float16 else 2.0)
+    fine = ops.gemm(a, (w * 0.001).to(OP16()), None, out_dtype=torch.float32)     # fp32 outputs are never clamped
+    assert abs(fine[0, 0].item() - 153.6) < 1.0
+
+
 def test_gemm_rejects_bad_shapes(ops):
     with pytest.raises(Exception):
         ops.gemm(bf(rnd(8, 12)).to(DEV), bf(rnd(8, 12)).to(DEV))  # K % 8 != 0
