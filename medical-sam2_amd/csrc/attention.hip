@@ -28,6 +28,7 @@ __device__ unsigned long long g_wgtime[4096][4];   // per workgroup: realtime at
 #define STAMP_DECL
 #endif
 #include <stdlib.h>
+#include <type_traits>
 
 struct AttnParams {
   const op16 *q, *k, *v;
@@ -1056,6 +1057,225 @@ extern "C" int msam2_attention_fwd_lse(const void* q, const int64_t* q_strides, 
                             lse, stream);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Hiera windowed attention, whole window resident (attn_win_kernel): one workgroup per (window, head), one wave per 32 queries.
+// The register-staged kernel above walks a window's keys in 32-key tiles with a global-load round trip and a barrier per tile; its
+// MFMA work per tile (12 instructions at D = 96) is far shorter than that latency, so a 196-key window cost seven exposed memory
+// latencies (37 us per stage-3 block: 17 % of the HBM roof).  Here every thread issues ALL of its K / V / Q gather loads up front
+// (one latency), the window's K and V land in LDS once (196 x 192 B each: two workgroups per CU), one barrier, and every wave then
+// runs its 32 queries against all keys out of LDS with no further synchronisation.
+//   K image [Lk][192 B]: 16-byte chunk c of key r at (c & ~3) | ((c & 3) ^ ((r >> 2) & 3)): rows 48 banks apart repeat every 4,
+//   the XOR separates the four rows of one residue in a ds_read_b128 lane group (conflict free).
+//   V image [ceil8(Lk)][192 B], plain: the four rows of a transposed read sit in four different 64-byte bank groups.
+// Zero-padded window tokens are unmasked keys whose K / V rows are kpad / vpad (the qkv bias), as in the reference.
+// ------------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(512) void attn_win_kernel(AttnParams p) {
+  static_assert(D == 96, "bank analysis of the 192-byte LDS rows is for D = 96");
+  constexpr int RB = D * 2, CPR = D / 8, DSTEPS = D / 16, DBLK = D / 32, BK = 32;
+  constexpr int BATCH = 6;                                   // gather chunks per operand and thread kept in flight at once
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef MSAM2_STAMP
+  const unsigned long long ws0_ = __builtin_amdgcn_s_memrealtime();
+  unsigned long long ws1_ = 0, ws2_ = 0, ws3_ = 0;
+#endif
+  const int tid = threadIdx.x, NT = blockDim.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.x, z = blockIdx.y;
+  const int nw = p.nwy * p.nwx;
+  const int b = z / nw, w = z - b * nw;
+  const int wy = w / p.nwx, wx = w - wy * p.nwx;
+  const op16* qb = p.q + (int64_t)b * p.q_bs + (int64_t)head * p.q_hs;
+  const op16* kb = p.k + (int64_t)b * p.k_bs + (int64_t)head * p.k_hs;
+  const op16* vb = p.v + (int64_t)b * p.v_bs + (int64_t)head * p.v_hs;
+  unsigned char* ksm = smem;
+  unsigned char* vsm = smem + p.Lk * RB;
+  const int lk8 = (p.Lk + 7) & ~7;
+
+  // ---- this lane's query row (issued first: its latency overlaps the K / V gather)
+  const int qi = wave * 32 + r;
+  bool qvalid = qi < p.Lq;
+  int64_t qtok = 0;
+  if (qvalid) qtok = win_token_offset(qi, p.ws_q, wy, wx, p.hq, p.wq, qvalid);
+  op16x8 qf[DSTEPS];
+#pragma unroll
+  for (int s = 0; s < DSTEPS; ++s) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (qvalid) v = *reinterpret_cast<const uint4*>(qb + qtok * p.q_ts + s * 16 + h * 8);
+    qf[s] = __builtin_bit_cast(op16x8, v);
+  }
+
+  // ---- gather the window's K and V rows into LDS: BATCH chunks per operand per thread in flight, then the LDS writes
+  const int chunks = p.Lk * CPR;
+  for (int c0 = 0; c0 < chunks; c0 += BATCH * NT) {
+    uint4 rk[BATCH], rv[BATCH];
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      const int c = c0 + i * NT + tid;
+      uint4 kk = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+      if (c < chunks) {
+        const int key = c / CPR, dc = (c - key * CPR) * 8;
+        bool valid;
+        const int64_t tok = win_token_offset(key, p.ws_k, wy, wx, p.hk, p.wk, valid);
+        if (valid) {
+          kk = *reinterpret_cast<const uint4*>(kb + tok * p.k_ts + dc);
+          vv = *reinterpret_cast<const uint4*>(vb + tok * p.v_ts + dc);
+        } else {
+          op16x8 a, bb;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            a[e] = f2op(p.kpad[head * D + dc + e]);
+            bb[e] = f2op(p.vpad[head * D + dc + e]);
+          }
+          kk = __builtin_bit_cast(uint4, a);
+          vv = __builtin_bit_cast(uint4, bb);
+        }
+      }
+      rk[i] = kk;
+      rv[i] = vv;
+    }
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      const int c = c0 + i * NT + tid;
+      if (c < chunks) {
+        const int key = c / CPR, cc = c - key * CPR;
+        *reinterpret_cast<uint4*>(ksm + key * RB + (((cc & ~3) | ((cc & 3) ^ ((key >> 2) & 3))) << 4)) = rk[i];
+        *reinterpret_cast<uint4*>(vsm + key * RB + (cc << 4)) = rv[i];
+      }
+    }
+  }
+  for (int c = chunks + tid; c < lk8 * CPR; c += NT) *reinterpret_cast<uint4*>(vsm + c * 16) = make_uint4(0, 0, 0, 0);   // V rows Lk .. ceil8(Lk): zero
+  __syncthreads();
+#ifdef MSAM2_STAMP
+  ws1_ = __builtin_amdgcn_s_memrealtime();
+#endif
+  if (wave * 32 >= p.Lq) return;                             // (no barrier below)
+
+  f32x16 o[DBLK];
+#pragma unroll
+  for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int li = lane & 15;
+  const int v_off = (4 * h + (li >> 2)) * RB + (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
+  const int ntiles = (p.Lk + BK - 1) / BK, nfull = p.Lk / BK;
+  // one key tile; MASKED = the partial last tile (keys past Lk get -inf, V rows past ceil8(Lk) are not read)
+  auto tile_step = [&](int tile, auto masked_tag) __attribute__((always_inline)) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    const int key0 = tile * BK;
+    const int krow = key0 + r;                               // rows past Lk read the V region behind the K image: finite, masked below
+    const unsigned char* kp = ksm + krow * RB;
+    const int kx = (krow >> 2) & 3;
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < DSTEPS; ++st) {
+      const int c = 2 * st + h;
+      const op16x8 kf = *reinterpret_cast<const op16x8*>(kp + (((c & ~3) | ((c & 3) ^ kx)) << 4));
+      s = MSAM2_MFMA_32x32x16(kf, qf[st], s, 0, 0, 0);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      if constexpr (MASKED) {
+        const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (key >= p.Lk) s[e] = -INFINITY;
+      }
+      mx = fmaxf(mx, s[e]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;   // scale > 0: max commutes with it
+    const float m_new = fmaxf(m_run, mx);
+    if (__any(m_new > m_run)) {
+      const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+      m_run = m_new;
+    }
+    float psum = 0.f;
+    op16x8 pf[2];
+    const float nm = -m_run;                                 // finite: every tile holds >= 1 valid key
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], p.scale_log2, nm));
+      psum += pe;
+      pf[e >> 3][e & 7] = f2op_fast(pe);
+    }
+    l_run += psum;
+    const int nv = MASKED ? min(BK, lk8 - key0) : BK;        // V rows of this tile that exist in LDS (multiple of 8)
+#pragma unroll
+    for (int d = 0; d < DBLK; ++d) {
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        typedef __attribute__((ext_vector_type(8))) short short8_t;
+        const unsigned char* a0 = vsm + (key0 + 16 * st) * RB + v_off + d * 64;
+        short4_t lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+        if (!MASKED || 16 * st < nv) lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0));
+        if (!MASKED || 16 * st + 8 < nv) hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0 + 8 * RB));
+        short8_t vv8;
+        vv8[0] = lo[0]; vv8[1] = lo[1]; vv8[2] = lo[2]; vv8[3] = lo[3];
+        vv8[4] = hi[0]; vv8[5] = hi[1]; vv8[6] = hi[2]; vv8[7] = hi[3];
+        o[d] = MSAM2_MFMA_32x32x16(__builtin_bit_cast(op16x8, vv8), pf[st], o[d], 0, 0, 0);
+      }
+    }
+  };
+  for (int tile = 0; tile < nfull; ++tile) tile_step(tile, std::false_type{});
+  if (nfull < ntiles) tile_step(nfull, std::true_type{});
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+#ifdef MSAM2_STAMP
+  ws2_ = __builtin_amdgcn_s_memrealtime();
+#endif
+  const float inv = 1.f / l_tot;
+  if (qvalid) {
+  op16* ob = p.o + (int64_t)b * p.o_bs + (int64_t)head * p.o_hs + qtok * p.o_ts;
+#pragma unroll
+  for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      op16x4 wv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wv[e] = f2op(o[d][4 * g + e] * inv);
+      *reinterpret_cast<op16x4*>(ob + d * 32 + 8 * g + 4 * h) = wv;
+    }
+  }
+#ifdef MSAM2_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ws3_ = __builtin_amdgcn_s_memrealtime();
+  if (tid == 0) {
+    const int wg = blockIdx.x + gridDim.x * blockIdx.y;
+    if (wg < 4096) { g_wgtime[wg][0] = ws0_; g_wgtime[wg][1] = ws1_; g_wgtime[wg][2] = ws2_; g_wgtime[wg][3] = ws3_; }
+  }
+#endif
+}
+
+// whole-window kernel: windows of 33 .. 256 queries whose K + V images (Lk + ceil8(Lk) rows of 192 B) let two workgroups share a CU
+static bool attn_win_applies(const AttnParams& p) {
+  const char* off = getenv("MSAM2_WIN_V1");
+  if (off && off[0] == '1') return false;
+  const int64_t lds = ((int64_t)p.Lk + ((p.Lk + 7) & ~7)) * 192;
+  // (q-pooled windows -- a quarter of the queries against the full key set -- are gather-bound either way and measured on par with
+  //  the tiled kernel: 26.7 vs 25.6 us at stage 3 -> 4; they stay there)
+  return p.Lq > 32 && p.Lq <= 256 && p.Lk >= 32 && 2 * p.Lq >= p.Lk && lds <= 80 * 1024;
+}
+
+static int launch_attn_win(const AttnParams& p, int Bz, hipStream_t s) {
+  const int lds = (p.Lk + ((p.Lk + 7) & ~7)) * 192;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)attn_win_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    attr_set = true;
+  }
+  // one wave per 32 queries; windows with few queries and many keys (q-pool blocks) get extra gather-only waves so that every thread
+  // still moves its share of the K / V rows in one batch (they leave after the barrier)
+  const int waves = min(8, max(cdiv(p.Lq, 32), cdiv((int64_t)p.Lk * 12, 6 * 64)));
+  hipLaunchKernelGGL((attn_win_kernel<96>), dim3(p.H, Bz), dim3(waves * 64), lds, s, p);
+  return msam2_check_launch("window_attention_fwd(win)");
+}
+
 // softmax(Q K^T * scale) V with 256-wide q / k rows and 64-wide value rows (attn_kv64_kernel): the memory cross-attention with the
 // value projection folded out of the attention (O' = P M; the caller applies W_v and b_v behind it).  o: [.., 64] rows; workspace and
 // merge as msam2_attention_fwd with D = 64 (msam2_attention_workspace_bytes(B, H, Lq, 64, splits), msam2_attention_merge(.., D = 64, ..)).
@@ -1156,7 +1376,7 @@ extern "C" int msam2_window_attention_fwd(const void* q, int64_t q_token_stride,
   hipStream_t s = (hipStream_t)stream;
   const int Bz = (int)B * nwy * nwx;
   switch (D) {
-    case 96: return dispatch_nw<96, true>(p, Bz, s);
+    case 96: return attn_win_applies(p) ? launch_attn_win(p, Bz, s) : dispatch_nw<96, true>(p, Bz, s);
     case 64: return dispatch_nw<64, true>(p, Bz, s);
     default: return dispatch_nw<128, true>(p, Bz, s);
   }
