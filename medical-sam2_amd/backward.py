@@ -490,11 +490,13 @@ def _convt_scatter_grad(dz, B, h, w):
 
 
 def mask_decoder_backward(dec, src_tokens: torch.Tensor, pe_tokens: torch.Tensor, sparse: torch.Tensor, feat_s0: torch.Tensor,
-                          feat_s1: torch.Tensor, B: int, h: int, w: int, d_masks: torch.Tensor):
+                          feat_s1: torch.Tensor, B: int, h: int, w: int, d_masks: torch.Tensor, aux: Optional[dict] = None):
     """Backward of `MaskDecoder.predict_masks_tokens` for a loss on the 4 mask logit maps: src_tokens fp32 [B*h*w, C] (image embedding +
     dense prompt), pe_tokens fp32 [h*w, C], sparse fp32 [B, P, C] prompt embeddings, feat_s0 / feat_s1 16-bit token-major high-res
     features, d_masks fp32 [B, 4, 4h, 4w].  The IoU and object-score heads do not see the mask loss and get no gradient.
-    Returns (d_src_tokens fp32 [B*h*w, C], d_sparse fp32 [B, P, C], {parameter name relative to the decoder: gradient})."""
+    Returns (d_src_tokens fp32 [B*h*w, C], d_sparse fp32 [B, P, C], {parameter name relative to the decoder: gradient}).
+    aux (optional dict) receives "d_feat_s0" / "d_feat_s1": the gradients of the two high-resolution feature maps (token-major, like the
+    inputs) -- what the image-encoder backward continues from (mask_decoder.py:244-247: both enter by a plain add)."""
     from .modeling.common import to_bf16, v_f32
     wc, C, L = dec._wc, dec.transformer_dim, h * w
     nm = dec.num_mask_tokens
@@ -536,11 +538,15 @@ def mask_decoder_backward(dec, src_tokens: torch.Tensor, pe_tokens: torch.Tensor
         ops.gemm(dm16[b], transpose16(u2b), out=d_hyper[b])                      # [nm, P] @ [P, Cu]
         ops.gemm(transpose16(dm16[b], 8), transpose16(hyper16[b], 8), out=d_u2[b * Pn:(b + 1) * Pn])   # [P, nm] @ [nm, Cu]
     dz2 = act_backward(z2, d_u2, ops.ACT_GELU)
+    if aux is not None:
+        aux["d_feat_s0"] = dz2                                                       # z2 = shuffle(g2) + b2 + feat_s0
     grads["output_upscaling.3.bias"] = colsum(dz2)
     d_u1, dw2, _ = linear_backward(u1, dc2_w, _convt_scatter_grad(dz2, B, 2 * h, 2 * w))
     grads["output_upscaling.3.weight"] = dw2.view(2, 2, C // 8, C // 4).permute(3, 2, 0, 1).contiguous()
     dy1 = act_backward(y1, d_u1, ops.ACT_GELU)
     dz1, grads["output_upscaling.1.weight"], grads["output_upscaling.1.bias"] = layernorm_backward(z1, lnw, dy1, 1e-6)
+    if aux is not None:
+        aux["d_feat_s1"] = dz1                                                       # z1 = shuffle(g1) + b1 + feat_s1
     grads["output_upscaling.0.bias"] = colsum(dz1)
     d_keys, dw1, _ = linear_backward(keys16, dc1_w, _convt_scatter_grad(dz1, B, h, w))
     grads["output_upscaling.0.weight"] = dw1.view(2, 2, C // 4, C).permute(3, 2, 0, 1).contiguous()

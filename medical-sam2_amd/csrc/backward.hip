@@ -972,3 +972,134 @@ extern "C" int msam2_attention_small_bwd(const void* q, int64_t q_bs, int64_t q_
 #undef ASB
   return msam2_check_launch("attention_small_bwd");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Adjoints of the Hiera trunk / FPN neck data-movement ops (the 2-D training loop differentiates the image encoder:
+// func_2d/function.py:70-72 under grad, 246-259).
+// ------------------------------------------------------------------------------------------------------------------
+// MaxPool2d(2, 2) backward on token-major [B*H*W, C] maps (do_pool, hieradet.py:23-34): dy goes to the FIRST maximum of each 2x2
+// window in scan order (what torch's max_pool2d keeps: a later element must be strictly greater), zeros elsewhere; every dx element
+// is written.
+template <typename TI>
+__global__ void maxpool2x2_bwd_kernel(const TI* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy, float* __restrict__ dx,
+                                      int64_t lddx, int B, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)B * Ho * Wo * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    int64_t t = i / C;
+    const int xo = t % Wo;
+    t /= Wo;
+    const int yo = t % Ho;
+    const int b = t / Ho;
+    const int64_t base = ((int64_t)b * H + 2 * yo) * W + 2 * xo;
+    const int64_t pos[4] = {base, base + 1, base + W, base + W + 1};
+    int arg = 0;
+    float best = (float)x[pos[0] * ldx + c];
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+      const float v = (float)x[pos[j] * ldx + c];
+      if (v > best || (v != v && best == best)) { best = v; arg = j; }
+    }
+    const float g = dy[(((int64_t)b * Ho + yo) * Wo + xo) * lddy + c];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dx[pos[j] * lddx + c] = (j == arg) ? g : 0.f;
+  }
+}
+
+extern "C" int msam2_maxpool2x2_bwd(const void* x, int x_is_16bit, int64_t ldx, const float* dy, int64_t lddy, float* dx, int64_t lddx,
+                                    int64_t B, int64_t H, int64_t W, int64_t C, void* stream) {
+  MSAM2_REQUIRE(x && dy && dx && B > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "maxpool2x2_bwd: bad arguments");
+  const int64_t total = B * (H / 2) * (W / 2) * C;
+  dim3 grid((unsigned)min((int64_t)8192, (total + 255) / 256)), block(256);
+  if (x_is_16bit) hipLaunchKernelGGL((maxpool2x2_bwd_kernel<op16>), grid, block, 0, (hipStream_t)stream, (const op16*)x, ldx, dy, lddy, dx, lddx, (int)B, (int)H, (int)W, (int)C);
+  else hipLaunchKernelGGL((maxpool2x2_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, ldx, dy, lddy, dx, lddx, (int)B, (int)H, (int)W, (int)C);
+  return msam2_check_launch("maxpool2x2_bwd");
+}
+
+// adjoint of the FPN's nearest-2x top-down step (msam2_upsample2x_add, image_encoder.py:113-124): out[b,i,j,c] = sum of the 2x2 block
+__global__ void sumpool2x2_kernel(const float* __restrict__ dy, float* __restrict__ out, int B, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)B * Ho * Wo * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    int64_t t = i / C;
+    const int xo = t % Wo;
+    t /= Wo;
+    const int yo = t % Ho;
+    const int b = t / Ho;
+    const int64_t base = (((int64_t)b * H + 2 * yo) * W + 2 * xo) * C + c;
+    out[i] = dy[base] + dy[base + C] + dy[base + (int64_t)W * C] + dy[base + (int64_t)W * C + C];
+  }
+}
+
+extern "C" int msam2_sumpool2x2(const float* dy, float* out, int64_t B, int64_t H, int64_t W, int64_t C, void* stream) {
+  MSAM2_REQUIRE(dy && out && B > 0 && C > 0 && H % 2 == 0 && W % 2 == 0, "sumpool2x2: bad arguments");
+  const int64_t total = B * (H / 2) * (W / 2) * C;
+  hipLaunchKernelGGL(sumpool2x2_kernel, dim3((unsigned)min((int64_t)8192, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, out,
+                     (int)B, (int)H, (int)W, (int)C);
+  return msam2_check_launch("sumpool2x2");
+}
+
+// Adjoint of msam2_hiera_pos_embed (Hiera._get_pos_embed, hieradet.py:269-277): d_table fp32 [h*w, C] (the gradient of the position
+// tokens, already summed over the batch) -> d pos_embed [C, bh, bw] through the transposed bicubic resize (same tap weights and border
+// clamping as the forward: the resize is separable, so the weight of source row y for output row yy is a 1-D table) and
+// d pos_embed_window [C, wsz, wsz] (sum over the tiling).  Gather form: one workgroup per source pixel, one thread per channel; no atomics.
+__device__ __forceinline__ float cubic1_b(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2_b(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+__global__ void hiera_pos_bwd_kernel(const float* __restrict__ d_table, float* __restrict__ d_bkg, float* __restrict__ d_win, int C, int bh,
+                                     int bw, int h, int w, int wsz) {
+  extern __shared__ float wts[];                             // [h] row weights, [w] column weights of this source pixel
+  float* wy = wts;
+  float* wx = wts + h;
+  const float A = -0.75f;
+  const int nb = bh * bw;
+  if ((int)blockIdx.x < nb) {
+    const int sy = blockIdx.x / bw, sx = blockIdx.x % bw;
+    for (int i = threadIdx.x; i < h + w; i += blockDim.x) {
+      const bool row = i < h;
+      const int o = row ? i : i - h, n_out = row ? h : w, n_src = row ? bh : bw, src = row ? sy : sx;
+      const float f = (o + 0.5f) * ((float)n_src / n_out) - 0.5f;
+      const int i0 = (int)floorf(f);
+      const float t = f - i0;
+      const float tap[4] = {cubic2_b(t + 1.f, A), cubic1_b(t, A), cubic1_b(1.f - t, A), cubic2_b(2.f - t, A)};
+      float acc = 0.f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        if (min(max(i0 - 1 + a, 0), n_src - 1) == src) acc += tap[a];
+      wts[i] = acc;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float acc = 0.f;
+      for (int yy = 0; yy < h; ++yy) {
+        const float a = wy[yy];
+        if (a == 0.f) continue;
+        float rowv = 0.f;
+        for (int xx = 0; xx < w; ++xx) {
+          const float bq = wx[xx];
+          if (bq != 0.f) rowv += bq * d_table[((int64_t)yy * w + xx) * C + c];
+        }
+        acc += a * rowv;
+      }
+      d_bkg[((int64_t)c * bh + sy) * bw + sx] = acc;
+    }
+  } else {
+    const int cell = blockIdx.x - nb, y = cell / wsz, x = cell % wsz;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float acc = 0.f;
+      for (int yy = y; yy < h; yy += wsz)
+        for (int xx = x; xx < w; xx += wsz) acc += d_table[((int64_t)yy * w + xx) * C + c];
+      d_win[((int64_t)c * wsz + y) * wsz + x] = acc;
+    }
+  }
+}
+
+extern "C" int msam2_hiera_pos_embed_bwd(const float* d_table, float* d_pos_embed, float* d_pos_embed_window, int64_t C, int64_t bh,
+                                         int64_t bw, int64_t h, int64_t w, int64_t window, void* stream) {
+  MSAM2_REQUIRE(d_table && d_pos_embed && d_pos_embed_window && C > 0 && h % window == 0 && w % window == 0, "hiera_pos_embed_bwd: bad arguments");
+  hipLaunchKernelGGL(hiera_pos_bwd_kernel, dim3((unsigned)(bh * bw + window * window)), dim3(128), (size_t)(h + w) * sizeof(float),
+                     (hipStream_t)stream, d_table, d_pos_embed, d_pos_embed_window, (int)C, (int)bh, (int)bw, (int)h, (int)w, (int)window);
+  return msam2_check_launch("hiera_pos_embed_bwd");
+}

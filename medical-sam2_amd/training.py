@@ -224,7 +224,7 @@ def memory_decoder_loss_grads(memory_attention, decoder, curr, curr_pos, memory,
         n_loss, extra = target_masks.numel(), 4
     scale = 2.0 ** (math.floor(math.log2(n_loss / max(float(pos_weight), 1.0))) - 4 - extra)
     d_masks.mul_(scale)
-    d_src, _, g_dec = bwd.mask_decoder_backward(decoder, src, pe_tokens, sparse, feat_s0, feat_s1, B, h, w, d_masks)
+    d_src, _, g_dec = bwd.mask_decoder_backward(decoder, src, pe_tokens, sparse, feat_s0, feat_s1, B, h, w, d_masks, aux=aux)
     if mem_scale is None:
         mem_scale = _shared_pow2_scale(d_src.abs().max().reshape(1), data_parallel)
     d_src = d_src * mem_scale
@@ -260,17 +260,25 @@ def memory_decoder_finetune_step(memory_attention, decoder, opt_mem: DecoderAdam
 
 @torch.no_grad()
 def train_step_2d(model, opt_mem: DecoderAdam, opt_dec: DecoderAdam, imgs, pts, labels, memory, memory_pos, target_masks, sync: bool = True,
-                  mask_index: int = None):
-    """One training iteration of the 2-D flow (func_2d/function.py:70-259) on the HIP path with the image and prompt encoders frozen
-    (train_3d.py:34-37's choice of trainable groups): image encoder forward -> memory attention over the (detached) bank -> prompt
-    encoder -> mask decoder -> BCE on the mask logits -> backward of decoder + memory attention -> Adam on both -> the new memory is
-    encoded from the predicted mask for the bank (forward only, stored detached as func_2d/function.py:204-243 does).
+                  mask_index: int = None, opt_enc: DecoderAdam = None, grads_out: dict = None):
+    """One training iteration of the 2-D flow (func_2d/function.py:70-259) on the HIP path: image encoder forward -> memory attention
+    over the (detached) bank -> prompt encoder (no gradient: it runs under torch.no_grad() in the reference, func_2d/function.py:140-149)
+    -> mask decoder -> BCE on the mask logits -> backward of decoder + memory attention (+ the image encoder) -> Adam -> the new memory
+    is encoded from the predicted mask for the bank (forward only, stored detached as func_2d/function.py:204-243 does).
+    opt_enc (a DecoderAdam over `model.image_encoder`): also differentiate and update the IMAGE ENCODER -- Hiera trunk + FPN neck, and
+    through the neck the mask decoder's conv_s0 / conv_s1 -- as train_2d.py:43-47 does (AdamW over every net.parameters(), the encoder
+    under grad at func_2d/function.py:70-72); None keeps it frozen (train_3d.py:34-37's choice of groups).
     imgs [B,3,S,S] normalised, pts [B,P,2] / labels [B,P] clicks, memory / memory_pos [Nk,B,64] (bench.assemble_memory layout),
     target_masks [B, num_mask_tokens, S/4, S/4], or with mask_index [B, 1, S, S] (the reference's loss on that up-sampled mask).
+    grads_out (optional dict): receives the TRUE gradients of every group ("decoder", "memory_attention", "image_encoder") for audits.
     Returns (loss, maskmem_features [B,64,S/16,S/16])."""
+    from . import backward_encoder as be
     from .modeling.common import to_bf16, tokens_of
     B = imgs.shape[0]
-    backbone_out = model.forward_image(imgs)
+    if opt_enc is not None:
+        backbone_out, enc_state = be.image_encoder_forward_saved(model, imgs)
+    else:
+        backbone_out = model.forward_image(imgs)
     _, vision_feats, vision_pos_embeds, feat_sizes = model._prepare_backbone_features(backbone_out)
     h, w = feat_sizes[-1]
     se, _ = model.sam_prompt_encoder(points=(pts, labels), boxes=None, masks=None, batch_size=B)
@@ -281,11 +289,31 @@ def train_step_2d(model, opt_mem: DecoderAdam, opt_dec: DecoderAdam, imgs, pts, 
     aux: dict = {}
     cal = getattr(opt_mem, "calibrated_loss_scales", {})                         # one calibration per loss form
     kwargs = dict(dense_tokens=dense, aux=aux, mem_scale=cal.get(mask_index), mask_index=mask_index)
-    loss, scale, scale_mem, g_dec, g_mem, _ = memory_decoder_loss_grads(
+    loss, scale, scale_mem, g_dec, g_mem, dcurr = memory_decoder_loss_grads(
         model.memory_attention, model.sam_mask_decoder, vision_feats[-1], vision_pos_embeds[-1], memory, memory_pos, 0, pe, se.to(torch.float32),
         f0, f1, B, h, w, target_masks, **kwargs)
     cal[mask_index] = scale_mem / scale
     opt_mem.calibrated_loss_scales = cal
+    if opt_enc is not None:
+        # the encoder's three outputs received: level 0 / 1 through the decoder's up-scaling adds (loss scale `scale`), level 2 through
+        # the memory attention's query stream (`scale_mem`); the encoder backward runs every block under its own cached scale
+        C = dcurr.shape[-1]
+        d_top = dcurr.transpose(0, 1).reshape(B * h * w, C).contiguous()
+        enc_scales = getattr(opt_enc, "calibrated_block_scales", None)
+        if enc_scales is None:
+            enc_scales = opt_enc.calibrated_block_scales = {}
+        g_all = be.image_encoder_backward(model, enc_state, [aux["d_feat_s0"], aux["d_feat_s1"], d_top], [scale, scale, scale_mem],
+                                          enc_scales.setdefault(mask_index, {}))
+        g_enc = {k[len("image_encoder."):]: v for k, v in g_all.items() if k.startswith("image_encoder.")}
+        for k, v in g_all.items():                                               # conv_s0 / conv_s1 live in the decoder's group
+            if k.startswith("sam_mask_decoder."):
+                g_dec[k[len("sam_mask_decoder."):]] = v * scale
+        opt_enc.step(g_enc, grad_scale=1.0)
+        if grads_out is not None:
+            grads_out["image_encoder"] = g_enc
+    if grads_out is not None:
+        grads_out["decoder"] = {k: v / scale for k, v in g_dec.items()}
+        grads_out["memory_attention"] = {k: v / scale_mem for k, v in g_mem.items()}
     opt_dec.step(g_dec, grad_scale=1.0 / scale)
     opt_mem.step(g_mem, grad_scale=1.0 / scale_mem)
     low_res = aux["masks"][:, :1].contiguous()                                   # single-mask output token (multimask_output=False)

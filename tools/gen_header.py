@@ -52,6 +52,9 @@ DOC = {
     "msam2_col2im3x3s2": "Adjoint of msam2_im2col3x3s2: input gradient of the mask down-sampler's k3 s2 p1 convolutions (memory_encoder.py:38-47) from the\ncolumn gradient of their GEMM form.",
     "msam2_gemm_tt": "Weight-gradient GEMM C[M,N] (fp32) = sum_k A[k][m] B[k][n] on k-major 16-bit operands: dW = dY^T X of nn.Linear under autograd\n(sam2_utils.py:127-131, memory_attention.py:96, transformer.py:241-261) straight from the token-major dY and X -- no transposed copies;\nthe token reduction is split over workgroups (fp32 atomics into the zeroed output).  a_colsum (optional, [M]) receives sum_k A[k][m]:\nthe bias gradient in the same pass over dY.",
     "msam2_bilinear_upsample_bwd": "Adjoint of msam2_bilinear_upsample: gradient of the video-resolution mask logits (sam2_video_predictor.py:724-744, the tensor the\ntraining loss of func_3d/function.py:137-170 is taken on) back to the decoder's low-resolution logits.",
+    "msam2_maxpool2x2_bwd": "Backward of MaxPool2d(2, 2) on token-major maps (do_pool, hieradet.py:23-34, under autograd in the 2-D training loop,\nfunc_2d/function.py:70-72): dy is routed to the first maximum of each 2x2 window, every dx element is written.",
+    "msam2_sumpool2x2": "Adjoint of msam2_upsample2x_add (FPN nearest-2x top-down step, image_encoder.py:113-124): sums of the 2x2 blocks.",
+    "msam2_hiera_pos_embed_bwd": "Adjoint of msam2_hiera_pos_embed (hieradet.py:269-277): gradient of the position-token table -> d pos_embed (transposed bicubic\nresize) and d pos_embed_window (sum over the tiling).",
     "msam2_adam_step": "One torch.optim.Adam step (no weight decay / amsgrad) on a flat fp32 parameter (train_3d.py:50).",
     "msam2_adam_step_multi": "The same Adam step over `count` parameters (host arrays of device pointers and element counts), 24 per launch;\ngradients are multiplied by grad_scale first (1 / loss scale);\nstep_counter (device int32, optional): the step count lives on the device and is incremented by the call (a kernel), so a captured\nhipGraph advances the bias corrections on every replay; non-finite gradient entries are skipped;\nweight_decay > 0 gives torch.optim.AdamW's decoupled decay (train_2d.py:43-47), 0 plain Adam (train_3d.py:50-54).",
     "msam2_attention_small_bwd": "Backward of the two-way decoder's attention (transformer.py:239-263 under autograd; 8 heads of 16 / 32 channels) when one side has\n<= 32 tokens: dq / dk / dv (fp32, token-major) from 16-bit q / k / v and the fp32 upstream gradient, one workgroup per (batch, head).",
