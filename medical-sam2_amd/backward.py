@@ -160,6 +160,67 @@ def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: to
     return dq, dk, dv
 
 
+DROP_SITES = {"sa_attn": 0, "drop1": 1, "ca_attn": 2, "drop2": 3, "ffn": 4, "drop3": 5}
+
+
+def drop_offset(layer_idx: int, site: str) -> int:
+    """start of the counter stream of one dropout site of one memory-attention layer (2^40 elements apart: the largest site, the
+    cross-attention probabilities, has B * L * Nk < 2^40 elements)"""
+    return (layer_idx * 8 + DROP_SITES[site]) << 40
+
+
+def _softmax_probs(qm: torch.Tensor, km: torch.Tensor, scale: float):
+    """16-bit P = softmax(q k^T * scale) of one (batch, head): [Lq, Lk] view of a buffer whose rows are zero-padded to a multiple of 8"""
+    Lq, Lk = qm.shape[0], km.shape[0]
+    Lkp = -(-Lk // 8) * 8
+    S = ops.gemm(qm, km, out_dtype=F32)
+    Pbuf = torch.zeros(Lq, Lkp, dtype=OP16, device=qm.device)
+    check(lib().msam2_softmax_rows(_p(S), S.stride(0), _p(Pbuf), Pbuf.stride(0), Lq, Lk, scale, _stream()))
+    return Pbuf, Lkp
+
+
+def attention_dropout_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p: float, seed: int, offset: int) -> torch.Tensor:
+    """Single-head attention with dropout on the probabilities (F.scaled_dot_product_attention(dropout_p=p), transformer.py:317-318
+    in train mode): q [B, Lq, C], k / v [B, Lk, C] 16-bit -> 16-bit [B*Lq, C].  Materialised per batch element (scores fp32, P 16-bit
+    in HBM): the flash kernels carry no mask generator yet.  Mask stream: element offset + (b * Lq + i) * Lk + j."""
+    B, Lq, C = q.shape
+    Lk = k.shape[1]
+    scale = C ** -0.5
+    out = torch.empty(B * Lq, C, dtype=OP16, device=q.device)
+    for b in range(B):
+        Pbuf, Lkp = _softmax_probs(q[b], k[b], scale)
+        Pd = torch.zeros(Lq, Lkp, dtype=OP16, device=q.device)
+        ops.dropout(Pbuf[:, :Lk], p, seed, offset + b * Lq * Lk, out=Pd[:, :Lk])
+        ops.gemm(Pd, transpose16(v[b], 8), out=out[b * Lq:(b + 1) * Lq])
+    return out
+
+
+def attention_dropout_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: torch.Tensor, p: float, seed: int, offset: int):
+    """Backward of `attention_dropout_forward` (P recomputed, the mask re-created from the same stream): do [B*Lq, C] any float type.
+    Returns fp32 (dq [B, Lq, C], dk [B, Lk, C], dv [B, Lk, C])."""
+    B, Lq, C = q.shape
+    Lk = k.shape[1]
+    scale = C ** -0.5
+    dq = torch.empty(B, Lq, C, dtype=F32, device=q.device)
+    dk = torch.empty(B, Lk, C, dtype=F32, device=q.device)
+    dv = torch.empty(B, Lk, C, dtype=F32, device=q.device)
+    do16 = _op16(do.reshape(B * Lq, C)).view(B, Lq, C)
+    for b in range(B):
+        off = offset + b * Lq * Lk
+        Pbuf, Lkp = _softmax_probs(q[b], k[b], scale)
+        P = Pbuf[:, :Lk]
+        Pd = ops.dropout(P, p, seed, off)                                          # [Lq, Lk] contiguous
+        ops.gemm(transpose16(Pd, 8), transpose16(do16[b], 8), out=dv[b])          # dV = Pd^T dO
+        dPd = ops.gemm(do16[b], v[b], out_dtype=F32)                               # dO V^T  [Lq, Lk]
+        dP = ops.dropout(dPd, p, seed, off)                                        # the same mask and 1 / (1 - p)
+        dSbuf = torch.zeros(Lq, Lkp, dtype=OP16, device=q.device)
+        dS = dSbuf[:, :Lk]
+        check(lib().msam2_softmax_bwd_rows(_p(P), P.stride(0), _p(dP), dP.stride(0), _p(dS), dS.stride(0), Lq, Lk, scale, _stream()))
+        ops.gemm(dSbuf, transpose16(k[b], 8), out=dq[b])                          # dQ = dS K
+        ops.gemm(transpose16(dS, 8), transpose16(q[b], 8), out=dk[b])             # dK = dS^T Q
+    return dq, dk, dv
+
+
 def _rope_adjoint_(t: torch.Tensor, n_rope: int, table) -> torch.Tensor:
     """adjoint of the axial RoPE rotation (a rotation by the negative angle), in place on a 16-bit [B, N, D] gradient"""
     cs, sn = table
@@ -167,9 +228,12 @@ def _rope_adjoint_(t: torch.Tensor, n_rope: int, table) -> torch.Tensor:
 
 
 def _memory_attention_layer_forward_saved(layer, x: torch.Tensor, mem_k: torch.Tensor, mem_v: torch.Tensor, B: int, L: int,
-                                          n_ptr_tokens: int):
-    """`MemoryAttentionLayer.run` (memory_attention.py:17-99, eval mode) with every intermediate the backward needs kept: returns
-    (y fp32 [B*L, C], context for `_memory_attention_layer_backward_saved`)."""
+                                          n_ptr_tokens: int, drop: Optional[dict] = None):
+    """`MemoryAttentionLayer.run` (memory_attention.py:17-99) with every intermediate the backward needs kept: returns
+    (y fp32 [B*L, C], context for `_memory_attention_layer_backward_saved`).
+    drop = {"p", "seed", "layer"}: TRAIN mode -- nn.Dropout(p) on the three residual branches (dropout1 / 2 / 3, memory_attention.py:63,
+    80, 98), inside the FFN (97) and on both attentions' probabilities (transformer.py:317-318), masks from the counter streams
+    `drop_offset(layer, site)` of `seed`; None: eval mode (dropout is the identity)."""
     from .modeling.common import v_f32, w_bf16
     sa, ca, wc = layer.self_attn, layer.cross_attn_image, layer._wc
     C, Nk = layer.d_model, mem_k.shape[1]
@@ -188,9 +252,15 @@ def _memory_attention_layer_forward_saved(layer, x: torch.Tensor, mem_k: torch.T
     ops.rope_(k1, L, tab)
     u4 = lambda t: t.unsqueeze(1)                                                 # [B, N, C] -> [B, 1, N, C]
     flash = C in (64, 96, 128, 256) and not os.environ.get("MSAM2_MATERIALISED_BWD")
-    ol1 = attention_forward_lse(u4(q1), u4(k1), u4(v1)) if flash else None
-    a1 = ol1[0].permute(0, 2, 1, 3).reshape(B * L, C) if flash else sa.core(q1, k1, v1)   # 16-bit [B*L, C]
-    x1 = sa.out(a1, x)
+    dp, dseed, dl = (drop["p"], drop["seed"], drop["layer"]) if drop else (0.0, 0, 0)
+    if drop:
+        flash, ol1 = False, None
+        a1 = attention_dropout_forward(q1, k1, v1, dp, dseed, drop_offset(dl, "sa_attn"))
+        x1 = ops.dropout(sa.out(a1, None), dp, dseed, drop_offset(dl, "drop1"), residual=x)
+    else:
+        ol1 = attention_forward_lse(u4(q1), u4(k1), u4(v1)) if flash else None
+        a1 = ol1[0].permute(0, 2, 1, 3).reshape(B * L, C) if flash else sa.core(q1, k1, v1)   # 16-bit [B*L, C]
+        x1 = sa.out(a1, x)
     t2 = ln("norm2", x1)
     wq, wk, wv = W("qw", ca.q_proj.weight), W("kw", ca.k_proj.weight), W("vw", ca.v_proj.weight)
     q2 = ops.gemm(t2, wq, Bv("qb", ca.q_proj.bias)).view(B, L, C)
@@ -199,14 +269,23 @@ def _memory_attention_layer_forward_saved(layer, x: torch.Tensor, mem_k: torch.T
     kk = ops.gemm(mk2, wk, Bv("kb", ca.k_proj.bias)).view(B, Nk, C)
     ops.rope_(kk, Nk - n_ptr_tokens, tab)
     vv = ops.gemm(mv2, wv, Bv("vb", ca.v_proj.bias)).view(B, Nk, C)
-    ol2 = attention_forward_lse(u4(q2), u4(kk), u4(vv)) if flash else None
-    a2 = ol2[0].permute(0, 2, 1, 3).reshape(B * L, C) if flash else ca.core(q2, kk, vv)
-    x2 = ca.out(a2, x1)
+    if drop:
+        ol2 = None
+        a2 = attention_dropout_forward(q2, kk, vv, dp, dseed, drop_offset(dl, "ca_attn"))
+        x2 = ops.dropout(ca.out(a2, None), dp, dseed, drop_offset(dl, "drop2"), residual=x1)
+    else:
+        ol2 = attention_forward_lse(u4(q2), u4(kk), u4(vv)) if flash else None
+        a2 = ol2[0].permute(0, 2, 1, 3).reshape(B * L, C) if flash else ca.core(q2, kk, vv)
+        x2 = ca.out(a2, x1)
     t3 = ln("norm3", x2)
     w1, w2 = W("f1", layer.linear1.weight), W("f2", layer.linear2.weight)
     hid = ops.gemm(t3, w1, Bv("f1b", layer.linear1.bias), act=ops.ACT_RELU)
-    y = ops.gemm(hid, w2, Bv("f2b", layer.linear2.bias), residual=x2, out_dtype=F32)
-    ctx = dict(x=x, t1=t1, w_qkv=w_qkv, q1=q1, k1=k1, v1=v1, ol1=ol1, a1=a1, x1=x1, t2=t2, wq=wq, wk=wk, wv=wv, q2=q2, mk2=mk2, mv2=mv2,
+    if drop:
+        hid = ops.dropout(hid, dp, dseed, drop_offset(dl, "ffn"))
+        y = ops.dropout(ops.gemm(hid, w2, Bv("f2b", layer.linear2.bias), out_dtype=F32), dp, dseed, drop_offset(dl, "drop3"), residual=x2)
+    else:
+        y = ops.gemm(hid, w2, Bv("f2b", layer.linear2.bias), residual=x2, out_dtype=F32)
+    ctx = dict(drop=drop, x=x, t1=t1, w_qkv=w_qkv, q1=q1, k1=k1, v1=v1, ol1=ol1, a1=a1, x1=x1, t2=t2, wq=wq, wk=wk, wv=wv, q2=q2, mk2=mk2, mv2=mv2,
                kk=kk, vv=vv, ol2=ol2, a2=a2, x2=x2, t3=t3, w1=w1, w2=w2, tab=tab, B=B, L=L, Nk=Nk, C=C, n_ptr=n_ptr_tokens)
     return y, ctx
 
@@ -222,13 +301,29 @@ def _memory_attention_layer_backward_saved(layer, ctx: dict, dy: torch.Tensor):
     wq, wk, wv, q2, mk2, mv2, kk, vv, ol2, a2, x2, t3 = (ctx[k] for k in ("wq", "wk", "wv", "q2", "mk2", "mv2", "kk", "vv", "ol2", "a2", "x2", "t3"))
     w1, w2, tab, B, L, Nk, C, n_ptr_tokens = (ctx[k] for k in ("w1", "w2", "tab", "B", "L", "Nk", "C", "n_ptr"))
     g = {}
-    dt3, g["linear1.weight"], g["linear1.bias"], g["linear2.weight"], g["linear2.bias"] = mlp_backward(
-        t3, w1, Bv("f1b", layer.linear1.bias), w2, Bv("f2b", layer.linear2.bias), dy, ops.ACT_RELU)
+    drop = ctx.get("drop")
+    dp, dseed, dl = (drop["p"], drop["seed"], drop["layer"]) if drop else (0.0, 0, 0)
+    if drop:
+        # FFN with its two dropouts: y = x2 + drop3(linear2(drop_ffn(relu(linear1(t3)))))
+        b1v = Bv("f1b", layer.linear1.bias)
+        pre = ops.gemm(t3, w1, b1v, out_dtype=F32)
+        hid_d = ops.dropout(ops.gemm(t3, w1, b1v, act=ops.ACT_RELU), dp, dseed, drop_offset(dl, "ffn"))
+        d_ffn = ops.dropout(dy.to(F32).contiguous(), dp, dseed, drop_offset(dl, "drop3"))
+        dhid_d, g["linear2.weight"], g["linear2.bias"] = linear_backward(hid_d, w2, d_ffn)
+        dpre = act_backward(pre, ops.dropout(dhid_d, dp, dseed, drop_offset(dl, "ffn")), ops.ACT_RELU)
+        dt3, g["linear1.weight"], g["linear1.bias"] = linear_backward(t3, w1, dpre)
+    else:
+        dt3, g["linear1.weight"], g["linear1.bias"], g["linear2.weight"], g["linear2.bias"] = mlp_backward(
+            t3, w1, Bv("f1b", layer.linear1.bias), w2, Bv("f2b", layer.linear2.bias), dy, ops.ACT_RELU)
     dx2, g["norm3.weight"], g["norm3.bias"] = layernorm_backward(x2, layer.norm3.weight.detach().float(), dt3, layer.norm3.eps,
                                                                  add=dy)          # residual branch + LayerNorm branch
     # cross attention
-    da2, g["cross_attn_image.out_proj.weight"], g["cross_attn_image.out_proj.bias"] = linear_backward(a2, W("ow", ca.out_proj.weight), dx2)
-    dq2, dkk, dvv = attention_backward(u4(q2), u4(kk), u4(vv), u4(da2.view(B, L, C)), o_lse=ol2)
+    d_ca = ops.dropout(dx2, dp, dseed, drop_offset(dl, "drop2")) if drop else dx2
+    da2, g["cross_attn_image.out_proj.weight"], g["cross_attn_image.out_proj.bias"] = linear_backward(a2, W("ow", ca.out_proj.weight), d_ca)
+    if drop:
+        dq2, dkk, dvv = attention_dropout_backward(q2, kk, vv, da2, dp, dseed, drop_offset(dl, "ca_attn"))
+    else:
+        dq2, dkk, dvv = attention_backward(u4(q2), u4(kk), u4(vv), u4(da2.view(B, L, C)), o_lse=ol2)
     dq2, dkk = _op16(dq2.view(B * L, C)).view(B, L, C), _op16(dkk.view(B * Nk, C)).view(B, Nk, C)
     _rope_adjoint_(dq2, L, tab)
     _rope_adjoint_(dkk, Nk - n_ptr_tokens, tab)
@@ -237,8 +332,12 @@ def _memory_attention_layer_backward_saved(layer, ctx: dict, dy: torch.Tensor):
     dmv, g["cross_attn_image.v_proj.weight"], g["cross_attn_image.v_proj.bias"] = linear_backward(mv2, wv, dvv.view(B * Nk, C))
     dx1, g["norm2.weight"], g["norm2.bias"] = layernorm_backward(x1, layer.norm2.weight.detach().float(), dt2, layer.norm2.eps, add=dx2)
     # self attention
-    da1, g["self_attn.out_proj.weight"], g["self_attn.out_proj.bias"] = linear_backward(a1, W("ow_s", sa.out_proj.weight), dx1)
-    dq1, dk1, dv1 = attention_backward(u4(q1), u4(k1), u4(v1), u4(da1.view(B, L, C)), o_lse=ol1)
+    d_sa = ops.dropout(dx1, dp, dseed, drop_offset(dl, "drop1")) if drop else dx1
+    da1, g["self_attn.out_proj.weight"], g["self_attn.out_proj.bias"] = linear_backward(a1, W("ow_s", sa.out_proj.weight), d_sa)
+    if drop:
+        dq1, dk1, dv1 = attention_dropout_backward(q1, k1, v1, da1, dp, dseed, drop_offset(dl, "sa_attn"))
+    else:
+        dq1, dk1, dv1 = attention_backward(u4(q1), u4(k1), u4(v1), u4(da1.view(B, L, C)), o_lse=ol1)
     dq16, dk16, dv16 = (_op16(t.view(B * L, C)).view(B, L, C) for t in (dq1, dk1, dv1))
     _rope_adjoint_(dq16, L, tab)
     _rope_adjoint_(dk16, L, tab)
@@ -263,9 +362,10 @@ def memory_attention_layer_backward(layer, x: torch.Tensor, mem_k: torch.Tensor,
 
 
 def memory_attention_forward_saved(module, curr: torch.Tensor, curr_pos: torch.Tensor, memory: torch.Tensor, memory_pos: torch.Tensor,
-                                   num_obj_ptr_tokens: int):
+                                   num_obj_ptr_tokens: int, dropout: Optional[Tuple[float, int]] = None):
     """`MemoryAttention.forward` (memory_attention.py:119-169; seq-first [L, B, C] tensors) keeping every layer's intermediates:
-    returns (y fp32 [L, B, C], state for `memory_attention_backward_saved`)."""
+    returns (y fp32 [L, B, C], state for `memory_attention_backward_saved`).  dropout = (p, seed): train mode (see
+    `_memory_attention_layer_forward_saved`); the backward re-creates every mask from the same seed."""
     from .modeling.common import v_f32
     L, B, C = curr.shape
     x = ops.add_cast(curr.transpose(0, 1), curr_pos.transpose(0, 1), 0.1, F32).reshape(B * L, C)
@@ -273,8 +373,9 @@ def memory_attention_forward_saved(module, curr: torch.Tensor, curr_pos: torch.T
     mem_k = ops.add_cast(mem_bf, memory_pos.transpose(0, 1), 1.0, OP16)
     mem_v = ops.add_cast(mem_bf, None, 1.0, OP16)
     ctxs = []
-    for layer in module.layers:
-        x, ctx = _memory_attention_layer_forward_saved(layer, x, mem_k, mem_v, B, L, num_obj_ptr_tokens)
+    for li, layer in enumerate(module.layers):
+        drop = {"p": float(dropout[0]), "seed": int(dropout[1]), "layer": li} if dropout and dropout[0] > 0 else None
+        x, ctx = _memory_attention_layer_forward_saved(layer, x, mem_k, mem_v, B, L, num_obj_ptr_tokens, drop=drop)
         ctxs.append(ctx)
     y = ops.layernorm(x, v_f32(module._wc, "nw", module.norm.weight), v_f32(module._wc, "nb", module.norm.bias), module.norm.eps, out_dtype=F32)
     return y.view(B, L, C).transpose(0, 1), dict(ctxs=ctxs, x_last=x, B=B, L=L, C=C)

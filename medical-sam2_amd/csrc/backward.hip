@@ -1103,3 +1103,48 @@ extern "C" int msam2_hiera_pos_embed_bwd(const float* d_table, float* d_pos_embe
                      (hipStream_t)stream, d_table, d_pos_embed, d_pos_embed_window, (int)C, (int)bh, (int)bw, (int)h, (int)w, (int)window);
   return msam2_check_launch("hiera_pos_embed_bwd");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Train-mode dropout (memory_attention.py:40-48,63,80,97-98: nn.Dropout(0.1) on the three residual branches and inside the FFN;
+// transformer.py:317-318: dropout_p on the attention probabilities) with a COUNTER-BASED generator: element i of stream
+// (seed, offset) is kept iff mix64(seed + (offset + i) * golden) >> 32 >= p * 2^32, so the backward re-creates the mask of the
+// forward from the same (seed, offset) -- nothing is stored.  y = keep ? x / (1 - p) : 0  (+ residual).  The same call on a gradient
+// is the backward.  (Not torch's Philox stream: masks match in distribution, not bit for bit -- parity is pinned with the oracle
+// consuming the masks this kernel produces.)
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, unsigned thr) {
+  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (unsigned)(z >> 32) >= thr;
+}
+
+template <typename TI, typename TO>
+__global__ void dropout_kernel(const TI* __restrict__ x, int64_t ldx, const float* __restrict__ res, int64_t ldr, TO* __restrict__ y, int64_t ldy,
+                               int64_t rows, int64_t cols, unsigned thr, float inv_keep, uint64_t seed, uint64_t offset) {
+  const int64_t total = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols, c = i - r * cols;
+    float v = dropout_keep(seed, offset + (uint64_t)i, thr) ? (float)x[r * ldx + c] * inv_keep : 0.f;
+    if (res) v += res[r * ldr + c];
+    y[r * ldy + c] = (TO)v;
+  }
+}
+
+// x / y: [rows, cols] with row strides (elements); residual (optional) fp32.  The element index of the stream is r * cols + c.
+extern "C" int msam2_dropout(const void* x, int x_is_16bit, int64_t ldx, const float* residual, int64_t ldr, void* y, int y_is_16bit, int64_t ldy,
+                             int64_t rows, int64_t cols, float p, uint64_t seed, uint64_t offset, void* stream) {
+  MSAM2_REQUIRE(x && y && rows > 0 && cols > 0 && p >= 0.f && p < 1.f, "dropout: bad arguments");
+  const unsigned thr = (unsigned)fmin(4294967295.0, (double)p * 4294967296.0);
+  const float inv_keep = 1.f / (1.f - p);
+  dim3 grid((unsigned)min((int64_t)8192, cdiv(rows * cols, 256))), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define DR(TI, TO) hipLaunchKernelGGL((dropout_kernel<TI, TO>), grid, block, 0, s, (const TI*)x, ldx, residual, ldr, (TO*)y, ldy, rows, cols, thr, inv_keep, seed, offset)
+  if (x_is_16bit && y_is_16bit) DR(op16, op16);
+  else if (x_is_16bit) DR(op16, float);
+  else if (y_is_16bit) DR(float, op16);
+  else DR(float, float);
+#undef DR
+  return msam2_check_launch("dropout");
+}

@@ -232,7 +232,8 @@ class MemoryAttentionLayer(nn.Module):
 
     def forward(self, tgt, memory, pos: Optional[torch.Tensor] = None, query_pos: Optional[torch.Tensor] = None,
                 num_k_exclude_rope: int = 0) -> torch.Tensor:
-        assert not self.training or self.dropout_value == 0.0, "dropout (train mode) is outside the forward hot path"
+        assert not self.training or self.dropout_value == 0.0, \
+            "train-mode dropout runs through MemoryAttention.forward / training.* (backward.memory_attention_forward_saved), not a bare layer"
         B, L, C = tgt.shape
         mem_k = ops.add_cast(memory, pos, 1.0, OP16)
         mem_v = ops.add_cast(memory, None, 1.0, OP16)
@@ -253,6 +254,17 @@ class MemoryAttention(nn.Module):
         self.pos_enc_at_input = pos_enc_at_input
         self.batch_first = batch_first
         self._wc = WeightCache()
+        self.dropout_seed = 0            # stream of the train-mode dropout masks; every train-mode forward draws a fresh sub-stream
+        self._dropout_calls = 0
+
+    def next_dropout(self):
+        """(p, seed) of the next train-mode forward, or None in eval mode / with dropout 0 (memory_attention.py:40-48: nn.Dropout(0.1)
+        in every layer, transformer.py:317-318: dropout_p on the attention probabilities while self.training)."""
+        p = float(self.layers[0].dropout_value) if len(self.layers) else 0.0
+        if not self.training or p <= 0.0:
+            return None
+        self._dropout_calls += 1
+        return p, (int(self.dropout_seed) << 32) + self._dropout_calls
 
     def forward(self, curr: torch.Tensor, memory: torch.Tensor, curr_pos: Optional[torch.Tensor] = None,
                 memory_pos: Optional[torch.Tensor] = None, num_obj_ptr_tokens: int = 0):
@@ -261,6 +273,12 @@ class MemoryAttention(nn.Module):
             curr, curr_pos = curr[0], curr_pos[0]
         assert curr.shape[1] == memory.shape[1], "Batch size must be the same for curr and memory"
         L, B, C = curr.shape
+        drop = self.next_dropout()
+        if drop is not None:
+            # train mode: the dropout-carrying path of the training steps (backward.memory_attention_forward_saved), forward half only
+            from .. import backward as bwd
+            zero = torch.zeros_like(curr) if curr_pos is None or not self.pos_enc_at_input else curr_pos
+            return bwd.memory_attention_forward_saved(self, curr, zero, memory, memory_pos, num_obj_ptr_tokens, dropout=drop)[0]
         # seq-first -> batch-first happens inside the add/cast kernels (strided reads), no separate transpose
         use_pos = self.pos_enc_at_input and curr_pos is not None
         x = ops.add_cast(curr.transpose(0, 1), curr_pos.transpose(0, 1) if use_pos else None, 0.1, F32).reshape(B * L, C)

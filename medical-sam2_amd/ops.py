@@ -276,6 +276,22 @@ def add_cast(a: torch.Tensor, b: Optional[torch.Tensor] = None, alpha: float = 1
     return out
 
 
+def dropout(x: torch.Tensor, p: float, seed: int, offset: int, residual: Optional[torch.Tensor] = None,
+            out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = residual + (keep ? x / (1 - p) : 0) on a [rows, cols] map (row-major, rows may be strided); the mask is element
+    (offset + r * cols + c) of the counter-based stream `seed`, so calling it again on a gradient with the same (seed, offset) is the
+    backward.  residual: fp32 [rows, cols]."""
+    _req(x.dim() == 2 and x.stride(1) == 1, "dropout: [rows, cols] row-major")
+    rows, cols = x.shape
+    y = out if out is not None else torch.empty(rows, cols, dtype=out_dtype or x.dtype, device=x.device)
+    _req(y.shape == x.shape and y.stride(1) == 1, "dropout: out must be [rows, cols] row-major (rows may be strided)")
+    if residual is not None:
+        _req(residual.dtype == F32 and residual.shape == x.shape and residual.stride(1) == 1, "dropout: residual must be fp32 [rows, cols]")
+    check(lib().msam2_dropout(_p(x), _is_bf16(x), x.stride(0), _p(residual), residual.stride(0) if residual is not None else 0, _p(y), _is_bf16(y),
+                              y.stride(0), rows, cols, float(p), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), _stream()))
+    return y
+
+
 def add_cast_into(out: torch.Tensor, a: torch.Tensor, b: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
     """Strided gather/copy(+add) of a [D0,D1,C] view into a contiguous slice of a larger buffer (memory-bank assembly)."""
     return add_cast(a, b, alpha, out=out)

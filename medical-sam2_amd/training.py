@@ -206,7 +206,9 @@ def memory_decoder_loss_grads(memory_attention, decoder, curr, curr_pos, memory,
     max|d_src| -- one host synchronisation; with data_parallel the maximum is taken over all ranks (one MAX all-reduce), because the
     ranks' gradients are summed afterwards and must carry the same scale."""
     L, _, C = curr.shape
-    y, state = bwd.memory_attention_forward_saved(memory_attention, curr, curr_pos, memory, memory_pos, num_obj_ptr_tokens)
+    # train() mode: nn.Dropout / attention dropout of the memory attention, masks re-created by the backward from the same counter stream
+    y, state = bwd.memory_attention_forward_saved(memory_attention, curr, curr_pos, memory, memory_pos, num_obj_ptr_tokens,
+                                                  dropout=memory_attention.next_dropout())
     src = y.transpose(0, 1).reshape(B * L, C)
     if dense_tokens is not None:                                                  # [L, C] or [1, C] (no_mask_embed), broadcast over the batch
         d2 = dense_tokens.reshape(-1, C).to(F32)

@@ -100,13 +100,17 @@ def gelu(x: Tensor) -> Tensor:
     return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))  # exact erf form (nn.GELU default)
 
 
-def softmax_attention(q: Tensor, k: Tensor, v: Tensor) -> Tensor:
+def softmax_attention(q: Tensor, k: Tensor, v: Tensor, pmask: Optional[Tensor] = None) -> Tensor:
     """softmax(q k^T / sqrt(D)) v on [..., L, D]; what F.scaled_dot_product_attention computes at
-    hieradet.py:72-76, transformer.py:258,318 (no mask, no dropout)."""
+    hieradet.py:72-76, transformer.py:258,318 (no attention mask).  pmask: train-mode dropout_p as an explicit multiplier on the
+    probabilities (keep / (1 - p) or 0), so that a test can hand over the masks of the implementation under test."""
     s = (q @ k.transpose(-1, -2)) / math.sqrt(q.shape[-1])
     s = s - s.amax(-1, keepdim=True)
     p = s.exp()
-    return (p / p.sum(-1, keepdim=True)) @ v
+    p = p / p.sum(-1, keepdim=True)
+    if pmask is not None:
+        p = p * pmask
+    return p @ v
 
 
 def mlp(P, pre: str, x: Tensor, n_layers: int, act, sigmoid_out: bool = False) -> Tensor:
@@ -292,7 +296,7 @@ def rope_rotate(x: Tensor, cos: Tensor, sin: Tensor) -> Tensor:
 
 
 def rope_attention(P, pre: str, q: Tensor, k: Tensor, v: Tensor, heads: int, theta: float,
-                   num_k_exclude_rope: int = 0) -> Tensor:
+                   num_k_exclude_rope: int = 0, pmask: Optional[Tensor] = None) -> Tensor:
     """RoPEAttention.forward (transformer.py:288-331), batch-first [B, L, C]; the table is recomputed for the query
     grid (302-305) and tiled over the keys (rope_k_repeat)."""
     q, k, v = lin(P, pre + ".q_proj", q), lin(P, pre + ".k_proj", k), lin(P, pre + ".v_proj", v)
@@ -310,24 +314,29 @@ def rope_attention(P, pre: str, q: Tensor, k: Tensor, v: Tensor, heads: int, the
     if n_rope > 0:
         r = n_rope // Lq
         k = torch.cat([rope_rotate(k[:, :, :n_rope], cos.repeat(r, 1), sin.repeat(r, 1)), k[:, :, n_rope:]], dim=2)
-    o = softmax_attention(q, k, v).transpose(1, 2).reshape(B, Lq, C)
+    o = softmax_attention(q, k, v, pmask).transpose(1, 2).reshape(B, Lq, C)
     return lin(P, pre + ".out_proj", o)
 
 
 def memory_attention(P, cfg: dict, curr: Tensor, memory: Tensor, curr_pos: Tensor, memory_pos: Tensor,
-                     num_obj_ptr_tokens: int = 0, pre: str = "memory_attention") -> Tensor:
-    """MemoryAttention.forward (memory_attention.py:119-169) with eval-mode layers (17-99); seq-first in/out."""
+                     num_obj_ptr_tokens: int = 0, pre: str = "memory_attention", masks: Optional[dict] = None) -> Tensor:
+    """MemoryAttention.forward (memory_attention.py:119-169), layers 17-99; seq-first in/out.  masks = None: eval mode.  Train mode:
+    masks[(layer, site)] are the dropout multipliers (keep / (1 - p) or 0) of the six sites of a layer -- "sa_attn" [B,1,L,L] and
+    "ca_attn" [B,1,L,Nk] on the attention probabilities (transformer.py:317-318), "drop1" / "drop2" / "drop3" [B,L,C] on the residual
+    branches (63, 80, 98) and "ffn" [B,L,hidden] inside the FFN (97)."""
+    one = lambda l, site: 1.0 if masks is None else masks[(l, site)]
+    pm = lambda l, site: None if masks is None else masks[(l, site)]
     x = (curr + 0.1 * curr_pos).transpose(0, 1)
     mem, mpos = memory.transpose(0, 1), memory_pos.transpose(0, 1)
     for l in range(cfg["memattn_layers"]):
         lp = f"{pre}.layers.{l}"
         t = lnorm(P, lp + ".norm1", x, 1e-5)
-        x = x + rope_attention(P, lp + ".self_attn", t, t, t, 1, cfg["rope_theta"])
+        x = x + one(l, "drop1") * rope_attention(P, lp + ".self_attn", t, t, t, 1, cfg["rope_theta"], pmask=pm(l, "sa_attn"))
         t = lnorm(P, lp + ".norm2", x, 1e-5)
-        x = x + rope_attention(P, lp + ".cross_attn_image", t, mem + mpos, mem, 1, cfg["rope_theta"],
-                               num_k_exclude_rope=num_obj_ptr_tokens)
+        x = x + one(l, "drop2") * rope_attention(P, lp + ".cross_attn_image", t, mem + mpos, mem, 1, cfg["rope_theta"],
+                                                  num_k_exclude_rope=num_obj_ptr_tokens, pmask=pm(l, "ca_attn"))
         t = lnorm(P, lp + ".norm3", x, 1e-5)
-        x = x + lin(P, lp + ".linear2", torch.relu(lin(P, lp + ".linear1", t)))
+        x = x + one(l, "drop3") * lin(P, lp + ".linear2", one(l, "ffn") * torch.relu(lin(P, lp + ".linear1", t)))
     return lnorm(P, pre + ".norm", x, 1e-5).transpose(0, 1)
 
 

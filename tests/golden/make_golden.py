@@ -533,8 +533,43 @@ def run_grads_case():
     return out, meta
 
 
+def run_encoder_grads_case():
+    """`.grad` of every image-encoder parameter (and of the decoder's conv_s0 / conv_s1, which act inside forward_image) of the
+    REFERENCE under torch.autograd: hiera_t at 256^2, two synthetic images, a seeded random linear functional of the three
+    backbone_fpn outputs (func_2d/function.py:70-72 differentiates exactly this sub-graph).  Stored like the other gradient fixtures:
+    strided subsample + fp64 sum / abs-sum per parameter."""
+    m = build_reference("hiera_t", 256)
+    train = lambda k: k.startswith("image_encoder.") or k.startswith("sam_mask_decoder.conv_s")
+    for k, p in m.named_parameters():
+        p.requires_grad_(train(k))
+    rnd = lambda *shape, seed=0, scale=1.0: torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+    img, _, _ = syn.image_batch([10, 11], 256)
+    bo = m.forward_image(img)
+    dys = [rnd(*f.shape, seed=60 + l, scale=0.05) for l, f in enumerate(bo["backbone_fpn"])]
+    sum((f * d).sum() for f, d in zip(bo["backbone_fpn"], dys)).backward()
+    out, meta = {}, {"model": "hiera_t", "image_size": 256, "image_seeds": [10, 11], "dy_seeds": [60, 61, 62], "dy_scale": 0.05, "grad_stats": {}}
+    n = 0
+    for k, p in m.named_parameters():
+        if train(k) and p.grad is not None:
+            out["enc_param." + k] = sub(p.grad, 256)
+            meta["grad_stats"]["enc_param." + k] = stats(p.grad)
+            n += 1
+    for l, f in enumerate(bo["backbone_fpn"]):
+        out[f"enc_fpn{l}_sub"] = sub(f, 1024)
+    meta["n_params"] = n
+    return out, meta
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "encgrads":
+        o, meta = run_encoder_grads_case()
+        np.savez_compressed(os.path.join(OUT, "grads_encoder_t256.npz"), **o)
+        allmeta = json.load(open(os.path.join(OUT, "meta.json")))
+        allmeta["grads_encoder_t256"] = meta
+        json.dump(allmeta, open(os.path.join(OUT, "meta.json"), "w"), indent=1)
+        print("grads_encoder_t256.npz", os.path.getsize(os.path.join(OUT, "grads_encoder_t256.npz")), meta["n_params"], "parameters")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "grads":
         o, meta = run_grads_case()
         np.savez_compressed(os.path.join(OUT, "grads_t256.npz"), **o)
@@ -606,6 +641,9 @@ def main():
     o, meta = run_grads_case()
     np.savez_compressed(os.path.join(OUT, "grads_t256.npz"), **o)
     allmeta["grads_t256"] = meta
+    o, meta = run_encoder_grads_case()
+    np.savez_compressed(os.path.join(OUT, "grads_encoder_t256.npz"), **o)
+    allmeta["grads_encoder_t256"] = meta
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(allmeta, f, indent=1)
     for fn in sorted(os.listdir(OUT)):

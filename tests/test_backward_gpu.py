@@ -865,3 +865,75 @@ def test_eager_forward_after_graph_replays_sees_fresh_weights(mods):
         want = x.float() @ lin.weight.detach().to(ops.OP16).float().t() + lin.bias.detach()
     assert (y1 - y0).abs().max().item() > 1e-2                           # the parameters moved (lr 0.1, constant gradient)
     assert torch.allclose(y1, want, rtol=1e-3, atol=1e-3)                # and the eager path used the moved ones
+
+
+def test_dropout_kernel_stream(mods):
+    """counter-based dropout: keep rate, 1 / (1 - p) scaling, determinism in (seed, offset), independence of the launch shape (the
+    backward re-creates the forward's mask by calling it on the gradient), fused residual"""
+    B_, ops = mods
+    x = torch.ones(512, 300, device=DEV)
+    y = ops.dropout(x, 0.1, 1234, 1 << 40)
+    keep = (y != 0)
+    assert abs(keep.float().mean().item() - 0.9) < 0.005 and torch.allclose(y[keep], torch.full_like(y[keep], 1 / 0.9))
+    assert torch.equal(y, ops.dropout(x, 0.1, 1234, 1 << 40))
+    assert not torch.equal(y, ops.dropout(x, 0.1, 1235, 1 << 40)) and not torch.equal(y, ops.dropout(x, 0.1, 1234, 2 << 40))
+    g = rnd(512, 300, seed=3).to(DEV)
+    assert torch.equal(ops.dropout(g, 0.1, 1234, 1 << 40) != 0, keep | (g == 0))            # same mask on a gradient
+    # the stream is indexed by element, not by launch geometry: rows [100, 200) alone reproduce their part
+    part = ops.dropout(x[100:200], 0.1, 1234, (1 << 40) + 100 * 300)
+    assert torch.equal(part, y[100:200])
+    r = rnd(512, 300, seed=4).to(DEV)
+    assert torch.allclose(ops.dropout(x.to(ops.OP16), 0.1, 1234, 1 << 40, residual=r, out_dtype=torch.float32), y + r, atol=1e-6)
+    assert torch.equal(ops.dropout(x, 0.0, 7, 0), x)
+
+
+def test_memory_attention_train_mode_dropout(mods):
+    """MemoryAttention in train() mode (dropout 0.1 on three residual branches, inside the FFN and on both attentions' probabilities:
+    memory_attention.py:40-48,63,80,97-98, transformer.py:317-318): forward output and every parameter / input gradient against
+    torch.autograd through the oracle that applies the SAME masks (extracted from the counter streams of the implementation)."""
+    B_, ops = mods
+    import medical_sam2_amd.build_sam as bs
+    import medical_sam2_amd.weights as wts
+    sd = wts.init_weights("hiera_t", 0)
+    m = bs.build_sam2("sam2_hiera_t", device="cpu", hydra_overrides_extra=["++model.image_size=256"])
+    m.load_state_dict(sd, strict=True)
+    ma = m.memory_attention.to(DEV)
+    cfg = O.model_config("hiera_t", 256)
+    B, L, C, n_ptr = 2, 256, 256, 4
+    Nk = 2 * L + n_ptr
+    curr, curr_pos = rnd(L, B, C, seed=500), rnd(L, B, C, seed=501)
+    memory, memory_pos = rnd(Nk, B, 64, seed=502), rnd(Nk, B, 64, seed=503)
+    dy = rnd(L, B, C, seed=504)
+    d = lambda t: t.to(DEV)
+    p, seed = 0.1, (77 << 32) + 1
+    # the masks the implementation will use, read off its own generator (dropout of ones = keep / (1 - p) or 0)
+    masks = {}
+    shapes = {"sa_attn": (B * L, L), "drop1": (B * L, C), "ca_attn": (B * L, Nk), "drop2": (B * L, C), "ffn": (B * L, 2048), "drop3": (B * L, C)}
+    for l in range(4):
+        for site, (r, c) in shapes.items():
+            mk = ops.dropout(torch.ones(r, c, device=DEV), p, seed, B_.drop_offset(l, site)).cpu()
+            masks[(l, site)] = mk.view(B, 1, L, c) if site.endswith("attn") else mk.view(B, L, c)
+    assert abs(sum(float((v != 0).float().mean()) for v in masks.values()) / len(masks) - 0.9) < 0.01
+    P = {k: v.clone().float().requires_grad_(k.startswith("memory_attention.")) for k, v in sd.items()}
+    cr, mr, mpr = curr.clone().requires_grad_(True), memory.clone().requires_grad_(True), memory_pos.clone().requires_grad_(True)
+    y_ref = O.memory_attention(P, cfg, cr, mr, curr_pos, mpr, n_ptr, masks=masks)
+    y_ref.backward(dy)
+    y_eval = O.memory_attention(P, cfg, curr, memory, curr_pos, memory_pos, n_ptr)
+    with torch.no_grad():
+        y, state = B_.memory_attention_forward_saved(ma, d(curr), d(curr_pos), d(memory), d(memory_pos), n_ptr, dropout=(p, seed))
+        dcurr, dmem, dmem_pos, grads = B_.memory_attention_backward_saved(ma, state, d(dy))
+        # train() mode through the module's own forward draws (p, fresh seed) itself
+        ma.train()
+        ma.dropout_seed, ma._dropout_calls = 77, 0
+        y_mod = ma(curr=[d(curr)], curr_pos=[d(curr_pos)], memory=d(memory), memory_pos=d(memory_pos), num_obj_ptr_tokens=n_ptr)
+        ma.eval()
+        y_ev_hip = ma(curr=[d(curr)], curr_pos=[d(curr_pos)], memory=d(memory), memory_pos=d(memory_pos), num_obj_ptr_tokens=n_ptr)
+    assert rel(y, y_ref) < 5e-3, rel(y, y_ref)
+    assert torch.equal(y_mod, y)                                                  # same (p, seed) -> same masks
+    assert rel(y_ev_hip, y_eval) < 3e-3 and rel(y, y_eval) > 0.05                 # and dropout really changed the output
+    errs = {"dcurr": rel(dcurr, cr.grad), "dmemory": rel(dmem, mr.grad), "dmemory_pos": rel(dmem_pos, mpr.grad)}
+    for k, v in grads.items():
+        errs[k] = rel(v, P["memory_attention." + k].grad)
+    assert len(grads) == 106
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    assert worst[0][1] < 4e-2, worst

@@ -235,3 +235,48 @@ def test_hip_backward_matches_reference_gradients():
             rep[name] = rel_sub(g, G["memenc_param." + name])
         worst = sorted(rep.items(), key=lambda kv: -kv[1])[:5]
         assert worst[0][1] < 4e-2, worst
+
+
+# ---- image encoder (tests/golden/grads_encoder_t256.npz: `.grad` of all 166 trunk / neck / conv_s0 / conv_s1 parameters of the reference)
+def _encoder_case():
+    import medical_sam2_amd.synthetic as syn
+    gold, meta = load_npz("grads_encoder_t256.npz"), load_meta()["grads_encoder_t256"]
+    img, _, _ = syn.image_batch(meta["image_seeds"], meta["image_size"])
+    return gold, meta, img
+
+
+def test_oracle_autograd_matches_reference_encoder_grads():
+    gold, meta, img = _encoder_case()
+    W = wts.init_weights("hiera_t", 0)
+    train = lambda k: k.startswith("image_encoder.") or k.startswith("sam_mask_decoder.conv_s")
+    P = {k: (v.clone().requires_grad_(True) if train(k) else v) for k, v in W.items()}
+    bo = O.forward_image(P, O.model_config("hiera_t", 256), img)
+    dys = [rnd(*f.shape, seed=s, scale=meta["dy_scale"]) for s, f in zip(meta["dy_seeds"], bo["backbone_fpn"])]
+    sum((f * d).sum() for f, d in zip(bo["backbone_fpn"], dys)).backward()
+    keys = [k for k in gold if k.startswith("enc_param.")]
+    assert len(keys) == meta["n_params"] == 166
+    worst = max((rel_sub(P[k[len("enc_param."):]].grad, gold[k]), k) for k in keys)
+    assert worst[0] < 2e-3, worst
+
+
+@pytest.mark.gpu
+def test_hip_encoder_backward_matches_reference_grads():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import medical_sam2_amd.backward_encoder as be
+    import medical_sam2_amd.build_sam as bs
+    gold, meta, img = _encoder_case()
+    m = bs.build_sam2("sam2_hiera_t", device="cpu", hydra_overrides_extra=["++model.image_size=256"])
+    m.load_state_dict(wts.init_weights("hiera_t", 0), strict=True)
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        out, st = be.image_encoder_forward_saved(m, img.to(DEV))
+        dys = [rnd(*f.shape, seed=s, scale=meta["dy_scale"]) for s, f in zip(meta["dy_seeds"], out["backbone_fpn"])]
+        d_fpn = [d.permute(0, 2, 3, 1).reshape(-1, d.shape[1]).contiguous().to(DEV) for d in dys]
+        grads = be.image_encoder_backward(m, st, d_fpn)
+    keys = [k for k in gold if k.startswith("enc_param.")]
+    errs = sorted(((rel_sub(grads[k[len("enc_param."):]], gold[k]), k) for k in keys), reverse=True)
+    stats = meta["grad_stats"]
+    num = sum((float(grads[k[len("enc_param."):]].double().abs().sum()) - stats[k]["abs_sum"]) ** 2 for k in keys)
+    assert errs[0][0] < 8e-2, errs[:5]                      # 16-bit operands; the worst entries are the position tables (4 %)
+    assert sum(e for e, _ in errs) / len(errs) < 2e-2, errs[:5]
