@@ -137,6 +137,56 @@ def time_dominant_kernel(device, batch):
     return t_kernel, flops, executed, bytes_, splits, t_pair
 
 
+def time_hiera_attention(device, batch):
+    """north_star's second figure: the Hiera attention kernels of this workload timed alone (HIP events on the launch stream, graph-free:
+    20 back-to-back launches), at the two shapes that carry the trunk's attention time:
+      * global blocks 7 / 10 / 13: attn_glds_kernel<96,128,4,3>, B x 4 heads x 4096 x 4096 x 96 -- MFMA-bound (AI ~ 2000);
+      * stage-3 windowed blocks (x7): attn_win_kernel<96>, 25 windows of 14x14 per image x 4 heads, 196 x 196 x 96 -- HBM-bound stand-alone
+        (AI ~ 98): priced on the algorithmic bytes q, k, v, o once in 16 bits.
+    Returns the `roofline_hiera_attention` object."""
+    import medical_sam2_amd.ops as ops
+    from medical_sam2_amd._lib import lib, check
+    g = torch.Generator().manual_seed(6)
+    stream = torch.cuda.current_stream().cuda_stream
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    check(lib().msam2_event_create(ctypes.byref(e0)))
+    check(lib().msam2_event_create(ctypes.byref(e1)))
+
+    def timed(fn, n=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        check(lib().msam2_event_record(e0, stream))
+        for _ in range(n):
+            fn()
+        check(lib().msam2_event_record(e1, stream))
+        ms = ctypes.c_float()
+        check(lib().msam2_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+        return ms.value / 1e3 / n
+
+    B, heads, L, D = batch, 4, 4096, 96
+    qkv = (torch.randn(B, L, 3, heads, D, generator=g) * 0.5).to(ops.OP16).to(device)
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    out = torch.empty(B, L, heads, D, dtype=ops.OP16, device=device).permute(0, 2, 1, 3)
+    t_glob = timed(lambda: ops.attention(q, k, v, out=out))
+    fl_glob = 4.0 * B * heads * L * L * D
+    T = B * 64 * 64
+    qkv2 = (torch.randn(T, 3 * heads * D, generator=g) * 0.5).to(ops.OP16).to(device)
+    bias = torch.zeros(3 * heads * D, device=device)
+    t_win = timed(lambda: ops.window_attention(qkv2, B, 64, 64, heads, 14, bias))
+    by_win = 2.0 * heads * D * 4 * T
+    fl_win = 4.0 * B * 25 * heads * 196 * 196 * D
+    lib().msam2_event_destroy(e0)
+    lib().msam2_event_destroy(e1)
+    return {"global": {"kernel": f"attn_glds_kernel<96,128,4,3> at B={B} heads=4 Lq=Lk=4096 D=96", "bound": "mfma", "avg_launch_us": t_glob * 1e6,
+                       "achieved": fl_glob / t_glob / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl_glob / t_glob / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                       "flops_per_launch": fl_glob},
+            "windowed": {"kernel": f"attn_win_kernel<96> at B={B} 25 windows x 4 heads, 196 x 196 x 96 (stage-3 blocks)", "bound": "hbm",
+                         "avg_launch_us": t_win * 1e6, "achieved": by_win / t_win / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": by_win / t_win / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": by_win,
+                         "mfma_TFLOPs": fl_win / t_win / 1e12, "note": "eager launches include ~4 us of launch gap per kernel at this size"}}
+
+
 def pmc_traffic():
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/, collected with
     `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on `tools/one_attn.py 4 1 4096 16384 kv64 <splits>` at this exact shape): counter units of
@@ -156,7 +206,7 @@ def pmc_traffic():
     return tot
 
 
-def train_iteration(m, imgs, pts, labels, memory, memory_pos, device):
+def train_iteration(m, imgs, pts, labels, memory, memory_pos, device, full=True):
     """Side figure, never part of `value`: one whole training iteration of the same configuration (SURVEY.md 8(d) config 2 "time
     forward (+backward when available)") -- frozen image / prompt encoders, forward + backward + Adam of memory attention and mask
     decoder, memory encoding of the new prediction (`training.train_step_2d`) -- replayed as a hipGraph.  Reported as
@@ -169,9 +219,10 @@ def train_iteration(m, imgs, pts, labels, memory, memory_pos, device):
         g = torch.Generator().manual_seed(3)
         target = (torch.randn(B, 4, 256, 256, generator=g) > 0.5).float().to(device)
         om, od = T.DecoderAdam(mt.memory_attention, lr=1e-6), T.DecoderAdam(mt.sam_mask_decoder, lr=1e-4)
-        step = lambda sync: T.train_step_2d(mt, om, od, imgs, pts, labels, memory, memory_pos, target, sync=sync)
+        oe = T.DecoderAdam(mt.image_encoder, lr=1e-6, weight_decay=0.0) if full else None
+        step = lambda sync: T.train_step_2d(mt, om, od, imgs, pts, labels, memory, memory_pos, target, sync=sync, opt_enc=oe)
         step(True)                                          # eager: calibrates the loss scale, packs weights
-        graph = T.GraphedStep(lambda: step(False), [om, od])   # capture; replays advance Adam's device-side step count
+        graph = T.GraphedStep(lambda: step(False), [o for o in (om, od, oe) if o is not None])   # replays advance Adam's device-side step count
         graph.replay()
         torch.cuda.synchronize()
         n = 10
@@ -180,8 +231,10 @@ def train_iteration(m, imgs, pts, labels, memory, memory_pos, device):
             graph.replay()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
-        return {"ms": dt * 1e3, "slices_per_s": B / dt, "what": "train_step_2d: frozen encoders fwd + memory attention & mask decoder fwd/bwd + Adam "
-                "+ memory encoding, hipGraph replay"}
+        what = ("train_step_2d, every group of net.parameters() the 2-D loop trains (train_2d.py:43-47): image encoder (Hiera trunk + FPN neck) + memory "
+                "attention + mask decoder forward / backward / Adam, + memory encoding; eval-mode dropout; hipGraph replay") if full else \
+               "train_step_2d: frozen encoders fwd + memory attention & mask decoder fwd/bwd + Adam + memory encoding, hipGraph replay"
+        return {"ms": dt * 1e3, "slices_per_s": B / dt, "what": what}
     except Exception as e:  # noqa: BLE001 -- a side figure: report, do not fail the benchmark line
         return {"ms": None, "error": f"{type(e).__name__}: {e}"[:300]}
 
@@ -361,12 +414,14 @@ def main():
                          "algorithmic_bytes_per_launch": k_bytes,
                          "hbm_GBs_on_algorithmic_bytes": k_bytes / k_s / 1e9, "hbm_frac_of_peak": k_bytes / k_s / 1e9 / HBM_PEAK_GBS},
         }
+        line["roofline_hiera_attention"] = time_hiera_attention(device, args.batch)
         if world == 1 and not args.no_cpu_baseline:
             c = lambda t: t.detach().float().cpu()
             sample = (c(imgs[:1]), c(pts[:1]), labels[:1].cpu(), c(memory[:, :1]), c(memory_pos[:, :1]), c(out[0][:1]))
             line["cpu_baseline"] = cpu_baseline(sample)
         if world == 1 and not args.no_train:
-            line["train_iteration"] = train_iteration(m, imgs, pts, labels, memory, memory_pos, device)
+            line["train_iteration"] = train_iteration(m, imgs, pts, labels, memory, memory_pos, device, full=True)
+            line["train_iteration_frozen_encoder"] = train_iteration(m, imgs, pts, labels, memory, memory_pos, device, full=False)
         print(json.dumps(line), flush=True)
     if dist is not None:
         par.barrier(sync_dev)

@@ -236,8 +236,8 @@ class TwoWayTransformer(nn.Module):
 
 
 class MaskDecoder(nn.Module):
-    """mask_decoder.py:15-317.  `cell_nums` keeps its position in the signature (the fork's func_2d call site passes it by
-    keyword) but defaults to None, which is the upstream one-prompt-set-per-image path (SURVEY.md shim S3)."""
+    """mask_decoder.py:15-317.  `cell_nums` (the fork's func_2d call site passes it by keyword, func_2d/function.py:159-168) repeats every
+    image embedding for its prompt sets (215-231); None is the upstream one-prompt-set-per-image path (SURVEY.md shim S3)."""
 
     def __init__(self, *, transformer_dim: int, transformer: nn.Module, num_multimask_outputs: int = 3,
                  activation: Type[nn.Module] = nn.GELU, iou_head_depth: int = 3, iou_head_hidden_dim: int = 256,
@@ -345,9 +345,30 @@ class MaskDecoder(nn.Module):
 
     def predict_masks(self, image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings, repeat_image,
                       cell_nums=None, high_res_features=None):
-        assert cell_nums is None, "per-image prompt repetition (cell_nums) belongs to the fork's nuclei pipeline, outside this path"
+        # mask_decoder.py:215-231: when there are more prompt sets than image embeddings, `cell_nums[i]` prompt sets belong to image i
+        # (torch.repeat_interleave of the embedding; the position encoding and the dense embedding broadcast).  The high-res skips are
+        # added un-repeated in the reference (244-247), which only broadcasts for ONE image: mirrored, anything else raises like torch.
+        n_sets = sparse_prompt_embeddings.shape[0]
+        if image_embeddings.shape[0] != n_sets:
+            if cell_nums is not None:
+                cn = torch.as_tensor(cell_nums, device=image_embeddings.device).reshape(-1).long()
+                if cn.numel() != image_embeddings.shape[0] or int(cn.sum()) != n_sets:
+                    raise RuntimeError(f"cell_nums {cn.tolist()} does not split {n_sets} prompt sets over {image_embeddings.shape[0]} images")
+                image_embeddings = torch.repeat_interleave(image_embeddings, cn, dim=0)          # data movement
+            elif image_embeddings.shape[0] == 1:
+                image_embeddings = image_embeddings.expand(n_sets, -1, -1, -1)
+            else:
+                raise RuntimeError(f"The size of tensor a ({image_embeddings.shape[0]}) must match the size of tensor b ({n_sets}) at non-singleton dimension 0")
+            hr = []
+            for f in high_res_features:
+                if f.shape[0] == 1:
+                    f = f.expand(n_sets, -1, -1, -1)
+                elif f.shape[0] != n_sets:
+                    raise RuntimeError(f"The size of tensor a ({n_sets}) must match the size of tensor b ({f.shape[0]}) at non-singleton dimension 0")
+                hr.append(f)
+            high_res_features = hr
         B, C, h, w = image_embeddings.shape
-        assert sparse_prompt_embeddings.shape[0] == B, "one prompt set per image embedding"
+        assert sparse_prompt_embeddings.shape[0] == B, "one prompt set per (repeated) image embedding"
         emb = image_embeddings.to(F32)
         dense = dense_prompt_embeddings.to(F32).expand(B, C, h, w)
         # image embedding + dense prompt embedding -> token-major fp32 (the spatially constant no-mask embedding is read as a

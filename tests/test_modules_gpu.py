@@ -177,3 +177,35 @@ def test_non_overlapping_constraints(net):
     assert torch.equal(y.cpu(), ref)
     one = x[:1].to(DEV)
     assert torch.equal(m._apply_non_overlapping_constraints(one), one)
+
+
+def test_mask_decoder_cell_nums_prompt_repetition(net):
+    """MaskDecoder.forward with `cell_nums` (mask_decoder.py:215-231; the 2-D loop's call, func_2d/function.py:159-168): one image
+    embedding, several prompt sets -- repeat_interleave of the embedding, broadcast position / dense embeddings and high-res skips --
+    against the oracle on the explicitly repeated inputs; plus the reference's failure modes."""
+    m, sd, cfg, tol = net
+    E, n = 16, 3
+    emb, pe = rnd(1, 256, E, E, seed=601), rnd(1, 256, E, E, seed=602)
+    sparse, dense = rnd(n, 2, 256, seed=603), rnd(1, 256, 1, 1, seed=604, scale=0.3).expand(1, 256, E, E)
+    hr = [rnd(1, 32, 4 * E, 4 * E, seed=605), rnd(1, 64, 2 * E, 2 * E, seed=606)]
+    ref, ref_iou, _, ref_obj = O.mask_decoder_predict(sd, emb.expand(n, -1, -1, -1), pe, sparse, dense.expand(n, -1, -1, -1), [h.expand(n, -1, -1, -1) for h in hr])
+    d = lambda t: t.to(DEV)
+    dec = m.sam_mask_decoder
+    with torch.no_grad():
+        masks, iou, toks, obj = dec(image_embeddings=d(emb), image_pe=d(pe), sparse_prompt_embeddings=d(sparse), dense_prompt_embeddings=d(dense),
+                                    multimask_output=True, repeat_image=False, cell_nums=torch.tensor([n]), high_res_features=[d(h) for h in hr])
+        assert masks.shape == (n, 3, 4 * E, 4 * E) and iou.shape == (n, 3) and toks.shape == (n, 3, 256) and obj.shape == (n, 1)
+        assert rel_err(masks.cpu(), ref[:, 1:]) < 2 * tol and rel_err(iou.cpu(), ref_iou[:, 1:]) < 2 * tol and rel_err(obj.cpu(), ref_obj) < 2 * tol
+        # two images, 2 + 1 prompt sets: the embedding is repeated per image; the high-res skips must then come per prompt set
+        emb2 = torch.cat([emb, rnd(1, 256, E, E, seed=607)])
+        hr2 = [torch.cat([h, h * 0.5])[[0, 0, 1]] for h in hr]
+        ref2, _, _, _ = O.mask_decoder_predict(sd, emb2[[0, 0, 1]], pe, sparse, dense.expand(n, -1, -1, -1), hr2)
+        masks2, _, _, _ = dec(image_embeddings=d(emb2), image_pe=d(pe), sparse_prompt_embeddings=d(sparse), dense_prompt_embeddings=d(dense),
+                              multimask_output=True, repeat_image=False, cell_nums=torch.tensor([2, 1]), high_res_features=[d(h) for h in hr2])
+        assert rel_err(masks2.cpu(), ref2[:, 1:]) < 2 * tol
+        with pytest.raises(RuntimeError):     # un-repeated skips of two images cannot broadcast over three prompt sets (the reference raises too)
+            dec(image_embeddings=d(emb2), image_pe=d(pe), sparse_prompt_embeddings=d(sparse), dense_prompt_embeddings=d(dense),
+                multimask_output=True, repeat_image=False, cell_nums=torch.tensor([2, 1]), high_res_features=[d(torch.cat([h, h])) for h in hr])
+        with pytest.raises(RuntimeError):
+            dec(image_embeddings=d(emb2), image_pe=d(pe), sparse_prompt_embeddings=d(sparse), dense_prompt_embeddings=d(dense),
+                multimask_output=True, repeat_image=False, cell_nums=torch.tensor([1, 1]), high_res_features=[d(h) for h in hr2])
