@@ -43,11 +43,16 @@ __device__ __forceinline__ float op2f(op16 x) { return (float)x; }
 // MLP / qkv activation, an un-scaled gradient -- must not become inf and travel through softmax / LayerNorm / the optimiser state.
 // NaN stays NaN.  f2op_fast is the plain conversion for values known to be bounded (softmax probabilities in [0, 1]).
 __device__ __forceinline__ op16 f2op_fast(float x) { return (op16)x; }
-#if MSAM2_OPERAND_IS_FP16
+#if MSAM2_OPERAND_IS_FP16 && !defined(MSAM2_NO_SATURATE)
 __device__ __forceinline__ op16 f2op(float x) { return (op16)__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f); }
 #else
 __device__ __forceinline__ op16 f2op(float x) { return (op16)x; }
 #endif
+
+// fp32 -> the output element type of a templated kernel (saturating for the fp16 operand type, identity for fp32)
+template <typename T> __device__ __forceinline__ T f2out(float x);
+template <> __device__ __forceinline__ float f2out<float>(float x) { return x; }
+template <> __device__ __forceinline__ op16 f2out<op16>(float x) { return f2op(x); }
 
 // exact-erf GELU (nn.GELU default).  erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. at fp32 round-off of the
 // surrounding arithmetic and far below the op16 rounding of every consumer) -- ~4x fewer VALU operations than erff().

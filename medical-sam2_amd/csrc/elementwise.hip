@@ -78,7 +78,7 @@ __global__ void layernorm_kernel(const TI* __restrict__ x, int64_t ldx, const fl
       for (int e = 0; e < 4; ++e) {
         float t = (v[j][e] - mean) * rstd * ww[e] + bb[e];
         if (act == 1) t = gelu_erf(t);
-        o[e] = (decltype(o[e] + o[e]))t;
+        o[e] = f2out<TO>(t);
       }
       *reinterpret_cast<VO*>(yr + ch * 4) = o;
     }
@@ -118,7 +118,7 @@ __global__ void layernorm_scalar_kernel(const TI* __restrict__ x, int64_t ldx, c
     if (c < C) {
       float o = (v[i] - mean) * rstd * w[c] + b[c];
       if (act == 1) o = gelu_erf(o);
-      yr[c] = (TO)o;
+      yr[c] = f2out<TO>(o);
     }
   }
 }
@@ -178,7 +178,7 @@ __global__ void add_cast_kernel(const TA* __restrict__ a, int64_t a_s0, int64_t 
     const int64_t j = rj % D1, r = rj / D1;
     float v = (float)a[r * a_s0 + j * a_s1 + c];
     if (b) v += alpha * (float)b[r * b_s0 + j * b_s1 + c];
-    out[i] = (TO)v;
+    out[i] = f2out<TO>(v);
   }
 }
 
@@ -205,7 +205,7 @@ __global__ void add_cast_vec_kernel(const TA* __restrict__ a, int64_t a_s0, int6
     }
     VO o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (decltype(o[e] + o[e]))v[e];
+    for (int e = 0; e < 4; ++e) o[e] = f2out<TO>(v[e]);
     *reinterpret_cast<VO*>(out + (int64_t)i * 4) = o;
   }
 }

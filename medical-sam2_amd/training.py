@@ -227,6 +227,8 @@ def memory_decoder_loss_grads(memory_attention, decoder, curr, curr_pos, memory,
     scale = 2.0 ** (math.floor(math.log2(n_loss / max(float(pos_weight), 1.0))) - 4 - extra)
     d_masks.mul_(scale)
     d_src, _, g_dec = bwd.mask_decoder_backward(decoder, src, pe_tokens, sparse, feat_s0, feat_s1, B, h, w, d_masks, aux=aux)
+    if aux is not None:
+        aux["d_src"] = d_src                                                     # gradient entering the memory attention, carrying `scale`
     if mem_scale is None:
         mem_scale = _shared_pow2_scale(d_src.abs().max().reshape(1), data_parallel)
     d_src = d_src * mem_scale
