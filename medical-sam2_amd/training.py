@@ -193,7 +193,7 @@ def decoder_finetune_step(decoder, optimizer: DecoderAdam, src_tokens, pe_tokens
 def memory_decoder_loss_grads(memory_attention, decoder, curr, curr_pos, memory, memory_pos, num_obj_ptr_tokens: int, pe_tokens, sparse,
                               feat_s0, feat_s1, B: int, h: int, w: int, target_masks: torch.Tensor, dense_tokens=None,
                               pos_weight: float = 1.0, mem_scale: float = None, aux: dict = None, mask_index: int = None,
-                              data_parallel: bool = False):
+                              data_parallel: bool = False, on_decoder_grads=None):
     """Forward + backward of the memory-conditioned slice step (func_2d/function.py:70-191 / sam2_base.py:705-790 with a frozen image
     encoder and a detached memory bank, as func_2d/function.py:204-243 stores it): curr / curr_pos [L, B, C] current-slice features,
     memory / memory_pos [Nk, B, 64] the assembled bank -> memory attention -> (+ dense prompt embedding) -> mask decoder -> mean BCE with
@@ -227,6 +227,8 @@ def memory_decoder_loss_grads(memory_attention, decoder, curr, curr_pos, memory,
     scale = 2.0 ** (math.floor(math.log2(n_loss / max(float(pos_weight), 1.0))) - 4 - extra)
     d_masks.mul_(scale)
     d_src, _, g_dec = bwd.mask_decoder_backward(decoder, src, pe_tokens, sparse, feat_s0, feat_s1, B, h, w, d_masks, aux=aux)
+    if on_decoder_grads is not None:
+        on_decoder_grads(g_dec)                                                  # e.g. start their all-reduce under the memory attention's backward
     if aux is not None:
         aux["d_src"] = d_src                                                     # gradient entering the memory attention, carrying `scale`
     if mem_scale is None:
@@ -248,15 +250,19 @@ def memory_decoder_finetune_step(memory_attention, decoder, opt_mem: DecoderAdam
     if kwargs.get("mem_scale") is None:
         kwargs["mem_scale"] = cal.get(kwargs.get("mask_index"))
     calibrating = kwargs.get("mem_scale") is None
-    loss, scale, scale_mem, g_dec, g_mem, _ = memory_decoder_loss_grads(memory_attention, decoder, *args, data_parallel=data_parallel, **kwargs)
+    pending = []
+    hook = (lambda g: pending.append(parallel.allreduce_gradients_async(g))) if data_parallel else None   # decoder sums overlap the next backward
+    loss, scale, scale_mem, g_dec, g_mem, _ = memory_decoder_loss_grads(memory_attention, decoder, *args, data_parallel=data_parallel,
+                                                                       on_decoder_grads=hook, **kwargs)
     cal[kwargs.get("mask_index")] = scale_mem / scale
     opt_mem.calibrated_loss_scales = cal
     inv_world = 1.0
     if data_parallel:
         if calibrating:                                 # the calibration was collective (MAX over ranks): every rank must hold the same scale
             _assert_same_on_all_ranks(scale_mem / scale, "memory-attention loss scale")
-        g_dec, inv_world = parallel.allreduce_gradients(g_dec)
-        g_mem, _ = parallel.allreduce_gradients(g_mem)
+        mem_pending = parallel.allreduce_gradients_async(g_mem)
+        g_dec, inv_world = pending[0].wait()
+        g_mem, _ = mem_pending.wait()
     opt_dec.step(g_dec, grad_scale=inv_world / scale)
     opt_mem.step(g_mem, grad_scale=inv_world / scale_mem)
     return float(loss.item()) if sync else loss
@@ -264,7 +270,7 @@ def memory_decoder_finetune_step(memory_attention, decoder, opt_mem: DecoderAdam
 
 @torch.no_grad()
 def train_step_2d(model, opt_mem: DecoderAdam, opt_dec: DecoderAdam, imgs, pts, labels, memory, memory_pos, target_masks, sync: bool = True,
-                  mask_index: int = None, opt_enc: DecoderAdam = None, grads_out: dict = None):
+                  mask_index: int = None, opt_enc: DecoderAdam = None, grads_out: dict = None, data_parallel: bool = False):
     """One training iteration of the 2-D flow (func_2d/function.py:70-259) on the HIP path: image encoder forward -> memory attention
     over the (detached) bank -> prompt encoder (no gradient: it runs under torch.no_grad() in the reference, func_2d/function.py:140-149)
     -> mask decoder -> BCE on the mask logits -> backward of decoder + memory attention (+ the image encoder) -> Adam -> the new memory
@@ -275,6 +281,9 @@ def train_step_2d(model, opt_mem: DecoderAdam, opt_dec: DecoderAdam, imgs, pts, 
     imgs [B,3,S,S] normalised, pts [B,P,2] / labels [B,P] clicks, memory / memory_pos [Nk,B,64] (bench.assemble_memory layout),
     target_masks [B, num_mask_tokens, S/4, S/4], or with mask_index [B, 1, S, S] (the reference's loss on that up-sampled mask).
     grads_out (optional dict): receives the TRUE gradients of every group ("decoder", "memory_attention", "image_encoder") for audits.
+    data_parallel: one process per GPU on its own images (BASELINE.json configs[4]); every group's gradients are summed over the ranks
+    by `parallel.allreduce_gradients_async`, started as soon as the group's backward is done so that the transfer runs under the next
+    group's backward (decoder under memory attention, memory attention under image encoder), and averaged inside Adam (grad_scale).
     Returns (loss, maskmem_features [B,64,S/16,S/16])."""
     from . import backward_encoder as be
     from .modeling.common import to_bf16, tokens_of
@@ -292,12 +301,17 @@ def train_step_2d(model, opt_mem: DecoderAdam, opt_dec: DecoderAdam, imgs, pts, 
     dense = model.sam_prompt_encoder.no_mask_embed.weight.detach().reshape(1, -1)
     aux: dict = {}
     cal = getattr(opt_mem, "calibrated_loss_scales", {})                         # one calibration per loss form
-    kwargs = dict(dense_tokens=dense, aux=aux, mem_scale=cal.get(mask_index), mask_index=mask_index)
+    pend: dict = {}
+    kwargs = dict(dense_tokens=dense, aux=aux, mem_scale=cal.get(mask_index), mask_index=mask_index, data_parallel=data_parallel,
+                  on_decoder_grads=(lambda g: pend.__setitem__("dec", parallel.allreduce_gradients_async(g))) if data_parallel else None)
     loss, scale, scale_mem, g_dec, g_mem, dcurr = memory_decoder_loss_grads(
         model.memory_attention, model.sam_mask_decoder, vision_feats[-1], vision_pos_embeds[-1], memory, memory_pos, 0, pe, se.to(torch.float32),
         f0, f1, B, h, w, target_masks, **kwargs)
     cal[mask_index] = scale_mem / scale
     opt_mem.calibrated_loss_scales = cal
+    inv_world = 1.0
+    if data_parallel:
+        pend["mem"] = parallel.allreduce_gradients_async(g_mem)
     if opt_enc is not None:
         # the encoder's three outputs received: level 0 / 1 through the decoder's up-scaling adds (loss scale `scale`), level 2 through
         # the memory attention's query stream (`scale_mem`); the encoder backward runs every block under its own cached scale
@@ -308,18 +322,24 @@ def train_step_2d(model, opt_mem: DecoderAdam, opt_dec: DecoderAdam, imgs, pts, 
             enc_scales = opt_enc.calibrated_block_scales = {}
         g_all = be.image_encoder_backward(model, enc_state, [aux["d_feat_s0"], aux["d_feat_s1"], d_top], [scale, scale, scale_mem],
                                           enc_scales.setdefault(mask_index, {}))
+        if data_parallel:
+            g_all, inv_world = parallel.allreduce_gradients(g_all)
         g_enc = {k[len("image_encoder."):]: v for k, v in g_all.items() if k.startswith("image_encoder.")}
-        for k, v in g_all.items():                                               # conv_s0 / conv_s1 live in the decoder's group
-            if k.startswith("sam_mask_decoder."):
-                g_dec[k[len("sam_mask_decoder."):]] = v * scale
-        opt_enc.step(g_enc, grad_scale=1.0)
+        g_convs = {k[len("sam_mask_decoder."):]: v * scale for k, v in g_all.items() if k.startswith("sam_mask_decoder.")}
+    if data_parallel:
+        g_dec, inv_world = pend["dec"].wait()
+        g_mem, _ = pend["mem"].wait()
+    if opt_enc is not None:
+        g_dec = dict(g_dec)
+        g_dec.update(g_convs)                                                    # conv_s0 / conv_s1 live in the decoder's group
+        opt_enc.step(g_enc, grad_scale=inv_world)
         if grads_out is not None:
             grads_out["image_encoder"] = g_enc
     if grads_out is not None:
         grads_out["decoder"] = {k: v / scale for k, v in g_dec.items()}
         grads_out["memory_attention"] = {k: v / scale_mem for k, v in g_mem.items()}
-    opt_dec.step(g_dec, grad_scale=1.0 / scale)
-    opt_mem.step(g_mem, grad_scale=1.0 / scale_mem)
+    opt_dec.step(g_dec, grad_scale=inv_world / scale)
+    opt_mem.step(g_mem, grad_scale=inv_world / scale_mem)
     low_res = aux["masks"][:, :1].contiguous()                                   # single-mask output token (multimask_output=False)
     high_res = ops.bilinear_upsample(low_res, model.image_size, model.image_size)
     maskmem_features, _ = model._encode_new_memory(current_vision_feats=vision_feats, feat_sizes=feat_sizes, pred_masks_high_res=high_res,

@@ -15,7 +15,14 @@ What is re-designed without changing any result:
   * frames are normalised on the device by one kernel-free broadcast; hole filling runs the batched HIP connected-components
     path (`ops.fill_holes_`); resizing uses the HIP bilinear kernel.
 The `train_*` entry points of the fork (179-248, 425-555, 641-722, 971-1039, 1126-1208: the same code without
-`torch.inference_mode`) are aliases of the forward path: the backward pass is outside this round's scope.
+`torch.inference_mode`) are aliases of the forward path; training on the HIP path goes through `training.py` (explicit backward, no
+autograd graph), not through the predictor.
+
+PROVENANCE: this file is a DERIVED work, not a re-design.  SURVEY.md section 2 #13 marks the predictor state machine "keep as-is": its
+`inference_state` dictionary layout, method signatures and the order of the consolidation / preflight / propagation steps ARE the
+contract that `func_3d/function.py` and the notebooks program against, so the host-side control flow below follows
+`sam2_train/sam2_video_predictor.py` step by step (condensed; the hot path it drives -- `SAM2Base.track_step` and everything under it
+-- is the from-scratch HIP implementation).  It is not counted as original work in DESIGN.md.
 """
 from __future__ import annotations
 
