@@ -275,6 +275,11 @@ def allreduce_gradients_async(grads: Dict[str, torch.Tensor], group=None, bucket
     names = sorted(grads)
     out = {n: (g if (g.dtype == torch.float32 and g.is_contiguous()) else g.detach().float().contiguous()) for n, g in ((n, grads[n]) for n in names)}
     works, i = [], 0
+    if dist.get_backend(group) != "nccl" and any(t.is_cuda for t in out.values()):
+        # rehearsal setups (gloo ranks sharing one GPU): gloo has no coalesced all-reduce for device tensors -> one async all-reduce per
+        # tensor in the same sorted order (RCCL, the production backend, takes the coalesced groups below)
+        works = [dist.all_reduce(out[n], op=dist.ReduceOp.SUM, group=group, async_op=True) for n in names]
+        i = len(names)
     while i < len(names):
         j, size = i, 0
         while j < len(names) and (j == i or size + out[names[j]].numel() * 4 <= bucket_bytes):
