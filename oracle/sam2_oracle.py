@@ -81,8 +81,34 @@ def hiera_block_specs(tc: dict) -> List[dict]:
 # --------------------------------------------------------------------------------------------------------------------
 # primitives
 # --------------------------------------------------------------------------------------------------------------------
+# Operand-rounding EMULATION (test infrastructure for the precision argument of DESIGN.md section 4): with OPERAND_DTYPE set (a 16-bit
+# torch dtype) every matrix product of the path rounds BOTH operands to that type and accumulates in fp32 -- what an MFMA kernel with
+# 16-bit operands does -- while residual streams, LayerNorm, softmax statistics and biases stay fp32.  None (default): plain fp32.
+OPERAND_DTYPE = None
+
+
+def _rop(t: Tensor) -> Tensor:
+    return t if OPERAND_DTYPE is None else t.to(OPERAND_DTYPE).to(t.dtype)
+
+
+class operand_rounding:
+    """`with operand_rounding(torch.float16): ...` -- run the oracle with emulated 16-bit matrix-product operands"""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global OPERAND_DTYPE
+        self.prev, OPERAND_DTYPE = OPERAND_DTYPE, self.dtype
+
+    def __exit__(self, *a):
+        global OPERAND_DTYPE
+        OPERAND_DTYPE = self.prev
+        return False
+
+
 def lin(P, pre: str, x: Tensor) -> Tensor:
-    return x @ P[pre + ".weight"].t() + P[pre + ".bias"]
+    return _rop(x) @ _rop(P[pre + ".weight"]).t() + P[pre + ".bias"]
 
 
 def lnorm(P, pre: str, x: Tensor, eps: float) -> Tensor:
@@ -104,13 +130,13 @@ def softmax_attention(q: Tensor, k: Tensor, v: Tensor, pmask: Optional[Tensor] =
     """softmax(q k^T / sqrt(D)) v on [..., L, D]; what F.scaled_dot_product_attention computes at
     hieradet.py:72-76, transformer.py:258,318 (no attention mask).  pmask: train-mode dropout_p as an explicit multiplier on the
     probabilities (keep / (1 - p) or 0), so that a test can hand over the masks of the implementation under test."""
-    s = (q @ k.transpose(-1, -2)) / math.sqrt(q.shape[-1])
+    s = (_rop(q) @ _rop(k).transpose(-1, -2)) / math.sqrt(q.shape[-1])
     s = s - s.amax(-1, keepdim=True)
     p = s.exp()
-    p = p / p.sum(-1, keepdim=True)
+    l = p.sum(-1, keepdim=True)
     if pmask is not None:
         p = p * pmask
-    return p @ v
+    return (_rop(p) @ _rop(v)) / l
 
 
 def mlp(P, pre: str, x: Tensor, n_layers: int, act, sigmoid_out: bool = False) -> Tensor:
@@ -222,7 +248,7 @@ def multiscale_block(P, pre: str, x: Tensor, spec: dict) -> Tensor:
 
 def hiera_trunk(P, cfg: dict, img: Tensor, pre: str = "image_encoder.trunk", collect: Optional[dict] = None) -> List[Tensor]:
     """Hiera.forward (hieradet.py:279-295): [B,3,S,S] -> list of NCHW stage outputs (high to low resolution)."""
-    x = F.conv2d(img, P[pre + ".patch_embed.proj.weight"], P[pre + ".patch_embed.proj.bias"], stride=4, padding=3)
+    x = F.conv2d(_rop(img), _rop(P[pre + ".patch_embed.proj.weight"]), P[pre + ".patch_embed.proj.bias"], stride=4, padding=3)
     x = x.permute(0, 2, 3, 1)
     x = x + hiera_pos_embed(P, pre, x.shape[1], x.shape[2])
     outs = []
@@ -239,7 +265,7 @@ def hiera_trunk(P, cfg: dict, img: Tensor, pre: str = "image_encoder.trunk", col
 # FPN neck + forward_image (a-8, a-9, a-10)
 # --------------------------------------------------------------------------------------------------------------------
 def conv1x1(P, pre: str, x: Tensor) -> Tensor:
-    return F.conv2d(x, P[pre + ".weight"], P[pre + ".bias"])
+    return F.conv2d(_rop(x), _rop(P[pre + ".weight"]), P[pre + ".bias"])
 
 
 def fpn_neck(P, cfg: dict, xs: Sequence[Tensor], pre: str = "image_encoder.neck") -> Tuple[List[Tensor], List[Tensor]]:
@@ -444,9 +470,9 @@ def mask_decoder_predict(P, image_embeddings: Tensor, image_pe: Tensor, sparse: 
     src = keys.transpose(1, 2).reshape(b, c, h, w)
     feat_s0, feat_s1 = high_res
     up = pre + ".output_upscaling"
-    u = F.conv_transpose2d(src, P[up + ".0.weight"], P[up + ".0.bias"], stride=2) + feat_s1
+    u = F.conv_transpose2d(_rop(src), _rop(P[up + ".0.weight"]), P[up + ".0.bias"], stride=2) + feat_s1
     u = gelu(lnorm2d(P, up + ".1", u))
-    u = gelu(F.conv_transpose2d(u, P[up + ".3.weight"], P[up + ".3.bias"], stride=2) + feat_s0)
+    u = gelu(F.conv_transpose2d(_rop(u), _rop(P[up + ".3.weight"]), P[up + ".3.bias"], stride=2) + feat_s0)
     hyper = torch.stack([mlp(P, f"{pre}.output_hypernetworks_mlps.{i}", mask_toks[:, i], 3, torch.relu)
                          for i in range(4)], dim=1)
     b, c, h, w = u.shape
