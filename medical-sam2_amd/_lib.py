@@ -25,6 +25,9 @@ SIGNATURES = {
     "msam2_gemm_qkv_pool2x2": (c_i, [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_l, c_l, c_l, c_l, c_l, c_l, c_p]),
     "msam2_gemm_tokens": (c_i, [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_i, c_l, c_l, c_l, c_i, c_p]),
     "msam2_gemm_rope": (c_i, [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_l, c_l, c_l, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_p]),
+    "msam2_ln_mlp_residual_supported": (c_i, [c_l]),
+    "msam2_mlp_fused_permute_w2": (c_i, [c_p, c_p, c_l, c_l, c_p]),
+    "msam2_ln_mlp_residual_fwd": (c_i, [c_p, c_l, c_l, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
     "msam2_layernorm": (c_i, [c_p, c_i, c_l, c_p, c_p, c_p, c_i, c_l, c_l, c_l, c_f, c_i, c_p]),
     "msam2_attention_workspace_bytes": (c_z, [c_l, c_l, c_l, c_l, c_i]),
     "msam2_attention_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_f, c_i, c_p, c_z, c_p]),

@@ -1,0 +1,268 @@
+// Fused pre-LN MLP block of the Hiera trunk for gfx950:   out = x + fc2( GELU( fc1( LayerNorm(x) ) ) )      (hieradet.py:166-167,
+// sam2_utils.py:108-132 with nn.GELU, LayerNorm eps 1e-6)
+//
+// Why one kernel.  At the two high-resolution stages (dim 96 / 192, 262144 / 65536 tokens at 4 x 1024^2) the three launches of the block --
+// LayerNorm, fc1 + GELU, fc2 + residual -- are bound by what they move, not by what they compute: the 4 x dim hidden activation
+// (201 MB at stage 1) is written and read back once, the LayerNorm output once more, and K = 96 / 192 GEMMs spend their life in prologue
+// and epilogue.  Here the hidden activation never leaves the registers:
+//
+//   * everything is computed TRANSPOSED so that a lane owns one token: H^T = W1 X^T (A = W1 rows from LDS, B = the token's normalised
+//     row held in registers), then Y^T += W2 H^T where the fp32 accumulator of H^T, after bias + GELU + conversion, IS the B operand
+//     (the accumulator of a 32x32x16 MFMA has the token on the lane and 8 consecutive k per register group: no LDS round trip, no
+//     shuffle); the k order of that operand is permuted, so W2 is given with its hidden dimension pre-permuted the same way (host);
+//   * a wave carries TB blocks of 32 tokens through the whole hidden dimension, so every weight fragment read from LDS feeds TB (fc1)
+//     MFMAs: LDS traffic per MFMA is well under the 1 KB of the 128 x 128 GEMM tiles;
+//   * the weights stream through LDS in hidden-dimension chunks of HC (both W1 rows and W2 columns of a chunk: 72 KB), double
+//     buffered by LDS-DMA (buffer_load ... lds) one chunk ahead, ONE barrier per chunk; workgroups are persistent over token passes
+//     and the chunk ring runs on across passes;
+//   * LayerNorm runs on the lane's half row (the other half sits 32 lanes away: one cross-half add), the residual is added in the
+//     store.
+// LDS images: rows of 192 B use chunk' = (c & ~3) | ((c & 3) ^ ((r >> 2) & 3)), rows of 384 B chunk' = (c & ~7) | ((c & 7) ^ ((r >> 1) & 7))
+// (both conflict free for the 32-row ds_read_b128 fragment reads); applied on the DMA source address and on the reads.
+#include "common.h"
+
+struct MlpFusedParams {
+  const float* x;        // [T, DIM] fp32 residual stream
+  float* out;            // [T, DIM]
+  const float *ln_w, *ln_b, *b1, *b2;
+  const op16* w1;        // [4*DIM, DIM]
+  const op16* w2p;       // [DIM, 4*DIM], hidden index permuted inside every 32-block (see mlp_fused_permute)
+  int64_t T;
+  float eps;
+};
+
+template <int RB>
+__device__ __forceinline__ int mlp_swz(int c, int r) {
+  if constexpr (RB == 192) return (c & ~3) | ((c & 3) ^ ((r >> 2) & 3));
+  else return (c & ~7) | ((c & 7) ^ ((r >> 1) & 7));
+}
+
+template <int DIM, int HC, int TB>
+__global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int HID = 4 * DIM, NCH = HID / HC, KS1 = DIM / 16, DB = DIM / 32, HB = HC / 32;
+  constexpr int RB1 = DIM * 2, RB2 = HC * 2;                 // LDS row bytes of the W1 chunk [HC][DIM] and the W2 chunk [DIM][HC]
+  constexpr int CPR1 = DIM / 8, CPR2 = HC / 8;               // 16-byte chunks per row
+  constexpr int W1B = HC * RB1, W2B = DIM * RB2, BUF = W1B + W2B;
+  constexpr int PIECES1 = W1B / 1024, PIECES2 = W2B / 1024, PW1 = PIECES1 / 4, PW2 = PIECES2 / 4;
+  static_assert((RB1 == 192 || RB1 == 384) && (RB2 == 192 || RB2 == 384), "row swizzles are built for 192 / 384-byte rows");
+  static_assert(PIECES1 % 4 == 0 && PIECES2 % 4 == 0 && 2 * BUF + (3 * DIM + HID) * 4 <= 160 * 1024, "LDS budget");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  float* prm = reinterpret_cast<float*>(smem + 2 * BUF);     // [gamma DIM | beta DIM | b2 DIM | b1 HID]
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  for (int i = tid; i < DIM; i += 256) {
+    prm[i] = p.ln_w[i];
+    prm[DIM + i] = p.ln_b[i];
+    prm[2 * DIM + i] = p.b2[i];
+  }
+  for (int i = tid; i < HID; i += 256) prm[3 * DIM + i] = p.b1[i];
+
+  // ---- weight stream: per-lane source offsets of this wave's DMA pieces (chunk-independent part), scalar chunk offset added per issue
+  const auto w1_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, HID * DIM * 2, 0x00020000);
+  const auto w2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2p, 0, HID * DIM * 2, 0x00020000);
+  unsigned off1[PW1], off2[PW2];
+#pragma unroll
+  for (int j = 0; j < PW1; ++j) {
+    const int f = (wave * PW1 + j) * 64 + lane, row = f / CPR1, c = f % CPR1;
+    off1[j] = (unsigned)(row * RB1 + mlp_swz<RB1>(c, row) * 16);                       // W1 rows are DIM * 2 bytes in memory too
+  }
+#pragma unroll
+  for (int j = 0; j < PW2; ++j) {
+    const int f = (wave * PW2 + j) * 64 + lane, row = f / CPR2, c = f % CPR2;
+    off2[j] = (unsigned)(row * HID * 2 + mlp_swz<RB2>(c, row) * 16);
+  }
+  auto issue = [&](int chunk, int buf) {
+    unsigned char* d1 = smem + buf * BUF + wave * PW1 * 1024;
+    unsigned char* d2 = smem + buf * BUF + W1B + wave * PW2 * 1024;
+    const unsigned s1 = (unsigned)chunk * HC * RB1, s2 = (unsigned)chunk * HC * 2;
+#pragma unroll
+    for (int j = 0; j < PW1; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w1_rsrc, (__attribute__((address_space(3))) void*)(d1 + j * 1024), 16, off1[j], s1, 0, 0);
+#pragma unroll
+    for (int j = 0; j < PW2; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w2_rsrc, (__attribute__((address_space(3))) void*)(d2 + j * 1024), 16, off2[j], s2, 0, 0);
+  };
+
+  const int64_t pass_tokens = 128 * TB;
+  const int64_t n_pass = (p.T + pass_tokens - 1) / pass_tokens;
+  int64_t g_chunk = 0;                                       // running chunk count of this workgroup (buffer = parity)
+  if ((int64_t)blockIdx.x < n_pass) issue(0, 0);
+  __syncthreads();                                           // parameters visible (the DMA is waited for inside the loop)
+
+  for (int64_t pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
+    // ---- this wave's TB token blocks: LayerNorm -> 16-bit B fragments
+    op16x8 xf[TB][KS1];
+    int64_t tok[TB];
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb) {
+      const int64_t t = pass * pass_tokens + (int64_t)(wave * TB + tb) * 32 + r;
+      tok[tb] = t;
+      const float* xr = p.x + (t < p.T ? t : p.T - 1) * DIM;
+      f32x4 v[KS1][2];
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < KS1; ++k)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          v[k][q] = *reinterpret_cast<const f32x4*>(xr + 16 * k + 8 * h + 4 * q);
+          s += v[k][q][0] + v[k][q][1] + v[k][q][2] + v[k][q][3];
+        }
+      s += __shfl_xor(s, 32, 64);
+      const float mean = s * (1.f / DIM);
+      float q2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < KS1; ++k)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float dlt = v[k][q][e] - mean;
+            q2 += dlt * dlt;
+          }
+      q2 += __shfl_xor(q2, 32, 64);
+      const float rstd = 1.0f / sqrtf(q2 * (1.f / DIM) + p.eps);
+#pragma unroll
+      for (int k = 0; k < KS1; ++k) {
+        op16x8 f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(prm + 16 * k + 8 * h + 4 * q);
+          const f32x4 bt = *reinterpret_cast<const f32x4*>(prm + DIM + 16 * k + 8 * h + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[4 * q + e] = f2op((v[k][q][e] - mean) * rstd * gm[e] + bt[e]);
+        }
+        xf[tb][k] = f;
+      }
+    }
+    f32x16 accy[TB][DB];
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accy[tb][d][e] = 0.f;
+
+    for (int chunk = 0; chunk < NCH; ++chunk, ++g_chunk) {
+      const int buf = (int)(g_chunk & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of the chunk have landed
+      __builtin_amdgcn_s_barrier();                          // ... every wave's; the other buffer is no longer read
+      {
+        const bool more_here = chunk + 1 < NCH;
+        const bool more = more_here || (pass + gridDim.x < n_pass);
+        if (more) issue(more_here ? chunk + 1 : 0, buf ^ 1);
+      }
+      const unsigned char* w1s = smem + buf * BUF;
+      const unsigned char* w2s = w1s + W1B;
+#pragma unroll 1
+      for (int hb = 0; hb < HB; ++hb) {
+        // fc1 fragments of this hidden block: read once, used by all TB token blocks
+        op16x8 a1[KS1];
+        const int row1 = hb * 32 + r;
+#pragma unroll
+        for (int k = 0; k < KS1; ++k) a1[k] = *reinterpret_cast<const op16x8*>(w1s + row1 * RB1 + (mlp_swz<RB1>(2 * k + h, row1) << 4));
+        // bias of the hidden rows this lane holds: (e & 3) + 8 (e >> 2) + 4 h  -> four float4 reads
+        f32x4 bias1[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias1[g] = *reinterpret_cast<const f32x4*>(prm + 3 * DIM + chunk * HC + hb * 32 + 8 * g + 4 * h);
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) {
+          f32x16 acch;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acch[e] = bias1[e >> 2][e & 3];
+#pragma unroll
+          for (int k = 0; k < KS1; ++k) acch = MSAM2_MFMA_32x32x16(a1[k], xf[tb][k], acch, 0, 0, 0);
+          op16x8 hf[2];
+#pragma unroll
+#ifdef MSAM2_MLP_NO_GELU   // timing experiment only: what the activation costs
+          for (int e = 0; e < 16; ++e) hf[e >> 3][e & 7] = f2op(acch[e]);
+#else
+          for (int e = 0; e < 16; ++e) hf[e >> 3][e & 7] = f2op(gelu_erf(acch[e]));
+#endif
+          // fc2: Y^T[d][token] += W2[d][hidden] H^T[hidden][token]; operand k order = the accumulator's register order (permuted W2)
+#pragma unroll
+          for (int d = 0; d < DB; ++d) {
+            const int row2 = d * 32 + r;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+              const op16x8 a2 = *reinterpret_cast<const op16x8*>(w2s + row2 * RB2 + (mlp_swz<RB2>(hb * 4 + 2 * s2 + h, row2) << 4));
+              accy[tb][d] = MSAM2_MFMA_32x32x16(a2, hf[s2], accy[tb][d], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    // ---- epilogue: + b2 + residual, fp32 store (a lane owns a token; 4 consecutive channels per register group)
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb) {
+      if (tok[tb] < p.T) {
+        const float* xr = p.x + tok[tb] * DIM;
+        float* yr = p.out + tok[tb] * DIM;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int ch = d * 32 + 8 * g + 4 * h;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + ch);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(prm + 2 * DIM + ch);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = accy[tb][d][4 * g + e] + bv[e] + xv[e];
+            *reinterpret_cast<f32x4*>(yr + ch) = o;
+          }
+      }
+    }
+  }
+#endif
+}
+
+// hidden-dimension permutation of W2 [DIM, HID] that matches the k order in which an H^T accumulator is consumed as the B operand:
+// position 16 s + 8 h + j of every 32-block holds hidden unit 16 s + 8 (j >> 2) + 4 h + (j & 3).
+__global__ void mlp_fused_permute_kernel(const op16* __restrict__ w2, op16* __restrict__ w2p, int dim, int hid) {
+  const int64_t total = (int64_t)dim * hid;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i / hid), pos = (int)(i % hid);
+    const int blk = pos >> 5, q = pos & 31, s = q >> 4, hh = (q >> 3) & 1, j = q & 7;
+    w2p[i] = w2[(int64_t)d * hid + blk * 32 + 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3)];
+  }
+}
+
+extern "C" int msam2_mlp_fused_permute_w2(const void* w2, void* w2p, int64_t dim, int64_t hidden, void* stream) {
+  MSAM2_REQUIRE(w2 && w2p && dim > 0 && hidden % 32 == 0, "mlp_fused_permute_w2: bad arguments");
+  hipLaunchKernelGGL(mlp_fused_permute_kernel, dim3((unsigned)min((int64_t)1024, cdiv(dim * hidden, 256))), dim3(256), 0, (hipStream_t)stream,
+                     (const op16*)w2, (op16*)w2p, (int)dim, (int)hidden);
+  return msam2_check_launch("mlp_fused_permute_w2");
+}
+
+// 1 when msam2_ln_mlp_residual_fwd is built for this width (hidden = 4 * dim, exact-erf GELU): dim 96 and 192 (Hiera stages 1 / 2)
+extern "C" int msam2_ln_mlp_residual_supported(int64_t dim) { return dim == 96 || dim == 192; }
+
+template <int DIM, int HC, int TB>
+static int launch_mlp_fused(const MlpFusedParams& p, hipStream_t s) {
+  constexpr int LDS = 2 * (2 * HC * DIM * 2) + (3 * DIM + 4 * DIM) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)mlp_fused_kernel<DIM, HC, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  const int64_t n_pass = (p.T + 128 * TB - 1) / (128 * TB);
+  hipLaunchKernelGGL((mlp_fused_kernel<DIM, HC, TB>), dim3((unsigned)min((int64_t)256, n_pass)), dim3(256), LDS, s, p);
+  return msam2_check_launch("ln_mlp_residual_fwd");
+}
+
+// out[T, dim] (fp32) = x + fc2(GELU(fc1(LayerNorm(x)))) with x fp32 [T, dim] contiguous, w1 16-bit [4 dim, dim], w2p 16-bit [dim, 4 dim]
+// permuted by msam2_mlp_fused_permute_w2, biases / LayerNorm parameters fp32.  dim in {96, 192}.
+extern "C" int msam2_ln_mlp_residual_fwd(const float* x, int64_t T, int64_t dim, const float* ln_w, const float* ln_b, float eps, const void* w1,
+                                         const float* b1, const void* w2p, const float* b2, float* out, void* stream) {
+  MSAM2_REQUIRE(x && out && ln_w && ln_b && w1 && b1 && w2p && b2 && T > 0, "ln_mlp_residual: null tensor / empty problem");
+  MSAM2_REQUIRE(msam2_ln_mlp_residual_supported(dim), "ln_mlp_residual: dim %lld not built (96 / 192)", (long long)dim);
+  MSAM2_REQUIRE((((uintptr_t)x | (uintptr_t)out | (uintptr_t)w1 | (uintptr_t)w2p | (uintptr_t)ln_w | (uintptr_t)ln_b | (uintptr_t)b1 | (uintptr_t)b2) & 15) == 0,
+                "ln_mlp_residual: 16-byte aligned tensors");
+  MSAM2_REQUIRE(x != out, "ln_mlp_residual: in-place not supported (a token's residual is re-read in the store)");
+  MlpFusedParams p = {x, out, ln_w, ln_b, b1, b2, (const op16*)w1, (const op16*)w2p, T, eps};
+  hipStream_t s = (hipStream_t)stream;
+  if (dim == 96) return launch_mlp_fused<96, 192, 4>(p, s);
+  return launch_mlp_fused<192, 96, 2>(p, s);
+}

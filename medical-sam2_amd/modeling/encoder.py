@@ -20,6 +20,7 @@ from .position import PositionEmbeddingSine
 import os as _os
 _POOL_GEMM = _os.environ.get("MSAM2_NO_POOL_GEMM") is None   # experiment switches
 _QPOOL_GEMM = _os.environ.get("MSAM2_NO_QPOOL_GEMM") is None
+_FUSED_MLP = _os.environ.get("MSAM2_NO_FUSED_MLP") is None
 
 
 class PatchEmbed(nn.Module):
@@ -200,6 +201,16 @@ class MultiScaleBlock(nn.Module):
             o = ops.attention(q, v5[:, :, 1].permute(0, 2, 1, 3), v5[:, :, 2].permute(0, 2, 1, 3), scale=scale)
             o = o.permute(0, 2, 1, 3).reshape(B * Hq * Wq, width)
         t = ops.gemm(o, proj_w, v_f32(wc, "ob", a.proj.bias), residual=shortcut, out_dtype=F32)
+        mlp = self.mlp
+        if (_FUSED_MLP and ops.ln_mlp_residual_supported(dim_out) and mlp.num_layers == 2 and mlp._act_code == ops.ACT_GELU
+                and mlp.layers[0].out_features == 4 * dim_out and Hq * Wq >= 1024):
+            # the two high-resolution stages: LayerNorm + fc1 + GELU + fc2 + residual as one kernel, the hidden map stays in registers
+            # (the gate looks at the tokens PER SLICE, never at the batch: a slice's features must not depend on its batch mates)
+            w2p = mlp._wc.get("w1p", [mlp.layers[1].weight], lambda: ops.mlp_fused_permute_w2(mlp.layers[1].weight.detach().to(OP16).contiguous()))
+            t = ops.ln_mlp_residual(t, v_f32(wc, "n2w", self.norm2.weight), v_f32(wc, "n2b", self.norm2.bias), 1e-6,
+                                    w_bf16(mlp._wc, "w0", mlp.layers[0].weight), v_f32(mlp._wc, "b0", mlp.layers[0].bias), w2p,
+                                    v_f32(mlp._wc, "b1", mlp.layers[1].bias))
+            return t, Hq, Wq
         xn2 = ops.layernorm(t, v_f32(wc, "n2w", self.norm2.weight), v_f32(wc, "n2b", self.norm2.bias), 1e-6)
         t = self.mlp.run(xn2, residual=t, out_dtype=F32)
         return t, Hq, Wq

@@ -138,6 +138,29 @@ def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: fl
     return y.reshape(x.shape)
 
 
+def ln_mlp_residual_supported(dim: int) -> bool:
+    return bool(lib().msam2_ln_mlp_residual_supported(dim))
+
+
+def mlp_fused_permute_w2(w2: torch.Tensor) -> torch.Tensor:
+    """kernel-ready copy of fc2's weight [dim, hidden] (16-bit) for ln_mlp_residual"""
+    _req(w2.dim() == 2 and w2.dtype == OP16 and w2.is_contiguous() and w2.shape[1] % 32 == 0, "mlp_fused_permute_w2: 16-bit [dim, hidden]")
+    out = torch.empty_like(w2)
+    check(lib().msam2_mlp_fused_permute_w2(_p(w2), _p(out), w2.shape[0], w2.shape[1], _stream()))
+    return out
+
+
+def ln_mlp_residual(x: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, eps: float, w1: torch.Tensor, b1: torch.Tensor, w2p: torch.Tensor,
+                    b2: torch.Tensor) -> torch.Tensor:
+    """fp32 [T, dim] = x + fc2(GELU(fc1(LayerNorm(x)))) in one kernel (dim 96 / 192; w2p from mlp_fused_permute_w2)."""
+    T, dim = x.shape
+    _req(x.dtype == F32 and x.is_contiguous() and w1.dtype == OP16 and w2p.dtype == OP16 and w1.shape == (4 * dim, dim) and w2p.shape == (dim, 4 * dim)
+         and w1.is_contiguous() and w2p.is_contiguous(), "ln_mlp_residual: x fp32 [T, dim], w1 [4 dim, dim], w2p [dim, 4 dim] 16-bit contiguous")
+    out = torch.empty_like(x)
+    check(lib().msam2_ln_mlp_residual_fwd(_p(x), T, dim, _p(ln_w), _p(ln_b), float(eps), _p(w1), _p(b1), _p(w2p), _p(b2), _p(out), _stream()))
+    return out
+
+
 def _strides3(t: torch.Tensor) -> "ctypes.Array":
     return (ctypes.c_int64 * 3)(t.stride(0), t.stride(1), t.stride(2))
 

@@ -637,3 +637,27 @@ def test_hip_graph_replay(ops):
         gr.replay()
         s.synchronize()
     close(out, a.float().cpu() @ w.float().cpu().t(), 2e-4, 1e-5, "graph replay")
+
+
+@pytest.mark.parametrize("dim,T", [(96, 512), (96, 4096 + 77), (192, 256), (192, 3000)])
+def test_ln_mlp_residual_fused(ops, dim, T):
+    """msam2_ln_mlp_residual_fwd (LayerNorm + fc1 + exact-erf GELU + fc2 + residual in one kernel, hieradet.py:166-167) against the
+    oracle's norm2 / MLP on the same 16-bit weights: ragged token counts (partial passes, clamped rows), several passes per workgroup."""
+    x = rnd(T, dim, seed=1, scale=1.5) + 0.3
+    P = {"n.weight": 1 + 0.1 * rnd(dim, seed=2), "n.bias": 0.1 * rnd(dim, seed=3),
+         "m.layers.0.weight": bf(rnd(4 * dim, dim, seed=4) / dim ** 0.5).float(), "m.layers.0.bias": 0.1 * rnd(4 * dim, seed=5),
+         "m.layers.1.weight": bf(rnd(dim, 4 * dim, seed=6) / (4 * dim) ** 0.5).float(), "m.layers.1.bias": 0.1 * rnd(dim, seed=7)}
+    h = O.lnorm(P, "n", x, 1e-6)
+    ref = x + O.lin(P, "m.layers.1", O.gelu(O.lin(P, "m.layers.0", h)))
+    d = lambda t: t.to(DEV)
+    w2p = ops.mlp_fused_permute_w2(bf(P["m.layers.1.weight"]).to(DEV))
+    out = ops.ln_mlp_residual(d(x), d(P["n.weight"]), d(P["n.bias"]), 1e-6, bf(P["m.layers.0.weight"]).to(DEV), d(P["m.layers.0.bias"]), w2p,
+                              d(P["m.layers.1.bias"]))
+    assert out.shape == x.shape and out.dtype == torch.float32
+    # two 16-bit roundings (normalised input, hidden activation) as in the three-launch path
+    close(out, ref, 6e-3, 4e-3, "fused LN+MLP")
+    # against the three-launch path of the same library: same operand roundings, different summation order only
+    xn = ops.layernorm(d(x), d(P["n.weight"]), d(P["n.bias"]), 1e-6)
+    hid = ops.gemm(xn, bf(P["m.layers.0.weight"]).to(DEV), d(P["m.layers.0.bias"]), act=ops.ACT_GELU)
+    three = ops.gemm(hid, bf(P["m.layers.1.weight"]).to(DEV), d(P["m.layers.1.bias"]), residual=d(x), out_dtype=torch.float32)
+    close(out, three, 4e-3, 2e-3, "fused vs three launches")

@@ -16,6 +16,9 @@ DOC = {
     "msam2_gemm_tokens": "Token-side linear layers of the two-way decoder (transformer.py:165-196, 239-263): M <= 32 rows, A in fp32 from the residual\nstream, columns < add_cols computed from A + A2 (queries + query_pe), add and 16-bit conversion fused into the operand load.",
     "msam2_gemm_rope": "Linear projection with the axial RoPE of RoPEAttention fused into the store (transformer.py:241-243 + 299-315,\nposition_encoding.py:200-216): C (16-bit) = rope(A W^T + bias) on columns < rope_cols (whole heads, adjacent channel pairs) of rows\nwhose position l = m % rows_per_batch is < n_rope, with table row l % n_pos of cos/sin [n_pos, head_dim/2] (rope_k_repeat).",
     "msam2_gemm": "C[M,N] = residual[m % res_mod] + colscale[n] * act(A[M,K] W[N,K]^T + bias[n]); A, W 16-bit (K contiguous), bias/colscale\nfp32, residual/C 16-bit or fp32.  act: 0 none, 1 exact-erf GELU, 2 ReLU, 3 sigmoid.\nReplaces every nn.Linear / 1x1 Conv2d / im2col'ed conv of the path: hieradet.py:61,79,141; sam2_utils.py:127-131;\ntransformer.py:241-243,261; memory_attention.py:96; image_encoder.py:112; mask_decoder.py:240-256;\nmemory_encoder.py:103-105,171-175; sam2_base.py:470-475.",
+    "msam2_ln_mlp_residual_supported": "1 when msam2_ln_mlp_residual_fwd is built for this width (96 / 192: Hiera stages 1 and 2).",
+    "msam2_mlp_fused_permute_w2": "Kernel-ready copy of the second MLP weight for msam2_ln_mlp_residual_fwd: the hidden index of every 32-block permuted to the k order\nin which the fc1 accumulator is consumed as an MFMA operand.",
+    "msam2_ln_mlp_residual_fwd": "The MLP half of MultiScaleBlock.forward as ONE kernel (hieradet.py:166-167: x = x + self.mlp(self.norm2(x)); sam2_utils.py:108-132 with\nnn.GELU): LayerNorm, fc1, exact-erf GELU, fc2 and the residual add; the 4x hidden activation never leaves the registers.  Block-level\nfused entry for the two high-resolution stages (dim 96 / 192), where the three separate launches are bound by the hidden map's HBM\nround trip.",
     "msam2_layernorm": "Row LayerNorm (fp32 statistics) on [rows, C], optional GELU: nn.LayerNorm at hieradet.py:138,166,\nmemory_attention.py:60,73,94,162, transformer.py:173-194,116; LayerNorm2d (sam2_utils.py:137-149) on NHWC tokens.",
     "msam2_attention_workspace_bytes": "Scratch needed by msam2_attention_fwd when splits > 1 (fp32 partial O, running max, partial sum).",
     "msam2_attention_merge": "Second half of a split-KV attention call issued with a NEGATIVE split count (the split pass alone, partials left in the\nworkspace): combines the per-split (max, sum, O) triples into o.  Lets a host time / overlap the two kernels separately.",
@@ -92,7 +95,7 @@ DOC = {
 
 def main():
     decls = []
-    for f in ["api.hip", "gemm.hip", "attention.hip", "attention_bwd.hip", "elementwise.hip", "conv.hip", "cc.hip", "backward.hip"]:
+    for f in ["api.hip", "gemm.hip", "attention.hip", "attention_bwd.hip", "elementwise.hip", "conv.hip", "cc.hip", "backward.hip", "mlp_fused.hip"]:
         s = open(os.path.join(CSRC, f)).read()
         for m in re.finditer(r'extern "C" ([^{;]+?)\s*\{', s, re.S):
             decls.append(" ".join(m.group(1).split()))

@@ -40,7 +40,7 @@ B = 4
 CASES = [("block0", 256, 96, 1, 8, False), ("block1", 256, 192, 2, 8, True), ("block2", 128, 192, 2, 4, False),
          ("block3", 128, 384, 4, 4, True), ("stage3", 64, 384, 4, 14, False), ("block14", 64, 768, 8, 14, True), ("block15", 32, 768, 8, 7, False)]
 g = torch.Generator().manual_seed(0)
-for name, hw, dim, heads, ws, pool in CASES:
+for name, hw, dim, heads, ws, pool in (CASES if __name__ == "__main__" else []):
     T = B * hw * hw
     qkv = (torch.randn(T, 3 * dim, generator=g) * 0.5).to(ops.OP16).cuda()
     bias = torch.randn(3 * dim, generator=g).cuda()
