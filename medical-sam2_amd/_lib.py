@@ -34,6 +34,8 @@ SIGNATURES = {
     "msam2_attention_fwd_lse": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_f, c_i, c_p, c_z, c_p, c_p]),
     "msam2_attention_kv64_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_f, c_i, c_p, c_z, c_p]),
     "msam2_attention_kv64_partial": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_f, c_i, c_i, c_i, c_p, c_z, c_p]),
+    "msam2_attention_kv64_dyn_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_p, c_f, c_i, c_p, c_z, c_p]),
+    "msam2_attention_kv64_dyn_partial": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_p, c_f, c_i, c_i, c_i, c_p, c_z, c_p]),
     "msam2_attention_effective_splits": (c_i, [c_l, c_i]),
     "msam2_attention_merge": (c_i, [c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_i, c_p, c_z, c_p]),
     "msam2_window_attention_fwd": (c_i, [c_p, c_l, c_l, c_l, c_l, c_l, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_p, c_p, c_p, c_l, c_l,

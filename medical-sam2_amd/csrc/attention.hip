@@ -43,6 +43,9 @@ struct AttnParams {
   int splits;
   int defer_merge;  // split-KV partials stay in the workspace; msam2_attention_merge finishes (benchmark / overlap use)
   int split_begin, split_cnt;  // attn_kv64_kernel only: this launch computes splits [split_begin, split_begin + split_cnt) of `splits`
+  // attn_kv64_kernel only: when non-null the key count is read from the device (1 <= *lk_dev <= Lk; Lk = the capacity the buffers and
+  // the split count were sized for).  A hipGraph captured once for a padded memory bank then serves every fill level of the bucket.
+  const int* lk_dev;
   op16* o_part;    // [splits][Bz][H][Lq][D] 16-bit, each split's own softmax-normalised output
   float* ml_part;  // [splits][Bz][H][Lq][2]  (running max in log2 domain, partial sum)
   // log-sum-exp rows [Bz][H][Lq] (log2 domain) for the backward; written by the merge kernel (split path) or by the
@@ -681,11 +684,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kv64_kernel(AttnParams p) {
     qf[s] = __builtin_bit_cast(op16x8, v);
   }
 
-  const int tiles_total = (p.Lk + BK - 1) / BK;
+  const int Lk = p.lk_dev ? min(*p.lk_dev, p.Lk) : p.Lk;   // wave-uniform scalar load
+  const int tiles_total = (Lk + BK - 1) / BK;
   const int tiles_per = (tiles_total + p.splits - 1) / p.splits;
   const int t_begin = split * tiles_per;
   const int t_end = min(tiles_total, t_begin + tiles_per);
-  const int t_full_end = min(t_end, p.Lk / BK);
+  const int t_full_end = min(t_end, Lk / BK);
 
   const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, 0x7fffffff, 0x00020000);
   const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, 0x7fffffff, 0x00020000);
@@ -776,7 +780,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kv64_kernel(AttnParams p) {
     for (int e = 0; e < 16; ++e) {
       if (masked) {
         const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (key >= p.Lk) s[e] = -INFINITY;
+        if (key >= Lk) s[e] = -INFINITY;
       }
       mx = fmaxf(mx, s[e]);
     }
@@ -838,7 +842,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kv64_kernel(AttnParams p) {
 #endif
   if (t_full_end < t_end) {
     // partial last tile: rows past Lk re-read the last valid key (their scores are masked to -inf)
-    const int key0 = t_full_end * BK, last = p.Lk - 1 - key0;
+    const int key0 = t_full_end * BK, last = Lk - 1 - key0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                             // every wave is done with the last full tile's stage
 #pragma unroll
@@ -865,7 +869,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kv64_kernel(AttnParams p) {
 #endif
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (!qvalid) return;
-  const float inv = 1.f / l_tot;   // > 0: every split owns at least one valid key
+  // l_tot > 0 whenever the split owns a key (always with a host-side key count); a device-side count below the capacity can leave a
+  // trailing split empty: it reports (max = -inf, sum = 0, O' = 0) and the merge gives it weight 0
+  const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
   op16* dst;
   if (p.splits == 1) {
     dst = p.o + (int64_t)z * p.o_bs + (int64_t)head * p.o_hs + (int64_t)qi * p.o_ts;
@@ -1282,7 +1288,7 @@ static int launch_attn_win(const AttnParams& p, int Bz, hipStream_t s) {
 static int attention_kv64_impl(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides, const void* v,
                                const int64_t* v_strides, void* o, const int64_t* o_strides, int64_t B, int64_t H, int64_t Lq,
                                int64_t Lk, float scale, int splits, int split_begin, int split_cnt, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+                               size_t workspace_bytes, void* stream, const int* lk_dev = nullptr) {
   MSAM2_REQUIRE(q && k && v && (o || split_cnt >= 0), "attention_kv64: null tensor");
   MSAM2_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attention_kv64: empty problem");
   bool defer = splits < 0;
@@ -1317,6 +1323,7 @@ static int attention_kv64_impl(const void* q, const int64_t* q_strides, const vo
   p.splits = splits;
   p.split_begin = split_begin;
   p.split_cnt = split_cnt;
+  p.lk_dev = lk_dev;
   p.defer_merge = defer ? 1 : 0;
   p.o_part = (op16*)workspace;
   p.ml_part = workspace ? reinterpret_cast<float*>(p.o_part + (size_t)splits * B * H * Lq * 64) : nullptr;
@@ -1345,6 +1352,30 @@ extern "C" int msam2_attention_kv64_partial(const void* q, const int64_t* q_stri
   MSAM2_REQUIRE(split_count >= 0, "attention_kv64_partial: negative split count");
   return attention_kv64_impl(q, q_strides, k, k_strides, v, v_strides, nullptr, nullptr, B, H, Lq, Lk, scale, splits, split_begin, split_count,
                              workspace, workspace_bytes, stream);
+}
+
+// msam2_attention_kv64_fwd / _partial with the key count read ON THE DEVICE: Lk is the capacity (buffers, split count and workspace
+// are sized for it, rows [*key_count_dev, Lk) of k / v must be readable but are never used), *key_count_dev in [1, Lk] the number
+// of keys attended to.  The launch is the same for every fill level, so a hipGraph captured once per memory-bank bucket is replayed
+// while the bank's object-pointer tail grows (volume.GraphedPropagation).  With *key_count_dev == Lk the result is bit-identical to
+// the host-count entries; below it, the split boundaries follow the device count exactly as a host-count call with that Lk and the
+// same effective split count would place them.
+extern "C" int msam2_attention_kv64_dyn_fwd(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
+                                            const void* v, const int64_t* v_strides, void* o, const int64_t* o_strides, int64_t B,
+                                            int64_t H, int64_t Lq, int64_t Lk, const void* key_count_dev, float scale, int splits,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
+  MSAM2_REQUIRE(o && key_count_dev, "attention_kv64_dyn: null output / key count");
+  return attention_kv64_impl(q, q_strides, k, k_strides, v, v_strides, o, o_strides, B, H, Lq, Lk, scale, splits, 0, -1, workspace, workspace_bytes,
+                             stream, (const int*)key_count_dev);
+}
+
+extern "C" int msam2_attention_kv64_dyn_partial(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
+                                                const void* v, const int64_t* v_strides, int64_t B, int64_t H, int64_t Lq, int64_t Lk,
+                                                const void* key_count_dev, float scale, int splits, int split_begin, int split_count,
+                                                void* workspace, size_t workspace_bytes, void* stream) {
+  MSAM2_REQUIRE(split_count >= 0 && key_count_dev, "attention_kv64_dyn_partial: negative split count / null key count");
+  return attention_kv64_impl(q, q_strides, k, k_strides, v, v_strides, nullptr, nullptr, B, H, Lq, Lk, scale, splits, split_begin, split_count,
+                             workspace, workspace_bytes, stream, (const int*)key_count_dev);
 }
 
 // Windowed attention straight from the un-partitioned token image (replaces window_partition + SDPA +

@@ -131,8 +131,9 @@ class RoPEAttention(Attention):
                                              + self.out_proj.bias.detach().float()).contiguous())
         return ops.gemm(o64, w, b, residual=residual, out_dtype=out_dtype)
 
-    def core_folded(self, q: torch.Tensor, k: torch.Tensor, mem_v: torch.Tensor) -> torch.Tensor:
-        """rotated q [B, Lq, 256], rotated k [B, Lk, 256], un-projected values mem_v [B, Lk, 64] -> 16-bit [B*Lq, 64]"""
+    def core_folded(self, q: torch.Tensor, k: torch.Tensor, mem_v: torch.Tensor, key_count: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """rotated q [B, Lq, 256], rotated k [B, Lk, 256], un-projected values mem_v [B, Lk, 64] -> 16-bit [B*Lq, 64].  key_count: int32
+        device scalar, the number of leading keys attended to when the bank is padded to a capacity Lk (ops.attention_kv64)."""
         from .. import parallel
         B, Lq, C = q.shape
         Lk = k.shape[1]
@@ -146,12 +147,12 @@ class RoPEAttention(Attention):
             # (max, sum, O') slots, then the library's merge -- bit-identical to the single-rank call below
             ws = ops.attention_workspace(B, 1, Lq, 64, eff, q.device)
             s0, s1 = kvs.share(eff)
-            ops.attention_kv64_partial(q4, k4, v4, splits=eff, split_begin=s0, split_count=s1 - s0, workspace=ws)
+            ops.attention_kv64_partial(q4, k4, v4, splits=eff, split_begin=s0, split_count=s1 - s0, workspace=ws, key_count=key_count)
             kvs.exchange(ws, eff, B * Lq)
             o = torch.empty(B, Lq, 1, 64, dtype=OP16, device=q.device).permute(0, 2, 1, 3)
             ops.attention_merge(o, Lk, eff, ws)
         else:
-            o = ops.attention_kv64(q4, k4, v4, splits=splits)
+            o = ops.attention_kv64(q4, k4, v4, splits=splits, key_count=key_count)
         return o.permute(0, 2, 1, 3).reshape(B * Lq, 64)
 
     def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_k_exclude_rope: int = 0) -> torch.Tensor:
@@ -195,8 +196,9 @@ class MemoryAttentionLayer(nn.Module):
         n = getattr(self, name)
         return ops.layernorm(x, v_f32(self._wc, name + "w", n.weight), v_f32(self._wc, name + "b", n.bias), n.eps)
 
-    def run(self, x: torch.Tensor, mem_k: torch.Tensor, mem_v: torch.Tensor, B: int, L: int, n_ptr_tokens: int) -> torch.Tensor:
-        """x fp32 [B*L, C]; mem_k (= memory + pos) / mem_v (= memory) bf16 [B, Nk, 64]."""
+    def run(self, x: torch.Tensor, mem_k: torch.Tensor, mem_v: torch.Tensor, B: int, L: int, n_ptr_tokens: int,
+            key_count: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x fp32 [B*L, C]; mem_k (= memory + pos) / mem_v (= memory) bf16 [B, Nk, 64]; key_count: see RoPEAttention.core_folded."""
         wc, sa, ca = self._wc, self.self_attn, self.cross_attn_image
         C = self.d_model
         Nk = mem_k.shape[1]
@@ -221,8 +223,10 @@ class MemoryAttentionLayer(nn.Module):
         kk = ca.proj_rope("k", mem_k.reshape(B * Nk, -1), B, Nk, Nk - n_ptr_tokens, tab)
         if ca.folds_values():
             # O' = softmax(q k^T) M on the 64-channel memory rows; v_proj is folded into the out-projection (5/8 of the MFMA work)
-            x = ca.out_folded(ca.core_folded(q, kk, mem_v), x)
+            x = ca.out_folded(ca.core_folded(q, kk, mem_v, key_count), x)
         else:
+            if key_count is not None:
+                raise RuntimeError("a padded memory bank (key_count) needs the value-folded cross-attention (MSAM2_NO_VALUE_FOLD is set)")
             vv = ca.proj("v", mem_v.reshape(B * Nk, -1)).view(B, Nk, C)
             x = ca.out(ca.core(q, kk, vv), x)
         # FFN
@@ -267,7 +271,9 @@ class MemoryAttention(nn.Module):
         return p, (int(self.dropout_seed) << 32) + self._dropout_calls
 
     def forward(self, curr: torch.Tensor, memory: torch.Tensor, curr_pos: Optional[torch.Tensor] = None,
-                memory_pos: Optional[torch.Tensor] = None, num_obj_ptr_tokens: int = 0):
+                memory_pos: Optional[torch.Tensor] = None, num_obj_ptr_tokens: int = 0, key_count: Optional[torch.Tensor] = None):
+        """key_count (not in the reference's signature): int32 device scalar, number of valid leading rows of a `memory` padded to a
+        fixed capacity; num_obj_ptr_tokens then counts the padded tail too (it only marks where RoPE stops)."""
         if isinstance(curr, list):
             assert isinstance(curr_pos, list) and len(curr) == len(curr_pos) == 1
             curr, curr_pos = curr[0], curr_pos[0]
@@ -277,6 +283,7 @@ class MemoryAttention(nn.Module):
         if drop is not None:
             # train mode: the dropout-carrying path of the training steps (backward.memory_attention_forward_saved), forward half only
             from .. import backward as bwd
+            assert key_count is None, "padded memory banks are an inference-path feature"
             zero = torch.zeros_like(curr) if curr_pos is None or not self.pos_enc_at_input else curr_pos
             return bwd.memory_attention_forward_saved(self, curr, zero, memory, memory_pos, num_obj_ptr_tokens, dropout=drop)[0]
         # seq-first -> batch-first happens inside the add/cast kernels (strided reads), no separate transpose
@@ -286,7 +293,7 @@ class MemoryAttention(nn.Module):
         mem_k = ops.add_cast(mem_bf, memory_pos.transpose(0, 1), 1.0, OP16)
         mem_v = ops.add_cast(mem_bf, None, 1.0, OP16)
         for layer in self.layers:
-            x = layer.run(x, mem_k, mem_v, B, L, num_obj_ptr_tokens)
+            x = layer.run(x, mem_k, mem_v, B, L, num_obj_ptr_tokens, key_count)
         y = ops.layernorm(x, v_f32(self._wc, "nw", self.norm.weight), v_f32(self._wc, "nb", self.norm.bias), self.norm.eps,
                           out_dtype=F32)
         return y.view(B, L, C).transpose(0, 1)

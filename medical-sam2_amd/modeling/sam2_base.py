@@ -218,20 +218,9 @@ class SAM2Base(nn.Module):
         return low_res_masks, high_res_masks, ious, low_res_masks, high_res_masks, obj_ptr, object_score_logits
 
     # ---------------------------------------------------------------------------------------------------------------
-    def _prepare_memory_conditioned_features(self, frame_idx, is_init_cond_frame, current_vision_feats, current_vision_pos_embeds,
-                                             feat_sizes, output_dict, num_frames, track_in_reverse=False):
-        """sam2_base.py:494-663: memory-bank selection is host logic (dict lookups); the bank itself is assembled into one
-        [N_k, B, 64] buffer by strided copy kernels and handed to memory attention."""
-        B = current_vision_feats[-1].size(1)
-        C = self.hidden_dim
-        H, W = feat_sizes[-1]
-        device = current_vision_feats[-1].device
-        if self.num_maskmem == 0:
-            return current_vision_feats[-1].permute(1, 2, 0).view(B, C, H, W)
-        if is_init_cond_frame:
-            # directly_add_no_mem_embed (sam2_base.py:640-644)
-            y = ops.add_cast(current_vision_feats[-1].transpose(0, 1), self.no_mem_embed.detach().to(F32).expand(B, H * W, C), 1.0, F32)
-            return y.view(B, H * W, C).transpose(0, 1).permute(1, 2, 0).view(B, C, H, W)
+    def _select_memory(self, frame_idx, output_dict, num_frames, track_in_reverse=False):
+        """The host half of sam2_base.py:494-663: which stored slices this one attends to.  Returns (spatial, ptrs): spatial =
+        [(t_pos, stored output)] in key order (conditioning slices first, t_pos 0), ptrs = the object pointers in key order."""
         assert len(output_dict["cond_frame_outputs"]) > 0
         cond_outputs = output_dict["cond_frame_outputs"]
         selected, unselected = select_closest_cond_frames(frame_idx, cond_outputs, self.max_cond_frames_in_attn)
@@ -264,9 +253,40 @@ class SAM2Base(nn.Module):
             out = output_dict["non_cond_frame_outputs"].get(t, unselected.get(t, None))
             if out is not None:
                 ptrs.append(out["obj_ptr"])
+        return spatial, ptrs
+
+    def _prepare_memory_conditioned_features(self, frame_idx, is_init_cond_frame, current_vision_feats, current_vision_pos_embeds,
+                                             feat_sizes, output_dict, num_frames, track_in_reverse=False, memory_selection=None):
+        """sam2_base.py:494-663: memory-bank selection is host logic (dict lookups, `_select_memory`); the bank itself is assembled
+        into one [N_k, B, 64] buffer by strided copy kernels and handed to memory attention.
+
+        memory_selection = (spatial, ptrs) skips the selection (the caller made it).  `ptrs` is then either the list of pointers or a
+        PADDED bank (ptr_bank [capacity, B, C] fp32, key_count int32 device scalar = n_spatial*HW + n_ptrs*C/mem_dim): the launch
+        shapes depend on the capacity only, the attention kernel reads the number of valid keys from the device -- the form a
+        hipGraph of the per-slice forward is captured in (graphs.GraphedPropagation); rows of the bank past the valid pointers are
+        never attended to."""
+        B = current_vision_feats[-1].size(1)
+        C = self.hidden_dim
+        H, W = feat_sizes[-1]
+        device = current_vision_feats[-1].device
+        if self.num_maskmem == 0:
+            return current_vision_feats[-1].permute(1, 2, 0).view(B, C, H, W)
+        if is_init_cond_frame:
+            # directly_add_no_mem_embed (sam2_base.py:640-644)
+            y = ops.add_cast(current_vision_feats[-1].transpose(0, 1), self.no_mem_embed.detach().to(F32).expand(B, H * W, C), 1.0, F32)
+            return y.view(B, H * W, C).transpose(0, 1).permute(1, 2, 0).view(B, C, H, W)
+        spatial, ptrs = memory_selection if memory_selection is not None else \
+            self._select_memory(frame_idx, output_dict, num_frames, track_in_reverse)
         split = C // self.mem_dim
         HW = H * W
-        n_sp, n_ptr_tok = len(spatial) * HW, len(ptrs) * split
+        key_count = None
+        if isinstance(ptrs, tuple):
+            ptr_bank, key_count = ptrs
+            assert ptr_bank.dim() == 3 and ptr_bank.shape[1] == B and ptr_bank.shape[2] == C and ptr_bank.dtype == F32
+            n_ptr_tok = ptr_bank.shape[0] * split
+        else:
+            ptr_bank, n_ptr_tok = None, len(ptrs) * split
+        n_sp = len(spatial) * HW
         Nk = n_sp + n_ptr_tok
         memory = torch.empty(Nk, B, self.mem_dim, dtype=F32, device=device)
         memory_pos = torch.zeros(Nk, B, self.mem_dim, dtype=F32, device=device) if n_ptr_tok else torch.empty(Nk, B, self.mem_dim, dtype=F32, device=device)
@@ -277,12 +297,17 @@ class SAM2Base(nn.Module):
             sl = slice(i * HW, (i + 1) * HW)
             ops.add_cast_into(memory[sl], feats.flatten(2).permute(2, 0, 1), None, 1.0)
             ops.add_cast_into(memory_pos[sl], enc.flatten(2).permute(2, 0, 1), tpos.expand(HW, B, self.mem_dim), 1.0)
-        for j, ptr in enumerate(ptrs):
-            # [B, C] -> (C // mem_dim) tokens of mem_dim (sam2_base.py:626-632)
-            sl = slice(n_sp + j * split, n_sp + (j + 1) * split)
-            ops.add_cast_into(memory[sl], ptr.to(F32).reshape(B, split, self.mem_dim).permute(1, 0, 2), None, 1.0)
+        if ptr_bank is not None:
+            # [capacity, B, C] -> capacity * (C // mem_dim) tokens of mem_dim, one strided fp32 copy (exact)
+            cap = ptr_bank.shape[0]
+            memory[n_sp:].view(cap, split, B, self.mem_dim).copy_(ptr_bank.view(cap, B, split, self.mem_dim).permute(0, 2, 1, 3))
+        else:
+            for j, ptr in enumerate(ptrs):
+                # [B, C] -> (C // mem_dim) tokens of mem_dim (sam2_base.py:626-632)
+                sl = slice(n_sp + j * split, n_sp + (j + 1) * split)
+                ops.add_cast_into(memory[sl], ptr.to(F32).reshape(B, split, self.mem_dim).permute(1, 0, 2), None, 1.0)
         pix = self.memory_attention(curr=current_vision_feats, curr_pos=current_vision_pos_embeds, memory=memory,
-                                    memory_pos=memory_pos, num_obj_ptr_tokens=n_ptr_tok)
+                                    memory_pos=memory_pos, num_obj_ptr_tokens=n_ptr_tok, key_count=key_count)
         return pix.permute(1, 2, 0).view(B, C, H, W)
 
     def _encode_new_memory(self, current_vision_feats, feat_sizes, pred_masks_high_res, is_mask_from_pts):
@@ -302,8 +327,9 @@ class SAM2Base(nn.Module):
         return maskmem_features, maskmem_pos_enc
 
     def track_step(self, frame_idx, is_init_cond_frame, current_vision_feats, current_vision_pos_embeds, feat_sizes, point_inputs,
-                   mask_inputs, output_dict, num_frames, track_in_reverse=False, run_mem_encoder=True, prev_sam_mask_logits=None):
-        """sam2_base.py:705-800."""
+                   mask_inputs, output_dict, num_frames, track_in_reverse=False, run_mem_encoder=True, prev_sam_mask_logits=None,
+                   memory_selection=None):
+        """sam2_base.py:705-800.  memory_selection: see _prepare_memory_conditioned_features (not part of the reference's signature)."""
         current_out = {"point_inputs": point_inputs, "mask_inputs": mask_inputs}
         if len(current_vision_feats) > 1:
             high_res_features = [x.permute(1, 2, 0).view(x.size(1), x.size(2), *s)
@@ -318,7 +344,7 @@ class SAM2Base(nn.Module):
             pix_feat_with_mem = self._prepare_memory_conditioned_features(
                 frame_idx=frame_idx, is_init_cond_frame=is_init_cond_frame, current_vision_feats=current_vision_feats[-1:],
                 current_vision_pos_embeds=current_vision_pos_embeds[-1:], feat_sizes=feat_sizes[-1:], output_dict=output_dict,
-                num_frames=num_frames, track_in_reverse=track_in_reverse)
+                num_frames=num_frames, track_in_reverse=track_in_reverse, memory_selection=memory_selection)
             if prev_sam_mask_logits is not None:
                 assert point_inputs is not None and mask_inputs is None
                 mask_inputs = prev_sam_mask_logits

@@ -196,13 +196,18 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, splits: int 
 
 
 def attention_kv64(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, splits: int = 1, scale: Optional[float] = None,
-                   workspace: Optional[torch.Tensor] = None, defer_merge: bool = False) -> torch.Tensor:
+                   workspace: Optional[torch.Tensor] = None, defer_merge: bool = False,
+                   key_count: Optional[torch.Tensor] = None) -> torch.Tensor:
     """softmax(q k^T / sqrt(256)) v for q [B,H,Lq,256], k [B,H,Lk,256] and 64-wide value rows v [B,H,Lk,64] (the memory bank itself:
     the memory cross-attention with v_proj folded into out_proj).  Returns the [B,H,Lq,64] view of a [B,Lq,H,64] buffer.
-    defer_merge: the split pass only (finish with attention_merge on the returned view)."""
+    defer_merge: the split pass only (finish with attention_merge on the returned view).
+    key_count: int32 device scalar in [1, Lk]: only the first `key_count` keys are attended to, Lk being the capacity the launch is
+    shaped for (a hipGraph captured for a padded memory bank serves every fill level)."""
     B, H, Lq, D = q.shape
     Lk = k.shape[2]
     _req(D == 256 and k.shape[3] == 256 and v.shape[3] == 64 and v.shape[2] == Lk, "attention_kv64: q/k rows of 256, v rows of 64")
+    _req(key_count is None or (key_count.dtype == torch.int32 and key_count.numel() == 1 and key_count.device == q.device),
+         "attention_kv64: key_count is one int32 on the tensors' device")
     for t in (q, k, v):
         _req(t.dtype == OP16 and t.stride(3) == 1, "attention tensors must be 16-bit (ops.OP16) with contiguous head dim")
     out = torch.empty(B, Lq, H, 64, dtype=OP16, device=q.device).permute(0, 2, 1, 3)
@@ -211,6 +216,11 @@ def attention_kv64(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, splits:
     _req(not defer_merge or (workspace is not None and splits > 1), "defer_merge needs splits > 1 and a caller-owned workspace")
     _req(ws is None or ws.numel() * ws.element_size() >= ws_bytes, "attention workspace too small")
     sc = scale if scale is not None else 1.0 / math.sqrt(D)
+    if key_count is not None:
+        check(lib().msam2_attention_kv64_dyn_fwd(_p(q), _strides3(q), _p(k), _strides3(k), _p(v), _strides3(v), _p(out), _strides3(out),
+                                                 B, H, Lq, Lk, _p(key_count), sc, -splits if defer_merge else splits, _p(ws),
+                                                 ws_bytes if ws is not None else 0, _stream()))
+        return out
     check(lib().msam2_attention_kv64_fwd(_p(q), _strides3(q), _p(k), _strides3(k), _p(v), _strides3(v), _p(out), _strides3(out),
                                          B, H, Lq, Lk, sc, -splits if defer_merge else splits, _p(ws), ws_bytes if ws is not None else 0, _stream()))
     return out
@@ -221,7 +231,7 @@ def attention_effective_splits(Lk: int, splits: int) -> int:
 
 
 def attention_kv64_partial(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, splits: int, split_begin: int, split_count: int,
-                           workspace: torch.Tensor, scale: Optional[float] = None) -> None:
+                           workspace: torch.Tensor, scale: Optional[float] = None, key_count: Optional[torch.Tensor] = None) -> None:
     """Splits [split_begin, split_begin + split_count) of a `splits`-way attention_kv64 (effective count) into `workspace`; finish with
     attention_merge on a [B,H,Lq,64] output view once every slot is filled (parallel.KVSplit all-gathers the other ranks' slots)."""
     B, H, Lq, D = q.shape
@@ -229,6 +239,12 @@ def attention_kv64_partial(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *,
     for t in (q, k, v):
         _req(t.dtype == OP16 and t.stride(3) == 1, "attention tensors must be 16-bit (ops.OP16) with contiguous head dim")
     sc = scale if scale is not None else 1.0 / math.sqrt(D)
+    if key_count is not None:
+        _req(key_count.dtype == torch.int32 and key_count.numel() == 1, "attention_kv64_partial: key_count is one int32 on the device")
+        check(lib().msam2_attention_kv64_dyn_partial(_p(q), _strides3(q), _p(k), _strides3(k), _p(v), _strides3(v), B, H, Lq, Lk, _p(key_count),
+                                                     sc, splits, split_begin, split_count, _p(workspace),
+                                                     workspace.numel() * workspace.element_size(), _stream()))
+        return
     check(lib().msam2_attention_kv64_partial(_p(q), _strides3(q), _p(k), _strides3(k), _p(v), _strides3(v), B, H, Lq, Lk, sc, splits,
                                              split_begin, split_count, _p(workspace), workspace.numel() * workspace.element_size(), _stream()))
 

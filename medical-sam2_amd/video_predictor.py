@@ -92,8 +92,12 @@ class SAM2VideoPredictor(SAM2Base):
     """sam2_video_predictor.py:17-1441 (see the module docstring for the mapping)."""
 
     def __init__(self, fill_hole_area=0, non_overlap_masks=False, clear_non_cond_mem_around_input=False,
-                 clear_non_cond_mem_for_multi_obj=False, feature_cache_frames: Optional[int] = None, **kwargs):
+                 clear_non_cond_mem_for_multi_obj=False, feature_cache_frames: Optional[int] = None, use_hip_graphs: bool = False,
+                 **kwargs):
         super().__init__(**kwargs)
+        # replay the prompt-free per-frame forward of propagate_in_video as hipGraphs (graphs.GraphedPropagation: one graph per
+        # memory-bank bucket).  Off by default: the graphs bake in the current weights and hold their own activation pool.
+        self.use_hip_graphs = use_hip_graphs
         self.fill_hole_area = fill_hole_area
         self.non_overlap_masks = non_overlap_masks
         self.clear_non_cond_mem_around_input = clear_non_cond_mem_around_input
@@ -467,12 +471,38 @@ class SAM2VideoPredictor(SAM2Base):
 
     def _run_single_frame_inference(self, inference_state, output_dict, frame_idx, batch_size, is_init_cond_frame, point_inputs,
                                     mask_inputs, reverse, run_mem_encoder, prev_sam_mask_logits=None):
-        _, _, feats, pos, sizes = self._get_image_feature(inference_state, frame_idx, batch_size)
         assert point_inputs is None or mask_inputs is None
-        current_out = self.track_step(frame_idx=frame_idx, is_init_cond_frame=is_init_cond_frame, current_vision_feats=feats,
-                                      current_vision_pos_embeds=pos, feat_sizes=sizes, point_inputs=point_inputs, mask_inputs=mask_inputs,
-                                      output_dict=output_dict, num_frames=inference_state["num_frames"], track_in_reverse=reverse,
-                                      run_mem_encoder=run_mem_encoder, prev_sam_mask_logits=prev_sam_mask_logits)
+        graphed = (self.use_hip_graphs and not is_init_cond_frame and point_inputs is None and mask_inputs is None and run_mem_encoder
+                   and prev_sam_mask_logits is None and not self.training and self.num_maskmem > 0
+                   and inference_state["storage_device"] == inference_state["device"])
+        if graphed:
+            current_out = self._graphed_track(inference_state, output_dict, frame_idx, batch_size, reverse)
+        else:
+            _, _, feats, pos, sizes = self._get_image_feature(inference_state, frame_idx, batch_size)
+            current_out = self._eager_track(inference_state, output_dict, frame_idx, is_init_cond_frame, feats, pos, sizes, point_inputs,
+                                            mask_inputs, reverse, run_mem_encoder, prev_sam_mask_logits)
+        return self._compact(inference_state, current_out)
+
+    def _graphed_track(self, inference_state, output_dict, frame_idx, batch_size, reverse):
+        from .graphs import GraphedPropagation, pointer_capacity
+        self._get_image_feature(inference_state, frame_idx, batch_size)          # fills the feature cache
+        _, one = inference_state["cached_features"][frame_idx]
+        one = {"backbone_fpn": one["backbone_fpn"][-self.num_feature_levels:], "vision_pos_enc": one["vision_pos_enc"][-self.num_feature_levels:]}
+        cap = pointer_capacity(self, len(output_dict["cond_frame_outputs"]), inference_state["num_frames"])
+        props = inference_state.setdefault("graphed_propagation", {})
+        prop = props.get((batch_size, cap))
+        if prop is None:
+            prop = props[(batch_size, cap)] = GraphedPropagation(self, batch_size, inference_state["num_frames"], cap)
+        return prop.track(frame_idx, one, output_dict, track_in_reverse=reverse)
+
+    def _eager_track(self, inference_state, output_dict, frame_idx, is_init_cond_frame, feats, pos, sizes, point_inputs, mask_inputs,
+                     reverse, run_mem_encoder, prev_sam_mask_logits):
+        return self.track_step(frame_idx=frame_idx, is_init_cond_frame=is_init_cond_frame, current_vision_feats=feats,
+                               current_vision_pos_embeds=pos, feat_sizes=sizes, point_inputs=point_inputs, mask_inputs=mask_inputs,
+                               output_dict=output_dict, num_frames=inference_state["num_frames"], track_in_reverse=reverse,
+                               run_mem_encoder=run_mem_encoder, prev_sam_mask_logits=prev_sam_mask_logits)
+
+    def _compact(self, inference_state, current_out):
         storage_device = inference_state["storage_device"]
         maskmem_features = current_out["maskmem_features"]
         if maskmem_features is not None:

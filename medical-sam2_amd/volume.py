@@ -26,6 +26,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
+from .graphs import GraphedPropagation, pointer_capacity
 from .parallel import KVSplit, gather_cond_memories, gather_object_shards, gather_slice_features, shard_range
 
 
@@ -69,13 +70,19 @@ def box_point_inputs(boxes: torch.Tensor) -> dict:
 
 @torch.no_grad()
 def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_hole_area: int = 0, group=None,
-                   shard_objects: bool = True, encode_batch: int = 8, kv_split: bool = True, return_state: bool = False):
+                   shard_objects: bool = True, encode_batch: int = 8, kv_split: bool = True, return_state: bool = False,
+                   graphs: bool = False, padded_bank: bool = False, stats: Optional[dict] = None, graph_cache: Optional[dict] = None):
     """volume: [T,3,S,S] normalised slices on the GPU; prompts: {slice_idx: {"boxes": [n,4]} | {"point_coords", "point_labels"}}
     for the conditioning slices (same n objects everywhere).  Returns {slice_idx: low-res mask logits [n,1,S/4,S/4]} for ALL slices
     and ALL objects on every rank.  encode_batch: slices per image-encoder call (results do not depend on it).  shard_objects /
     kv_split: the two ways the propagation chain uses several ranks (module docstring); with both off it is replicated.
     return_state: also return the chain's `output_dict` ({"cond_frame_outputs", "non_cond_frame_outputs"}: per slice the track_step
-    outputs with memories and pointers, this rank's object share) -- what a caller needs to continue or to audit the propagation."""
+    outputs with memories and pointers, this rank's object share) -- what a caller needs to continue or to audit the propagation.
+    graphs: replay the prompt-free per-slice forward as hipGraphs, one per memory-bank bucket (graphs.GraphedPropagation; not combined
+    with the cross-GPU key split, whose exchange runs between the partial pass and the merge).  padded_bank: the same padded-bank
+    launches without capturing them -- what `graphs=True` is bit-identical to.  stats: filled with the replay / capture counts of this
+    call.  graph_cache: a dict the caller keeps between volumes of the same shape (slices, objects, prompt schedule): the captured
+    graphs are reused, a later volume replays from its first steady-state slice on."""
     T = volume.shape[0]
     cond_ids = sorted(prompts)
     assert cond_ids, "at least one conditioning slice is needed"
@@ -134,18 +141,34 @@ def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_h
     output_dict = {"cond_frame_outputs": chain_cond, "non_cond_frame_outputs": {}}
     masks: Dict[int, torch.Tensor] = {}
     split_ctx = KVSplit(model, group) if (distributed and kv_split and not obj_shard) else None
+    prop = None
+    if (graphs or padded_bank) and split_ctx is None:
+        cap = pointer_capacity(model, len(cond_ids), T)
+        ck = (id(model), oe - ob, T, cap, bool(graphs))
+        prop = graph_cache.get(ck) if graph_cache is not None else None
+        if prop is None:
+            prop = GraphedPropagation(model, oe - ob, T, cap, enabled=graphs)
+            if graph_cache is not None:
+                graph_cache[ck] = prop
+        before = (prop.replays, prop.captures, prop.eager_steps)
     try:
         for t in range(T):
             if t in cond_set:
                 continue
-            feats, pos, sizes = _expand(model, feats_all.pop(t), oe - ob)
-            cur = model.track_step(frame_idx=t, is_init_cond_frame=False, current_vision_feats=feats, current_vision_pos_embeds=pos,
-                                   feat_sizes=sizes, point_inputs=None, mask_inputs=None, output_dict=output_dict, num_frames=T)
+            if prop is not None:
+                cur = prop.track(t, feats_all.pop(t), output_dict)
+            else:
+                feats, pos, sizes = _expand(model, feats_all.pop(t), oe - ob)
+                cur = model.track_step(frame_idx=t, is_init_cond_frame=False, current_vision_feats=feats, current_vision_pos_embeds=pos,
+                                       feat_sizes=sizes, point_inputs=None, mask_inputs=None, output_dict=output_dict, num_frames=T)
             output_dict["non_cond_frame_outputs"][t] = cur
             masks[t] = cur["pred_masks"]
     finally:
         if split_ctx is not None:
             split_ctx.close()
+        if prop is not None and stats is not None:
+            stats.update(replays=prop.replays - before[0], captures=prop.captures - before[1], eager_steps=prop.eager_steps - before[2],
+                         buckets=len(prop.buckets))
 
     # 4. everything everywhere: conditioning masks from their owners, propagated masks from the object shards
     if distributed:

@@ -148,9 +148,9 @@ def test_long_chain_steady_state_memory_bank(build):
     seen = {}
     real = m.memory_attention.forward
 
-    def spy(curr, memory, curr_pos=None, memory_pos=None, num_obj_ptr_tokens=0):
+    def spy(curr, memory, curr_pos=None, memory_pos=None, num_obj_ptr_tokens=0, **kw):
         seen["n"] = [int(memory.shape[0]), int(num_obj_ptr_tokens)]
-        return real(curr=curr, memory=memory, curr_pos=curr_pos, memory_pos=memory_pos, num_obj_ptr_tokens=num_obj_ptr_tokens)
+        return real(curr=curr, memory=memory, curr_pos=curr_pos, memory_pos=memory_pos, num_obj_ptr_tokens=num_obj_ptr_tokens, **kw)
 
     m.memory_attention.forward = spy
     od = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
@@ -334,9 +334,9 @@ def test_config3_volume_at_size_sampled_slices_vs_oracle(build):
     seen = []
     real = m.memory_attention.forward
 
-    def spy(curr, memory, curr_pos=None, memory_pos=None, num_obj_ptr_tokens=0):
+    def spy(curr, memory, curr_pos=None, memory_pos=None, num_obj_ptr_tokens=0, **kw):
         seen.append((int(memory.shape[0]), int(num_obj_ptr_tokens)))
-        return real(curr=curr, memory=memory, curr_pos=curr_pos, memory_pos=memory_pos, num_obj_ptr_tokens=num_obj_ptr_tokens)
+        return real(curr=curr, memory=memory, curr_pos=curr_pos, memory_pos=memory_pos, num_obj_ptr_tokens=num_obj_ptr_tokens, **kw)
 
     m.memory_attention.forward = spy
     try:

@@ -24,6 +24,8 @@ DOC = {
     "msam2_attention_merge": "Second half of a split-KV attention call issued with a NEGATIVE split count (the split pass alone, partials left in the\nworkspace): combines the per-split (max, sum, O) triples into o.  Lets a host time / overlap the two kernels separately.",
     "msam2_attention_fwd": "softmax(Q K^T * scale) V, non-causal, 16-bit in/out, fp32 softmax/accumulate; head dim 64/96/128/256; q/k/v/o given by\nelement strides {batch, head, token}.  splits > 1 = split-KV (flash-decoding) with an in-library merge; splits < 0 = the split pass only\n(finish with msam2_attention_merge).\nReplaces F.scaled_dot_product_attention at hieradet.py:72-76 (global blocks) and transformer.py:318 (RoPEAttention,\nmemory attention self/cross).",
     "msam2_attention_kv64_fwd": "Memory cross-attention of RoPEAttention with kv_in_dim = 64 (transformer.py:288-331 as called at memory_attention.py:76-85) with\nthe value product contracted in the 64-channel memory space: O' = softmax(Q K^T * scale) M for 256-wide rotated q / k rows and the\n64-wide memory rows M.  Because the values carry no rotary encoding and softmax rows sum to one, P (M W_v^T + b_v) = O' W_v^T + b_v:\nthe caller folds v_proj into out_proj (one K = 64 GEMM).  Strides / splits / workspace / merge as msam2_attention_fwd with D = 64.",
+    "msam2_attention_kv64_dyn_fwd": "msam2_attention_kv64_fwd with the key count read on the device: Lk is the CAPACITY (buffers, split count, workspace), *key_count_dev\n(int32, 1 .. Lk) the number of memory tokens attended to.  One launch shape serves every fill level of a padded memory bank, so the\nper-slice forward of the 3-D propagation (sam2_video_predictor.py:1302-1367 -> sam2_base.py:494-663, whose bank grows by one object\npointer per slice) can be captured into one hipGraph per bank bucket and replayed.",
+    "msam2_attention_kv64_dyn_partial": "msam2_attention_kv64_partial with the device-side key count of msam2_attention_kv64_dyn_fwd (cross-GPU key split under a hipGraph).",
     "msam2_attention_effective_splits": "The split count msam2_attention_fwd / msam2_attention_kv64_fwd actually run with for a requested one (every split owns at least one\n32-key tile); what msam2_attention_kv64_partial expects as `splits`.",
     "msam2_attention_kv64_partial": "Splits [split_begin, split_begin + split_count) of a `splits`-way msam2_attention_kv64_fwd: the partial (max, sum, O') triples land in\nthe workspace slots the full call would use, nothing is merged.  Cross-GPU key split of the 3-D propagation chain (the reference has no\ncounterpart: sam2_base.py:494-663 attends to the whole bank on one device): every rank computes its share of the splits, the slots are\nall-gathered, msam2_attention_merge (D = 64) finishes -- bit-identical to one rank computing all splits.",
     "msam2_window_attention_fwd": "Windowed Hiera attention straight from un-partitioned qkv tokens: replaces window_partition -> SDPA ->\nwindow_unpartition (backbones/utils.py:16-62 + hieradet.py:138-158,72-76).  Zero-padded window tokens are unmasked keys\nwhose K/V rows are kpad/vpad (= qkv bias), exactly what the reference computes; q may come from a 2x2 max-pooled image\n(q-pool at stage changes, hieradet.py:65-69).",

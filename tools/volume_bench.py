@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[2]: sam2_hiera_s, synthetic 64-slice volume at 1024^2, bbox prompt every 2 slices, propagation through the
-rest with the memory bank (1 GPU).  Prints slices/s (eager launches; the memory bank grows, so shapes change per slice)."""
+rest with the memory bank (1 GPU).  Prints slices/s for eager launches and for hipGraph replays of the per-slice forward (graphs.GraphedPropagation: one graph per
+memory-bank bucket, pointer tail padded, key count on the device)."""
 import os
 import sys
 import time
@@ -32,9 +33,25 @@ def box_at(t):
 prompts = {t: {"boxes": box_at(t)} for t in range(0, T, 2)}
 vol.segment_volume(m, volume[:4], {0: prompts[0], 2: prompts[2]})  # warm-up (weight packing, tables, code objects)
 torch.cuda.synchronize()
-t0 = time.perf_counter()
-masks = vol.segment_volume(m, volume, prompts, fill_hole_area=8)
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
-fg = sum(float((v > 0).float().mean()) for v in masks.values()) / len(masks)
-print(f"volume T={T} n_obj={n_obj}: {dt:.3f} s -> {T / dt:.1f} slices/s (mean foreground fraction {fg:.3f})")
+
+
+def timed(label, **kw):
+    st = {}
+    t0 = time.perf_counter()
+    masks = vol.segment_volume(m, volume, prompts, fill_hole_area=8, stats=st, **kw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fg = sum(float((v > 0).float().mean()) for v in masks.values()) / len(masks)
+    print(f"volume T={T} n_obj={n_obj} {label}: {dt:.3f} s -> {T / dt:.1f} slices/s (mean foreground fraction {fg:.3f}) {st}", flush=True)
+    return masks
+
+
+eager = timed("eager launches")
+cache = {}
+first = timed("hipGraph replay, first volume (captures inside)", graphs=True, graph_cache=cache)
+again = timed("hipGraph replay, graphs kept from the previous volume", graphs=True, graph_cache=cache)
+padded = timed("padded bank, eager launches", padded_bank=True)
+same = all(torch.equal(first[t], padded[t]) and torch.equal(again[t], padded[t]) for t in first)
+worst = max(float((eager[t] - padded[t]).abs().max()) for t in eager)
+flips = sum(int(((eager[t] > 0) != (padded[t] > 0)).sum()) for t in eager)
+print(f"graphed == padded eager bit for bit: {same}; padded vs un-padded eager: max |dlogit| {worst:.4f}, {flips} flipped mask pixels")
