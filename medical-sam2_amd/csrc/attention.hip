@@ -30,6 +30,15 @@ __device__ unsigned long long g_wgtime[4096][4];   // per workgroup: realtime at
 #include <stdlib.h>
 #include <type_traits>
 
+// Online-softmax rescaling is lazy: the running reference m_run of a row moves only when a tile's maximum exceeds it by more than this
+// many powers of two (a wave-wide vote), so P = exp2(s - m_run) <= 2^SLACK instead of <= 1 -- exact arithmetic is unchanged (the
+// reference cancels in O / l), the 16-bit P keeps its relative precision (256 is far inside the fp16 range), and the rescale of the
+// D/32 output accumulators (as many VALU slots as the tile's exponentials when D = 96) runs on the first tiles of a row only instead
+// of on ~60 % of them.  0 reproduces the eager rescale.
+#ifndef MSAM2_RESCALE_SLACK
+#define MSAM2_RESCALE_SLACK 8.f
+#endif
+
 struct AttnParams {
   const op16 *q, *k, *v;
   op16* o;
@@ -202,9 +211,9 @@ __global__ __launch_bounds__(NW * 64, (WIN && NW == 4) ? 3 : 1) void attn_fwd_ke
       s[e] = (key < p.Lk) ? s[e] * p.scale_log2 : -INFINITY;
       mx = fmaxf(mx, s[e]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = half_max(mx);
     const float m_new = fmaxf(m_run, mx);
-    if (__any(m_new > m_run)) {
+    if (__any(m_new > m_run + MSAM2_RESCALE_SLACK)) {
       const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
 #pragma unroll
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(NW * 64, (WIN && NW == 4) ? 3 : 1) void attn_fwd_ke
   }
 
   // ---- epilogue
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float l_tot = half_sum(l_run);
   if (!qvalid) return;
   if (p.splits == 1) {
     const float inv = 1.f / l_tot;
@@ -475,9 +484,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_glds_kernel(AttnParams p) {
       }
       mx = fmaxf(mx, s[e]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;   // scale > 0: max commutes with it
+    mx = half_max(mx) * p.scale_log2;   // scale > 0: max commutes with it
     const float m_new = fmaxf(m_run, mx);
-    if (__any(m_new > m_run)) {
+    if (__any(m_new > m_run + MSAM2_RESCALE_SLACK)) {
       const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
 #pragma unroll
@@ -593,7 +602,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_glds_kernel(AttnParams p) {
     compute(0, key0, true);
   }
 
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float l_tot = half_sum(l_run);
   if (!qvalid) return;
   if (p.splits == 1) {
     const float inv = 1.f / l_tot;
@@ -784,9 +793,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kv64_kernel(AttnParams p) {
       }
       mx = fmaxf(mx, s[e]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;   // scale > 0: max commutes with it
+    mx = half_max(mx) * p.scale_log2;   // scale > 0: max commutes with it
     const float m_new = fmaxf(m_run, mx);
-    if (__any(m_new > m_run)) {
+    if (__any(m_new > m_run + MSAM2_RESCALE_SLACK)) {
       const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
 #pragma unroll
@@ -867,7 +876,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kv64_kernel(AttnParams p) {
 #ifdef MSAM2_STAMP
   const unsigned long long wg_t2_ = __builtin_amdgcn_s_memrealtime();
 #endif
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float l_tot = half_sum(l_run);
   if (!qvalid) return;
   // l_tot > 0 whenever the split owns a key (always with a host-side key count); a device-side count below the capacity can leave a
   // trailing split empty: it reports (max = -inf, sum = 0, O' = 0) and the merge gives it weight 0
@@ -906,12 +915,354 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kv64_kernel(AttnParams p) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// attn_kv64x2_kernel: the same contraction with 64 queries per wave (two 32-query MFMA column blocks).
+//
+// Why.  In attn_kv64_kernel every MFMA consumes one fragment read from LDS (1 KiB per wave: a K fragment for S^T = K Q^T, a V^T
+// fragment for O'^T = V^T P^T) while the Q / P operand sits in registers.  Four SIMDs x 1 KiB per 32-cycle MFMA is 128 B/clk --
+// exactly the LDS read bandwidth of a CU -- so with 32 queries per wave the LDS pipe has to run at 100 % for the MFMA pipe to
+// run at 100 %: the kernel was LDS-bandwidth-bound (800 LDS cycles against 640 MFMA cycles per workgroup-tile), not clock-bound.
+// Here each fragment read feeds TWO MFMAs (query blocks a and b): 800 LDS cycles against 1280 MFMA cycles per workgroup-tile.
+//
+// How.  256 queries per workgroup (4 waves x 64), one workgroup per CU, one wave per SIMD with the whole 512-register file: the
+// Q fragments of both blocks (128 registers) stay resident.  With a single wave per SIMD nothing hides the softmax behind another
+// wave's MFMAs, so the loop is software-pipelined inside the wave: the 32 MFMAs of S(t+1) are independent of the softmax of S(t)
+// and sit in the same basic block (the MFMA pipe runs them while the VALU does the exponentials), then the 8 MFMAs of P(t) V(t).
+// That needs K(t+1) and V(t) at the same time while tile t+2 streams in: a three-stage LDS ring (60 KiB), still ONE barrier per
+// tile -- at iteration t the barrier says "tile t+1 has landed for every wave" and "every wave is done with iteration t-1", which
+// frees stage (t+2) % 3 == (t-1) % 3 for the DMA of tile t+2.
+// Layouts, swizzles, split-KV outputs, lazy rescale and the device-side key count are those of attn_kv64_kernel.
+// Measured (B=4, Lq=4096, Lk=16384, 4 splits, same box, interleaved): 171-181 us against 179-189 us for the 32-query kernel.  The
+// gain is small because neither kernel is bound by what it looks bound by: with the softmax removed altogether this loop still takes
+// 165-176 us, a deeper K prefetch window (8, 16) or a hand-interleaved MFMA / exp2 stream (slower: 192 us) change nothing -- the
+// chip holds ~1.6 GHz under this MFMA density (MI355X_MICROARCH.md, DVFS give-back) and every variant lands on ~1.0 PFLOP/s of
+// executed MFMA work.  What this kernel buys is the halved LDS read traffic (energy per MFMA) at equal cycles.
+// ------------------------------------------------------------------------------------------------------------------
+#ifndef MSAM2_KV64X2_KPF
+#define MSAM2_KV64X2_KPF 4
+#endif
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 1) void attn_kv64x2_kernel(AttnParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int D = 256, DV = 64, BK = 32, QB = 2;
+  constexpr int RB = D * 2, CPR = D / 8;
+  constexpr int RBV = DV * 2, CPRV = DV / 8;
+  constexpr int TILE_K = BK * RB, TILE_V = BK * RBV, STAGE = TILE_K + TILE_V;
+  constexpr int PWK = TILE_K / 1024 / NW, PWV = TILE_V / 1024 / NW;
+  constexpr int DSTEPS = D / 16, DBLK = DV / 32;
+  static_assert(TILE_K % (1024 * NW) == 0 && TILE_V % (1024 * NW) == 0, "tiles must split evenly over the waves");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int nwg = gx * gy * gridDim.z;
+  int lid = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  {
+    const int q8 = nwg / 8, rem = nwg % 8, xcd = lid % 8;
+    lid = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + lid / 8;
+  }
+  const int qtile = lid % gx;
+  const int head = (lid / gx) % gy;
+  const int zz = lid / (gx * gy);
+  const int split = p.split_begin + zz % p.split_cnt, z = zz / p.split_cnt;
+  const op16* qb = p.q + (int64_t)z * p.q_bs + (int64_t)head * p.q_hs;
+  const op16* kb = p.k + (int64_t)z * p.k_bs + (int64_t)head * p.k_hs;
+  const op16* vb = p.v + (int64_t)z * p.v_bs + (int64_t)head * p.v_hs;
+
+  int qi[QB];
+  bool qvalid[QB];
+  op16x8 qf[QB][DSTEPS];
+#pragma unroll
+  for (int b = 0; b < QB; ++b) {
+    qi[b] = qtile * (NW * 64) + wave * 64 + b * 32 + r;
+    qvalid[b] = qi[b] < p.Lq;
+#pragma unroll
+    for (int s = 0; s < DSTEPS; ++s) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (qvalid[b]) v = *reinterpret_cast<const uint4*>(qb + (int64_t)qi[b] * p.q_ts + s * 16 + h * 8);
+      qf[b][s] = __builtin_bit_cast(op16x8, v);
+    }
+  }
+
+  const int Lk = p.lk_dev ? min(*p.lk_dev, p.Lk) : p.Lk;   // wave-uniform scalar load
+  const int tiles_total = (Lk + BK - 1) / BK;
+  const int tiles_per = (tiles_total + p.splits - 1) / p.splits;
+  const int t_begin = split * tiles_per;
+  const int t_end = min(tiles_total, t_begin + tiles_per);
+  const int t_full_end = min(t_end, Lk / BK);
+  const int nt = t_end - t_begin;
+
+  const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, 0x7fffffff, 0x00020000);
+  const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, 0x7fffffff, 0x00020000);
+  const int k_rb = (int)p.k_ts * 2, v_rb = (int)p.v_ts * 2;
+  // DMA piece j of this wave: LDS row / swizzled chunk it fills (fixed), global offset of that row in a full tile
+  int krow[PWK], kchunk[PWK], vrow[PWV], vchunk[PWV];
+  unsigned koff[PWK], voff[PWV];
+#pragma unroll
+  for (int j = 0; j < PWK; ++j) {
+    const int f = (wave * PWK + j) * 64 + lane;
+    const int row = f / CPR, c = f % CPR;
+    krow[j] = row;
+    kchunk[j] = ((c & ~15) | ((c & 15) ^ (row & 15))) << 4;
+    koff[j] = (unsigned)(row * k_rb + kchunk[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < PWV; ++j) {
+    const int f = (wave * PWV + j) * 64 + lane;
+    const int row = f / CPRV, c = f % CPRV;
+    vrow[j] = row;
+    vchunk[j] = (c ^ (((row >> 1) & 1) << 2)) << 4;
+    voff[j] = (unsigned)(row * v_rb + vchunk[j]);
+  }
+  // tile -> stage: full tiles by scalar offset; the partial last tile re-reads its last valid key for the rows past Lk
+  auto issue = [&](int tile, int stage) {
+    unsigned char* kdst = smem + stage * STAGE + wave * PWK * 1024;
+    unsigned char* vdst = smem + stage * STAGE + TILE_K + wave * PWV * 1024;
+    if (tile < t_full_end) {
+      const unsigned ks = (unsigned)(tile * BK) * (unsigned)k_rb, vs = (unsigned)(tile * BK) * (unsigned)v_rb;
+#pragma unroll
+      for (int j = 0; j < PWK; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(kdst + j * 1024), 16, koff[j], ks, 0, 0);
+#pragma unroll
+      for (int j = 0; j < PWV; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(vdst + j * 1024), 16, voff[j], vs, 0, 0);
+    } else {
+      const int key0 = tile * BK, last = Lk - 1 - key0;
+#pragma unroll
+      for (int j = 0; j < PWK; ++j) {
+        const unsigned ko = (unsigned)((key0 + min(krow[j], last)) * k_rb + kchunk[j]);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(kdst + j * 1024), 16, ko, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < PWV; ++j) {
+        const unsigned vo = (unsigned)((key0 + min(vrow[j], last)) * v_rb + vchunk[j]);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(vdst + j * 1024), 16, vo, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x16 o[QB][DBLK];
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int b = 0; b < QB; ++b) {
+    m_run[b] = -INFINITY;
+    l_run[b] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[b][d][e] = 0.f;
+  }
+
+  const int k_row = r * RB, k_x = r & 15;
+  const int li = lane & 15, vq = li >> 2, vp = li & 3, cgrp = (lane >> 4) & 1;
+  const int v_row = (4 * h + vq) * RBV + ((vp & 1) << 3);
+  const int v_sw = ((vq >> 1) & 1) << 2, v_c0 = 2 * cgrp + (vp >> 1);
+  typedef __attribute__((ext_vector_type(8))) short short8_t;
+
+  // S^T(a), S^T(b) = K Q_a^T, K Q_b^T: every K fragment read feeds two MFMAs; a rolling window of 4 fragments stays in flight
+  auto s_phase = [&](int stage, f32x16 (&s)[QB]) __attribute__((always_inline)) {
+    const unsigned char* kbase = smem + stage * STAGE;
+    auto kread = [&](int st) {
+      const int c = 2 * st + h;
+      return *reinterpret_cast<const op16x8*>(kbase + k_row + (((c & ~15) | ((c & 15) ^ k_x)) << 4));
+    };
+#pragma unroll
+    for (int b = 0; b < QB; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[b][e] = 0.f;
+    constexpr int KPF = MSAM2_KV64X2_KPF;
+    op16x8 kf[KPF];
+#pragma unroll
+    for (int g = 0; g < KPF; ++g) kf[g] = kread(g);
+#pragma unroll
+    for (int g = 0; g < DSTEPS; ++g) {
+#pragma unroll
+      for (int b = 0; b < QB; ++b) s[b] = MSAM2_MFMA_32x32x16(kf[g % KPF], qf[b][g], s[b], 0, 0, 0);
+      if (g + KPF < DSTEPS) kf[g % KPF] = kread(g + KPF);
+    }
+  };
+  // The online softmax in three pieces so that the long VALU part shares a basic block with independent MFMAs (one wave per SIMD:
+  // whatever overlap there is has to be in program order): row maxima (cheap, run under the P V MFMAs), the rare reference move
+  // (the only branch, between the blocks), exponentials + sums + 16-bit conversion (run under the next tile's S MFMAs).
+  // Row maxima need no masking: rows of the partial last tile past Lk hold copies of the last valid key.
+  auto row_max = [&](const f32x16 (&s)[QB], float (&mx)[QB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) m = fmaxf(m, s[b][e]);
+      mx[b] = half_max(m) * p.scale_log2;   // scale > 0: max commutes with it
+    }
+  };
+  auto move_reference = [&](const float (&mx)[QB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+      const float m_new = fmaxf(m_run[b], mx[b]);
+      if (__any(m_new > m_run[b] + MSAM2_RESCALE_SLACK)) {
+        const float alpha = (m_run[b] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run[b] - m_new);
+        l_run[b] *= alpha;
+        // The O' accumulators live in AGPRs (the Q fragments fill the VGPR half of the register file).  Written as plain C++ the
+        // compiler hoists the 64 AGPR -> VGPR reads this path needs above the branch, i.e. into EVERY tile; the explicit, volatile
+        // read / write keeps them here.  The compiler does not track hazards into inline asm: the s_nops cover the
+        // "MFMA writes AGPR -> v_accvgpr_read" wait states of the P V MFMAs issued just before (rare path, 2 x 16 cycles).
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+        for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            float t;
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(o[b][d][e]));
+            t *= alpha;
+            asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(o[b][d][e]) : "v"(t));
+          }
+        m_run[b] = m_new;
+      }
+    }
+  };
+  auto exponentials = [&](const f32x16 (&s)[QB], op16x8 (&pf)[QB][2], int key0, const bool masked) __attribute__((always_inline)) {
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+      float psum = 0.f;
+      const float nm = -m_run[b];   // finite: every tile holds >= 1 valid key
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[b][e], p.scale_log2, nm));
+        if (masked) {
+          const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (key >= Lk) pe = 0.f;
+        }
+        psum += pe;
+        pf[b][e >> 3][e & 7] = f2op_fast(pe);
+      }
+      l_run[b] += psum;
+    }
+  };
+  // the four V^T fragments of a tile (16 registers): fetched at the top of block A, a whole S phase before P V consumes them
+  auto v_fetch = [&](int stage, op16x8 (&vf)[DBLK][2]) __attribute__((always_inline)) {
+    const unsigned char* vbase = smem + stage * STAGE + TILE_K;
+#pragma unroll
+    for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const int cch = (d * 4 + v_c0) ^ v_sw;
+        const unsigned char* a0 = vbase + v_row + (16 * st) * RBV + (cch << 4);
+        const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0));
+        const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0 + 8 * RBV));
+        short8_t vv8;
+        vv8[0] = lo[0]; vv8[1] = lo[1]; vv8[2] = lo[2]; vv8[3] = lo[3];
+        vv8[4] = hi[0]; vv8[5] = hi[1]; vv8[6] = hi[2]; vv8[7] = hi[3];
+        vf[d][st] = __builtin_bit_cast(op16x8, vv8);
+      }
+  };
+  auto pv_phase = [&](const op16x8 (&vf)[DBLK][2], const op16x8 (&pf)[QB][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int b = 0; b < QB; ++b) o[b][d] = MSAM2_MFMA_32x32x16(vf[d][st], pf[b][st], o[b][d], 0, 0, 0);
+  };
+
+  if (nt > 0) {
+    issue(t_begin, 0);
+    if (nt > 1) {
+      issue(t_begin + 1, 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PWK + PWV) : "memory");   // tile 0 landed, tile 1 may still be in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    // two score buffers used alternately (the loop is unrolled by two): no copy between iterations, the AGPR -> VGPR reads of the
+    // scores happen where the exponentials consume them, inside block A
+    f32x16 s0[QB], s1[QB];
+    op16x8 pf[QB][2], vf[DBLK][2];
+    float mx[QB];
+    int st_cur = 0, st_nxt = 1, st_ld = 2;
+    auto iteration = [&](int i, f32x16 (&s_cur)[QB], f32x16 (&s_nxt)[QB]) __attribute__((always_inline)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // tile i+1 has landed for every wave; every wave is done with iteration i-1 => stage st_ld is free
+      if (i + 2 < nt) issue(t_begin + i + 2, st_ld);
+      // block A: V fragments of tile i, 32 MFMAs of S(i+1), the exponentials of tile i (independent of the MFMAs)
+      v_fetch(st_cur, vf);
+      s_phase(st_nxt, s_nxt);
+      exponentials(s_cur, pf, 0, false);            // tile i is full: only the last tile can be partial
+      // block B: 8 MFMAs of P(i) V(i) + the row maxima of tile i+1
+      pv_phase(vf, pf);
+      row_max(s_nxt, mx);
+      move_reference(mx);                           // rare branch: rescales o (tile i included) and l
+      const int t = st_cur;
+      st_cur = st_nxt; st_nxt = st_ld; st_ld = t;
+    };
+    auto last = [&](f32x16 (&s_cur)[QB]) __attribute__((always_inline)) {
+      v_fetch(st_cur, vf);
+      if (t_full_end < t_end) exponentials(s_cur, pf, (t_end - 1) * BK, true);
+      else exponentials(s_cur, pf, 0, false);
+      pv_phase(vf, pf);
+    };
+    s_phase(0, s0);
+    row_max(s0, mx);
+    move_reference(mx);
+    int i = 0;
+    for (; i + 2 < nt; i += 2) {
+      iteration(i, s0, s1);
+      iteration(i + 1, s1, s0);
+    }
+    if (i + 1 < nt) {
+      iteration(i, s0, s1);
+      last(s1);
+    } else {
+      last(s0);
+    }
+  }
+
+#pragma unroll
+  for (int b = 0; b < QB; ++b) {
+    const float l_tot = half_sum(l_run[b]);
+    if (!qvalid[b]) continue;
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;   // an empty trailing split (device-side key count) reports (-inf, 0, 0)
+    op16* dst;
+    if (p.splits == 1) {
+      dst = p.o + (int64_t)z * p.o_bs + (int64_t)head * p.o_hs + (int64_t)qi[b] * p.o_ts;
+    } else {
+      const int64_t Bz = gridDim.z / p.split_cnt;
+      const int64_t row = (((int64_t)split * Bz + z) * p.H + head) * p.Lq + qi[b];
+      dst = p.o_part + row * DV;
+      if (h == 0) {
+        p.ml_part[row * 2 + 0] = m_run[b];
+        p.ml_part[row * 2 + 1] = l_tot;
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        op16x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = f2op(o[b][d][4 * g + e] * inv);
+        *reinterpret_cast<op16x4*>(dst + d * 32 + 8 * g + 4 * h) = w;
+      }
+  }
+#endif
+}
+
 #ifndef MSAM2_KV64_OCC
 #define MSAM2_KV64_OCC 3
 #endif
+// 64 queries per wave (attn_kv64x2_kernel) whenever a workgroup's 256 queries exist; MSAM2_KV64_V1=1 keeps the 32-query kernel
+static bool kv64_use_x2(const AttnParams& p) {
+  static const bool v1 = getenv("MSAM2_KV64_V1") != nullptr;
+  return !v1 && p.Lq >= 256;
+}
 static int launch_attn_kv64(const AttnParams& p, int Bz, hipStream_t s) {
-  dim3 grid(cdiv(p.Lq, 128), p.H, Bz * p.split_cnt);
-  hipLaunchKernelGGL((attn_kv64_kernel<4, MSAM2_KV64_OCC>), grid, dim3(256), 0, s, p);
+  if (kv64_use_x2(p)) {
+    dim3 grid(cdiv(p.Lq, 256), p.H, Bz * p.split_cnt);
+    hipLaunchKernelGGL((attn_kv64x2_kernel<4>), grid, dim3(256), 0, s, p);
+  } else {
+    dim3 grid(cdiv(p.Lq, 128), p.H, Bz * p.split_cnt);
+    hipLaunchKernelGGL((attn_kv64_kernel<4, MSAM2_KV64_OCC>), grid, dim3(256), 0, s, p);
+  }
   if (p.splits > 1 && !p.defer_merge) {
     const int64_t rows = (int64_t)Bz * p.H * p.Lq;
     hipLaunchKernelGGL((attn_merge_kernel<64>), dim3(cdiv(rows * 64, 256)), dim3(256), 0, s, p, Bz);
@@ -1191,9 +1542,9 @@ __global__ __launch_bounds__(512) void attn_win_kernel(AttnParams p) {
       }
       mx = fmaxf(mx, s[e]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;   // scale > 0: max commutes with it
+    mx = half_max(mx) * p.scale_log2;   // scale > 0: max commutes with it
     const float m_new = fmaxf(m_run, mx);
-    if (__any(m_new > m_run)) {
+    if (__any(m_new > m_run + MSAM2_RESCALE_SLACK)) {
       const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
 #pragma unroll
@@ -1231,7 +1582,7 @@ __global__ __launch_bounds__(512) void attn_win_kernel(AttnParams p) {
   };
   for (int tile = 0; tile < nfull; ++tile) tile_step(tile, std::false_type{});
   if (nfull < ntiles) tile_step(nfull, std::true_type{});
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float l_tot = half_sum(l_run);
 #ifdef MSAM2_STAMP
   ws2_ = __builtin_amdgcn_s_memrealtime();
 #endif

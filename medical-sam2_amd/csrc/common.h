@@ -41,6 +41,20 @@ int msam2_check_launch(const char* what);
 __device__ __forceinline__ float op2f(op16 x) { return (float)x; }
 // fp32 -> operand.  The fp16 build SATURATES at +-65504 (one v_med3_f32): a value beyond the fp16 range -- a real checkpoint's large
 // MLP / qkv activation, an un-scaled gradient -- must not become inf and travel through softmax / LayerNorm / the optimiser state.
+// Reductions across the two 32-lane halves of a wave (the row halves of a 32x32 MFMA accumulator): v_permlane32_swap_b32 (gfx950)
+// exchanges the halves in the VALU -- __shfl_xor(v, 32) compiles to ds_bpermute_b32, an LDS round trip plus an lgkmcnt wait in the
+// middle of every softmax tile.  Both results are identical in all 64 lanes and bit-equal to the shuffle forms (max, + commute).
+__device__ __forceinline__ float half_max(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+__device__ __forceinline__ float half_sum(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
 // NaN stays NaN.  f2op_fast is the plain conversion for values known to be bounded (softmax probabilities in [0, 1]).
 __device__ __forceinline__ op16 f2op_fast(float x) { return (op16)x; }
 #if MSAM2_OPERAND_IS_FP16 && !defined(MSAM2_NO_SATURATE)

@@ -97,8 +97,12 @@ def _chain(build, model, image_size, n_slices, tag, gold, meta=None):
             ref = gold[f"{tag}_t{t}_pred_masks"]
             got = cur["pred_masks"].float().cpu().numpy()
             iou, mx, mean = mask_iou(got, ref), max_abs(got, ref), _mean_abs(got, ref)
-            REPORT[f"{tag}_t{t}"] = dict(iou=iou, max_abs=mx, mean_abs=mean)
-            worst["iou"] = min(worst["iou"], iou)
+            flips = int(((got > 0) != (ref > 0)).sum())
+            REPORT[f"{tag}_t{t}"] = dict(iou=iou, max_abs=mx, mean_abs=mean, flips=flips)
+            # mask bar per slice: IoU, or -- for the small masks of some fixtures (50-200 of 4096 pixels, where ONE flipped border pixel
+            # is 1-2 % of IoU) -- the flipped-pixel count (<= 0.1 % of the map with fp16 operands, <= 0.5 % with bf16), as in the long chain
+            if flips > (0.001 if _fp16() else 0.005) * got.size:
+                worst["iou"] = min(worst["iou"], iou)
             if t == 0:
                 worst.update(max=max(worst["max"], mx), mean=max(worst["mean"], mean))
             else:
