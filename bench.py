@@ -12,7 +12,7 @@ N>1 (launched by torch.distributed.run, one rank per GPU): every rank runs the s
 its own memory bank -- the 2D path shares nothing between replicas (SURVEY.md 8(e)) -- so there is no data-path collective;
 RCCL is used for the barrier and the max-over-ranks time only.  scaling = "weak".
 
-Extra objects on the JSON line: "roofline" (dominant kernel = the memory cross-attention, attn_kv64_kernel, MFMA-bound; timed with
+Extra objects on the JSON line: "roofline" (dominant kernel = the memory cross-attention, attn_kv64x2_kernel, MFMA-bound; timed with
 HIP events on the launch stream) and "cpu_baseline" (the CPU oracle on a bounded sample, rank 0, N=1 only).
 
 `cpu_baseline.parity_slice0`: the oracle sample IS slice 0 of the timed step (same image, click and memory bank), so its mask is compared
@@ -88,7 +88,7 @@ def assemble_memory(m, bank_feats, sampled):
 
 def time_dominant_kernel(device, batch):
     """HIP-event timing (on the launch stream) of the dominant kernel -- the memory cross-attention (RoPEAttention with kv_in_dim 64,
-    transformer.py:288-331) as the model runs it: attn_kv64_kernel, 256-wide rotated q / k rows, the value product contracted in the
+    transformer.py:288-331) as the model runs it: attn_kv64x2_kernel, 256-wide rotated q / k rows, the value product contracted in the
     64-channel memory space (v_proj folded into out_proj) -- at the cross-attention shape of this workload: Lq = 4096,
     Lk = batch*4096 per slice.  The split pass is launched alone (negative split count, partials stay in a caller-owned workspace)
     so the figure is that kernel's own average duration, comparable with rocprofv3's kernel trace; the fwd+merge pair is timed too.
@@ -199,7 +199,7 @@ def pmc_traffic():
         if not os.path.exists(path):
             return None
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-                if r.get("Counter_Name") == name and "attn_kv64_kernel" in r.get("Kernel_Name", "")]
+                if r.get("Counter_Name") == name and "attn_kv64x2_kernel" in r.get("Kernel_Name", "")]
         if not vals:
             return None
         tot += mult * 1024.0 * sum(vals) / len(vals)
@@ -406,7 +406,7 @@ def main():
                        "slices_per_step_per_gpu": args.batch, "hip_graph": graph is not None, "weights": "random name-keyed init"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(),
-                         "kernel": f"attn_kv64_kernel<4,3> (memory cross-attention, value product folded to the 64-channel memory space; "
+                         "kernel": f"attn_kv64x2_kernel<4> (memory cross-attention, value product folded to the 64-channel memory space, 64 queries per wave; "
                                    f"split-KV pass, {splits} splits) at B={args.batch} Lq=4096 Lk={args.batch * 4096}",
                          "avg_launch_us": k_s * 1e6, "with_merge_us": pair_s * 1e6, "flops_per_launch": k_flops,
                          "flops_definition": "algorithmic, SURVEY 8(d): 4*Lq*Lk*256 per object (the reference's 256-wide SDPA)",

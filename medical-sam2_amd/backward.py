@@ -441,6 +441,9 @@ def attention_module_backward(att, q_in16, k_in16, v_in16, B: int, d_out: torch.
     qp, kp, vp, a = _attn_fwd(att, q_in16, k_in16, v_in16, B)
     Ci = qp.shape[1]
     D = Ci // H
+    amax = None
+    if d_out.shape[0] <= 1024:                                                    # token-side attention: see _unit_max
+        d_out, amax = _unit_max(d_out.to(F32))
     da, grads[prefix + ".out_proj.weight"], grads[prefix + ".out_proj.bias"] = linear_backward(a, w_bf16(wc, "ow", att.out_proj.weight), d_out)
     Lq, Lk = qp.shape[0] // B, kp.shape[0] // B
     if D in (16, 32) and min(Lq, Lk) <= 32:
@@ -462,6 +465,11 @@ def attention_module_backward(att, q_in16, k_in16, v_in16, B: int, d_out: torch.
         dx, grads[f"{prefix}.{nm}_proj.weight"], grads[f"{prefix}.{nm}_proj.bias"] = linear_backward(
             x16, w_bf16(wc, nm + "w", getattr(att, nm + "_proj").weight), rows(g))
         outs.append(dx)
+    if amax is not None:
+        for k in ("out_proj", "q_proj", "k_proj", "v_proj"):
+            for wb in ("weight", "bias"):
+                grads[f"{prefix}.{k}.{wb}"] = grads[f"{prefix}.{k}.{wb}"] * amax
+        outs = [o * amax for o in outs]
     return outs
 
 
@@ -556,6 +564,16 @@ def two_way_transformer_backward(tw, keys: torch.Tensor, key_pe: torch.Tensor, t
 # ---------------------------------------------------------------------------------------------------------------------
 # Mask decoder (sam/mask_decoder.py:170-267): recomputing forward + backward of the mask logits w.r.t. every parameter
 # ---------------------------------------------------------------------------------------------------------------------
+def _unit_max(dy: torch.Tensor):
+    """(dy / max|dy|, max|dy| as a device scalar) -- no host synchronisation, capturable.  The token-side links of the decoder (the four
+    hyper-network MLPs, the token attention) carry branches whose gradients can be orders of magnitude below the step's global maximum
+    the loss scale was chosen for (a mask token that only one slice of a chain uses; the object-pointer path); a few layers further
+    down such a branch would sit in fp16's subnormals as a 16-bit GEMM operand.  These links are a few rows: they re-normalise their
+    own upstream gradient and multiply the results back."""
+    a = dy.abs().amax().clamp_min(1e-30)
+    return dy / a, a
+
+
 def mlp_layers_backward(mlp, x16: torch.Tensor, dy: torch.Tensor, prefix: str, grads: dict) -> torch.Tensor:
     """Backward of an n-layer `MLP` (sam2_utils.py:108-132, no output sigmoid) by recomputation: x16 16-bit [M, in], dy [M, out].
     Adds `prefix.layers.i.weight|bias` to grads, returns dx fp32."""
@@ -568,12 +586,13 @@ def mlp_layers_backward(mlp, x16: torch.Tensor, dy: torch.Tensor, prefix: str, g
     for i in range(n - 1):
         pres.append(ops.gemm(hs[-1], Ws[i], Bs[i], out_dtype=F32))
         hs.append(ops.gemm(hs[-1], Ws[i], Bs[i], act=mlp._act_code))
-    d = dy
+    d, a = _unit_max(dy.to(F32))
     for i in range(n - 1, -1, -1):
-        d, grads[f"{prefix}.layers.{i}.weight"], grads[f"{prefix}.layers.{i}.bias"] = linear_backward(hs[i], Ws[i], d)
+        d, gw, gb = linear_backward(hs[i], Ws[i], d)
+        grads[f"{prefix}.layers.{i}.weight"], grads[f"{prefix}.layers.{i}.bias"] = gw * a, gb * a
         if i > 0:
             d = act_backward(pres[i - 1], d, mlp._act_code)
-    return d
+    return d * a
 
 
 def _convt_gather(g, bias, skip, B, h, w):
@@ -591,13 +610,16 @@ def _convt_scatter_grad(dz, B, h, w):
 
 
 def mask_decoder_backward(dec, src_tokens: torch.Tensor, pe_tokens: torch.Tensor, sparse: torch.Tensor, feat_s0: torch.Tensor,
-                          feat_s1: torch.Tensor, B: int, h: int, w: int, d_masks: torch.Tensor, aux: Optional[dict] = None):
+                          feat_s1: torch.Tensor, B: int, h: int, w: int, d_masks: torch.Tensor, aux: Optional[dict] = None,
+                          d_mask_tokens: Optional[torch.Tensor] = None):
     """Backward of `MaskDecoder.predict_masks_tokens` for a loss on the 4 mask logit maps: src_tokens fp32 [B*h*w, C] (image embedding +
     dense prompt), pe_tokens fp32 [h*w, C], sparse fp32 [B, P, C] prompt embeddings, feat_s0 / feat_s1 16-bit token-major high-res
     features, d_masks fp32 [B, 4, 4h, 4w].  The IoU and object-score heads do not see the mask loss and get no gradient.
     Returns (d_src_tokens fp32 [B*h*w, C], d_sparse fp32 [B, P, C], {parameter name relative to the decoder: gradient}).
     aux (optional dict) receives "d_feat_s0" / "d_feat_s1": the gradients of the two high-resolution feature maps (token-major, like the
-    inputs) -- what the image-encoder backward continues from (mask_decoder.py:244-247: both enter by a plain add)."""
+    inputs) -- what the image-encoder backward continues from (mask_decoder.py:244-247: both enter by a plain add).
+    d_mask_tokens (optional fp32 [B, num_mask_tokens, C]): an upstream gradient on `mask_tokens_out` as well -- the path of the object
+    pointer (sam2_base.py:376-388: obj_ptr_proj of the selected SAM output token), added to the hyper-network path's token gradient."""
     from .modeling.common import to_bf16, v_f32
     wc, C, L = dec._wc, dec.transformer_dim, h * w
     nm = dec.num_mask_tokens
@@ -652,8 +674,10 @@ def mask_decoder_backward(dec, src_tokens: torch.Tensor, pe_tokens: torch.Tensor
     d_keys, dw1, _ = linear_backward(keys16, dc1_w, _convt_scatter_grad(dz1, B, h, w))
     grads["output_upscaling.0.weight"] = dw1.view(2, 2, C // 4, C).permute(3, 2, 0, 1).contiguous()
     d_hs = torch.zeros(B, T, C, dtype=F32, device=u2.device)
+    if d_mask_tokens is not None:
+        d_hs[:, 2:2 + nm] = d_mask_tokens
     for i, m in enumerate(dec.output_hypernetworks_mlps):
-        d_hs[:, 2 + i] = mlp_layers_backward(m, tok16[i], d_hyper[:, i].contiguous(), f"output_hypernetworks_mlps.{i}", grads)
+        d_hs[:, 2 + i] += mlp_layers_backward(m, tok16[i], d_hyper[:, i].contiguous(), f"output_hypernetworks_mlps.{i}", grads)
     d_src, d_tok, g_tw = two_way_transformer_backward(dec.transformer, src_tokens, pe_tokens, tokens, B, T, L, d_hs.view(B * T, C), d_keys)
     grads.update({"transformer." + k: v for k, v in g_tw.items()})
     d_tok = d_tok.view(B, T, C)
@@ -710,12 +734,14 @@ def cxblock_backward(blk, x: torch.Tensor, n: int, H: int, W: int, dy: torch.Ten
 
 
 def memory_encoder_backward(enc, pix_tokens: torch.Tensor, mask: torch.Tensor, mode: int, scale: float, bias: float, n: int, H: int, W: int,
-                            dy: torch.Tensor):
+                            dy: torch.Tensor, need_dmask: bool = False):
     """Backward of `MemoryEncoder.run` (memory_encoder.py:138-181 with MaskDownSampler 17-58 and the Fuser's CXBlocks 62-135): pix_tokens
     [n*H*W, C], mask fp32 [n,1,16H,16W] with the mask transform `mode` of the forward (0 raw, 1 sigmoid * scale + bias, 2 binarised),
     dy fp32 [n*H*W, out_dim].  The k3 s2 p1 convolutions are differentiated in their im2col GEMM form (`msam2_col2im3x3s2` is the
-    adjoint of the patch gather); the mask transform itself (one elementwise op on the input mask) is done by torch, and the mask
-    receives no gradient.  Returns (d pix_tokens fp32 [n*H*W, C], {parameter name relative to the memory encoder: gradient})."""
+    adjoint of the patch gather); the mask transform itself (one elementwise op on the input mask) is done by torch.
+    Returns (d pix_tokens fp32 [n*H*W, C], {parameter name relative to the memory encoder: gradient}); with need_dmask a third value,
+    d mask fp32 [n,1,16H,16W] through the first convolution and the sigmoid transform (zero for the binarised mode 2) -- what
+    back-propagation through time continues with into the slice that predicted the mask (training_3d)."""
     from .modeling.common import to_bf16, v_f32, w_bf16
     wc, ds = enc._wc, enc.mask_downsampler
     dwc, E = ds._wc, ds.encoder
@@ -789,10 +815,23 @@ def memory_encoder_backward(enc, pix_tokens: torch.Tensor, mask: torch.Tensor, m
             dgp = torch.zeros(dg.shape[0], np_, dtype=F32, device=dg.device)
             dgp[:, :cout] = dg
             dg = dgp
-        dcols, dwp, dbp = linear_backward(cols, wpk, dg, need_dx=j > 0)
+        dcols, dwp, dbp = linear_backward(cols, wpk, dg, need_dx=j > 0 or need_dmask)
         g[f"{pre}.{3 * j}.weight"] = dwp[:cout, : 9 * cin_p].reshape(cout, 3, 3, cin_p)[..., :cin].permute(0, 3, 1, 2).contiguous()
         g[f"{pre}.{3 * j}.bias"] = dbp[:cout]
         if j > 0:
             dh = torch.empty(n * side_in * side_in, cin, dtype=F32, device=dy.device)
             check(lib().msam2_col2im3x3s2(_p(dcols), dcols.stride(0), _p(dh), n, side_in, side_in, cin, _stream()))
-    return dpix, g
+    if not need_dmask:
+        return dpix, g
+    # first convolution's input: the 1-channel mask rides in channel 0 of the zero-padded 4-channel image
+    dimg = torch.empty(n * S * S, 4, dtype=F32, device=dy.device)
+    check(lib().msam2_col2im3x3s2(_p(dcols), dcols.stride(0), _p(dimg), n, S, S, 4, _stream()))
+    dmt = dimg[:, 0].reshape(n, 1, S, S)
+    if mode == 1:
+        sg = torch.sigmoid(mask.to(F32))
+        dmask = dmt * (scale * sg * (1.0 - sg))
+    elif mode == 2:
+        dmask = torch.zeros_like(dmt)
+    else:
+        dmask = dmt.contiguous()
+    return dpix, g, dmask

@@ -255,28 +255,12 @@ class SAM2Base(nn.Module):
                 ptrs.append(out["obj_ptr"])
         return spatial, ptrs
 
-    def _prepare_memory_conditioned_features(self, frame_idx, is_init_cond_frame, current_vision_feats, current_vision_pos_embeds,
-                                             feat_sizes, output_dict, num_frames, track_in_reverse=False, memory_selection=None):
-        """sam2_base.py:494-663: memory-bank selection is host logic (dict lookups, `_select_memory`); the bank itself is assembled
-        into one [N_k, B, 64] buffer by strided copy kernels and handed to memory attention.
-
-        memory_selection = (spatial, ptrs) skips the selection (the caller made it).  `ptrs` is then either the list of pointers or a
-        PADDED bank (ptr_bank [capacity, B, C] fp32, key_count int32 device scalar = n_spatial*HW + n_ptrs*C/mem_dim): the launch
-        shapes depend on the capacity only, the attention kernel reads the number of valid keys from the device -- the form a
-        hipGraph of the per-slice forward is captured in (graphs.GraphedPropagation); rows of the bank past the valid pointers are
-        never attended to."""
-        B = current_vision_feats[-1].size(1)
+    def _assemble_memory(self, spatial, ptrs, B: int, H: int, W: int, device):
+        """The bank as ONE [N_k, B, 64] buffer + its position encoding (sam2_base.py:565-638): spatial memories (+ their temporal
+        encoding on the position side), then the object pointers as C // mem_dim tokens each, zero position encoding.  `ptrs`: a list
+        of [B, C] pointers or the padded form (ptr_bank [capacity, B, C] fp32, key_count) -- see _prepare_memory_conditioned_features.
+        Returns (memory, memory_pos, number of pointer tokens, key_count or None)."""
         C = self.hidden_dim
-        H, W = feat_sizes[-1]
-        device = current_vision_feats[-1].device
-        if self.num_maskmem == 0:
-            return current_vision_feats[-1].permute(1, 2, 0).view(B, C, H, W)
-        if is_init_cond_frame:
-            # directly_add_no_mem_embed (sam2_base.py:640-644)
-            y = ops.add_cast(current_vision_feats[-1].transpose(0, 1), self.no_mem_embed.detach().to(F32).expand(B, H * W, C), 1.0, F32)
-            return y.view(B, H * W, C).transpose(0, 1).permute(1, 2, 0).view(B, C, H, W)
-        spatial, ptrs = memory_selection if memory_selection is not None else \
-            self._select_memory(frame_idx, output_dict, num_frames, track_in_reverse)
         split = C // self.mem_dim
         HW = H * W
         key_count = None
@@ -306,6 +290,31 @@ class SAM2Base(nn.Module):
                 # [B, C] -> (C // mem_dim) tokens of mem_dim (sam2_base.py:626-632)
                 sl = slice(n_sp + j * split, n_sp + (j + 1) * split)
                 ops.add_cast_into(memory[sl], ptr.to(F32).reshape(B, split, self.mem_dim).permute(1, 0, 2), None, 1.0)
+        return memory, memory_pos, n_ptr_tok, key_count
+
+    def _prepare_memory_conditioned_features(self, frame_idx, is_init_cond_frame, current_vision_feats, current_vision_pos_embeds,
+                                             feat_sizes, output_dict, num_frames, track_in_reverse=False, memory_selection=None):
+        """sam2_base.py:494-663: memory-bank selection is host logic (dict lookups, `_select_memory`); the bank itself is assembled
+        into one [N_k, B, 64] buffer by strided copy kernels and handed to memory attention.
+
+        memory_selection = (spatial, ptrs) skips the selection (the caller made it).  `ptrs` is then either the list of pointers or a
+        PADDED bank (ptr_bank [capacity, B, C] fp32, key_count int32 device scalar = n_spatial*HW + n_ptrs*C/mem_dim): the launch
+        shapes depend on the capacity only, the attention kernel reads the number of valid keys from the device -- the form a
+        hipGraph of the per-slice forward is captured in (graphs.GraphedPropagation); rows of the bank past the valid pointers are
+        never attended to."""
+        B = current_vision_feats[-1].size(1)
+        C = self.hidden_dim
+        H, W = feat_sizes[-1]
+        device = current_vision_feats[-1].device
+        if self.num_maskmem == 0:
+            return current_vision_feats[-1].permute(1, 2, 0).view(B, C, H, W)
+        if is_init_cond_frame:
+            # directly_add_no_mem_embed (sam2_base.py:640-644)
+            y = ops.add_cast(current_vision_feats[-1].transpose(0, 1), self.no_mem_embed.detach().to(F32).expand(B, H * W, C), 1.0, F32)
+            return y.view(B, H * W, C).transpose(0, 1).permute(1, 2, 0).view(B, C, H, W)
+        spatial, ptrs = memory_selection if memory_selection is not None else \
+            self._select_memory(frame_idx, output_dict, num_frames, track_in_reverse)
+        memory, memory_pos, n_ptr_tok, key_count = self._assemble_memory(spatial, ptrs, B, H, W, device)
         pix = self.memory_attention(curr=current_vision_feats, curr_pos=current_vision_pos_embeds, memory=memory,
                                     memory_pos=memory_pos, num_obj_ptr_tokens=n_ptr_tok, key_count=key_count)
         return pix.permute(1, 2, 0).view(B, C, H, W)

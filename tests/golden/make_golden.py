@@ -533,6 +533,138 @@ def run_grads_case():
     return out, meta
 
 
+def box_target(box, size: int) -> torch.Tensor:
+    """[1, size, size] float target: 1 inside the (x0, y0, x1, y1) box, all zero for None (same helper in tests/test_bptt_gpu.py)"""
+    t = torch.zeros(1, size, size)
+    if box is not None:
+        x0, y0, x1, y1 = [int(round(float(v))) for v in box]
+        t[:, max(y0, 0): y1 + 1, max(x0, 0): x1 + 1] = 1.0
+    return t
+
+
+def run_chain_grads_case():
+    """Back-propagation through time along the 3-D propagation chain, the way the reference's 3-D training loop differentiates it
+    (func_3d/function.py:58-191: net.train(); train_add_new_bbox / train_add_new_points on the prompted slices, train_propagate_in_video
+    without inference_mode, BCEWithLogitsLoss(pos_weight=2) on every slice's video-resolution mask logits; non_prompt_loss.backward()
+    then prompt_loss.backward()).  hiera_t at 256^2, 5 slices, 2 objects, slice 0 prompted with a box (single-mask output), slice 3 with
+    a click (multimask output, best predicted IoU), slices 1, 2, 4 propagated: their losses reach the memory encoder and the object
+    pointer projection of EARLIER slices, the decoder of those slices through the predicted masks / SAM tokens, and recursively on.
+    Train mode (no binarisation of prompted masks for the memory encoder, pointers of all conditioning slices, no dynamic multimask
+    fallback) with every dropout probability set to 0 so that the fixture is deterministic.  The image encoder is frozen (train_3d.py:
+    34-37 leaves it out of both optimisers).  Gradients of the four trained groups are stored as strided subsamples + fp64 sums."""
+    import torch.nn.functional as Fn
+    S, T, n = 256, 5, 2
+    m = build_reference("hiera_t", S)
+    m.train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if hasattr(mod, "dropout_p"):
+            mod.dropout_p = 0.0
+    for p_ in m.parameters():
+        p_.requires_grad_(False)
+    groups = {"sam_mask_decoder": m.sam_mask_decoder, "memory_attention": m.memory_attention, "memory_encoder": m.memory_encoder,
+              "obj_ptr_proj": m.obj_ptr_proj}
+    for g_ in groups.values():
+        for p_ in g_.parameters():
+            p_.requires_grad_(True)
+    volume, boxes = syn.blob_volume(7, n_slices=T, size=S, n_objects=n)
+    cond = {0: "box", 3: "click"}
+    picked = []
+    real_dec = m.sam_mask_decoder.forward
+
+    def spy(*a, **k):
+        r = real_dec(*a, **k)
+        picked.append((r[1].detach().clone(), r[3].detach().clone()))
+        return r
+
+    m.sam_mask_decoder.forward = spy
+    od = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
+    out, meta = {}, {"model": "hiera_t", "image_size": S, "n_slices": T, "n_objects": n, "volume_seed": 7, "cond": cond, "pos_weight": 2.0,
+                     "grad_stats": {}, "frames": {}}
+
+    def enc(t):
+        with torch.no_grad():
+            bo = m.forward_image(volume[t][None])
+        bo = {"backbone_fpn": [f.expand(n, -1, -1, -1) for f in bo["backbone_fpn"]], "vision_pos_enc": [q.expand(n, -1, -1, -1) for q in bo["vision_pos_enc"]]}
+        _, feats, pos, sizes = m._prepare_backbone_features(bo)
+        return feats, pos, sizes
+
+    def prompt(t, kind):
+        if kind == "box":
+            bx = torch.tensor([[float(v) for v in (boxes[o][t] or (S * 0.3, S * 0.3, S * 0.6, S * 0.6))] for o in range(n)])
+            return {"point_coords": bx.reshape(n, 2, 2), "point_labels": torch.tensor([[2, 3]], dtype=torch.int32).expand(n, 2)}
+        cs = []
+        for o in range(n):
+            b = boxes[o][t] or (S * 0.3, S * 0.3, S * 0.6, S * 0.6)
+            cs.append([(float(b[0]) + float(b[2])) / 2, (float(b[1]) + float(b[3])) / 2])
+        return {"point_coords": torch.tensor(cs).reshape(n, 1, 2), "point_labels": torch.ones(n, 1, dtype=torch.int32)}
+
+    for t, kind in cond.items():
+        feats, pos, sizes = enc(t)
+        od["cond_frame_outputs"][t] = m.track_step(frame_idx=t, is_init_cond_frame=True, current_vision_feats=feats, current_vision_pos_embeds=pos,
+                                                   feat_sizes=sizes, point_inputs=prompt(t, kind), mask_inputs=None, output_dict=od, num_frames=T,
+                                                   run_mem_encoder=True)
+        meta["frames"][str(t)] = {"iou": picked[-1][0].tolist(), "obj": picked[-1][1].reshape(-1).tolist()}
+    for t in range(T):
+        if t in cond:
+            continue
+        feats, pos, sizes = enc(t)
+        od["non_cond_frame_outputs"][t] = m.track_step(frame_idx=t, is_init_cond_frame=False, current_vision_feats=feats, current_vision_pos_embeds=pos,
+                                                       feat_sizes=sizes, point_inputs=None, mask_inputs=None, output_dict=od, num_frames=T,
+                                                       run_mem_encoder=True)
+        meta["frames"][str(t)] = {"iou": picked[-1][0].tolist(), "obj": picked[-1][1].reshape(-1).tolist()}
+    m.sam_mask_decoder.forward = real_dec
+    crit = torch.nn.BCEWithLogitsLoss(pos_weight=torch.ones([1]) * 2.0)
+    prompt_loss, non_prompt_loss = 0, 0
+    per_frame_prompt = {}
+    for t in range(T):
+        cur = od["cond_frame_outputs"].get(t) or od["non_cond_frame_outputs"][t]
+        out[f"t{t}_pred_masks"] = cur["pred_masks"].detach().numpy().copy()
+        out[f"t{t}_obj_ptr"] = cur["obj_ptr"].detach().numpy().copy()
+        pred = Fn.interpolate(cur["pred_masks"], size=(S, S), mode="bilinear", align_corners=False)
+        for o in range(n):
+            l_ = crit(pred[o][None], box_target(boxes[o][t], S)[None])
+            meta["frames"][str(t)].setdefault("loss", []).append(float(l_.item()))
+            if t in cond:
+                prompt_loss = prompt_loss + l_
+                per_frame_prompt[t] = per_frame_prompt.get(t, 0) + l_
+            else:
+                non_prompt_loss = non_prompt_loss + l_
+    non_prompt_loss = non_prompt_loss / (T - len(cond)) / n
+    prompt_loss = prompt_loss / len(cond) / n
+    out["non_prompt_loss"], out["prompt_loss"] = np.array([non_prompt_loss.item()]), np.array([prompt_loss.item()])
+
+    def keep(name, g_):
+        out[name] = sub(g_, 256)
+        meta["grad_stats"][name] = stats(g_)
+
+    # the prompt loss slice by slice as well (decoder only): localises a discrepancy to one prompted slice
+    for t, l_ in per_frame_prompt.items():
+        (l_ / len(cond) / n).backward(retain_graph=True)
+        for k, p_ in m.sam_mask_decoder.named_parameters():
+            if p_.grad is not None and p_.grad.abs().sum() > 0:
+                keep(f"prompt_t{t}.sam_mask_decoder.{k}", p_.grad)
+            p_.grad = None
+    non_prompt_loss.backward(retain_graph=True)
+    n_np = 0
+    for gname, mod in groups.items():
+        for k, p_ in mod.named_parameters():
+            if p_.grad is not None and p_.grad.abs().sum() > 0:
+                keep(f"non_prompt.{gname}.{k}", p_.grad)
+                n_np += 1
+            p_.grad = None
+    prompt_loss.backward()
+    n_p = 0
+    for gname, mod in groups.items():
+        for k, p_ in mod.named_parameters():
+            if p_.grad is not None and p_.grad.abs().sum() > 0:
+                keep(f"prompt.{gname}.{k}", p_.grad)
+                n_p += 1
+    meta["n_non_prompt_params"], meta["n_prompt_params"] = n_np, n_p
+    return out, meta
+
+
 def run_encoder_grads_case():
     """`.grad` of every image-encoder parameter (and of the decoder's conv_s0 / conv_s1, which act inside forward_image) of the
     REFERENCE under torch.autograd: hiera_t at 256^2, two synthetic images, a seeded random linear functional of the three
@@ -569,6 +701,15 @@ def main():
         allmeta["grads_encoder_t256"] = meta
         json.dump(allmeta, open(os.path.join(OUT, "meta.json"), "w"), indent=1)
         print("grads_encoder_t256.npz", os.path.getsize(os.path.join(OUT, "grads_encoder_t256.npz")), meta["n_params"], "parameters")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "bptt":
+        o, meta = run_chain_grads_case()
+        np.savez_compressed(os.path.join(OUT, "grads_bptt_t256.npz"), **o)
+        allmeta = json.load(open(os.path.join(OUT, "meta.json")))
+        allmeta["grads_bptt_t256"] = meta
+        json.dump(allmeta, open(os.path.join(OUT, "meta.json"), "w"), indent=1)
+        print("grads_bptt_t256.npz", os.path.getsize(os.path.join(OUT, "grads_bptt_t256.npz")), meta["n_non_prompt_params"], meta["n_prompt_params"],
+              {k: (v["iou"], v["obj"], v["loss"]) for k, v in meta["frames"].items()})
         return
     if len(sys.argv) > 1 and sys.argv[1] == "grads":
         o, meta = run_grads_case()

@@ -291,7 +291,8 @@ def test_two_way_transformer_backward(mods):
     assert worst[0][1] < 3e-2, worst
 
 
-def test_mask_decoder_backward(mods):
+@pytest.mark.parametrize("Pp,with_tokens", [(2, False), (3, False), (1, True), (3, True)])
+def test_mask_decoder_backward(mods, Pp, with_tokens):
     """MaskDecoder.predict_masks (mask_decoder.py:170-267): gradients of a loss on the 4 mask logit maps w.r.t. the image embedding,
     the prompt embeddings and every decoder parameter the masks depend on (two-way transformer, both ConvTranspose stages + LayerNorm2d,
     the 4 hyper-network MLPs, the learned output tokens) against autograd through oracle.mask_decoder_predict."""
@@ -304,7 +305,7 @@ def test_mask_decoder_backward(mods):
     dec = m.sam_mask_decoder.to(DEV).eval()
     pre = "sam_mask_decoder"
     P = {k: v.clone().float().requires_grad_(k.startswith(pre)) for k, v in sd.items()}
-    B, E, C, Pp = 2, 16, 256, 2
+    B, E, C = 2, 16, 256
     L = E * E
     q16 = lambda t: t.to(ops.OP16).float()
     emb = rnd(B, C, E, E, seed=60).requires_grad_(True)
@@ -312,11 +313,15 @@ def test_mask_decoder_backward(mods):
     sparse = rnd(B, Pp, C, seed=62).requires_grad_(True)
     f0, f1 = q16(rnd(B, 32, 4 * E, 4 * E, seed=63)), q16(rnd(B, 64, 2 * E, 2 * E, seed=64))
     dmask = rnd(B, 4, 4 * E, 4 * E, seed=65, scale=0.1)
-    masks, _, _, _ = O.mask_decoder_predict(P, emb, pe, sparse, torch.zeros_like(emb), [f0, f1])
-    (masks * dmask).sum().backward()
+    masks, _, toks, _ = O.mask_decoder_predict(P, emb, pe, sparse, torch.zeros_like(emb), [f0, f1])
+    # with_tokens: an upstream gradient on the SAM output tokens as well (the object-pointer path of back-propagation through time);
+    # Pp = 3 is the box prompt (two corners + the padding point): 9 decoder tokens, not a multiple of 8
+    dtok = rnd(B, 4, C, seed=66, scale=0.05) if with_tokens else None
+    ((masks * dmask).sum() + ((toks * dtok).sum() if with_tokens else 0.0)).backward()
     d = lambda t: t.detach().to(DEV)
     tm = lambda t: d(t).permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()       # NCHW -> token-major
-    d_src, d_sparse, grads = B_.mask_decoder_backward(dec, tm(emb), tm(pe), d(sparse), tm(f0).to(ops.OP16), tm(f1).to(ops.OP16), B, E, E, d(dmask))
+    d_src, d_sparse, grads = B_.mask_decoder_backward(dec, tm(emb), tm(pe), d(sparse), tm(f0).to(ops.OP16), tm(f1).to(ops.OP16), B, E, E, d(dmask),
+                                                      d_mask_tokens=d(dtok) if with_tokens else None)
     report = {"d_emb": rel(d_src.view(B, L, C), emb.grad.flatten(2).permute(0, 2, 1)), "d_sparse": rel(d_sparse, sparse.grad)}
     for name, g in grads.items():
         ref = P[f"{pre}.{name}"].grad
@@ -330,7 +335,8 @@ def test_mask_decoder_backward(mods):
     expect = {k[len(pre) + 1:] for k, v in P.items() if k.startswith(pre + ".") and v.grad is not None and v.grad.abs().sum() > 0}
     assert expect <= set(grads), sorted(expect - set(grads))
     worst = sorted(report.items(), key=lambda kv: -kv[1])[:6]
-    assert worst[0][1] < 4e-2, worst
+    # (9 decoder tokens / the extra token gradient: the same 16-bit links, the worst single parameter sits at 5-7 % instead of < 4 %)
+    assert worst[0][1] < (4e-2 if (Pp, with_tokens) == (2, False) else 8e-2), worst
 
 
 def test_bce_and_adam_kernels(mods):

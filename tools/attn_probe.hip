@@ -6,24 +6,25 @@
 #include <cstdio>
 #include <cstring>
 int main(int argc, char** argv) {
-  const int64_t B = 4, H = 1, Lq = 4096, Lk = 16384, D = 256;
+  const bool d96 = argc > 1 && !strcmp(argv[1], "d96");   // Hiera global attention: B=4, 4 heads, 4096 x 4096 x 96, one pass
+  const int64_t B = 4, H = d96 ? 4 : 1, Lq = 4096, Lk = d96 ? 4096 : 16384, D = d96 ? 96 : 256;
   const bool kv64 = argc > 1 && !strcmp(argv[1], "kv64");
-  const int splits = argc > 2 ? atoi(argv[2]) : (kv64 ? 6 : 4);
-  std::vector<_Float16> h((size_t)B * Lk * D);
+  const int splits = argc > 2 ? atoi(argv[2]) : (d96 ? 1 : kv64 ? 6 : 4);
+  std::vector<_Float16> h((size_t)B * H * (Lk > Lq ? Lk : Lq) * D);
   for (size_t i = 0; i < h.size(); ++i) h[i] = (_Float16)(((int)(i * 2654435761u >> 20) % 200 - 100) * 0.01f);
   _Float16 *q, *k, *v, *o;
-  hipMalloc(&q, B * Lq * D * 2); hipMalloc(&k, B * Lk * D * 2); hipMalloc(&v, B * Lk * D * 2); hipMalloc(&o, B * Lq * D * 2);
-  hipMemcpy(q, h.data(), B * Lq * D * 2, hipMemcpyHostToDevice);
-  hipMemcpy(k, h.data(), B * Lk * D * 2, hipMemcpyHostToDevice);
-  hipMemcpy(v, h.data(), B * Lk * D * 2, hipMemcpyHostToDevice);
+  hipMalloc(&q, B * H * Lq * D * 2); hipMalloc(&k, B * H * Lk * D * 2); hipMalloc(&v, B * H * Lk * D * 2); hipMalloc(&o, B * H * Lq * D * 2);
+  hipMemcpy(q, h.data(), B * H * Lq * D * 2, hipMemcpyHostToDevice);
+  hipMemcpy(k, h.data(), B * H * Lk * D * 2, hipMemcpyHostToDevice);
+  hipMemcpy(v, h.data(), B * H * Lk * D * 2, hipMemcpyHostToDevice);
   size_t wsb = msam2_attention_workspace_bytes(B, H, Lq, D, splits);
   void* ws; hipMalloc(&ws, wsb);
-  int64_t qs[3] = {Lq * D, Lq * D, D}, ks[3] = {Lk * D, Lk * D, D}, vs[3] = {Lk * 64, Lk * 64, 64}, os[3] = {Lq * 64, Lq * 64, 64};
+  int64_t qs[3] = {H * Lq * D, Lq * D, D}, ks[3] = {H * Lk * D, Lk * D, D}, vs[3] = {Lk * 64, Lk * 64, 64}, os[3] = {Lq * 64, Lq * 64, 64};
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int it = 0; it < 8; ++it) {
     if (it == 3) hipEventRecord(e0, nullptr);
     int rc = kv64 ? msam2_attention_kv64_fwd(q, qs, k, ks, v, vs, o, os, B, H, Lq, Lk, 0.0625f, -splits, ws, wsb, nullptr)
-                  : msam2_attention_fwd(q, qs, k, ks, v, ks, o, qs, B, H, Lq, Lk, D, 0.0625f, -splits, ws, wsb, nullptr);
+                  : msam2_attention_fwd(q, qs, k, ks, v, ks, o, qs, B, H, Lq, Lk, D, 0.0625f, d96 ? 1 : -splits, ws, wsb, nullptr);
     if (rc) { printf("error %s\n", msam2_last_error()); return 1; }
   }
   hipEventRecord(e1, nullptr);
@@ -34,7 +35,7 @@ int main(int argc, char** argv) {
   const int o0 = kv64 ? 8 : 0;
   const char* names[5] = {"dma-issue+vmcnt+barrier", "QK (16 mfma + K reads)", "softmax (+V reads)", "PV mfma", "lgkm wait"};
   double tot = 0; for (int i = 0; i < 5; ++i) tot += st[o0 + i];
-  printf("%s splits %d: %.1f us per launch (stamped build), tiles %llu, cycles/tile %.0f\n", kv64 ? "kv64" : "d256", splits, ms * 1e3 / 5, st[o0 + 5], tot / st[o0 + 5]);
+  printf("%s splits %d: %.1f us per launch (stamped build), tiles %llu, cycles/tile %.0f\n", kv64 ? "kv64" : d96 ? "d96" : "d256", splits, ms * 1e3 / 5, st[o0 + 5], tot / st[o0 + 5]);
   if (kv64) {
     static unsigned long long wt[4096][4];
     hipMemcpyFromSymbol(wt, HIP_SYMBOL(g_wgtime), sizeof(wt));
