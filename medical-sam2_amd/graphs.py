@@ -123,6 +123,8 @@ class GraphedPropagation:
     @torch.no_grad()
     def track(self, frame_idx: int, feats_one: dict, output_dict: dict, track_in_reverse: bool = False) -> dict:
         m = self.model
+        if m.training:
+            raise RuntimeError("GraphedPropagation is an inference path: train-mode dropout draws a host-side stream per forward")
         spatial, ptrs = m._select_memory(frame_idx, output_dict, self.num_frames, track_in_reverse)
         assert spatial, "propagation needs at least one stored memory"
         if self._version_sum() != self._versions:          # a parameter was written: the graphs hold stale weight copies

@@ -243,7 +243,10 @@ def test_attention_vs_oracle(ops, B, H, Lq, Lk, D, splits):
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk,splits", [(1, 1, 32, 32, 1), (2, 1, 200, 520, 1), (1, 1, 130, 2100, 4), (2, 1, 64, 4096 + 8, 8),
-                                              (1, 2, 256, 1000, 3), (1, 1, 1024, 33, 1)])
+                                              (1, 2, 256, 1000, 3), (1, 1, 1024, 33, 1),
+                                              # 64-queries-per-wave kernel (Lq >= 256): ragged query tile, a single full tile, a single
+                                              # partial tile, splits with odd / even tile counts per split
+                                              (2, 1, 300, 520, 1), (1, 1, 4096, 32, 1), (1, 1, 512, 31, 1), (1, 1, 260, 4100, 7), (1, 1, 384, 96, 3)])
 def test_attention_kv64_vs_oracle(ops, B, H, Lq, Lk, splits):
     """memory cross-attention with 64-wide value rows (msam2_attention_kv64_fwd): partial tiles, ragged query tiles, splits"""
     q, k, v = bf(rnd(B, H, Lq, 256, seed=1)), bf(rnd(B, H, Lk, 256, seed=2)), bf(rnd(B, H, Lk, 64, seed=3))
@@ -254,10 +257,12 @@ def test_attention_kv64_vs_oracle(ops, B, H, Lq, Lk, splits):
     close(out, ref, 0.02, 0.01, "attention kv64")
 
 
-def test_attention_kv64_strided_and_rescale(ops):
-    """k / v as strided views (the [B, Nk, C] layouts of the memory bank), a peaked key in a late tile (running-max rescale), and
-    the deferred merge == the fused call bit for bit"""
-    B, Lq, Lk = 2, 96, 700
+@pytest.mark.parametrize("Lq", [96, 320])
+def test_attention_kv64_strided_and_rescale(ops, Lq):
+    """k / v as strided views (the [B, Nk, C] layouts of the memory bank), a peaked key in a late tile (running-max rescale: in the
+    64-queries-per-wave kernel, Lq = 320, the AGPR read / write path of the O accumulators), and the deferred merge == the fused call
+    bit for bit"""
+    B, Lk = 2, 700
     q = bf(rnd(B, 1, Lq, 256, seed=1))
     kbig, vbig = bf(rnd(B, Lk, 320, seed=2) * 0.2), bf(rnd(B, Lk, 128, seed=3))
     kbig[0, 610, 64:] = bf(q[0, 0, 7].float() * 3)
