@@ -79,7 +79,8 @@ SIGNATURES = {
     "msam2_bilinear_upsample_bwd": (c_i, [c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_p]),
     "msam2_maxpool2x2_bwd": (c_i, [c_p, c_i, c_l, c_p, c_l, c_p, c_l, c_l, c_l, c_l, c_l, c_p]),
     "msam2_sumpool2x2": (c_i, [c_p, c_p, c_l, c_l, c_l, c_l, c_p]),
-    "msam2_hiera_pos_embed_bwd": (c_i, [c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_l, c_p]),
+    "msam2_hiera_pos_embed_bwd": (c_i, [c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_l, c_p, c_z, c_p]),
+    "msam2_hiera_pos_embed_bwd_workspace_bytes": (c_z, [c_l, c_l, c_l, c_l]),
     "msam2_dropout": (c_i, [c_p, c_i, c_l, c_p, c_l, c_p, c_i, c_l, c_l, c_l, c_f, ctypes.c_uint64, ctypes.c_uint64, c_p]),
     "msam2_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_l, c_p]),
     "msam2_adam_step_multi": (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_l, c_f, c_f, c_p, c_p]),

@@ -309,8 +309,11 @@ def image_encoder_backward(model, state: dict, d_fpn: List[Optional[torch.Tensor
         h = w = state["S"] // 4
         d_table = bwd.colsum(dt.view(B, h * w * E)).view(h * w, E)                     # the table is broadcast over the batch
         dpe, dpw = torch.empty_like(trunk.pos_embed, dtype=F32), torch.empty_like(trunk.pos_embed_window, dtype=F32)
+        wsz = trunk.pos_embed_window.shape[-1]
+        nb = lib().msam2_hiera_pos_embed_bwd_workspace_bytes(E, trunk.pos_embed.shape[3], h, wsz)
+        ws = torch.empty(nb, dtype=torch.uint8, device=d_table.device)
         check(lib().msam2_hiera_pos_embed_bwd(_p(d_table), _p(dpe), _p(dpw), E, trunk.pos_embed.shape[2], trunk.pos_embed.shape[3], h, w,
-                                              trunk.pos_embed_window.shape[-1], _stream()))
+                                              wsz, _p(ws), nb, _stream()))
         grads["image_encoder.trunk.pos_embed"], grads["image_encoder.trunk.pos_embed_window"] = dpe * inv, dpw * inv
     scales["done"] = True
     return grads

@@ -1044,63 +1044,102 @@ extern "C" int msam2_sumpool2x2(const float* dy, float* out, int64_t B, int64_t 
 // Adjoint of msam2_hiera_pos_embed (Hiera._get_pos_embed, hieradet.py:269-277): d_table fp32 [h*w, C] (the gradient of the position
 // tokens, already summed over the batch) -> d pos_embed [C, bh, bw] through the transposed bicubic resize (same tap weights and border
 // clamping as the forward: the resize is separable, so the weight of source row y for output row yy is a 1-D table) and
-// d pos_embed_window [C, wsz, wsz] (sum over the tiling).  Gather form: one workgroup per source pixel, one thread per channel; no atomics.
+// d pos_embed_window [C, wsz, wsz] (sum over the tiling).
 __device__ __forceinline__ float cubic1_b(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
 __device__ __forceinline__ float cubic2_b(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
 
-__global__ void hiera_pos_bwd_kernel(const float* __restrict__ d_table, float* __restrict__ d_bkg, float* __restrict__ d_win, int C, int bh,
-                                     int bw, int h, int w, int wsz) {
-  extern __shared__ float wts[];                             // [h] row weights, [w] column weights of this source pixel
-  float* wy = wts;
-  float* wx = wts + h;
+// Two passes, both gather form (no atomics: the gradients are run-to-run reproducible):
+//   rows pass   one workgroup per output row yy, one thread per channel: the row's w x C gradients are read once (coalesced over the
+//               channels) and reduced over xx into bw column sums weighted by the bicubic column weights of each source column plus
+//               wsz plain sums per window column -> workspace [h][bw + wsz][C];
+//   final pass  one workgroup per source pixel / window cell: the weighted sum over the 256 rows of the workspace.
+// (The first version looped over the whole 256 x 256 table inside 113 workgroups of 96 threads: 7.2 ms per call, 11 % of a training
+// iteration; this form reads the table once: ~25 MB.)
+__device__ __forceinline__ float pos_bwd_weight(int o, int n_out, int n_src, int src) {
+  // weight with which source index `src` enters output index `o` of the clamped 4-tap bicubic resize
   const float A = -0.75f;
-  const int nb = bh * bw;
+  const float f = (o + 0.5f) * ((float)n_src / n_out) - 0.5f;
+  const int i0 = (int)floorf(f);
+  const float t = f - i0;
+  const float tap[4] = {cubic2_b(t + 1.f, A), cubic1_b(t, A), cubic1_b(1.f - t, A), cubic2_b(2.f - t, A)};
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+    if (min(max(i0 - 1 + a, 0), n_src - 1) == src) acc += tap[a];
+  return acc;
+}
+
+template <int MAXB, int MAXW>
+__global__ void hiera_pos_bwd_rows_kernel(const float* __restrict__ d_table, float* __restrict__ part, int C, int bw, int w, int wsz) {
+  extern __shared__ float wx[];                              // [bw][w] column weights
+  for (int i = threadIdx.x; i < bw * w; i += blockDim.x) wx[i] = pos_bwd_weight(i % w, w, bw, i / w);
+  __syncthreads();
+  const int yy = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float ab[MAXB], aw[MAXW];
+#pragma unroll
+    for (int j = 0; j < MAXB; ++j) ab[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXW; ++j) aw[j] = 0.f;
+    const float* row = d_table + (int64_t)yy * w * C + c;
+    for (int x0 = 0; x0 < w; x0 += MAXW) {
+#pragma unroll
+      for (int j = 0; j < MAXW; ++j) {
+        const int xx = x0 + j;                               // w % wsz == 0 and wsz <= MAXW: column xx belongs to window column xx % wsz
+        if (xx < w) {
+          const float v = row[(int64_t)xx * C];
+          aw[xx % wsz] += v;
+#pragma unroll
+          for (int sx = 0; sx < MAXB; ++sx)
+            if (sx < bw) ab[sx] += wx[sx * w + xx] * v;
+        }
+      }
+    }
+    float* o = part + (int64_t)yy * (bw + wsz) * C + c;
+    for (int sx = 0; sx < bw; ++sx) o[(int64_t)sx * C] = ab[sx];
+    for (int x = 0; x < wsz; ++x) o[(int64_t)(bw + x) * C] = aw[x];
+  }
+}
+
+__global__ void hiera_pos_bwd_final_kernel(const float* __restrict__ part, float* __restrict__ d_bkg, float* __restrict__ d_win, int C, int bh,
+                                           int bw, int h, int wsz) {
+  extern __shared__ float wy[];                              // [h] row weights of this source row
+  const int nb = bh * bw, slots = bw + wsz;
   if ((int)blockIdx.x < nb) {
     const int sy = blockIdx.x / bw, sx = blockIdx.x % bw;
-    for (int i = threadIdx.x; i < h + w; i += blockDim.x) {
-      const bool row = i < h;
-      const int o = row ? i : i - h, n_out = row ? h : w, n_src = row ? bh : bw, src = row ? sy : sx;
-      const float f = (o + 0.5f) * ((float)n_src / n_out) - 0.5f;
-      const int i0 = (int)floorf(f);
-      const float t = f - i0;
-      const float tap[4] = {cubic2_b(t + 1.f, A), cubic1_b(t, A), cubic1_b(1.f - t, A), cubic2_b(2.f - t, A)};
-      float acc = 0.f;
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-        if (min(max(i0 - 1 + a, 0), n_src - 1) == src) acc += tap[a];
-      wts[i] = acc;
-    }
+    for (int i = threadIdx.x; i < h; i += blockDim.x) wy[i] = pos_bwd_weight(i, h, bh, sy);
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       float acc = 0.f;
-      for (int yy = 0; yy < h; ++yy) {
-        const float a = wy[yy];
-        if (a == 0.f) continue;
-        float rowv = 0.f;
-        for (int xx = 0; xx < w; ++xx) {
-          const float bq = wx[xx];
-          if (bq != 0.f) rowv += bq * d_table[((int64_t)yy * w + xx) * C + c];
-        }
-        acc += a * rowv;
-      }
+      for (int yy = 0; yy < h; ++yy) acc += wy[yy] * part[((int64_t)yy * slots + sx) * C + c];
       d_bkg[((int64_t)c * bh + sy) * bw + sx] = acc;
     }
   } else {
     const int cell = blockIdx.x - nb, y = cell / wsz, x = cell % wsz;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       float acc = 0.f;
-      for (int yy = y; yy < h; yy += wsz)
-        for (int xx = x; xx < w; xx += wsz) acc += d_table[((int64_t)yy * w + xx) * C + c];
+      for (int yy = y; yy < h; yy += wsz) acc += part[((int64_t)yy * slots + bw + x) * C + c];
       d_win[((int64_t)c * wsz + y) * wsz + x] = acc;
     }
   }
 }
 
+extern "C" size_t msam2_hiera_pos_embed_bwd_workspace_bytes(int64_t C, int64_t bw, int64_t h, int64_t window) {
+  return (size_t)(h * (bw + window) * C) * sizeof(float);
+}
+
 extern "C" int msam2_hiera_pos_embed_bwd(const float* d_table, float* d_pos_embed, float* d_pos_embed_window, int64_t C, int64_t bh,
-                                         int64_t bw, int64_t h, int64_t w, int64_t window, void* stream) {
+                                         int64_t bw, int64_t h, int64_t w, int64_t window, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
   MSAM2_REQUIRE(d_table && d_pos_embed && d_pos_embed_window && C > 0 && h % window == 0 && w % window == 0, "hiera_pos_embed_bwd: bad arguments");
-  hipLaunchKernelGGL(hiera_pos_bwd_kernel, dim3((unsigned)(bh * bw + window * window)), dim3(128), (size_t)(h + w) * sizeof(float),
-                     (hipStream_t)stream, d_table, d_pos_embed, d_pos_embed_window, (int)C, (int)bh, (int)bw, (int)h, (int)w, (int)window);
+  MSAM2_REQUIRE(bw <= 8 && window <= 8, "hiera_pos_embed_bwd: built for pos_embed up to 8 columns and windows up to 8 (hieradet.py:222-227: 7x7 / 8x8)");
+  MSAM2_REQUIRE(workspace && workspace_bytes >= msam2_hiera_pos_embed_bwd_workspace_bytes(C, bw, h, window), "hiera_pos_embed_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  hipLaunchKernelGGL((hiera_pos_bwd_rows_kernel<8, 8>), dim3((unsigned)h), dim3(128), (size_t)(bw * w) * sizeof(float), s, d_table, part, (int)C,
+                     (int)bw, (int)w, (int)window);
+  hipLaunchKernelGGL(hiera_pos_bwd_final_kernel, dim3((unsigned)(bh * bw + window * window)), dim3(128), (size_t)h * sizeof(float), s, part,
+                     d_pos_embed, d_pos_embed_window, (int)C, (int)bh, (int)bw, (int)h, (int)window);
   return msam2_check_launch("hiera_pos_embed_bwd");
 }
 

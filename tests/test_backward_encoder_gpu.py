@@ -72,7 +72,9 @@ def test_adjoint_kernels():
     d = rnd(h * w, 24, seed=7)
     table.backward(d.t().reshape(1, 24, h, w))
     dpe, dpw = torch.empty(1, 24, 7, 7, device=DEV), torch.empty(1, 24, 8, 8, device=DEV)
-    check(lib().msam2_hiera_pos_embed_bwd(ops._p(d.to(DEV)), ops._p(dpe), ops._p(dpw), 24, 7, 7, h, w, 8, ops._stream()))
+    nb = lib().msam2_hiera_pos_embed_bwd_workspace_bytes(24, 7, h, 8)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    check(lib().msam2_hiera_pos_embed_bwd(ops._p(d.to(DEV)), ops._p(dpe), ops._p(dpw), 24, 7, 7, h, w, 8, ops._p(ws), nb, ops._stream()))
     assert rel(dpw, pw.grad) < 1e-5 and rel(dpe, pe.grad) < 1e-4
 
 

@@ -59,7 +59,8 @@ DOC = {
     "msam2_bilinear_upsample_bwd": "Adjoint of msam2_bilinear_upsample: gradient of the video-resolution mask logits (sam2_video_predictor.py:724-744, the tensor the\ntraining loss of func_3d/function.py:137-170 is taken on) back to the decoder's low-resolution logits.",
     "msam2_maxpool2x2_bwd": "Backward of MaxPool2d(2, 2) on token-major maps (do_pool, hieradet.py:23-34, under autograd in the 2-D training loop,\nfunc_2d/function.py:70-72): dy is routed to the first maximum of each 2x2 window, every dx element is written.",
     "msam2_sumpool2x2": "Adjoint of msam2_upsample2x_add (FPN nearest-2x top-down step, image_encoder.py:113-124): sums of the 2x2 blocks.",
-    "msam2_hiera_pos_embed_bwd": "Adjoint of msam2_hiera_pos_embed (hieradet.py:269-277): gradient of the position-token table -> d pos_embed (transposed bicubic\nresize) and d pos_embed_window (sum over the tiling).",
+    "msam2_hiera_pos_embed_bwd": "Adjoint of msam2_hiera_pos_embed (hieradet.py:269-277): gradient of the position-token table -> d pos_embed (transposed bicubic\nresize) and d pos_embed_window (sum over the tiling).  Two gather passes through a caller-owned workspace, no atomics.",
+    "msam2_hiera_pos_embed_bwd_workspace_bytes": "Scratch needed by msam2_hiera_pos_embed_bwd (per-row partial sums).",
     "msam2_dropout": "Train-mode nn.Dropout / SDPA dropout_p (memory_attention.py:40-48,63,80,97-98; transformer.py:317-318): y = keep ? x / (1 - p) : 0\n(+ fp32 residual) with a counter-based mask -- element i of stream (seed, offset) -- so the backward re-creates the forward's mask by\ncalling it on the gradient with the same (seed, offset).",
     "msam2_adam_step": "One torch.optim.Adam step (no weight decay / amsgrad) on a flat fp32 parameter (train_3d.py:50).",
     "msam2_adam_step_multi": "The same Adam step over `count` parameters (host arrays of device pointers and element counts), 24 per launch;\ngradients are multiplied by grad_scale first (1 / loss scale);\nstep_counter (device int32, optional): the step count lives on the device and is incremented by the call (a kernel), so a captured\nhipGraph advances the bias corrections on every replay; non-finite gradient entries are skipped;\nweight_decay > 0 gives torch.optim.AdamW's decoupled decay (train_2d.py:43-47), 0 plain Adam (train_3d.py:50-54).",
