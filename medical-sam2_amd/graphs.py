@@ -7,8 +7,9 @@ The bank a slice attends to changes from slice to slice, a captured graph cannot
   * WHICH stored slices are attended to and their temporal positions -- host logic (`SAM2Base._select_memory`).  The tuple of temporal
     positions is the BUCKET KEY: one graph per distinct tuple.  In steady state (all conditioning slices + the last `num_maskmem - 1`
     tracked ones) the tuple repeats with the period of the prompts, so a volume needs a handful of graphs.
-  * the CONTENTS of those memories: copied into per-position static slots before the replay, only when the slot's source changed
-    (conditioning memories are copied once);
+  * the CONTENTS of those memories: every bucket owns its assembled bank (memory rows + position rows, the latter a constant of the
+    bucket); before a replay only the entries whose source changed are re-written (conditioning memories once per bucket, the few
+    recent memories every slice) -- the 70 strided copies per slice that assemble a 35-entry bank run neither eagerly nor in the graph;
   * the NUMBER of object pointers grows with every slice: the pointer tail of the bank is padded to a fixed capacity and the number of
     valid keys is a device-side scalar the attention kernel reads (`msam2_attention_kv64_dyn_fwd`); launch shapes depend on the
     capacity only.
@@ -35,10 +36,12 @@ def pointer_capacity(model, n_cond: int, num_frames: int, multiple: int = 16) ->
 
 
 class _Bucket:
-    __slots__ = ("graph", "outputs", "seen")
+    __slots__ = ("graph", "outputs", "seen", "memory", "memory_pos", "row_src", "n_ptr_tok")
 
     def __init__(self):
         self.graph, self.outputs, self.seen = None, None, 0
+        self.memory = self.memory_pos = None      # the ASSEMBLED bank of this bucket [N_k capacity, n_obj, 64] fp32 (+ its position side)
+        self.row_src, self.n_ptr_tok = [], 0      # the stored output each spatial entry currently mirrors
 
 
 class GraphedPropagation:
@@ -58,8 +61,6 @@ class GraphedPropagation:
         self.buckets: Dict[Tuple[int, ...], _Bucket] = {}
         self.feat: Optional[List[torch.Tensor]] = None        # static copies of the slice's feature levels
         self.pos: Optional[List[torch.Tensor]] = None         # position tables (constants)
-        self.slots: List[torch.Tensor] = []                   # static memory slots, one per spatial position
-        self.slot_src: List[object] = []                      # the stored output each slot currently mirrors
         self.mem_pos_enc: Optional[torch.Tensor] = None       # the memory encoder's position table (a constant)
         self.ptr_bank: Optional[torch.Tensor] = None          # [capacity, n_obj, C] fp32
         self.key_count: Optional[torch.Tensor] = None         # int32 device scalar
@@ -79,43 +80,50 @@ class GraphedPropagation:
             self.ptr_bank = torch.zeros(self.cap, self.n_obj, m.hidden_dim, dtype=F32, device=device)
             self.key_count = torch.zeros(1, dtype=torch.int32, device=device)
             self.mem_pos_enc = spatial[0][1]["maskmem_pos_enc"][-1].to(device).clone()
-        like = spatial[0][1]["maskmem_features"]
-        while len(self.slots) < len(spatial):
-            self.slots.append(torch.empty_like(like))
-            self.slot_src.append(None)
 
-    def _fill(self, feats_one: dict, spatial, ptrs):
+    def _fill(self, bucket: _Bucket, feats_one: dict, spatial, ptrs):
         """host -> static buffers: a handful of device copies, no synchronisation"""
-        m = self.model
+        from . import ops
+        m, n_obj = self.model, self.n_obj
         for dst, src in zip(self.feat, feats_one["backbone_fpn"]):
             dst.copy_(src)
-        for i, (_, prev) in enumerate(spatial):
-            if self.slot_src[i] is not prev:
-                self.slots[i].copy_(prev["maskmem_features"])
-                self.slot_src[i] = prev
         n = len(ptrs)
         if n > self.cap:
             raise RuntimeError(f"{n} object pointers exceed the capacity {self.cap} this GraphedPropagation was sized for")
+        H, W = spatial[0][1]["maskmem_features"].shape[-2:]
+        HW, split = H * W, m.hidden_dim // m.mem_dim
         if n:
             self.ptr_bank[:n].copy_(torch.stack([p.to(F32) for p in ptrs]))
-        H, W = self.slots[0].shape[-2:]
-        self.key_count.fill_(len(spatial) * H * W + n * (m.hidden_dim // m.mem_dim))
+        if bucket.memory is None:
+            # first sight of the bucket: the model's own assembly (memory rows, position rows with this bucket's temporal encodings,
+            # pointer tail from the padded bank) becomes the bucket's static bank
+            bucket.memory, bucket.memory_pos, bucket.n_ptr_tok, _ = m._assemble_memory(spatial, (self.ptr_bank, self.key_count), n_obj, H, W,
+                                                                                         self.ptr_bank.device)
+            bucket.row_src = [prev for _, prev in spatial]
+        else:
+            for i, (_, prev) in enumerate(spatial):
+                if bucket.row_src[i] is not prev:
+                    ops.add_cast_into(bucket.memory[i * HW:(i + 1) * HW], prev["maskmem_features"].flatten(2).permute(2, 0, 1), None, 1.0)
+                    bucket.row_src[i] = prev
+            if n:
+                tail = bucket.memory[len(spatial) * HW:].view(self.cap, split, n_obj, m.mem_dim)
+                tail[:n].copy_(self.ptr_bank[:n].view(n, n_obj, split, m.mem_dim).permute(0, 2, 1, 3))
+        self.key_count.fill_(len(spatial) * HW + n * split)
 
-    def _body(self, t_pos_key: Tuple[int, ...]) -> dict:
+    def _body(self, bucket: _Bucket) -> dict:
         """the prompt-free track_step on the static buffers (what is captured)"""
         m, n = self.model, self.n_obj
         bo = {"backbone_fpn": [f.expand(n, -1, -1, -1) for f in self.feat], "vision_pos_enc": [p.expand(n, -1, -1, -1) for p in self.pos]}
         _, feats, pos, sizes = m._prepare_backbone_features(bo)
-        spatial = [(t_pos, {"maskmem_features": self.slots[i], "maskmem_pos_enc": [self.mem_pos_enc]}) for i, t_pos in enumerate(t_pos_key)]
         return m.track_step(frame_idx=-1, is_init_cond_frame=False, current_vision_feats=feats, current_vision_pos_embeds=pos,
                             feat_sizes=sizes, point_inputs=None, mask_inputs=None, output_dict=None, num_frames=self.num_frames,
-                            memory_selection=(spatial, (self.ptr_bank, self.key_count)))
+                            memory_selection=("assembled", bucket.memory, bucket.memory_pos, bucket.n_ptr_tok, self.key_count))
 
     def _capture(self, key, bucket: _Bucket):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            out = self._body(key)
+            out = self._body(bucket)
         bucket.graph, bucket.outputs = g, out
         self.captures += 1
 
@@ -132,14 +140,14 @@ class GraphedPropagation:
             self._versions = self._version_sum()
         key = tuple(t_pos for t_pos, _ in spatial)
         self._statics(feats_one, spatial, spatial[0][1]["maskmem_features"].device)
-        self._fill(feats_one, spatial, ptrs)
         bucket = self.buckets.setdefault(key, _Bucket())
+        self._fill(bucket, feats_one, spatial, ptrs)
         bucket.seen += 1
         if bucket.graph is None and self.enabled and bucket.seen > self.capture_after:
             self._capture(key, bucket)
         if bucket.graph is None:
             self.eager_steps += 1
-            out = self._body(key)                     # fresh tensors: nothing to copy
+            out = self._body(bucket)                  # fresh tensors: nothing to copy
             cur = {k: out[k] for k in self.KEEP if k != "pred_masks_high_res" or self.keep_high_res}
         else:
             bucket.graph.replay()

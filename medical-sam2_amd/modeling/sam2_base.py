@@ -312,9 +312,14 @@ class SAM2Base(nn.Module):
             # directly_add_no_mem_embed (sam2_base.py:640-644)
             y = ops.add_cast(current_vision_feats[-1].transpose(0, 1), self.no_mem_embed.detach().to(F32).expand(B, H * W, C), 1.0, F32)
             return y.view(B, H * W, C).transpose(0, 1).permute(1, 2, 0).view(B, C, H, W)
-        spatial, ptrs = memory_selection if memory_selection is not None else \
-            self._select_memory(frame_idx, output_dict, num_frames, track_in_reverse)
-        memory, memory_pos, n_ptr_tok, key_count = self._assemble_memory(spatial, ptrs, B, H, W, device)
+        if memory_selection is not None and memory_selection[0] == "assembled":
+            # ("assembled", memory, memory_pos, number of pointer tokens, key_count): the caller keeps the bank assembled between slices
+            # and re-writes only the entries that changed (graphs.GraphedPropagation)
+            _, memory, memory_pos, n_ptr_tok, key_count = memory_selection
+        else:
+            spatial, ptrs = memory_selection if memory_selection is not None else \
+                self._select_memory(frame_idx, output_dict, num_frames, track_in_reverse)
+            memory, memory_pos, n_ptr_tok, key_count = self._assemble_memory(spatial, ptrs, B, H, W, device)
         pix = self.memory_attention(curr=current_vision_feats, curr_pos=current_vision_pos_embeds, memory=memory,
                                     memory_pos=memory_pos, num_obj_ptr_tokens=n_ptr_tok, key_count=key_count)
         return pix.permute(1, 2, 0).view(B, C, H, W)

@@ -71,16 +71,19 @@ def box_point_inputs(boxes: torch.Tensor) -> dict:
 @torch.no_grad()
 def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_hole_area: int = 0, group=None,
                    shard_objects: bool = True, encode_batch: int = 8, kv_split: bool = True, return_state: bool = False,
-                   graphs: bool = False, padded_bank: bool = False, stats: Optional[dict] = None, graph_cache: Optional[dict] = None):
+                   graphs: bool = False, padded_bank: bool = True, stats: Optional[dict] = None, graph_cache: Optional[dict] = None):
     """volume: [T,3,S,S] normalised slices on the GPU; prompts: {slice_idx: {"boxes": [n,4]} | {"point_coords", "point_labels"}}
     for the conditioning slices (same n objects everywhere).  Returns {slice_idx: low-res mask logits [n,1,S/4,S/4]} for ALL slices
     and ALL objects on every rank.  encode_batch: slices per image-encoder call (results do not depend on it).  shard_objects /
     kv_split: the two ways the propagation chain uses several ranks (module docstring); with both off it is replicated.
     return_state: also return the chain's `output_dict` ({"cond_frame_outputs", "non_cond_frame_outputs"}: per slice the track_step
     outputs with memories and pointers, this rank's object share) -- what a caller needs to continue or to audit the propagation.
-    graphs: replay the prompt-free per-slice forward as hipGraphs, one per memory-bank bucket (graphs.GraphedPropagation; not combined
-    with the cross-GPU key split, whose exchange runs between the partial pass and the merge).  padded_bank: the same padded-bank
-    launches without capturing them -- what `graphs=True` is bit-identical to.  stats: filled with the replay / capture counts of this
+    padded_bank (default): the propagation keeps one assembled memory bank per bucket (graphs.GraphedPropagation without capture):
+    only the entries that changed since the previous slice are re-written instead of re-assembling all ~35 of them, the pointer tail is
+    padded to a fixed capacity and the attention kernel reads the valid key count from the device (measured at 64 slices, one
+    object: 245 -> 287 slices/s).  False: the reference-shaped assembly per slice.  graphs: additionally replay the per-slice forward as
+    hipGraphs, one per bucket -- bit-identical to the padded-bank launches; not combined with the cross-GPU key split, whose exchange
+    runs between the partial pass and the merge (the padded bank itself is).  stats: filled with the replay / capture counts of this
     call.  graph_cache: a dict the caller keeps between volumes of the same shape (slices, objects, prompt schedule): the captured
     graphs are reused, a later volume replays from its first steady-state slice on."""
     T = volume.shape[0]
@@ -142,7 +145,8 @@ def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_h
     masks: Dict[int, torch.Tensor] = {}
     split_ctx = KVSplit(model, group) if (distributed and kv_split and not obj_shard) else None
     prop = None
-    if (graphs or padded_bank) and split_ctx is None:
+    if graphs or padded_bank:
+        graphs = graphs and split_ctx is None
         cap = pointer_capacity(model, len(cond_ids), T)
         ck = (id(model), oe - ob, T, cap, bool(graphs))
         prop = graph_cache.get(ck) if graph_cache is not None else None

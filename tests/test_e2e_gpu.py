@@ -339,7 +339,11 @@ def test_config3_volume_at_size_sampled_slices_vs_oracle(build):
     real = m.memory_attention.forward
 
     def spy(curr, memory, curr_pos=None, memory_pos=None, num_obj_ptr_tokens=0, **kw):
-        seen.append((int(memory.shape[0]), int(num_obj_ptr_tokens)))
+        n_k, n_ptr = int(memory.shape[0]), int(num_obj_ptr_tokens)
+        if kw.get("key_count") is not None:       # the default padded bank: the pointer tail is padded, the valid count sits on the device
+            valid = int(kw["key_count"].item())
+            n_k, n_ptr = valid, valid - (n_k - n_ptr)
+        seen.append((n_k, n_ptr))
         return real(curr=curr, memory=memory, curr_pos=curr_pos, memory_pos=memory_pos, num_obj_ptr_tokens=num_obj_ptr_tokens, **kw)
 
     m.memory_attention.forward = spy

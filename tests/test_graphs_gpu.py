@@ -90,7 +90,7 @@ def test_graphed_propagation_is_the_padded_eager_path_bit_for_bit():
     T = volume.shape[0]
     st_g, st_p = {}, {}
     with torch.no_grad():
-        plain, s_plain = vol.segment_volume(m, volume, prompts, return_state=True)
+        plain, s_plain = vol.segment_volume(m, volume, prompts, return_state=True, padded_bank=False)
         padded, s_pad = vol.segment_volume(m, volume, prompts, return_state=True, padded_bank=True, stats=st_p)
         graphed, s_gr = vol.segment_volume(m, volume, prompts, return_state=True, graphs=True, stats=st_g)
     assert st_p["captures"] == 0 and st_p["replays"] == 0
@@ -128,7 +128,7 @@ def test_graph_cache_reuse_and_weight_change():
         assert all(torch.equal(a[t], a2[t]) and torch.equal(a[t], a3[t]) for t in a)
         m.sam_mask_decoder.output_hypernetworks_mlps[0].layers[0].weight.mul_(1.5)
         b = vol.segment_volume(m, volume, prompts, graphs=True, graph_cache=cache, stats=s3)
-        c = vol.segment_volume(m, volume, prompts)
+        c = vol.segment_volume(m, volume, prompts, padded_bank=False)
     assert s3["captures"] > 0
     t = max(a)
     assert not torch.equal(a[t], b[t])

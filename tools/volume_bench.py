@@ -31,7 +31,7 @@ def box_at(t):
 
 
 prompts = {t: {"boxes": box_at(t)} for t in range(0, T, 2)}
-vol.segment_volume(m, volume[:4], {0: prompts[0], 2: prompts[2]})  # warm-up (weight packing, tables, code objects)
+vol.segment_volume(m, volume[:4], {0: prompts[0], 2: prompts[2]}, padded_bank=False)  # warm-up (weight packing, tables, code objects)
 torch.cuda.synchronize()
 
 
@@ -46,11 +46,11 @@ def timed(label, **kw):
     return masks
 
 
-eager = timed("eager launches")
+eager = timed("eager launches, bank re-assembled per slice", padded_bank=False)
 cache = {}
 first = timed("hipGraph replay, first volume (captures inside)", graphs=True, graph_cache=cache)
 again = timed("hipGraph replay, graphs kept from the previous volume", graphs=True, graph_cache=cache)
-padded = timed("padded bank, eager launches", padded_bank=True)
+padded = timed("eager launches, assembled bank kept per bucket (default)", padded_bank=True)
 same = all(torch.equal(first[t], padded[t]) and torch.equal(again[t], padded[t]) for t in first)
 worst = max(float((eager[t] - padded[t]).abs().max()) for t in eager)
 flips = sum(int(((eager[t] > 0) != (padded[t] > 0)).sum()) for t in eager)
