@@ -37,8 +37,8 @@ __device__ __forceinline__ int mlp_swz(int c, int r) {
   else return (c & ~7) | ((c & 7) ^ ((r >> 1) & 7));
 }
 
-template <int DIM, int HC, int TB>
-__global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
+template <int DIM, int HC, int TB, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void mlp_fused_kernel(MlpFusedParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int HID = 4 * DIM, NCH = HID / HC, KS1 = DIM / 16, DB = DIM / 32, HB = HC / 32;
   constexpr int RB1 = DIM * 2, RB2 = HC * 2;                 // LDS row bytes of the W1 chunk [HC][DIM] and the W2 chunk [DIM][HC]
@@ -239,16 +239,16 @@ extern "C" int msam2_mlp_fused_permute_w2(const void* w2, void* w2p, int64_t dim
 // 1 when msam2_ln_mlp_residual_fwd is built for this width (hidden = 4 * dim, exact-erf GELU): dim 96 and 192 (Hiera stages 1 / 2)
 extern "C" int msam2_ln_mlp_residual_supported(int64_t dim) { return dim == 96 || dim == 192; }
 
-template <int DIM, int HC, int TB>
+template <int DIM, int HC, int TB, int OCC = 1>
 static int launch_mlp_fused(const MlpFusedParams& p, hipStream_t s) {
   constexpr int LDS = 2 * (2 * HC * DIM * 2) + (3 * DIM + 4 * DIM) * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)mlp_fused_kernel<DIM, HC, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)mlp_fused_kernel<DIM, HC, TB, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   const int64_t n_pass = (p.T + 128 * TB - 1) / (128 * TB);
-  hipLaunchKernelGGL((mlp_fused_kernel<DIM, HC, TB>), dim3((unsigned)min((int64_t)256, n_pass)), dim3(256), LDS, s, p);
+  hipLaunchKernelGGL((mlp_fused_kernel<DIM, HC, TB, OCC>), dim3((unsigned)min((int64_t)256 * OCC, n_pass)), dim3(256), LDS, s, p);
   return msam2_check_launch("ln_mlp_residual_fwd");
 }
 
