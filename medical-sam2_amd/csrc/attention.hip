@@ -1291,7 +1291,10 @@ static int launch_attn(const AttnParams& p, int Bz, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(cdiv(p.Lq, NW * 32), p.H, Bz * p.splits);
-  hipLaunchKernelGGL((attn_fwd_kernel<D, NW, WIN>), grid, dim3(NW * 64), C::LDS_BYTES, s, p);
+  // a single key tile per workgroup (the 4 x 4 windows of Hiera blocks 2 / 3: 16 keys) never touches the second stage: half the LDS
+  // doubles the workgroups a CU holds, and these launches are bound by how many loads are in flight
+  const int lds = ((p.Lk + C::BK - 1) / C::BK <= p.splits) ? C::STAGE : C::LDS_BYTES;
+  hipLaunchKernelGGL((attn_fwd_kernel<D, NW, WIN>), grid, dim3(NW * 64), lds, s, p);
   if (p.splits > 1 && !p.defer_merge) {
     const int64_t rows = (int64_t)Bz * p.H * p.Lq;
     hipLaunchKernelGGL((attn_merge_kernel<D>), dim3(cdiv(rows * 64, 256)), dim3(256), 0, s, p, Bz);
