@@ -466,6 +466,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     }
   }
   if (mode == 0 * 4 + 2 + 0) gemm_epilogue_spec<FM, FN, 0, 1, false>(p, acc, scr, row0, col0, lane);   // patch embed: + pos[m % res_mod]
+  else if (mode == 0 * 4 + 2 + 1) gemm_epilogue_spec<FM, FN, 0, 1, true>(p, acc, scr, row0, col0, lane);  // decoder image-side k|v|q: + (pe W^T)[m % L] -> 16-bit
   else gemm_epilogue_generic<FM, FN>(p, acc, scr, row0, col0, lane);
 }
 

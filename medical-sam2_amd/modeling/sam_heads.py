@@ -112,6 +112,28 @@ class PromptEncoder(nn.Module):
         return sparse, dense
 
 
+def _image_side_projections(wc: WeightCache, key: str, keys_b: torch.Tensor, key_pe: torch.Tensor, L: int, lins, with_pe):
+    """All projections a two-way block takes of the IMAGE tokens as one GEMM.  lins: the nn.Linear modules, with_pe: which of them see
+    keys + key_pe (the others see keys).  (keys + pe) W^T = keys W^T + pe W^T, and pe is the batch-shared, input-independent dense
+    position encoding: pe W^T is a cached [L, N] constant added as a row-modulo residual in the GEMM's store -- one launch instead of one
+    per projection, no `keys + pe` pass over the tokens (transformer.py:165-196 calls three separate nn.Linear on keys / keys + pe).
+    Returns the 16-bit [B*L, sum(out_i)] result (column blocks in the order of `lins`)."""
+    ws = [l.weight for l in lins]
+    W = w_bf16(wc, key + "w", *ws)
+    b = v_f32(wc, key + "b", *[l.bias for l in lins])
+
+    def build_pe():
+        R = ops.gemm(to_bf16(key_pe.contiguous()), W, None, out_dtype=F32)            # [L, N] fp32
+        col = 0
+        for l, use in zip(lins, with_pe):
+            if not use:
+                R[:, col: col + l.out_features] = 0.0
+            col += l.out_features
+        return R
+    R = wc.get(key + "pe", ws + [key_pe], build_pe)
+    return ops.gemm(keys_b, W, b, residual=R, res_mod=L)
+
+
 class TwoWayAttentionBlock(nn.Module):
     """transformer.py:121-196."""
 
@@ -155,15 +177,18 @@ class TwoWayAttentionBlock(nn.Module):
             qb = ops.add_cast(queries.view(1, B * T, C), query_pe.view(1, B * T, C), 1.0, OP16)[0]
             queries = sa.out(sa.core(q3(sa.proj("q", qb), T), q3(sa.proj("k", qb), T), q3(sa.proj("v", to_bf16(queries)), T)), queries)
         queries = self._ln("norm1", queries)
-        # tokens -> image
-        kb = ops.add_cast(keys.view(B, L, C), key_pe.view(1, L, C), 1.0, OP16).view(B * L, C)
+        # tokens -> image.  The three image-side projections of the block (k, v of this attention and q of the image -> token attention
+        # further down: `keys` does not change in between) are one GEMM
         keys_b = to_bf16(keys)
+        Cc, Ci2 = ca.internal_dim, ia.internal_dim
+        kvq = _image_side_projections(wc, "ikvq", keys_b, key_pe, L, [ca.k_proj, ca.v_proj, ia.q_proj], [True, False, True])
+        k_img, v_img, q_img = kvq[:, :Cc], kvq[:, Cc:2 * Cc], kvq[:, 2 * Cc:2 * Cc + Ci2]
         if fused:
             qp = ops.gemm_tokens(queries, w_bf16(wc, "cqw", ca.q_proj.weight), v_f32(wc, "cqb", ca.q_proj.bias), addend=query_pe,
                                  add_cols=ca.internal_dim)
         else:
             qp = ca.proj("q", ops.add_cast(queries.view(1, B * T, C), query_pe.view(1, B * T, C), 1.0, OP16)[0])
-        o = ca.core(q3(qp, T), q3(ca.proj("k", kb), L), q3(ca.proj("v", keys_b), L))
+        o = ca.core(q3(qp, T), q3(k_img, L), q3(v_img, L))
         queries = self._ln("norm2", ca.out(o, queries))
         if fused and self.mlp.num_layers == 2:
             l1, l2 = self.mlp.layers
@@ -176,10 +201,10 @@ class TwoWayAttentionBlock(nn.Module):
             Cd = ia.internal_dim
             kv = ops.gemm_tokens(queries, w_bf16(wc, "ikv", ia.k_proj.weight, ia.v_proj.weight), v_f32(wc, "ikvb", ia.k_proj.bias, ia.v_proj.bias),
                                  addend=query_pe, add_cols=Cd).view(B, T, 2 * Cd)
-            o = ia.core(q3(ia.proj("q", kb), L), kv[:, :, :Cd], kv[:, :, Cd:])
+            o = ia.core(q3(q_img, L), kv[:, :, :Cd], kv[:, :, Cd:])
         else:
             qb = ops.add_cast(queries.view(1, B * T, C), query_pe.view(1, B * T, C), 1.0, OP16)[0]
-            o = ia.core(q3(ia.proj("q", kb), L), q3(ia.proj("k", qb), T), q3(ia.proj("v", to_bf16(queries)), T))
+            o = ia.core(q3(q_img, L), q3(ia.proj("k", qb), T), q3(ia.proj("v", to_bf16(queries)), T))
         keys = self._ln("norm4", ia.out(o, keys))
         return queries, keys
 
@@ -214,14 +239,15 @@ class TwoWayTransformer(nn.Module):
         for layer in self.layers:
             queries, keys = layer.run(queries, keys, qpe, key_pe, B, T, L)
         fa = self.final_attn_token_to_image
-        kb = ops.add_cast(keys.view(B, L, C), key_pe.view(1, L, C), 1.0, OP16).view(B * L, C)
+        kv_img = _image_side_projections(self._wc, "fkv", to_bf16(keys), key_pe, L, [fa.k_proj, fa.v_proj], [True, False])
+        Cf = fa.internal_dim
         q3 = lambda t, n: t.view(B, n, -1)
         if B * T <= 32 and fa.internal_dim % 32 == 0:
             qp = ops.gemm_tokens(queries, w_bf16(self._wc, "fqw", fa.q_proj.weight), v_f32(self._wc, "fqb", fa.q_proj.bias), addend=qpe,
                                  add_cols=fa.internal_dim)
         else:
             qp = fa.proj("q", ops.add_cast(queries.view(1, B * T, C), qpe.view(1, B * T, C), 1.0, OP16)[0])
-        o = fa.core(q3(qp, T), q3(fa.proj("k", kb), L), q3(fa.proj("v", to_bf16(keys)), L))
+        o = fa.core(q3(qp, T), q3(kv_img[:, :Cf], L), q3(kv_img[:, Cf:], L))
         n = self.norm_final_attn
         queries = ops.layernorm(fa.out(o, queries), v_f32(self._wc, "nw", n.weight), v_f32(self._wc, "nb", n.bias), n.eps, out_dtype=F32)
         return queries, keys
