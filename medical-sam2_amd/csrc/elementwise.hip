@@ -402,10 +402,42 @@ __global__ void bilinear_kernel(const float* __restrict__ x, float* __restrict__
   }
 }
 
+// W % 4 == 0: four consecutive output pixels per thread, one 16-byte store (the scalar form above wrote 4 bytes per lane and did its
+// index arithmetic in 64 bits: 21.7 us for the 16.8 MB of 4 x 1024^2 masks).  Same expression per pixel as the scalar form: bit-identical.
+__global__ void bilinear4_kernel(const float* __restrict__ x, float* __restrict__ y, int P, int h, int w, int H, int W) {
+  const float sy = (float)h / H, sx = (float)w / W;
+  const int W4 = W >> 2;
+  const unsigned total = (unsigned)P * (unsigned)H * (unsigned)W4;      // checked on the host: < 2^31
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned X4 = i % (unsigned)W4, t = i / (unsigned)W4;
+    const unsigned Y = t % (unsigned)H, pl = t / (unsigned)H;
+    const float fy = fmaxf((Y + 0.5f) * sy - 0.5f, 0.f);
+    const int y0 = (int)fy, y1 = min(y0 + 1, h - 1);
+    const float ly = fy - y0;
+    const float* p0 = x + ((int64_t)pl * h + y0) * w;
+    const float* p1 = x + ((int64_t)pl * h + y1) * w;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int X = (int)X4 * 4 + e;
+      const float fx = fmaxf((X + 0.5f) * sx - 0.5f, 0.f);
+      const int x0 = (int)fx, x1 = min(x0 + 1, w - 1);
+      const float lx = fx - x0;
+      o[e] = (1.f - ly) * ((1.f - lx) * p0[x0] + lx * p0[x1]) + ly * ((1.f - lx) * p1[x0] + lx * p1[x1]);
+    }
+    *reinterpret_cast<f32x4*>(y + ((int64_t)pl * H + Y) * W + X4 * 4) = o;
+  }
+}
+
 extern "C" int msam2_bilinear_upsample(const float* x, float* y, int64_t planes, int64_t h, int64_t w, int64_t H, int64_t W,
                                        void* stream) {
   MSAM2_REQUIRE(x && y && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bilinear: bad arguments");
   const int64_t total = planes * H * W;
+  if (W % 4 == 0 && ((uintptr_t)y & 15) == 0 && total / 4 < (1ll << 31)) {
+    hipLaunchKernelGGL(bilinear4_kernel, dim3((unsigned)min((int64_t)16384, (total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, y, (int)planes, (int)h, (int)w, (int)H, (int)W);
+    return msam2_check_launch("bilinear_upsample");
+  }
   hipLaunchKernelGGL(bilinear_kernel, dim3((unsigned)min((int64_t)16384, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      x, y, (int)planes, (int)h, (int)w, (int)H, (int)W);
   return msam2_check_launch("bilinear_upsample");
