@@ -919,10 +919,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kv64_kernel(AttnParams p) {
 // attn_kv64x2_kernel: the same contraction with 64 queries per wave (two 32-query MFMA column blocks).
 //
 // Why.  In attn_kv64_kernel every MFMA consumes one fragment read from LDS (1 KiB per wave: a K fragment for S^T = K Q^T, a V^T
-// fragment for O'^T = V^T P^T) while the Q / P operand sits in registers.  Four SIMDs x 1 KiB per 32-cycle MFMA is 128 B/clk --
-// exactly the LDS read bandwidth of a CU -- so with 32 queries per wave the LDS pipe has to run at 100 % for the MFMA pipe to
-// run at 100 %: the kernel was LDS-bandwidth-bound (800 LDS cycles against 640 MFMA cycles per workgroup-tile), not clock-bound.
-// Here each fragment read feeds TWO MFMAs (query blocks a and b): 800 LDS cycles against 1280 MFMA cycles per workgroup-tile.
+// fragment for O'^T = V^T P^T) while the Q / P operand sits in registers: four SIMDs x 1 KiB per 32-cycle MFMA = 128 B/clk, half of
+// what the LDS array delivers (256 B/clk, MI355X_MICROARCH.md) before DMA writes and bank-group effects.  Here each fragment read
+// feeds TWO MFMAs (query blocks a and b), which halves the LDS bytes (and their energy) per MFMA.
 //
 // How.  256 queries per workgroup (4 waves x 64), one workgroup per CU, one wave per SIMD with the whole 512-register file: the
 // Q fragments of both blocks (128 registers) stay resident.  With a single wave per SIMD nothing hides the softmax behind another
