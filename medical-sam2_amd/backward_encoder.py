@@ -77,10 +77,13 @@ def hiera_block_backward(blk, t: torch.Tensor, B: int, H: int, W: int, dy: torch
     [B*H'*W', dim_out] the gradient of its output.  Returns (dt fp32 [B*H*W, dim], {parameter name relative to the block: gradient})."""
     wc, a = blk._wc, blk.attn
     heads, dim, dim_out = a.num_heads, blk.dim, blk.dim_out
-    D, Dp, qkv_w, qkv_b, proj_w = blk._packed_attn_weights()
-    assert Dp == D, "the trunk backward is built for head dims the attention kernels take unpadded (hiera_t / hiera_s: 96)"
+    Dt, Dp, qkv_w, qkv_b, proj_w = blk._packed_attn_weights()
+    # Head dims the attention kernels do not take as they are (56 of Hiera-B+) run zero-padded per head to Dp, in the backward as in the
+    # forward: a padded q / k channel is zero on both sides of the score product and a padded v channel meets a zero proj column, so the
+    # gradients of the padded weight rows / columns are exactly zero and are dropped when the packed gradients are un-padded below.
+    D = Dp
     width = heads * D
-    scale = D ** -0.5
+    scale = Dt ** -0.5
     T = B * H * W
     pool = blk.q_stride is not None
     Hq, Wq = (H // 2, W // 2) if pool else (H, W)
@@ -131,6 +134,8 @@ def hiera_block_backward(blk, t: torch.Tensor, B: int, H: int, W: int, dy: torch
     dt_mid, g["norm2.weight"], g["norm2.bias"] = bwd.layernorm_backward(t_mid, n2w, dxn2, 1e-6, add=dy.to(F32).contiguous())
     # ---- attention output projection
     do, g["attn.proj.weight"], g["attn.proj.bias"] = bwd.linear_backward(o, proj_w, dt_mid)      # do fp32 [Tq, width]
+    if Dp != Dt:
+        g["attn.proj.weight"] = g["attn.proj.weight"].view(dim_out, heads, Dp)[:, :, :Dt].reshape(dim_out, heads * Dt)
     # ---- attention core
     do_img = do.view(B, Hq, Wq, heads, D)
     if ws > 0:
@@ -157,6 +162,9 @@ def hiera_block_backward(blk, t: torch.Tensor, B: int, H: int, W: int, dy: torch
     dxn, g["attn.qkv.weight"], g["attn.qkv.bias"] = bwd.linear_backward(xn, qkv_w, dqkv)
     if pad_bias is not None:
         g["attn.qkv.bias"] = g["attn.qkv.bias"] + pad_bias
+    if Dp != Dt:
+        g["attn.qkv.weight"] = g["attn.qkv.weight"].view(3, heads, Dp, dim)[:, :, :Dt].reshape(3 * heads * Dt, dim)
+        g["attn.qkv.bias"] = g["attn.qkv.bias"].view(3, heads, Dp)[:, :, :Dt].reshape(3 * heads * Dt)
     # ---- shortcut + norm1
     if dim != dim_out:
         d_pre = maxpool2x2_backward(pre, dt_mid, B, H, W) if pool else dt_mid

@@ -1132,12 +1132,16 @@ extern "C" int msam2_hiera_pos_embed_bwd(const float* d_table, float* d_pos_embe
                                          int64_t bw, int64_t h, int64_t w, int64_t window, void* workspace, size_t workspace_bytes,
                                          void* stream) {
   MSAM2_REQUIRE(d_table && d_pos_embed && d_pos_embed_window && C > 0 && h % window == 0 && w % window == 0, "hiera_pos_embed_bwd: bad arguments");
-  MSAM2_REQUIRE(bw <= 8 && window <= 8, "hiera_pos_embed_bwd: built for pos_embed up to 8 columns and windows up to 8 (hieradet.py:222-227: 7x7 / 8x8)");
+  MSAM2_REQUIRE(bw <= 16 && window <= 8, "hiera_pos_embed_bwd: built for pos_embed up to 16 columns and windows up to 8 (7x7 / 8x8 in hiera_t / s, 14x14 / 8x8 in hiera_b+)");
   MSAM2_REQUIRE(workspace && workspace_bytes >= msam2_hiera_pos_embed_bwd_workspace_bytes(C, bw, h, window), "hiera_pos_embed_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   float* part = (float*)workspace;
-  hipLaunchKernelGGL((hiera_pos_bwd_rows_kernel<8, 8>), dim3((unsigned)h), dim3(128), (size_t)(bw * w) * sizeof(float), s, d_table, part, (int)C,
-                     (int)bw, (int)w, (int)window);
+  if (bw <= 8)
+    hipLaunchKernelGGL((hiera_pos_bwd_rows_kernel<8, 8>), dim3((unsigned)h), dim3(128), (size_t)(bw * w) * sizeof(float), s, d_table, part, (int)C,
+                       (int)bw, (int)w, (int)window);
+  else
+    hipLaunchKernelGGL((hiera_pos_bwd_rows_kernel<16, 8>), dim3((unsigned)h), dim3(128), (size_t)(bw * w) * sizeof(float), s, d_table, part, (int)C,
+                       (int)bw, (int)w, (int)window);
   hipLaunchKernelGGL(hiera_pos_bwd_final_kernel, dim3((unsigned)(bh * bw + window * window)), dim3(128), (size_t)h * sizeof(float), s, part,
                      d_pos_embed, d_pos_embed_window, (int)C, (int)bh, (int)bw, (int)h, (int)window);
   return msam2_check_launch("hiera_pos_embed_bwd");

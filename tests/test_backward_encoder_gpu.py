@@ -108,15 +108,17 @@ def test_hiera_block_backward_variants():
     print("worst per block:", worst)
 
 
-def test_image_encoder_backward_vs_autograd():
+@pytest.mark.parametrize("name", ["hiera_t", "hiera_b+"])
+def test_image_encoder_backward_vs_autograd(name):
     """whole encoder: gradients of a random linear functional of the three FPN outputs w.r.t. every image_encoder parameter and the two
-    folded high-res convs of the mask decoder"""
+    folded high-res convs of the mask decoder.  hiera_b+ is BASELINE configs[4]'s model (24 blocks, head dim 56 zero-padded to the
+    64-wide attention kernels, in the backward as in the forward)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import medical_sam2_amd.backward_encoder as be
     import medical_sam2_amd.synthetic as syn
-    m, W = _model()
-    cfg = O.model_config("hiera_t", 256)
+    m, W = _model(name)
+    cfg = O.model_config(name, 256)
     img, _, _ = syn.image_batch([10, 11], 256)
     train = lambda k: k.startswith("image_encoder.") or k.startswith("sam_mask_decoder.conv_s")
     P = {k: (v.clone().requires_grad_(True) if train(k) else v) for k, v in W.items()}
@@ -192,6 +194,31 @@ def test_train_step_2d_with_image_encoder():
         key = k.split(".blocks.")[1].split(".")[0] if ".blocks." in k else k.split(".")[1]
         by_stage[key] = max(by_stage.get(key, 0.0), e)
     print("worst per block / part:", by_stage)
+    with torch.no_grad():
+        before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        opts = [T.DecoderAdam(m.memory_attention, lr=1e-5), T.DecoderAdam(m.sam_mask_decoder, lr=1e-4), T.DecoderAdam(m.image_encoder, lr=1e-5)]
+        losses = [T.train_step_2d(m, opts[0], opts[1], *args, opt_enc=opts[2])[0] for _ in range(4)]
+        moved = {k.split(".")[0] for k, v in m.state_dict().items() if not torch.equal(v, before[k])}
+    assert moved == {"memory_attention", "sam_mask_decoder", "image_encoder"}, moved
+    assert min(losses[1:]) < losses[0], losses
+    assert all(torch.isfinite(v).all() for v in m.state_dict().values())
+
+
+def test_train_step_2d_hiera_bplus():
+    """BASELINE configs[4]'s model through the whole 2-D training iteration (train_2d.py:43-47 trains every parameter): Hiera-B+ -- 24 blocks,
+    head dim 56 zero-padded to 64 in the attention forward AND backward, 14 x 14 position embedding -- runs, moves the three groups, stays
+    finite and lowers the loss (its encoder gradients are pinned above against autograd)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import medical_sam2_amd.synthetic as syn
+    import medical_sam2_amd.training as T
+    m, _ = _model("hiera_b+")
+    B, S, E = 2, 256, 16
+    imgs = torch.stack([syn.normalize_image(syn.blob_image(i, S)[0]) for i in range(B)])
+    pts, labels = torch.tensor([[[100.0, 120.0]], [[60.0, 200.0]]]), torch.ones(B, 1, dtype=torch.int32)
+    memory, memory_pos = rnd(2 * E * E, B, 64, seed=150, scale=0.5), rnd(2 * E * E, B, 64, seed=151)
+    target = (rnd(B, 4, S // 4, S // 4, seed=152) > 0.3).float()
+    args = tuple(t.to(DEV) for t in (imgs, pts, labels, memory, memory_pos, target))
     with torch.no_grad():
         before = {k: v.detach().clone() for k, v in m.state_dict().items()}
         opts = [T.DecoderAdam(m.memory_attention, lr=1e-5), T.DecoderAdam(m.sam_mask_decoder, lr=1e-4), T.DecoderAdam(m.image_encoder, lr=1e-5)]
