@@ -221,14 +221,17 @@ def volume_backward(model, tape: dict, d_low: Dict[int, torch.Tensor]) -> Dict[s
 
 @torch.no_grad()
 def train_step_3d(model, optimizers: Dict[str, DecoderAdam], volume: torch.Tensor, prompts: Dict[int, dict], targets: Dict[int, torch.Tensor],
-                  pos_weight: float = 2.0, grads_out: Optional[dict] = None):
+                  pos_weight: float = 2.0, grads_out: Optional[dict] = None, data_parallel: bool = False, group=None):
     """One iteration of func_3d/function.py:58-191 on one volume.  targets {slice: [n,1,S,S] in {0,1}} for every slice.  optimizers maps
     "decoder" (the reference's optimizer1 / `sam_layers`) and "memory_attention" / "memory_encoder" / "obj_ptr_proj" (optimizer2 /
     `mem_layers`) to DecoderAdam instances over the respective module; missing groups are left alone.
     As in the reference the memory groups step on the gradient of the NON-PROMPT loss alone, the decoder on non-prompt + prompt
     (function.py:176-186: non_prompt_loss.backward(), optimizer2.step(), prompt_loss.backward(), optimizer1.step(); the second backward
     does not reach the memory groups).  Returns {"loss", "prompt_loss", "non_prompt_loss"} (floats) and fills grads_out (TRUE gradients
-    per group: "non_prompt" / "prompt") when given."""
+    per group: "non_prompt" / "prompt") when given.
+    data_parallel: one process per GPU, every rank on its OWN volume (volumes share nothing: SURVEY 8(e) row 1): the per-group
+    gradients -- true gradients, no loss scale to agree on -- are summed over the ranks in place (`parallel.allreduce_gradients_async`,
+    all groups in flight together) and averaged inside the Adam kernel; the returned losses stay this rank's."""
     tape, low = volume_forward_saved(model, volume, prompts)
     T = volume.shape[0]
     cond = set(prompts)
@@ -248,13 +251,19 @@ def train_step_3d(model, optimizers: Dict[str, DecoderAdam], volume: torch.Tenso
     g_p = volume_backward(model, tape, d_p)
     if grads_out is not None:
         grads_out["non_prompt"], grads_out["prompt"] = g_np, g_p
-    for grp in ("memory_attention", "memory_encoder", "obj_ptr_proj"):
-        if grp in optimizers and g_np[grp]:
-            optimizers[grp].step(g_np[grp], grad_scale=1.0)
-    if "decoder" in optimizers:
-        g_dec = dict(g_p["decoder"])
-        for k, v in g_np["decoder"].items():
-            g_dec[k] = g_dec[k] + v if k in g_dec else v
-        optimizers["decoder"].step(g_dec, grad_scale=1.0)
+    g_dec = dict(g_p["decoder"])
+    for k, v in g_np["decoder"].items():
+        g_dec[k] = g_dec[k] + v if k in g_dec else v
+    step_grads = {"decoder": g_dec, "memory_attention": g_np["memory_attention"], "memory_encoder": g_np["memory_encoder"],
+                  "obj_ptr_proj": g_np["obj_ptr_proj"]}
+    inv_world = 1.0
+    if data_parallel:
+        from . import parallel
+        pend = {grp: parallel.allreduce_gradients_async(g, group) for grp, g in step_grads.items() if g}
+        for grp, pnd in pend.items():
+            step_grads[grp], inv_world = pnd.wait()
+    for grp in ("memory_attention", "memory_encoder", "obj_ptr_proj", "decoder"):
+        if grp in optimizers and step_grads[grp]:
+            optimizers[grp].step(step_grads[grp], grad_scale=inv_world)
     lp, lnp = float(loss_p.item()), float(loss_np.item())
     return {"loss": (lp * n_c + lnp * n_nc) / T, "prompt_loss": lp, "non_prompt_loss": lnp}

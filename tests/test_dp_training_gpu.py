@@ -231,3 +231,75 @@ def test_data_parallel_decoder_step_two_ranks():
     for rank, rel, same in res:
         assert rel < 1e-2, (rank, rel)          # all-reduced half-batch gradients == full-batch gradients (16-bit operand noise)
         assert same, rank                       # identical parameters on both ranks after the step
+
+
+def _bptt_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    torch.set_grad_enabled(False)
+    import medical_sam2_amd.training as T
+    import medical_sam2_amd.training_3d as t3
+    import test_bptt_gpu as tb
+    # every rank: the fixture's volume, its own time-reversed copy as "its" volume (rank 0: as is, rank 1: slices reversed)
+    m, G, meta, volume, prompts, targets = tb._case()
+    Tn = volume.shape[0]
+    def mine(r):
+        if r == 0:
+            return volume, prompts, targets
+        idx = list(range(Tn - 1, -1, -1))
+        return volume[idx], {Tn - 1 - t: p for t, p in prompts.items()}, {Tn - 1 - t: v for t, v in targets.items()}
+    # single-process reference: mean of the two ranks' gradients
+    ref = []
+    for r in range(world):
+        out = {}
+        t3.train_step_3d(m, {}, *mine(r), pos_weight=meta["pos_weight"], grads_out=out)
+        g = {("d." + k): v for k, v in out["prompt"]["decoder"].items()}
+        for k, v in out["non_prompt"]["decoder"].items():
+            g["d." + k] = g["d." + k] + v
+        for grp in ("memory_attention", "memory_encoder", "obj_ptr_proj"):
+            g.update({grp[:8] + "." + k: v for k, v in out["non_prompt"][grp].items()})
+        ref.append(g)
+    mean = {k: (ref[0][k] + ref[1][k]) * 0.5 for k in ref[0]}
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lr = 1e-3
+    opts = {"decoder": T.DecoderAdam(m.sam_mask_decoder, lr=lr), "memory_attention": T.DecoderAdam(m.memory_attention, lr=lr),
+            "memory_encoder": T.DecoderAdam(m.memory_encoder, lr=lr), "obj_ptr_proj": T.DecoderAdam(m.obj_ptr_proj, lr=lr)}
+    before = {k: p.detach().clone() for k, p in m.named_parameters()}
+    t3.train_step_3d(m, opts, *mine(rank), pos_weight=meta["pos_weight"], data_parallel=True)
+    # first Adam step = -lr * sign-ish(g): compare the update direction with the mean gradient where it is not within rounding of zero
+    agree, total = 0, 0
+    pre = {"d": "sam_mask_decoder", "memory_a": "memory_attention", "memory_e": "memory_encoder", "obj_ptr_": "obj_ptr_proj"}
+    for k, g in mean.items():
+        grp, name = k.split(".", 1)
+        p = dict(m.named_parameters())[pre[grp] + "." + name]
+        delta = (p.detach() - before[pre[grp] + "." + name])
+        big = g.abs() > 0.05 * g.abs().max()
+        if big.any():
+            agree += int((torch.sign(delta[big]) == -torch.sign(g[big])).sum())
+            total += int(big.sum())
+    flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu()
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    q.put((rank, agree / max(total, 1), bool(all(torch.equal(gathered[0], t) for t in gathered[1:])), bool(torch.isfinite(flat).all())))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_train_step_3d_two_ranks():
+    """train_step_3d(data_parallel=True), two ranks on different volumes: the Adam update follows the MEAN of the two ranks' chained
+    (back-propagation-through-time) gradients and both ranks end with bit-identical parameters."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_bptt_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    for rank, frac, same, finite in sorted(q.get(timeout=10) for _ in range(2)):
+        assert same and finite and frac > 0.97, (rank, frac, same, finite)
