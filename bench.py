@@ -8,12 +8,24 @@ Workload at N=1 (BASELINE.json configs[1], the 2D `train_2d.py` SAM2 sub-sequenc
 One "step" = that sequence for the batch of 4 slices; value = slices / second with inputs resident in HBM.
 The step is captured into one hipGraph (torch.cuda.graph: PyTorch provides the stream + memory pool) and replayed.
 
-N>1 (launched by torch.distributed.run, one rank per GPU): every rank runs the same per-GPU workload on its own slices and
-its own memory bank -- the 2D path shares nothing between replicas (SURVEY.md 8(e)) -- so there is no data-path collective;
-RCCL is used for the barrier and the max-over-ranks time only.  scaling = "weak".
+N>1, one rank per GPU.  Either the driver launches the ranks (torch.distributed.run sets RANK / WORLD_SIZE) or `python bench.py --gpus N`
+does it itself: with WORLD_SIZE unset the parent process -- before it makes any GPU call -- starts `python -m torch.distributed.run
+--nproc-per-node N ... bench.py <same flags>` as a child and only relays its exit code; rank 0 of the child prints the line.  (On a box
+with fewer than N GPUs the ranks share device 0 over gloo: a rehearsal of the launch path, flagged as such on the line.)
+  --mode 2d (default): every rank runs the same per-GPU workload on its own slices and its own memory bank -- the 2D path shares
+      nothing between replicas -- so there is no data-path collective; RCCL is used for the barrier and the
+      max-over-ranks time only.  scaling = "weak".
+  --mode volume: BASELINE.json configs[3] -- ONE 512-slice 1024^2 volume, bbox prompt on every 2nd slice, one object, through
+      `volume.segment_volume` on all N ranks (slice-sharded image encoder + conditioning pass, one RCCL exchange of memories / features,
+      the propagation chain with the memory cross-attention's key range split over the ranks).  A step = one whole volume;
+      scaling = "strong"; the per-phase seconds of the last volume are on the line.
+The 2d line also carries that volume pass as the side object `volume_3d` (after the timed region; guarded by a watchdog: if the exchange
+hangs, rank 0 still prints the line with the error recorded in it).
 
 Extra objects on the JSON line: "roofline" (dominant kernel = the memory cross-attention, attn_kv64x2_kernel, MFMA-bound; timed with
-HIP events on the launch stream) and "cpu_baseline" (the CPU oracle on a bounded sample, rank 0, N=1 only).
+HIP events on the launch stream), "roofline_gemm" (the GEMM family of the step: every distinct shape the step launches, timed the same
+way; flop-weighted fraction of the MFMA peak), "roofline_hiera_attention" and "cpu_baseline" (the CPU oracle on a bounded sample,
+rank 0, N=1 only).
 
 `cpu_baseline.parity_slice0`: the oracle sample IS slice 0 of the timed step (same image, click and memory bank), so its mask is compared
 with the HIP path's -- mask IoU and max / mean |delta logit| at the full 1024^2 size.
@@ -303,25 +315,271 @@ def cpu_baseline(sample=None):
                                 "max_abs_dlogit": (hip_low.float() - last["masks"]).abs().max().item(),
                                 "mean_abs_dlogit": (hip_low.float() - last["masks"]).abs().mean().item(),
                                 "foreground_pixels": int(b.sum().item())}
+    res["_oracle_low"] = last["masks"]          # popped by the caller (parity of the bf16 side run)
     return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the GEMM family of the step (half of the step, no roofline object so far)
+GEMM_ENTRY_POINTS = ("gemm", "gemm_rope", "gemm_pool2x2", "gemm_qkv_pool2x2", "gemm_tokens")
+
+
+def time_gemm_family(m, imgs, pts, labels, memory, memory_pos, device):
+    """Every GEMM launch of one eager step (all five entry points of ops: plain, +RoPE store, pooled shortcut, pooled qkv, token rows),
+    grouped by (entry point, M, N, K, output type, residual, activation); one representative call per group is re-launched 10 times on
+    its own live operands and timed with HIP events on the launch stream.  `achieved` = the step's GEMM flops (2 M N K per launch)
+    over the sum of count x average launch time: the flop-weighted rate of the family against the dense MFMA peak."""
+    import medical_sam2_amd.ops as ops
+    from medical_sam2_amd._lib import lib, check
+    groups = {}
+    real = {n: getattr(ops, n) for n in GEMM_ENTRY_POINTS}
+
+    def spy(name):
+        fn = real[name]
+
+        def wrapped(a, w, *args, **kw):
+            out = fn(a, w, *args, **kw)
+            o = out[0] if isinstance(out, tuple) else out
+            key = (name, int(a.shape[0]), int(w.shape[0]), int(a.shape[1]), str(o.dtype).replace("torch.", ""),
+                   kw.get("residual") is not None, int(kw.get("act", 0)))
+            g = groups.setdefault(key, {"n": 0, "call": (fn, (a, w) + args, kw)})
+            g["n"] += 1
+            return out
+        return wrapped
+
+    for n in GEMM_ENTRY_POINTS:
+        setattr(ops, n, spy(n))
+    try:
+        step_2d(m, imgs, pts, labels, memory, memory_pos)
+    finally:
+        for n in GEMM_ENTRY_POINTS:
+            setattr(ops, n, real[n])
+    stream = torch.cuda.current_stream().cuda_stream
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    check(lib().msam2_event_create(ctypes.byref(e0)))
+    check(lib().msam2_event_create(ctypes.byref(e1)))
+    rows, reps = [], 10
+    for key, g in groups.items():
+        fn, a, kw = g["call"]
+        kw = {k: v for k, v in kw.items() if k != "out"}        # never re-write a live buffer of the model (out= aliases)
+        for _ in range(2):
+            fn(*a, **kw)
+        torch.cuda.synchronize()
+        check(lib().msam2_event_record(e0, stream))
+        for _ in range(reps):
+            fn(*a, **kw)
+        check(lib().msam2_event_record(e1, stream))
+        ms = ctypes.c_float()
+        check(lib().msam2_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+        t = ms.value / 1e3 / reps
+        name, M, N, K = key[:4]
+        rows.append({"entry": name, "M": M, "N": N, "K": K, "out": key[4], "residual": key[5], "act": key[6], "launches_per_step": g["n"],
+                     "avg_launch_us": t * 1e6, "TFLOPs": 2.0 * M * N * K / t / 1e12, "step_us": g["n"] * t * 1e6,
+                     "step_flops": 2.0 * M * N * K * g["n"]})
+    lib().msam2_event_destroy(e0)
+    lib().msam2_event_destroy(e1)
+    groups.clear()
+    tot_t = sum(r["step_us"] for r in rows) * 1e-6
+    tot_f = sum(r["step_flops"] for r in rows)
+    rows.sort(key=lambda r: -r["step_us"])
+    for r in rows:
+        r["share_of_gemm_time"] = r["step_us"] * 1e-6 / tot_t
+    ach = tot_f / tot_t / 1e12
+    return {"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+            "traffic": None, "what": "all GEMM launches of one step (flop-weighted): sum of 2MNK over sum of launches x stand-alone average launch time",
+            "gemm_ms_per_step": tot_t * 1e3, "flops_per_step": tot_f, "launches_per_step": sum(r["launches_per_step"] for r in rows),
+            "distinct_shapes": len(rows), "top_shapes": rows[:8],
+            "pmc": "profiles/r03_gemm_16384x1536x384_pmc_*.csv, profiles/r03_gemm_16384x384x1536_pmc_*.csv (stage-3 fc1 / fc2: HBM bytes, L2 hit rate, "
+                   "MFMA-busy, LDS activity; summary in profiles/README.md)"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[3]: one 3-D volume through segment_volume on all ranks (strong scaling)
+def make_volume(device, T, S=1024, seed=0):
+    """Synthetic one-organ volume [T,3,S,S] generated ON the device (the 512-slice volume is 6.4 GB: half a minute of host arithmetic
+    per rank through synthetic.blob_volume): the same model -- an ellipsoid "organ" of Gaussian intensity over noise, ImageNet
+    normalisation, the per-slice bounding box of its iso-surface -- with the noise drawn by the device generator."""
+    import math
+    g = torch.Generator().manual_seed(5000 + seed)
+    cx, cy, cz = (torch.rand(3, generator=g) * 0.5 + 0.25).tolist()
+    rx, ry, rz = (torch.rand(3, generator=g) * 0.12 + 0.1).tolist()
+    dg = torch.Generator(device=device).manual_seed(77 + seed)
+    ys = torch.arange(S, dtype=torch.float32, device=device)[:, None]
+    xs = torch.arange(S, dtype=torch.float32, device=device)[None, :]
+    gains = torch.tensor([1.0, 0.92, 0.85], device=device)[:, None, None]
+    mean = torch.tensor([0.485, 0.456, 0.406], device=device)[:, None, None]
+    std = torch.tensor([0.229, 0.224, 0.225], device=device)[:, None, None]
+    plane = ((xs / S - cx) / rx) ** 2 + ((ys / S - cy) / ry) ** 2
+    vol = torch.empty(T, 3, S, S, device=device)
+    boxes = []
+    for t in range(T):
+        dz = ((t + 0.5) / T - cz) / rz
+        sl = 30.0 + 6.0 * torch.randn(S, S, generator=dg, device=device) + 150.0 * torch.exp(-1.5 * (plane + dz * dz))
+        vol[t] = ((sl.clamp(0, 255)[None] * gains) / 255.0 - mean) / std
+        if abs(dz) < 1.0:
+            r = math.sqrt(1.0 - dz * dz)
+            boxes.append(((cx - rx * r) * S, (cy - ry * r) * S, (cx + rx * r) * S, (cy + ry * r) * S))
+        else:
+            boxes.append((S * 0.3, S * 0.3, S * 0.6, S * 0.6))
+    return vol, boxes
+
+
+def volume_workload(device, T):
+    volume, boxes = make_volume(device, T)
+    prompts = {t: {"boxes": torch.tensor([[float(v) for v in boxes[t]]], device=device)} for t in range(0, T, 2)}
+    return volume, prompts
+
+
+def run_volume(m, device, T, world, sync_dev, steps, warmup):
+    """`steps` timed passes of the whole T-slice volume through segment_volume (all ranks, strong scaling).  Returns (seconds for all
+    steps = max over ranks, phase seconds of the last pass on this rank, how the chain used the ranks, foreground fraction)."""
+    import medical_sam2_amd.parallel as par
+    import medical_sam2_amd.volume as vol
+    volume, prompts = volume_workload(device, T)
+    small = {t: prompts[t] for t in (0, 2)}
+    vol.segment_volume(m, volume[:4], small, fill_hole_area=8)       # code objects, weight packing, tables (and the exchange, once)
+    for _ in range(warmup):
+        vol.segment_volume(m, volume, prompts, fill_hole_area=8)
+    torch.cuda.synchronize()
+    par.barrier(sync_dev)
+    torch.cuda.synchronize()
+    st = {}
+    t0 = time.perf_counter()
+    for i in range(steps):
+        st = {"time_phases": i == steps - 1}
+        masks = vol.segment_volume(m, volume, prompts, fill_hole_area=8, stats=st)
+    torch.cuda.synchronize()
+    par.barrier(sync_dev)
+    torch.cuda.synchronize()
+    dt = par.max_over_ranks(time.perf_counter() - t0, sync_dev)
+    fg = sum(float((v > 0).float().mean()) for v in masks.values()) / len(masks)
+    chain = "single rank" if world == 1 else "memory cross-attention key range split over the ranks (1 object < ranks), rest of the chain replicated"
+    return dt, st.get("phase_s"), chain, fg, len(masks)
+
+
+VOLUME_WORKLOAD = ("configs[3]: sam2_hiera_s 3D, ONE {T}-slice 1024x1024 synthetic volume, bbox prompt on every 2nd slice ({C} conditioning "
+                   "slices), one object, segment_volume over all ranks: slice-sharded image encoder + conditioning pass, one exchange "
+                   "(conditioning memories + non-conditioning features), propagation chain attending to up to {K} memory keys, hole filling")
+
+
+def volume_side_object(m, device, T, world, sync_dev):
+    dt, phases, chain, fg, n = run_volume(m, device, T, world, sync_dev, steps=1, warmup=0)
+    return {"workload": VOLUME_WORKLOAD.format(T=T, C=T // 2, K=(T // 2 + 3) * 4096), "scaling": "strong", "n_gpus": world, "slices": n,
+            "seconds_per_volume": dt, "slices_per_s": T / dt, "phase_s_rank0": phases, "chain": chain, "mean_foreground_fraction": fg}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def bf16_side_object(steps, warmup, oracle_low):
+    """BASELINE.json configs[1] names bf16; the default library computes on fp16 operands.  The same benchmark
+    step through libmsam2_hip_bf16.so in a CHILD process (the operand type is fixed when the library is loaded): its slices/s and the
+    parity of its slice-0 mask against the oracle mask of `cpu_baseline`."""
+    import subprocess
+    import tempfile
+    so = os.path.join(ROOT, "medical-sam2_amd", "libmsam2_hip_bf16.so")
+    if not os.path.exists(so):
+        return {"error": "libmsam2_hip_bf16.so not built (__graft_entry__.build())"}
+    with tempfile.TemporaryDirectory() as td:
+        dump = os.path.join(td, "slice0.pt")
+        env = dict(os.environ, MSAM2_LIB_PATH=so)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline",
+               "--no-train", "--no-volume", "--no-bf16", "--no-rooflines", "--dump-slice0", dump]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            return {"error": f"bf16 child exited {r.returncode}: {r.stderr[-300:]}"}
+        child = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        res = {"dtype": child["dtype"], "value": child["value"], "unit": child["unit"], "ms_per_step": child["ms_per_step"],
+               "library": "libmsam2_hip_bf16.so (-DMSAM2_OPERAND_BF16), same step, same graph capture, child process"}
+        if oracle_low is not None and os.path.exists(dump):
+            low = torch.load(dump).float()
+            a, b = low > 0, oracle_low > 0
+            union = (a | b).sum().item()
+            res["parity_slice0"] = {"mask_iou_vs_oracle": (a & b).sum().item() / union if union else 1.0,
+                                    "max_abs_dlogit": (low - oracle_low).abs().max().item(),
+                                    "mean_abs_dlogit": (low - oracle_low).abs().mean().item()}
+        return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a CHILD (`python -m torch.distributed.run`, one process per GPU,
+    rendezvous on 127.0.0.1) and return its exit code.  This parent makes no GPU call before or after (torch.cuda.device_count() does not
+    initialise the runtime on this image), so nothing that has touched the GPU is ever replaced or forked."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    have = torch.cuda.device_count()
+    if have < n and env.get("MSAM2_BENCH_ONE_GPU") != "1":
+        print(f"bench.py: {n} ranks requested, {have} GPU(s) visible -> rehearsal: all ranks share device 0 over gloo (not a scaling figure)",
+              file=sys.stderr, flush=True)
+        env["MSAM2_BENCH_ONE_GPU"], env["MSAM2_BENCH_BACKEND"] = "1", "gloo"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+class Watchdog:
+    """Side legs that talk to other ranks run under a deadline: when it passes, rank 0 prints the line it has (with the reason recorded
+    in `key`) and every rank leaves -- a hung exchange must not cost the headline figure."""
+
+    def __init__(self, seconds, rank, line, key):
+        import threading
+        self.rank, self.line, self.key, self.seconds = rank, line, key, seconds
+        self.timer = threading.Timer(seconds, self.fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def fire(self):
+        if self.rank == 0 and self.line is not None:
+            self.line[self.key] = {"error": f"no result within {self.seconds} s (stuck exchange?); the other figures of this line are unaffected"}
+            print(json.dumps(self.line), flush=True)
+        os._exit(0)
+
+    def cancel(self):
+        self.timer.cancel()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; 3 volumes with --mode volume)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 3; 1 volume with --mode volume)")
     ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--mode", choices=("2d", "volume"), default="2d")
+    ap.add_argument("--slices", type=int, default=512, help="slices of the 3-D volume (--mode volume and the volume_3d side object)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("MSAM2_BENCH_STREAMS", "1")),
                     help="process the step's slices as this many concurrent sub-batches on separate HIP streams (same work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the (untimed-in-value) training-iteration figure")
+    ap.add_argument("--no-volume", action="store_true", help="skip the volume_3d side object of the 2d line")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the bf16-library side object (N=1 only)")
+    ap.add_argument("--no-rooflines", action="store_true", help="skip the per-kernel roofline legs (used by the bf16 child run)")
+    ap.add_argument("--dump-slice0", default=None, help="write the low-res mask logits of slice 0 to this file (bf16 child run)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 20 if args.mode == "2d" else 3
+    if args.warmup is None:
+        args.warmup = 3 if args.mode == "2d" else 1
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))        # before any GPU call in this process
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is used", file=sys.stderr, flush=True)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP library is the only compute path (no CPU fallback)")
     # rehearsal mode for a 1-GPU box: several ranks share device 0 and talk over gloo (RCCL refuses duplicate devices)
@@ -335,9 +593,30 @@ def main():
         par.init_distributed(backend=backend, device=device)
     dist = torch.distributed if world > 1 else None
     sync_dev = device if backend == "nccl" else torch.device("cpu")
+    rehearsal = {"rehearsal": f"{world} ranks share ONE GPU over {backend}: launch-path check, not a scaling figure"} if (one_gpu and world > 1) else {}
 
     torch.set_grad_enabled(False)
     m = build_model(device)
+    import medical_sam2_amd.ops as ops
+    dtype = "f16" if ops.OP16 == torch.float16 else "bf16"
+
+    if args.mode == "volume":
+        T = args.slices
+        dt, phases, chain, fg, n = run_volume(m, device, T, world, sync_dev, args.steps, args.warmup)
+        if rank == 0:
+            line = {"metric": "slices/sec @1024^2 (Hiera-S)", "value": T * args.steps / dt, "unit": "slices/s", "n_gpus": world,
+                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+                    "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+                    "config": {"workload": VOLUME_WORKLOAD.format(T=T, C=T // 2, K=(T // 2 + 3) * 4096), "slices_per_step": n,
+                               "step": "one whole volume", "backend": backend if world > 1 else None, "chain": chain,
+                               "weights": "random name-keyed init", **rehearsal},
+                    "phase_s_rank0_last_volume": phases, "mean_foreground_fraction": fg}
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            par.barrier(sync_dev)
+            dist.destroy_process_group()
+        return
+
     imgs, pts, labels, bank_feats, sampled = make_inputs(device, args.batch, rank)
     memory, memory_pos = assemble_memory(m, bank_feats, sampled)
 
@@ -390,42 +669,68 @@ def main():
     par.barrier(sync_dev)
     torch.cuda.synchronize()
     dt = par.max_over_ranks(time.perf_counter() - t0, sync_dev)
+    low0 = (out[0][0] if isinstance(out, list) else out[0])[:1]
+    if args.dump_slice0 and rank == 0:
+        torch.save(low0.detach().float().cpu(), args.dump_slice0)
 
-    import medical_sam2_amd.ops as ops
+    line = None
     if rank == 0:
         slices = args.batch * args.steps * world
-        k_s, k_flops, k_exec, k_bytes, splits, pair_s = time_dominant_kernel(device, args.batch)
-        achieved = k_flops / k_s / 1e12
         line = {
             "metric": "slices/sec @1024^2 (Hiera-S)", "value": slices / dt, "unit": "slices/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16" if ops.OP16 == torch.float16 else "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "configs[1]: sam2_hiera_s 2D (train_2d SAM2 sub-sequence, forward), b=4 x 1024x1024 per GPU, "
                                    "16-entry memory bank with 4 sampled memories per slice, one click per slice; "
                                    "forward_image -> memory_attention -> prompt encoder -> mask decoder -> memory encoder",
-                       "slices_per_step_per_gpu": args.batch, "hip_graph": graph is not None, "weights": "random name-keyed init"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(),
-                         "kernel": f"attn_kv64x2_kernel<4> (memory cross-attention, value product folded to the 64-channel memory space, 64 queries per wave; "
-                                   f"split-KV pass, {splits} splits) at B={args.batch} Lq=4096 Lk={args.batch * 4096}",
-                         "avg_launch_us": k_s * 1e6, "with_merge_us": pair_s * 1e6, "flops_per_launch": k_flops,
-                         "flops_definition": "algorithmic, SURVEY 8(d): 4*Lq*Lk*256 per object (the reference's 256-wide SDPA)",
-                         "executed_flops_per_launch": k_exec, "frac_on_executed_flops": k_exec / k_s / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                         "algorithmic_bytes_per_launch": k_bytes,
-                         "hbm_GBs_on_algorithmic_bytes": k_bytes / k_s / 1e9, "hbm_frac_of_peak": k_bytes / k_s / 1e9 / HBM_PEAK_GBS},
-        }
-        line["roofline_hiera_attention"] = time_hiera_attention(device, args.batch)
+                       "slices_per_step_per_gpu": args.batch, "hip_graph": graph is not None, "weights": "random name-keyed init",
+                       "backend": backend if world > 1 else None, **rehearsal}}
+        if not args.no_rooflines:
+            k_s, k_flops, k_exec, k_bytes, splits, pair_s = time_dominant_kernel(device, args.batch)
+            achieved = k_flops / k_s / 1e12
+            line["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(),
+                                "kernel": f"attn_kv64x2_kernel<4> (memory cross-attention, value product folded to the 64-channel memory space, 64 queries per wave; "
+                                          f"split-KV pass, {splits} splits) at B={args.batch} Lq=4096 Lk={args.batch * 4096}",
+                                "avg_launch_us": k_s * 1e6, "with_merge_us": pair_s * 1e6, "flops_per_launch": k_flops,
+                                "flops_definition": "algorithmic, SURVEY 8(d): 4*Lq*Lk*256 per object (the reference's 256-wide SDPA)",
+                                "executed_flops_per_launch": k_exec, "frac_on_executed_flops": k_exec / k_s / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                "algorithmic_bytes_per_launch": k_bytes,
+                                "hbm_GBs_on_algorithmic_bytes": k_bytes / k_s / 1e9, "hbm_frac_of_peak": k_bytes / k_s / 1e9 / HBM_PEAK_GBS,
+                                "note": "largest single kernel of the step; the largest kernel FAMILY is the GEMMs: roofline_gemm"}
+            line["roofline_gemm"] = time_gemm_family(m, imgs, pts, labels, memory, memory_pos, device)
+            line["roofline_hiera_attention"] = time_hiera_attention(device, args.batch)
+        oracle_low = None
         if world == 1 and not args.no_cpu_baseline:
             c = lambda t: t.detach().float().cpu()
-            sample = (c(imgs[:1]), c(pts[:1]), labels[:1].cpu(), c(memory[:, :1]), c(memory_pos[:, :1]), c(out[0][:1]))
+            sample = (c(imgs[:1]), c(pts[:1]), labels[:1].cpu(), c(memory[:, :1]), c(memory_pos[:, :1]), c(low0))
             line["cpu_baseline"] = cpu_baseline(sample)
+            oracle_low = line["cpu_baseline"].pop("_oracle_low", None)
         if world == 1 and not args.no_train:
             line["train_iteration"] = train_iteration(m, imgs, pts, labels, memory, memory_pos, device, full=True)
             line["train_iteration_frozen_encoder"] = train_iteration(m, imgs, pts, labels, memory, memory_pos, device, full=False)
+        if world == 1 and not args.no_bf16 and dtype == "f16":
+            try:
+                line["bf16"] = bf16_side_object(args.steps, args.warmup, oracle_low)
+            except Exception as e:  # noqa: BLE001 -- a side figure
+                line["bf16"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if not args.no_volume:
+        # all ranks: the 3-D path at configs[3]'s size (strong scaling), after the timed region; never part of `value`
+        dog = Watchdog(420, rank, line, "volume_3d")
+        try:
+            side_obj = volume_side_object(m, device, args.slices, world, sync_dev)
+        except Exception as e:  # noqa: BLE001 -- a side figure: report, do not fail the benchmark line
+            side_obj = {"error": f"{type(e).__name__}: {e}"[:300]}
+        dog.cancel()
+        if rank == 0:
+            line["volume_3d"] = side_obj
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
+        dog = Watchdog(120, rank, None, "")
         par.barrier(sync_dev)
         dist.destroy_process_group()
+        dog.cancel()
 
 
 if __name__ == "__main__":

@@ -81,9 +81,10 @@ SIGNATURES = {
     "msam2_sumpool2x2": (c_i, [c_p, c_p, c_l, c_l, c_l, c_l, c_p]),
     "msam2_hiera_pos_embed_bwd": (c_i, [c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_l, c_p, c_z, c_p]),
     "msam2_hiera_pos_embed_bwd_workspace_bytes": (c_z, [c_l, c_l, c_l, c_l]),
-    "msam2_dropout": (c_i, [c_p, c_i, c_l, c_p, c_l, c_p, c_i, c_l, c_l, c_l, c_f, ctypes.c_uint64, ctypes.c_uint64, c_p]),
+    "msam2_dropout": (c_i, [c_p, c_i, c_l, c_p, c_l, c_p, c_i, c_l, c_l, c_l, c_f, ctypes.c_uint64, ctypes.c_uint64, c_p, c_p]),
+    "msam2_counter_bump": (c_i, [c_p, c_p, c_p]),
     "msam2_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_l, c_p]),
-    "msam2_adam_step_multi": (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_l, c_f, c_f, c_p, c_p]),
+    "msam2_adam_step_multi": (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_l, c_f, c_f, c_p, c_p, c_p]),
     "msam2_attention_small_bwd": (c_i, [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_f, c_p]),
     "msam2_seg_counts": (c_i, [c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_p]),
     "msam2_non_overlap": (c_i, [c_p, c_p, c_l, c_l, c_p]),

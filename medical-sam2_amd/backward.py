@@ -374,7 +374,8 @@ def memory_attention_forward_saved(module, curr: torch.Tensor, curr_pos: torch.T
     mem_v = ops.add_cast(mem_bf, None, 1.0, OP16)
     ctxs = []
     for li, layer in enumerate(module.layers):
-        drop = {"p": float(dropout[0]), "seed": int(dropout[1]), "layer": li} if dropout and dropout[0] > 0 else None
+        seed = dropout[1] if (dropout and isinstance(dropout[1], ops.DeviceSeed)) else (int(dropout[1]) if dropout else 0)
+        drop = {"p": float(dropout[0]), "seed": seed, "layer": li} if dropout and dropout[0] > 0 else None
         x, ctx = _memory_attention_layer_forward_saved(layer, x, mem_k, mem_v, B, L, num_obj_ptr_tokens, drop=drop)
         ctxs.append(ctx)
     y = ops.layernorm(x, v_f32(module._wc, "nw", module.norm.weight), v_f32(module._wc, "nb", module.norm.bias), module.norm.eps, out_dtype=F32)

@@ -227,6 +227,34 @@ def _pow2_scale(amax: float) -> float:
     return 2.0 ** (-3 - math.ceil(math.log2(amax))) if amax > 0 and math.isfinite(amax) else 1.0
 
 
+def record_scaled_amax(scales: dict, key: str, scaled: torch.Tensor, calibrating: bool) -> None:
+    """Running max|scaled gradient| of one link, kept ON THE DEVICE next to its cached scale (scales["_amax"][key], a 1-element tensor
+    created while calibrating and updated in place afterwards, so the update is part of a captured graph).  The scales are calibrated
+    once and then frozen for every replay: as gradient magnitudes drift over training, a frozen scale lets 16-bit operands
+    saturate or flush to zero without any visible sign -- `scale_drift` reads these slots and says when to calibrate again."""
+    slots = scales.setdefault("_amax", {})
+    a = scaled.detach().abs().max().reshape(1).to(F32)
+    if calibrating or key not in slots:
+        slots[key] = a.clone()
+    else:
+        torch.maximum(slots[key], a, out=slots[key])
+
+
+def scale_drift(scales: dict, lo: float = 2.0 ** -11, hi: float = 2.0 ** 3, reset: bool = True) -> Dict[str, float]:
+    """{link: max|scaled gradient| since the last check} for the links that left the safe band (one host read).  Calibration puts the
+    maximum at 2^-3; `hi` = 64x growth (fp16 saturates at 2^16, but products inside a block's backward run ahead of its input), `lo` =
+    256x shrinkage (the small entries of the operand are then below fp16's normal range).  A non-finite maximum counts as drift."""
+    import math
+    out = {}
+    for key, slot in scales.get("_amax", {}).items():
+        v = float(slot.item())
+        if not math.isfinite(v) or v > hi or (0.0 < v < lo):
+            out[key] = v
+        if reset:
+            slot.zero_()
+    return out
+
+
 def image_encoder_backward(model, state: dict, d_fpn: List[Optional[torch.Tensor]], d_fpn_scales: Optional[List[float]] = None,
                            scales: Optional[dict] = None) -> Dict[str, torch.Tensor]:
     """d_fpn: gradients of `backbone_fpn` levels 0, 1, 2 as token-major maps ([B*256^2, 32], [B*128^2, 64], [B*64^2, 256] at 1024^2;
@@ -262,6 +290,7 @@ def image_encoder_backward(model, state: dict, d_fpn: List[Optional[torch.Tensor
         for t, s in parts:
             u = t.to(F32) * (s_new / s)                    # fp32, exact power-of-two factors
             acc = u if acc is None else acc + u
+        record_scaled_amax(scales, key, acc, calibrate)
         return acc, s_new
 
     # ---- neck: output gradients per level, the top-down contribution pushed to the coarser level, then the lateral convs

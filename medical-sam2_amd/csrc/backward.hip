@@ -697,7 +697,8 @@ __global__ void adam_tick_kernel(int* step) {
 }
 
 __global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable tb, float lr, float b1, float b2, float eps, float bc1, float bc2,
-                                                         float gscale, float decay, const int* __restrict__ step) {
+                                                         float gscale, float decay, const int* __restrict__ step,
+                                                         int* __restrict__ skipped) {
   const int t = blockIdx.y;
   float* __restrict__ p = tb.p[t];
   const float* __restrict__ g = tb.g[t];
@@ -711,7 +712,10 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable tb, float lr,
   }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float gi = g[i] * gscale;
-    if (!isfinite(gi)) continue;
+    if (!isfinite(gi)) {
+      if (skipped) atomicAdd(skipped, 1);                 // rare by construction; visible to the host as DecoderAdam.skipped_elements
+      continue;
+    }
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi;
@@ -721,10 +725,12 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable tb, float lr,
 }
 
 // step_counter (int32 on the device, may be null): when given, the library increments it once (a kernel, so that it is part of a
-// captured graph) and the update reads t from it; the host `step` is then ignored.
+// captured graph) and the update reads t from it; the host `step` is then ignored.  skipped_counter (int32 on the device, may be null):
+// incremented once per gradient ELEMENT that was non-finite and therefore left its parameter untouched -- the overflow of a 16-bit
+// backward operand (a stale loss scale) is silent otherwise.
 extern "C" int msam2_adam_step_multi(void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
                                      const int64_t* numel, int64_t count, float lr, float beta1, float beta2, float eps, int64_t step,
-                                     float grad_scale, float weight_decay, void* step_counter, void* stream) {
+                                     float grad_scale, float weight_decay, void* step_counter, void* skipped_counter, void* stream) {
   MSAM2_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel && count > 0 && (step >= 1 || step_counter), "adam_step_multi: bad arguments");
   const float bc1 = 1.f - powf(beta1, (float)(step >= 1 ? step : 1)), bc2 = 1.f - powf(beta2, (float)(step >= 1 ? step : 1));
   if (step_counter) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (int*)step_counter);
@@ -741,7 +747,7 @@ extern "C" int msam2_adam_step_multi(void* const* params, const void* const* gra
     }
     dim3 grid((unsigned)min((int64_t)128, cdiv(nmax, 256)), (unsigned)nt);
     hipLaunchKernelGGL(adam_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, tb, lr, beta1, beta2, eps, bc1, bc2, grad_scale,
-                       1.f - lr * weight_decay, (const int*)step_counter);
+                       1.f - lr * weight_decay, (const int*)step_counter, (int*)skipped_counter);
   }
   return msam2_check_launch("adam_step_multi");
 }
@@ -1154,6 +1160,9 @@ extern "C" int msam2_hiera_pos_embed_bwd(const float* d_table, float* d_pos_embe
 // forward from the same (seed, offset) -- nothing is stored.  y = keep ? x / (1 - p) : 0  (+ residual).  The same call on a gradient
 // is the backward.  (Not torch's Philox stream: masks match in distribution, not bit for bit -- parity is pinned with the oracle
 // consuming the masks this kernel produces.)
+// The stream id may come from the DEVICE (seed_dev, optional uint64: added to `seed` by every thread): a training step captured into a
+// hipGraph bakes its by-value arguments in, so the per-forward sub-stream counter has to live in device memory and be advanced by a
+// kernel of the step itself (msam2_counter_bump) for a replay to draw fresh masks.
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, unsigned thr) {
   uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
@@ -1165,7 +1174,9 @@ __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, unsign
 
 template <typename TI, typename TO>
 __global__ void dropout_kernel(const TI* __restrict__ x, int64_t ldx, const float* __restrict__ res, int64_t ldr, TO* __restrict__ y, int64_t ldy,
-                               int64_t rows, int64_t cols, unsigned thr, float inv_keep, uint64_t seed, uint64_t offset) {
+                               int64_t rows, int64_t cols, unsigned thr, float inv_keep, uint64_t seed, uint64_t offset,
+                               const uint64_t* __restrict__ seed_dev) {
+  if (seed_dev) seed += *seed_dev;
   const int64_t total = rows * cols;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / cols, c = i - r * cols;
@@ -1177,17 +1188,31 @@ __global__ void dropout_kernel(const TI* __restrict__ x, int64_t ldx, const floa
 
 // x / y: [rows, cols] with row strides (elements); residual (optional) fp32.  The element index of the stream is r * cols + c.
 extern "C" int msam2_dropout(const void* x, int x_is_16bit, int64_t ldx, const float* residual, int64_t ldr, void* y, int y_is_16bit, int64_t ldy,
-                             int64_t rows, int64_t cols, float p, uint64_t seed, uint64_t offset, void* stream) {
+                             int64_t rows, int64_t cols, float p, uint64_t seed, uint64_t offset, const void* seed_dev, void* stream) {
   MSAM2_REQUIRE(x && y && rows > 0 && cols > 0 && p >= 0.f && p < 1.f, "dropout: bad arguments");
   const unsigned thr = (unsigned)fmin(4294967295.0, (double)p * 4294967296.0);
   const float inv_keep = 1.f / (1.f - p);
   dim3 grid((unsigned)min((int64_t)8192, cdiv(rows * cols, 256))), block(256);
   hipStream_t s = (hipStream_t)stream;
-#define DR(TI, TO) hipLaunchKernelGGL((dropout_kernel<TI, TO>), grid, block, 0, s, (const TI*)x, ldx, residual, ldr, (TO*)y, ldy, rows, cols, thr, inv_keep, seed, offset)
+#define DR(TI, TO) hipLaunchKernelGGL((dropout_kernel<TI, TO>), grid, block, 0, s, (const TI*)x, ldx, residual, ldr, (TO*)y, ldy, rows, cols, thr, inv_keep, seed, offset, (const uint64_t*)seed_dev)
   if (x_is_16bit && y_is_16bit) DR(op16, op16);
   else if (x_is_16bit) DR(op16, float);
   else if (y_is_16bit) DR(float, op16);
   else DR(float, float);
 #undef DR
   return msam2_check_launch("dropout");
+}
+
+__global__ void counter_bump_kernel(uint64_t* ctr, uint64_t* snapshot) {
+  const uint64_t v = *ctr + 1;
+  *ctr = v;
+  if (snapshot) *snapshot = v;
+}
+
+// *counter += 1 on the device, the new value also written to *snapshot (optional): the sub-stream counter of the train-mode dropout,
+// advanced inside the step so that hipGraph replays move it (see above).
+extern "C" int msam2_counter_bump(void* counter_u64, void* snapshot_u64, void* stream) {
+  MSAM2_REQUIRE(counter_u64, "counter_bump: null counter");
+  hipLaunchKernelGGL(counter_bump_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (uint64_t*)counter_u64, (uint64_t*)snapshot_u64);
+  return msam2_check_launch("counter_bump");
 }

@@ -259,16 +259,30 @@ class MemoryAttention(nn.Module):
         self.batch_first = batch_first
         self._wc = WeightCache()
         self.dropout_seed = 0            # stream of the train-mode dropout masks; every train-mode forward draws a fresh sub-stream
-        self._dropout_calls = 0
+        self._dropout_calls = 0          # host-visible count of eager train-mode forwards (reset it together with dropout_seed to replay a stream)
+        self._drop_ctr = None            # the count the kernels read: int64 [1] on the device, advanced by a kernel of every forward
+        self._drop_ctr_host = -1
 
     def next_dropout(self):
         """(p, seed) of the next train-mode forward, or None in eval mode / with dropout 0 (memory_attention.py:40-48: nn.Dropout(0.1)
-        in every layer, transformer.py:317-318: dropout_p on the attention probabilities while self.training)."""
+        in every layer, transformer.py:317-318: dropout_p on the attention probabilities while self.training).
+        The seed is (dropout_seed << 32) + the number of train-mode forwards so far, and that number lives ON THE DEVICE
+        (`ops.DeviceSeed`): it is advanced by a kernel of this call and snapshotted for this forward (and its backward), so a training
+        step captured into a hipGraph draws fresh masks on every replay instead of re-applying the captured ones."""
         p = float(self.layers[0].dropout_value) if len(self.layers) else 0.0
         if not self.training or p <= 0.0:
             return None
+        dev = self.norm.weight.device
+        if self._drop_ctr is None or self._drop_ctr.device != dev or self._drop_ctr_host != self._dropout_calls:
+            # first use, a moved module, or a caller re-positioned the stream through `_dropout_calls`: (re)load the device counter
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("the first train-mode forward of a MemoryAttention must run eagerly (it creates the device-side dropout counter)")
+            self._drop_ctr = torch.full((1,), int(self._dropout_calls), dtype=torch.int64, device=dev)
+        snap = torch.empty(1, dtype=torch.int64, device=dev)
+        ops.counter_bump(self._drop_ctr, snap)
         self._dropout_calls += 1
-        return p, (int(self.dropout_seed) << 32) + self._dropout_calls
+        self._drop_ctr_host = self._dropout_calls
+        return p, ops.DeviceSeed(int(self.dropout_seed) << 32, snap)
 
     def forward(self, curr: torch.Tensor, memory: torch.Tensor, curr_pos: Optional[torch.Tensor] = None,
                 memory_pos: Optional[torch.Tensor] = None, num_obj_ptr_tokens: int = 0, key_count: Optional[torch.Tensor] = None):

@@ -315,11 +315,32 @@ def add_cast(a: torch.Tensor, b: Optional[torch.Tensor] = None, alpha: float = 1
     return out
 
 
-def dropout(x: torch.Tensor, p: float, seed: int, offset: int, residual: Optional[torch.Tensor] = None,
+class DeviceSeed:
+    """Stream id of a dropout call whose low part lives on the device: effective seed = base + *dev (int64 [1] tensor, written by
+    `counter_bump`).  A hipGraph replay of a training step then draws new masks, because the counter is advanced by a kernel of the
+    step instead of being baked into the captured arguments."""
+    __slots__ = ("base", "dev")
+
+    def __init__(self, base: int, dev: torch.Tensor):
+        assert dev.dtype == torch.int64 and dev.numel() == 1 and dev.is_cuda
+        self.base, self.dev = int(base), dev
+
+
+def counter_bump(counter: torch.Tensor, snapshot: Optional[torch.Tensor] = None) -> None:
+    """counter[0] += 1 on the device (int64 [1]); snapshot[0] = the new value."""
+    _req(counter.dtype == torch.int64 and counter.numel() == 1 and (snapshot is None or (snapshot.dtype == torch.int64 and snapshot.numel() == 1)),
+         "counter_bump: int64 [1] tensors")
+    check(lib().msam2_counter_bump(_p(counter), _p(snapshot), _stream()))
+
+
+def dropout(x: torch.Tensor, p: float, seed, offset: int, residual: Optional[torch.Tensor] = None,
             out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = residual + (keep ? x / (1 - p) : 0) on a [rows, cols] map (row-major, rows may be strided); the mask is element
-    (offset + r * cols + c) of the counter-based stream `seed`, so calling it again on a gradient with the same (seed, offset) is the
-    backward.  residual: fp32 [rows, cols]."""
+    (offset + r * cols + c) of the counter-based stream `seed` (an int, or a `DeviceSeed`), so calling it again on a gradient with the
+    same (seed, offset) is the backward.  residual: fp32 [rows, cols]."""
+    seed_dev = None
+    if isinstance(seed, DeviceSeed):
+        seed, seed_dev = seed.base, seed.dev
     _req(x.dim() == 2 and x.stride(1) == 1, "dropout: [rows, cols] row-major")
     rows, cols = x.shape
     y = out if out is not None else torch.empty(rows, cols, dtype=out_dtype or x.dtype, device=x.device)
@@ -327,7 +348,7 @@ def dropout(x: torch.Tensor, p: float, seed: int, offset: int, residual: Optiona
     if residual is not None:
         _req(residual.dtype == F32 and residual.shape == x.shape and residual.stride(1) == 1, "dropout: residual must be fp32 [rows, cols]")
     check(lib().msam2_dropout(_p(x), _is_bf16(x), x.stride(0), _p(residual), residual.stride(0) if residual is not None else 0, _p(y), _is_bf16(y),
-                              y.stride(0), rows, cols, float(p), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), _stream()))
+                              y.stride(0), rows, cols, float(p), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), _p(seed_dev), _stream()))
     return y
 
 

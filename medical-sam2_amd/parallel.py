@@ -58,8 +58,13 @@ def barrier(device: Optional[torch.device] = None, group=None):
             dist.barrier(group=group)
 
 
+# Tests on a ONE-GPU box set this to run every collective of this module through the real backend (RCCL) in a world of one rank: the
+# calls, their stream ordering against the kernels around them and the ragged / coalesced forms then execute instead of being skipped.
+FORCE_SINGLE_RANK_COLLECTIVES = False
+
+
 def _is_dist(group=None) -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE_SINGLE_RANK_COLLECTIVES)
 
 
 def _to_nhwc(x: torch.Tensor) -> torch.Tensor:
@@ -145,6 +150,8 @@ def gather_slice_features(local: Dict[int, dict], slice_ids: List[int], owners: 
     the rank encoded nothing -- the caller then supplies them)."""
     if not _is_dist(group):
         return dict(local)
+    if not slice_ids:                       # every slice is a conditioning slice: the same on all ranks, so no collective is skipped one-sidedly
+        return {}
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     counts = [sum(1 for o in owners if o == r) for r in range(world)]
     my_ids = [t for t, o in zip(slice_ids, owners) if o == rank]
@@ -266,8 +273,8 @@ def allreduce_gradients_async(grads: Dict[str, torch.Tensor], group=None, bucket
     that the backward of the NEXT parameter group runs while this group's gradients are on the links (the decoder's 16 MB travel under
     the memory attention's backward, the memory attention's 23 MB under the image encoder's).
     IN PLACE and without a pack pass: the gradients (sorted by name, so every rank issues the same sequence) are handed to the
-    backend as coalesced groups of <= `bucket_bytes` -- RCCL fuses a group into one launch (ncclGroupStart/End) over the tensors
-    where they are; gloo (the CPU tests) flattens internally.  Non-fp32 or strided entries are made fp32 contiguous first (a copy for
+    backend as coalesced groups of <= `bucket_bytes` (torch.distributed's coalescing manager -> one `allreduce_coalesced` per group) --
+    RCCL fuses a group into one launch (ncclGroupStart/End) over the tensors where they are; gloo (the CPU tests) flattens internally.  Non-fp32 or strided entries are made fp32 contiguous first (a copy for
     those entries only).  xGMI rings are per-link bound, so few large groups beat one message per parameter."""
     if not _is_dist(group):
         return _PendingAllReduce([], dict(grads), 1.0)
@@ -285,9 +292,32 @@ def allreduce_gradients_async(grads: Dict[str, torch.Tensor], group=None, bucket
         while j < len(names) and (j == i or size + out[names[j]].numel() * 4 <= bucket_bytes):
             size += out[names[j]].numel() * 4
             j += 1
-        works.append(dist.all_reduce_coalesced([out[n] for n in names[i:j]], op=dist.ReduceOp.SUM, group=group, async_op=True))
+        with dist._coalescing_manager(group=group, async_ops=True) as cm:
+            for n in names[i:j]:
+                dist.all_reduce(out[n], op=dist.ReduceOp.SUM, group=group)
+        works.append(cm)
         i = j
     return _PendingAllReduce(works, out, 1.0 / world)
+
+
+def union_gradient_keys(step_grads: Dict[str, Dict[str, torch.Tensor]], modules: Dict[str, torch.nn.Module], order, group=None):
+    """Make the gradient dictionaries of a data-parallel step the same SHAPE on every rank before any all-reduce is issued: one
+    `all_gather_object` of the per-group name lists, then every rank holds, per group (in `order`), the sorted UNION of the names --
+    names this rank has no gradient for are zero-filled (shape / device of the module's parameter).  Parameters no rank reached stay
+    absent, so the optimiser leaves them alone exactly as torch.optim does for `.grad is None`."""
+    if not _is_dist(group):
+        return step_grads
+    world = dist.get_world_size(group)
+    mine = {g: sorted(step_grads.get(g, {})) for g in order}
+    every = [None] * world
+    dist.all_gather_object(every, mine, group=group)
+    out: Dict[str, Dict[str, torch.Tensor]] = {}
+    for g in order:
+        names = sorted(set().union(*[set(e[g]) for e in every]))
+        have = step_grads.get(g, {})
+        params = dict(modules[g].named_parameters()) if len(names) != len(have) else {}
+        out[g] = {n: (have[n] if n in have else torch.zeros_like(params[n], dtype=torch.float32)) for n in names}
+    return out
 
 
 def allreduce_gradients(grads: Dict[str, torch.Tensor], group=None, bucket_bytes: int = 64 << 20) -> Tuple[Dict[str, torch.Tensor], float]:

@@ -67,12 +67,19 @@ class DecoderAdam:
         """weight_decay = 0: torch.optim.Adam as train_3d.py:50-54 builds it; > 0: torch.optim.AdamW's decoupled decay (train_2d.py:43-47)."""
         self.decoder, self.lr, self.betas, self.eps, self.weight_decay = decoder, lr, betas, eps, weight_decay
         self.state: Dict[str, tuple] = {}
-        self._t_dev = None          # int32 [1] on the parameters' device: the step count t (advanced by a kernel inside every step)
+        self._t_dev = None          # int32 [2] on the parameters' device: [step count t (advanced by a kernel inside every step), number of
+                                    # non-finite gradient elements skipped so far]
 
     @property
     def t(self) -> int:
         """number of steps taken so far, eager and replayed (one device -> host read)"""
-        return 0 if self._t_dev is None else int(self._t_dev.item())
+        return 0 if self._t_dev is None else int(self._t_dev[0].item())
+
+    @property
+    def skipped_elements(self) -> int:
+        """gradient elements that were non-finite (an overflowed 16-bit backward operand: stale loss scale) and left their parameter
+        untouched, summed over all steps so far, eager and replayed (one device -> host read).  Non-zero = re-calibrate."""
+        return 0 if self._t_dev is None else int(self._t_dev[1].item())
 
     def mark_updated(self):
         """Bump the version counters of the parameters (no kernel).  `step` does it itself; a hipGraph REPLAY of a captured step
@@ -90,7 +97,7 @@ class DecoderAdam:
         import ctypes
         params = dict(self.decoder.named_parameters())
         if self._t_dev is None:
-            self._t_dev = torch.zeros(1, dtype=torch.int32, device=next(iter(params.values())).device)
+            self._t_dev = torch.zeros(2, dtype=torch.int32, device=next(iter(params.values())).device)
         names = list(grads.keys())
         keep = []                                      # fp32 contiguous gradient copies stay alive until the launches are queued
         tabs = [[], [], [], []]
@@ -109,7 +116,8 @@ class DecoderAdam:
         n = len(names)
         arr = [(ctypes.c_void_p * n)(*tab) for tab in tabs]
         check(lib().msam2_adam_step_multi(arr[0], arr[1], arr[2], arr[3], (ctypes.c_int64 * n)(*numel), n, self.lr, self.betas[0],
-                                          self.betas[1], self.eps, 0, float(grad_scale), float(self.weight_decay), _p(self._t_dev), _stream()))
+                                          self.betas[1], self.eps, 0, float(grad_scale), float(self.weight_decay), _p(self._t_dev),
+                                          self._t_dev.data_ptr() + 4, _stream()))
         # the update went through raw pointers: bump the tensor versions (no kernel) so cached kernel-ready weights are rebuilt
         ps = tuple(params[name] for name in names)
         torch._C._autograd._unsafe_set_version_counter(ps, tuple(p._version + 1 for p in ps))
@@ -119,25 +127,78 @@ class GraphedStep:
     """A training step captured into a hipGraph together with what a replay needs on the host side: `replay()` relaunches the graph and
     then bumps the version counters of every parameter the captured optimisers update (`DecoderAdam.mark_updated`), so that eager code
     running between replays (validation, the predictor, `_encode_new_memory`) rebuilds its 16-bit weight copies instead of reading
-    stale ones.  The step function must be capturable (sync=False: no host reads) and already calibrated by one eager call."""
+    stale ones.  The step function must be capturable (sync=False: no host reads) and already calibrated by one eager call.
 
-    def __init__(self, step_fn, optimizers):
-        self.optimizers = list(optimizers)
+    Frozen loss scales.  The power-of-two scales of the 16-bit backward operands are calibrated on the eager step and baked
+    into the graph; gradient magnitudes drift over training.  Every link records its scaled max|gradient| on the device inside the step
+    (`backward_encoder.record_scaled_amax`) and Adam counts the non-finite elements it skipped: `drift()` reads both (one host
+    synchronisation), `check_every=N` does so every N replays, and when anything left the safe band and an `eager_fn` (the same step with
+    sync=True) was given, the calibrations are dropped, the step runs eagerly once (re-calibrating) and the graph is captured again."""
+
+    def __init__(self, step_fn, optimizers, eager_fn=None, check_every: int = 0):
+        self.optimizers, self.step_fn, self.eager_fn, self.check_every = list(optimizers), step_fn, eager_fn, int(check_every)
+        self.replays = self.recalibrations = 0
+        self._skipped = 0
+        self._capture()
+
+    def _capture(self):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            step_fn()                                   # warm-up on a side stream (allocator, lazy module loads)
+            self.step_fn()                              # warm-up on a side stream (allocator, lazy module loads)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.out = step_fn()
+            self.out = self.step_fn()
 
     def replay(self):
         self.graph.replay()
         for o in self.optimizers:
             o.mark_updated()
+        self.replays += 1
+        if self.check_every and self.replays % self.check_every == 0:
+            self.check()
         return self.out
+
+    def _scale_dicts(self):
+        for o in self.optimizers:
+            if getattr(o, "scale_monitor", None):
+                yield o.scale_monitor
+            for d in (getattr(o, "calibrated_block_scales", None) or {}).values():
+                yield d
+
+    def drift(self) -> dict:
+        """{link: scaled max|gradient| outside the safe band since the last call} plus {"skipped_elements": n} when Adam skipped non-finite
+        gradient elements since the last call; empty = the frozen scales still fit.  One host synchronisation."""
+        from .backward_encoder import scale_drift
+        out = {}
+        for d in self._scale_dicts():
+            out.update(scale_drift(d))
+        skipped = sum(o.skipped_elements for o in self.optimizers)
+        if skipped != self._skipped:
+            out["skipped_elements"] = skipped - self._skipped
+            self._skipped = skipped
+        return out
+
+    def check(self) -> dict:
+        d = self.drift()
+        if d and self.eager_fn is not None:
+            self.recalibrate()
+        return d
+
+    def recalibrate(self):
+        """drop every cached scale, run the step eagerly once (it calibrates afresh, with host reads) and capture it again"""
+        for o in self.optimizers:
+            if hasattr(o, "calibrated_loss_scales"):
+                o.calibrated_loss_scales = {}
+            if hasattr(o, "calibrated_block_scales"):
+                o.calibrated_block_scales = None
+            if hasattr(o, "scale_monitor"):
+                o.scale_monitor = {}
+        self.eager_fn()
+        self._capture()
+        self.recalibrations += 1
 
 
 def _shared_pow2_scale(amax: torch.Tensor, data_parallel: bool, group=None) -> float:
@@ -193,7 +254,7 @@ def decoder_finetune_step(decoder, optimizer: DecoderAdam, src_tokens, pe_tokens
 def memory_decoder_loss_grads(memory_attention, decoder, curr, curr_pos, memory, memory_pos, num_obj_ptr_tokens: int, pe_tokens, sparse,
                               feat_s0, feat_s1, B: int, h: int, w: int, target_masks: torch.Tensor, dense_tokens=None,
                               pos_weight: float = 1.0, mem_scale: float = None, aux: dict = None, mask_index: int = None,
-                              data_parallel: bool = False, on_decoder_grads=None):
+                              data_parallel: bool = False, on_decoder_grads=None, monitor: dict = None):
     """Forward + backward of the memory-conditioned slice step (func_2d/function.py:70-191 / sam2_base.py:705-790 with a frozen image
     encoder and a detached memory bank, as func_2d/function.py:204-243 stores it): curr / curr_pos [L, B, C] current-slice features,
     memory / memory_pos [Nk, B, 64] the assembled bank -> memory attention -> (+ dense prompt embedding) -> mask decoder -> mean BCE with
@@ -204,7 +265,8 @@ def memory_decoder_loss_grads(memory_attention, decoder, curr, curr_pos, memory,
     (it has crossed two attention blocks and two transposed convolutions), again below the fp16 operand range, so it is re-scaled by a
     second power of two: `mem_scale` if given (a captured graph must pass the value calibrated on an eager step), else chosen from
     max|d_src| -- one host synchronisation; with data_parallel the maximum is taken over all ranks (one MAX all-reduce), because the
-    ranks' gradients are summed afterwards and must carry the same scale."""
+    ranks' gradients are summed afterwards and must carry the same scale.  monitor (a dict kept by the caller between steps): receives
+    the device-side running max of the re-scaled gradient (`backward_encoder.record_scaled_amax`), what `GraphedStep.drift` reads."""
     L, _, C = curr.shape
     # train() mode: nn.Dropout / attention dropout of the memory attention, masks re-created by the backward from the same counter stream
     y, state = bwd.memory_attention_forward_saved(memory_attention, curr, curr_pos, memory, memory_pos, num_obj_ptr_tokens,
@@ -231,9 +293,13 @@ def memory_decoder_loss_grads(memory_attention, decoder, curr, curr_pos, memory,
         on_decoder_grads(g_dec)                                                  # e.g. start their all-reduce under the memory attention's backward
     if aux is not None:
         aux["d_src"] = d_src                                                     # gradient entering the memory attention, carrying `scale`
-    if mem_scale is None:
+    calibrating = mem_scale is None
+    if calibrating:
         mem_scale = _shared_pow2_scale(d_src.abs().max().reshape(1), data_parallel)
     d_src = d_src * mem_scale
+    if monitor is not None:
+        from .backward_encoder import record_scaled_amax
+        record_scaled_amax(monitor, "mem_scale", d_src, calibrating)
     dcurr, dmemory, dmemory_pos, g_mem = bwd.memory_attention_backward_saved(memory_attention, state, d_src.view(B, L, C).transpose(0, 1))
     if aux is not None:
         aux["dmemory"], aux["dmemory_pos"] = dmemory, dmemory_pos                # [Nk, B, 64] each, carrying scale * mem_scale
@@ -302,7 +368,10 @@ def train_step_2d(model, opt_mem: DecoderAdam, opt_dec: DecoderAdam, imgs, pts, 
     aux: dict = {}
     cal = getattr(opt_mem, "calibrated_loss_scales", {})                         # one calibration per loss form
     pend: dict = {}
-    kwargs = dict(dense_tokens=dense, aux=aux, mem_scale=cal.get(mask_index), mask_index=mask_index, data_parallel=data_parallel,
+    mon = getattr(opt_mem, "scale_monitor", None)
+    if mon is None:
+        mon = opt_mem.scale_monitor = {}
+    kwargs = dict(dense_tokens=dense, aux=aux, mem_scale=cal.get(mask_index), mask_index=mask_index, data_parallel=data_parallel, monitor=mon,
                   on_decoder_grads=(lambda g: pend.__setitem__("dec", parallel.allreduce_gradients_async(g))) if data_parallel else None)
     loss, scale, scale_mem, g_dec, g_mem, dcurr = memory_decoder_loss_grads(
         model.memory_attention, model.sam_mask_decoder, vision_feats[-1], vision_pos_embeds[-1], memory, memory_pos, 0, pe, se.to(torch.float32),

@@ -259,8 +259,15 @@ def train_step_3d(model, optimizers: Dict[str, DecoderAdam], volume: torch.Tenso
     inv_world = 1.0
     if data_parallel:
         from . import parallel
-        pend = {grp: parallel.allreduce_gradients_async(g, group) for grp, g in step_grads.items() if g}
-        for grp, pnd in pend.items():
+        # every rank on its OWN volume: which groups / parameters got a gradient depends on that volume (all slices prompted -> no
+        # memory groups; a pointer never attended to -> no obj_ptr_proj), so the collective schedule must not follow the local
+        # dictionaries: the ranks first agree on the union of the parameter names per group, absent ones are zero-filled,
+        # and every rank then issues the same all-reduces over the same lists in the fixed GROUPS order.
+        mods = {"decoder": model.sam_mask_decoder, "memory_attention": model.memory_attention, "memory_encoder": model.memory_encoder,
+                "obj_ptr_proj": model.obj_ptr_proj}
+        step_grads = parallel.union_gradient_keys(step_grads, mods, GROUPS, group)
+        pend = [(grp, parallel.allreduce_gradients_async(step_grads[grp], group)) for grp in GROUPS]
+        for grp, pnd in pend:
             step_grads[grp], inv_world = pnd.wait()
     for grp in ("memory_attention", "memory_encoder", "obj_ptr_proj", "decoder"):
         if grp in optimizers and step_grads[grp]:

@@ -27,7 +27,7 @@ import torch.distributed as dist
 
 from . import ops
 from .graphs import GraphedPropagation, pointer_capacity
-from .parallel import KVSplit, gather_cond_memories, gather_object_shards, gather_slice_features, shard_range
+from .parallel import KVSplit, _is_dist, gather_cond_memories, gather_object_shards, gather_slice_features, shard_range
 
 
 class _SliceEncoder:
@@ -91,10 +91,21 @@ def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_h
     assert cond_ids, "at least one conditioning slice is needed"
     first = prompts[cond_ids[0]]
     n_obj = (first["boxes"] if "boxes" in first else first["point_coords"]).shape[0]
-    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    distributed = _is_dist(group)      # (a world of one rank counts when parallel.FORCE_SINGLE_RANK_COLLECTIVES is set: RCCL test)
     rank = dist.get_rank(group) if distributed else 0
     world = dist.get_world_size(group) if distributed else 1
     cond_set = set(cond_ids)
+    phase_s: Optional[dict] = {} if (stats is not None and stats.get("time_phases")) else None
+    import time as _time
+    _t = [_time.perf_counter()]
+
+    def _phase(name: str):
+        """wall seconds of the phase that just ended (device drained first): only when the caller asked for `time_phases`"""
+        if phase_s is not None:
+            torch.cuda.synchronize(volume.device)
+            now = _time.perf_counter()
+            phase_s[name] = phase_s.get(name, 0.0) + now - _t[0]
+            _t[0] = now
 
     # 1. this rank's contiguous share of ALL slices: image encoder; conditioning slices also run their heads + memory encoder
     b, e = shard_range(T, rank, world)
@@ -120,6 +131,7 @@ def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_h
         pos_tables = model.forward_image(volume[:1])["vision_pos_enc"]
         pos_tables = [p[:1] for p in pos_tables[-model.num_feature_levels:]]
 
+    _phase("encode_all_slices_and_conditioning_pass")
     # 2. the one exchange step
     if distributed:
         owner = lambda t: next(r for r in range(world) if shard_range(T, r, world)[0] <= t < shard_range(T, r, world)[1])
@@ -136,6 +148,7 @@ def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_h
     else:
         cond, feats_all = local_cond, local_feats
 
+    _phase("exchange_memories_and_features")
     # 3. propagation (sequential in t): object-sharded, key-split or replicated
     obj_shard = distributed and shard_objects and n_obj >= world
     ob, oe = shard_range(n_obj, rank, world) if obj_shard else (0, n_obj)
@@ -174,6 +187,7 @@ def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_h
             stats.update(replays=prop.replays - before[0], captures=prop.captures - before[1], eager_steps=prop.eager_steps - before[2],
                          buckets=len(prop.buckets))
 
+    _phase("propagation_chain")
     # 4. everything everywhere: conditioning masks from their owners, propagated masks from the object shards
     if distributed:
         cond_masks = {t: o["pred_masks"] for t, o in cond.items()}            # gathered with the memories (full object batch)
@@ -186,6 +200,9 @@ def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_h
         for t in masks:
             masks[t] = ops.fill_holes_(masks[t].contiguous().clone(), fill_hole_area)
     out = {t: masks[t] for t in sorted(masks)}
+    _phase("gather_object_shards_and_hole_filling")
+    if phase_s is not None:
+        stats["phase_s"] = phase_s
     return (out, output_dict) if return_state else out
 
 

@@ -130,6 +130,10 @@ def softmax_attention(q: Tensor, k: Tensor, v: Tensor, pmask: Optional[Tensor] =
     """softmax(q k^T / sqrt(D)) v on [..., L, D]; what F.scaled_dot_product_attention computes at
     hieradet.py:72-76, transformer.py:258,318 (no attention mask).  pmask: train-mode dropout_p as an explicit multiplier on the
     probabilities (keep / (1 - p) or 0), so that a test can hand over the masks of the implementation under test."""
+    if pmask is None and q.shape[-2] * k.shape[-2] > (1 << 28) and q.shape[-2] > 512:
+        # a score matrix of > 2^28 entries per head (the 1.06 M-key bank of BASELINE configs[3]: 17 GB in fp32): query rows are
+        # independent, so the rows are processed in blocks of 512 -- the same arithmetic per row
+        return torch.cat([softmax_attention(q[..., i:i + 512, :], k, v) for i in range(0, q.shape[-2], 512)], dim=-2)
     s = (_rop(q) @ _rop(k).transpose(-1, -2)) / math.sqrt(q.shape[-1])
     s = s - s.amax(-1, keepdim=True)
     p = s.exp()

@@ -79,7 +79,7 @@ def test_argument_errors_cross_the_abi_as_codes_not_exceptions():
         "gemm_tt: M, N": lambda: L.msam2_gemm_tt(ptr, 12, ptr, 16, ptr, 16, None, 12, 16, 64, None),
         "layernorm_bwd: C": lambda: L.msam2_layernorm_bwd(ptr, 2048, ptr, 0, 2048, ptr, ptr, 2048, ptr, ptr, 4, 2048, 1e-6, None, 0, None),
         "col2im3x3s2": lambda: L.msam2_col2im3x3s2(ptr, 8, ptr, 1, 3, 4, 4, None),
-        "adam_step_multi": lambda: L.msam2_adam_step_multi(None, None, None, None, None, 0, 1e-4, 0.9, 0.999, 1e-8, 1, 1.0, 0.0, None, None),
+        "adam_step_multi": lambda: L.msam2_adam_step_multi(None, None, None, None, None, 0, 1e-4, 0.9, 0.999, 1e-8, 1, 1.0, 0.0, None, None, None),
     }
     for what, call in cases.items():
         rc = call()

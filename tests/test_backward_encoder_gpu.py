@@ -204,6 +204,48 @@ def test_train_step_2d_with_image_encoder():
     assert all(torch.isfinite(v).all() for v in m.state_dict().values())
 
 
+def test_graphed_step_detects_scale_drift_and_recalibrates():
+    """the power-of-two loss scales are calibrated once and frozen into the captured graph.  Every link records its scaled
+    max|gradient| on the device inside the step and Adam counts skipped non-finite elements; `GraphedStep.drift()` reads them, and with
+    an eager step function given a drift triggers a fresh calibration + capture."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import medical_sam2_amd.synthetic as syn
+    import medical_sam2_amd.training as T
+    m, _ = _model()
+    B, S, E = 2, 256, 16
+    imgs = torch.stack([syn.normalize_image(syn.blob_image(i, S)[0]) for i in range(B)])
+    pts, labels = torch.tensor([[[100.0, 120.0]], [[60.0, 200.0]]]), torch.ones(B, 1, dtype=torch.int32)
+    memory, memory_pos = rnd(2 * E * E, B, 64, seed=150, scale=0.5), rnd(2 * E * E, B, 64, seed=151)
+    target = (rnd(B, 4, S // 4, S // 4, seed=152) > 0.3).float()
+    args = tuple(t.to(DEV) for t in (imgs, pts, labels, memory, memory_pos, target))
+    with torch.no_grad():
+        opts = [T.DecoderAdam(m.memory_attention, lr=1e-6), T.DecoderAdam(m.sam_mask_decoder, lr=1e-5), T.DecoderAdam(m.image_encoder, lr=1e-6)]
+        step = lambda sync: T.train_step_2d(m, opts[0], opts[1], *args, sync=sync, opt_enc=opts[2])
+        step(True)                                                # eager: calibrates
+        gs = T.GraphedStep(lambda: step(False), opts, eager_fn=lambda: step(True), check_every=2)
+        mon = opts[0].scale_monitor["_amax"]
+        blocks = opts[2].calibrated_block_scales[None]["_amax"]
+        assert "mem_scale" in mon and any(k.startswith("block") for k in blocks) and any(k.startswith("neck") for k in blocks)
+        gs.replay()
+        assert 2.0 ** -5 < float(mon["mem_scale"].item()) <= 2.0 ** -2        # calibration put the maximum at 2^-3; one step later it still is
+        gs.replay()                                               # second replay: the periodic check runs, nothing drifted
+        assert gs.recalibrations == 0 and gs.drift() == {}
+        assert all(o.skipped_elements == 0 for o in opts)
+        # simulate what a drifting gradient does to the monitor (a link 2^9 above its calibration point) -> check() recalibrates
+        blocks["block3"].fill_(2.0 ** 6)
+        d = gs.check()
+        assert list(d) == ["block3"] and gs.recalibrations == 1
+        loss = gs.replay()[0]
+        assert torch.isfinite(loss).all() and gs.drift() == {}
+        # a non-finite gradient element is skipped by Adam AND counted
+        bad = {k: torch.full_like(v, float("nan")) for k, v in list(m.sam_mask_decoder.named_parameters())[:1]}
+        opts[1].step(bad)
+        assert opts[1].skipped_elements == next(iter(bad.values())).numel()
+        assert gs.drift().get("skipped_elements") == next(iter(bad.values())).numel()
+    assert all(torch.isfinite(v).all() for v in m.state_dict().values())
+
+
 def test_train_step_2d_hiera_bplus():
     """BASELINE configs[4]'s model through the whole 2-D training iteration (train_2d.py:43-47 trains every parameter): Hiera-B+ -- 24 blocks,
     head dim 56 zero-padded to 64 in the attention forward AND backward, 14 x 14 position embedding -- runs, moves the three groups, stays

@@ -903,6 +903,48 @@ def test_dropout_kernel_stream(mods):
     assert torch.equal(ops.dropout(x, 0.0, 7, 0), x)
 
 
+def test_graph_replays_of_a_train_mode_forward_draw_fresh_dropout_masks(mods):
+    """ADVICE r2 (training.py GraphedStep): the dropout sub-stream counter lives on the device and is advanced by a kernel of the forward
+    itself, so a hipGraph REPLAY of a captured train-mode step draws new masks (a by-value seed would be baked into the graph and every
+    replay would re-apply the captured masks); the backward of the same replay re-creates the forward's masks from the snapshot."""
+    B_, ops = mods
+    import medical_sam2_amd.build_sam as bs
+    import medical_sam2_amd.weights as wts
+    m = bs.build_sam2("sam2_hiera_t", device="cpu", hydra_overrides_extra=["++model.image_size=256"])
+    m.load_state_dict(wts.init_weights("hiera_t", 0), strict=True)
+    ma = m.memory_attention.to(DEV).train()
+    B, L, C = 1, 256, 256
+    d = lambda t: t.to(DEV)
+    curr, curr_pos, memory, memory_pos = d(rnd(L, B, C, seed=1)), d(rnd(L, B, C, seed=2)), d(rnd(L, B, 64, seed=3)), d(rnd(L, B, 64, seed=4))
+    dy = d(rnd(L, B, C, seed=5))
+
+    def step():
+        y, state = B_.memory_attention_forward_saved(ma, curr, curr_pos, memory, memory_pos, 0, dropout=ma.next_dropout())
+        dcurr, _, _, _ = B_.memory_attention_backward_saved(ma, state, dy)
+        return y, dcurr
+
+    with torch.no_grad():
+        ma.dropout_seed, ma._dropout_calls = 5, 0
+        e1, g1 = (t.clone() for t in step())             # eager forwards 1, 2, 3 of the stream
+        e2, g2 = (t.clone() for t in step())
+        e3, g3 = (t.clone() for t in step())
+        ma._dropout_calls = 0                            # rewind the stream (re-loads the device counter)
+        w, _ = step()                                    # call 1 again, eagerly
+        assert torch.equal(w, e1)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = step()
+        graph.replay()
+        r2 = [t.clone() for t in out]
+        graph.replay()
+        r3 = [t.clone() for t in out]
+    assert not torch.equal(e1, e2) and not torch.equal(e2, e3)
+    # replays continue the stream exactly where eager calls would: masks (forward) and their re-creation (backward) of calls 2 and 3
+    assert torch.equal(r2[0], e2) and torch.equal(r3[0], e3)
+    assert torch.equal(r2[1], g2) and torch.equal(r3[1], g3)
+
+
 def test_memory_attention_train_mode_dropout(mods):
     """MemoryAttention in train() mode (dropout 0.1 on three residual branches, inside the FFN and on both attentions' probabilities:
     memory_attention.py:40-48,63,80,97-98, transformer.py:317-318): forward output and every parameter / input gradient against

@@ -94,6 +94,19 @@ def _worker(rank, world, port, q):
     for i, (k, sh) in enumerate(shapes.items()):
         want = sum(gen(r, i, sh) for r in range(world))
         ok &= red[k].shape == want.shape and torch.allclose(red[k], want, atol=1e-6)
+    # ragged gradient dictionaries (every rank on its own volume -> different groups / parameters reached): the ranks agree on
+    # the union first, absent entries are zero-filled, a group nobody reached stays empty, and the reductions then pair up
+    mods = {"dec": torch.nn.Linear(3, 2), "mem": torch.nn.Linear(4, 1), "ptr": torch.nn.Linear(2, 2)}
+    sg = {"dec": {"weight": torch.full((2, 3), 1.0 + rank)}, "mem": ({"weight": torch.ones(1, 4), "bias": torch.ones(1)} if rank == 1 else {}), "ptr": {}}
+    if rank == 0:
+        sg["dec"]["bias"] = torch.full((2,), 5.0)
+    un = par.union_gradient_keys(sg, mods, ("dec", "mem", "ptr"))
+    ok &= [sorted(un[g]) for g in ("dec", "mem", "ptr")] == [["bias", "weight"], ["bias", "weight"], []]
+    red = {g: par.allreduce_gradients(un[g])[0] for g in ("dec", "mem", "ptr")}
+    ok &= bool((red["dec"]["weight"] == 3.0).all()) and bool((red["dec"]["bias"] == 5.0).all()) and bool((red["mem"]["weight"] == 1.0).all())
+    ok &= red["ptr"] == {}
+    # a volume whose slices are ALL conditioning slices has no features to exchange (was StopIteration on multi-rank)
+    ok &= par.gather_slice_features({}, [], []) == {}
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 

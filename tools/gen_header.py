@@ -61,9 +61,10 @@ DOC = {
     "msam2_sumpool2x2": "Adjoint of msam2_upsample2x_add (FPN nearest-2x top-down step, image_encoder.py:113-124): sums of the 2x2 blocks.",
     "msam2_hiera_pos_embed_bwd": "Adjoint of msam2_hiera_pos_embed (hieradet.py:269-277): gradient of the position-token table -> d pos_embed (transposed bicubic\nresize) and d pos_embed_window (sum over the tiling).  Two gather passes through a caller-owned workspace, no atomics.",
     "msam2_hiera_pos_embed_bwd_workspace_bytes": "Scratch needed by msam2_hiera_pos_embed_bwd (per-row partial sums).",
-    "msam2_dropout": "Train-mode nn.Dropout / SDPA dropout_p (memory_attention.py:40-48,63,80,97-98; transformer.py:317-318): y = keep ? x / (1 - p) : 0\n(+ fp32 residual) with a counter-based mask -- element i of stream (seed, offset) -- so the backward re-creates the forward's mask by\ncalling it on the gradient with the same (seed, offset).",
+    "msam2_dropout": "Train-mode nn.Dropout / SDPA dropout_p (memory_attention.py:40-48,63,80,97-98; transformer.py:317-318): y = keep ? x / (1 - p) : 0\n(+ fp32 residual) with a counter-based mask -- element i of stream (seed, offset) -- so the backward re-creates the forward's mask by\ncalling it on the gradient with the same (seed, offset).  seed_dev (optional device uint64): added to `seed` on the device, see\nmsam2_counter_bump.",
+    "msam2_counter_bump": "*counter += 1 on the device (uint64), the new value copied to *snapshot (optional): the per-forward sub-stream counter of the\ntrain-mode dropout (MemoryAttention in train(), memory_attention.py:40-48), advanced by a kernel of the step itself so that a hipGraph\nreplay of a training step draws fresh masks -- pass the snapshot as msam2_dropout's seed_dev.",
     "msam2_adam_step": "One torch.optim.Adam step (no weight decay / amsgrad) on a flat fp32 parameter (train_3d.py:50).",
-    "msam2_adam_step_multi": "The same Adam step over `count` parameters (host arrays of device pointers and element counts), 24 per launch;\ngradients are multiplied by grad_scale first (1 / loss scale);\nstep_counter (device int32, optional): the step count lives on the device and is incremented by the call (a kernel), so a captured\nhipGraph advances the bias corrections on every replay; non-finite gradient entries are skipped;\nweight_decay > 0 gives torch.optim.AdamW's decoupled decay (train_2d.py:43-47), 0 plain Adam (train_3d.py:50-54).",
+    "msam2_adam_step_multi": "The same Adam step over `count` parameters (host arrays of device pointers and element counts), 24 per launch;\ngradients are multiplied by grad_scale first (1 / loss scale);\nstep_counter (device int32, optional): the step count lives on the device and is incremented by the call (a kernel), so a captured\nhipGraph advances the bias corrections on every replay; non-finite gradient entries are skipped (and counted into skipped_counter, device int32, optional);\nweight_decay > 0 gives torch.optim.AdamW's decoupled decay (train_2d.py:43-47), 0 plain Adam (train_3d.py:50-54).",
     "msam2_attention_small_bwd": "Backward of the two-way decoder's attention (transformer.py:239-263 under autograd; 8 heads of 16 / 32 channels) when one side has\n<= 32 tokens: dq / dk / dv (fp32, token-major) from 16-bit q / k / v and the fp32 upstream gradient, one workgroup per (batch, head).",
     "msam2_seg_counts": "Counts behind eval_seg (func_3d/utils.py:139-214, func_2d/utils.py:505-580): per threshold, batch element and class the\ninteger |pred>t & gt>t|, |pred>t|, |gt>t| in one pass; IoU / Dice follow on the host.",
     "msam2_non_overlap": "SAM2Base._apply_non_overlapping_constraints (sam2_base.py:812-830): keep the arg-max object per pixel, clamp the\nothers to <= -10.",
