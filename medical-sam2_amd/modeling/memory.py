@@ -293,6 +293,11 @@ class MemoryAttention(nn.Module):
             curr, curr_pos = curr[0], curr_pos[0]
         assert curr.shape[1] == memory.shape[1], "Batch size must be the same for curr and memory"
         L, B, C = curr.shape
+        from .. import autograd as ag
+        if ag.active(self) and key_count is None:
+            # train() + grad mode (the reference's training loops): the grad-carrying form, dropout drawn inside
+            pos = curr_pos if (curr_pos is not None and self.pos_enc_at_input) else torch.zeros_like(curr)
+            return ag.memory_attention(self, curr, pos, memory, memory_pos, num_obj_ptr_tokens)
         drop = self.next_dropout()
         if drop is not None:
             # train mode: the dropout-carrying path of the training steps (backward.memory_attention_forward_saved), forward half only

@@ -129,7 +129,10 @@ class SAM2Base(nn.Module):
 
     # ---------------------------------------------------------------------------------------------------------------
     def forward_image(self, img_batch: torch.Tensor):
-        """sam2_base.py:464-476."""
+        """sam2_base.py:464-476.  train() + grad mode: the grad-carrying form (autograd.py)."""
+        from .. import autograd as ag
+        if ag.active(self):
+            return ag.forward_image(self, img_batch)
         if not self.use_high_res_features_in_sam:
             return self.image_encoder(img_batch)
         # conv_s0 / conv_s1 (sam2_base.py:470-475) are folded into the neck's lateral convs of levels 0 / 1 (FpnNeck.forward)
@@ -153,6 +156,9 @@ class SAM2Base(nn.Module):
                            multimask_output=False):
         """sam2_base.py:252-410.  Returns the same 7-tuple; the multimask high-res maps are up-sampled from all candidates
         (as the reference does) and the best one is a view into them."""
+        from .. import autograd as ag
+        if ag.active(self):
+            return ag.forward_sam_heads(self, backbone_features, point_inputs, mask_inputs, high_res_features, multimask_output)
         B = backbone_features.size(0)
         device = backbone_features.device
         E = self.sam_image_embedding_size
@@ -326,6 +332,9 @@ class SAM2Base(nn.Module):
 
     def _encode_new_memory(self, current_vision_feats, feat_sizes, pred_masks_high_res, is_mask_from_pts):
         """sam2_base.py:665-703; the sigmoid / binarise + scale + bias is fused into the first down-sampler conv."""
+        from .. import autograd as ag
+        if ag.active(self):
+            return ag.encode_new_memory(self, current_vision_feats, feat_sizes, pred_masks_high_res, is_mask_from_pts)
         B = current_vision_feats[-1].size(1)
         C = self.hidden_dim
         H, W = feat_sizes[-1]
@@ -343,7 +352,14 @@ class SAM2Base(nn.Module):
     def track_step(self, frame_idx, is_init_cond_frame, current_vision_feats, current_vision_pos_embeds, feat_sizes, point_inputs,
                    mask_inputs, output_dict, num_frames, track_in_reverse=False, run_mem_encoder=True, prev_sam_mask_logits=None,
                    memory_selection=None):
-        """sam2_base.py:705-800.  memory_selection: see _prepare_memory_conditioned_features (not part of the reference's signature)."""
+        """sam2_base.py:705-800.  memory_selection: see _prepare_memory_conditioned_features (not part of the reference's signature).
+        In train() mode with gradients enabled -- the state the reference's training loops put the net in -- the step runs through
+        `autograd.track_step`: the same control flow with every module behind a torch.autograd.Function, so the returned tensors carry a
+        graph and `loss.backward()` reaches the parameters (func_3d/function.py:176-186)."""
+        from .. import autograd as ag
+        if ag.active(self) and memory_selection is None:
+            return ag.track_step(self, frame_idx, is_init_cond_frame, current_vision_feats, current_vision_pos_embeds, feat_sizes,
+                                 point_inputs, mask_inputs, output_dict, num_frames, track_in_reverse, run_mem_encoder, prev_sam_mask_logits)
         current_out = {"point_inputs": point_inputs, "mask_inputs": mask_inputs}
         if len(current_vision_feats) > 1:
             high_res_features = [x.permute(1, 2, 0).view(x.size(1), x.size(2), *s)

@@ -395,6 +395,13 @@ class MaskDecoder(nn.Module):
             high_res_features = hr
         B, C, h, w = image_embeddings.shape
         assert sparse_prompt_embeddings.shape[0] == B, "one prompt set per (repeated) image embedding"
+        from .. import autograd as ag
+        if ag.active(self):
+            # train() + grad mode (func_2d/function.py:140-170 calls this module directly): differentiable glue + the decoder's Function
+            src = tokens_of(image_embeddings.to(F32)).view(B, h * w, C) + tokens_of(dense_prompt_embeddings.to(F32).expand(B, C, h, w)).view(B, h * w, C)
+            f0, f1 = high_res_features
+            return ag.mask_decoder(self, src.reshape(B * h * w, C), tokens_of(image_pe.to(F32))[: h * w].detach(), sparse_prompt_embeddings.to(F32),
+                                   tokens_of(f0), tokens_of(f1), B, h, w)
         emb = image_embeddings.to(F32)
         dense = dense_prompt_embeddings.to(F32).expand(B, C, h, w)
         # image embedding + dense prompt embedding -> token-major fp32 (the spatially constant no-mask embedding is read as a

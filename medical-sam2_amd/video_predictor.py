@@ -15,8 +15,11 @@ What is re-designed without changing any result:
   * frames are normalised on the device by one kernel-free broadcast; hole filling runs the batched HIP connected-components
     path (`ops.fill_holes_`); resizing uses the HIP bilinear kernel.
 The `train_*` entry points of the fork (179-248, 425-555, 641-722, 971-1039, 1126-1208: the same code without
-`torch.inference_mode`) are aliases of the forward path; training on the HIP path goes through `training.py` (explicit backward, no
-autograd graph), not through the predictor.
+`torch.inference_mode`) are the same method bodies run WITHOUT `torch.no_grad()`: with the net in `train()` mode every `track_step` /
+`_encode_new_memory` / `forward_image` then goes through the torch.autograd bridge (`autograd.py`), the state machine's own arithmetic
+(resizes, per-object consolidation, hole filling) stays differentiable torch, and the loop of `func_3d/function.py:130-191` --
+`train_add_new_* -> train_propagate_in_video -> non_prompt_loss.backward(retain_graph=True) / prompt_loss.backward() ->
+optimizer.step()` -- runs against this class as written.  (The explicit, graph-capturable training steps live in `training*.py`.)
 
 PROVENANCE: this file is a DERIVED work, not a re-design.  SURVEY.md section 2 #13 marks the predictor state machine "keep as-is": its
 `inference_state` dictionary layout, method signatures and the order of the consolidation / preflight / propagation steps ARE the
@@ -127,8 +130,7 @@ class SAM2VideoPredictor(SAM2Base):
         images, h, w = load_video_frames(video_path, self.image_size, offload_video_to_cpu, async_loading_frames)
         return self._new_state(images, h, w, offload_video_to_cpu, offload_state_to_cpu)
 
-    @torch.no_grad()
-    def val_init_state(self, imgs_tensor, video_height=None, video_width=None, offload_video_to_cpu=False,
+    def _val_init_state(self, imgs_tensor, video_height=None, video_width=None, offload_video_to_cpu=False,
                        offload_state_to_cpu=False, async_loading_frames=False):
         if video_height is None or video_width is None:
             video_height = video_width = self.image_size
@@ -172,8 +174,7 @@ class SAM2VideoPredictor(SAM2Base):
         _, video_res_masks = self._get_orig_video_res_output(inference_state, consolidated_out["pred_masks_video_res"])
         return frame_idx, inference_state["obj_ids"], video_res_masks
 
-    @torch.no_grad()
-    def add_new_points(self, inference_state, frame_idx, obj_id, points, labels, clear_old_points=True, normalize_coords=True):
+    def _add_new_points(self, inference_state, frame_idx, obj_id, points, labels, clear_old_points=True, normalize_coords=True):
         obj_idx = self._obj_id_to_idx(inference_state, obj_id)
         point_inputs_per_frame = inference_state["point_inputs_per_obj"][obj_idx]
         mask_inputs_per_frame = inference_state["mask_inputs_per_obj"][obj_idx]
@@ -212,16 +213,14 @@ class SAM2VideoPredictor(SAM2Base):
         obj_temp_output_dict[storage_key][frame_idx] = current_out
         return self._finish_interaction(inference_state, frame_idx, is_cond)
 
-    @torch.no_grad()
-    def add_new_bbox(self, inference_state, frame_idx, obj_id, bbox, clear_old_points=True, normalize_coords=True):
+    def _add_new_bbox(self, inference_state, frame_idx, obj_id, bbox, clear_old_points=True, normalize_coords=True):
         if not isinstance(bbox, torch.Tensor):
             bbox = torch.tensor(bbox, dtype=F32)
-        return self.add_new_points(inference_state=inference_state, frame_idx=frame_idx, obj_id=obj_id, points=bbox.reshape(-1, 2, 2),
+        return self._add_new_points(inference_state=inference_state, frame_idx=frame_idx, obj_id=obj_id, points=bbox.reshape(-1, 2, 2),
                                    labels=torch.tensor([2, 3], dtype=torch.int), clear_old_points=clear_old_points,
                                    normalize_coords=normalize_coords)
 
-    @torch.no_grad()
-    def add_new_mask(self, inference_state, frame_idx, obj_id, mask):
+    def _add_new_mask(self, inference_state, frame_idx, obj_id, mask):
         obj_idx = self._obj_id_to_idx(inference_state, obj_id)
         point_inputs_per_frame = inference_state["point_inputs_per_obj"][obj_idx]
         mask_inputs_per_frame = inference_state["mask_inputs_per_obj"][obj_idx]
@@ -251,6 +250,8 @@ class SAM2VideoPredictor(SAM2Base):
         """F.interpolate(mode="bilinear", align_corners=False) on [n,1,h,w] fp32 (HIP kernel)."""
         if masks.shape[-2:] == (H, W):
             return masks
+        if torch.is_grad_enabled() and masks.requires_grad:      # train_* twins: keep the graph (same arithmetic, torch's kernel)
+            return torch.nn.functional.interpolate(masks.to(F32), size=(H, W), mode="bilinear", align_corners=False)
         return ops.bilinear_upsample(masks.to(F32).contiguous(), H, W)
 
     def _get_orig_video_res_output(self, inference_state, any_res_masks):
@@ -316,8 +317,7 @@ class SAM2VideoPredictor(SAM2Base):
         return current_out["obj_ptr"]
 
     # -------------------------------------------------------------------------------------------------------- propagation
-    @torch.no_grad()
-    def propagate_in_video_preflight(self, inference_state):
+    def _propagate_in_video_preflight(self, inference_state):
         inference_state["tracking_has_started"] = True
         batch_size = self._get_obj_num(inference_state)
         temp_output_dict_per_obj = inference_state["temp_output_dict_per_obj"]
@@ -356,9 +356,8 @@ class SAM2VideoPredictor(SAM2Base):
             input_frames_inds.update(per_frame.keys())
         assert all_consolidated == input_frames_inds
 
-    @torch.no_grad()
-    def propagate_in_video(self, inference_state, start_frame_idx=None, max_frame_num_to_track=None, reverse=False):
-        self.propagate_in_video_preflight(inference_state)
+    def _propagate_in_video(self, inference_state, start_frame_idx=None, max_frame_num_to_track=None, reverse=False):
+        self._propagate_in_video_preflight(inference_state)
         output_dict = inference_state["output_dict"]
         consolidated_frame_inds = inference_state["consolidated_frame_inds"]
         obj_ids = inference_state["obj_ids"]
@@ -509,7 +508,12 @@ class SAM2VideoPredictor(SAM2Base):
             maskmem_features = maskmem_features.to(storage_device, non_blocking=True)
         pred_masks_gpu = current_out["pred_masks"]
         if self.fill_hole_area > 0:
-            pred_masks_gpu = ops.fill_holes_(pred_masks_gpu.to(F32).contiguous().clone(), self.fill_hole_area)
+            filled = ops.fill_holes_(pred_masks_gpu.detach().to(F32).contiguous().clone(), self.fill_hole_area)
+            if torch.is_grad_enabled() and pred_masks_gpu.requires_grad:
+                # torch.where(is_hole, 0.1, mask) of utils/misc.py:247-258: the gradient flows through the pixels that were kept
+                pred_masks_gpu = torch.where(filled != pred_masks_gpu.detach(), filled, pred_masks_gpu)
+            else:
+                pred_masks_gpu = filled
         pred_masks = pred_masks_gpu.to(storage_device, non_blocking=True)
         compact_current_out = {"maskmem_features": maskmem_features, "maskmem_pos_enc": self._get_maskmem_pos_enc(inference_state, current_out),
                                "pred_masks": pred_masks, "obj_ptr": current_out["obj_ptr"]}
@@ -542,10 +546,17 @@ class SAM2VideoPredictor(SAM2Base):
             for obj_output_dict in inference_state["output_dict_per_obj"].values():
                 obj_output_dict["non_cond_frame_outputs"].pop(t, None)
 
-    # the fork's gradient-enabled twins: same forward (no backward on this path yet)
-    train_init_state = val_init_state
-    train_add_new_points = add_new_points
-    train_add_new_bbox = add_new_bbox
-    train_add_new_mask = add_new_mask
-    train_propagate_in_video_preflight = propagate_in_video_preflight
-    train_propagate_in_video = propagate_in_video
+    # public entry points: the inference forms run under torch.no_grad() (the reference: torch.inference_mode), the fork's train_*
+    # twins are the SAME bodies in the caller's gradient mode (sam2_video_predictor.py:179-248, 425-555, 641-722, 971-1039, 1126-1208)
+    val_init_state = torch.no_grad()(_val_init_state)
+    add_new_points = torch.no_grad()(_add_new_points)
+    add_new_bbox = torch.no_grad()(_add_new_bbox)
+    add_new_mask = torch.no_grad()(_add_new_mask)
+    propagate_in_video_preflight = torch.no_grad()(_propagate_in_video_preflight)
+    propagate_in_video = torch.no_grad()(_propagate_in_video)
+    train_init_state = _val_init_state
+    train_add_new_points = _add_new_points
+    train_add_new_bbox = _add_new_bbox
+    train_add_new_mask = _add_new_mask
+    train_propagate_in_video_preflight = _propagate_in_video_preflight
+    train_propagate_in_video = _propagate_in_video

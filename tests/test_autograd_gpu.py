@@ -1,0 +1,281 @@
+"""The reference's training loops run against the drop-in modules AS WRITTEN (VERDICT r2 row +2, north_star: "the predictor/trainer API is
+a drop-in"): `loss.backward()` + `torch.optim` through the torch.autograd bridge (medical_sam2_amd/autograd.py), whose Functions call the
+explicit HIP backward of every module.
+
+  * a loop with the shape of func_3d/function.py:130-191 on `SAM2Base.track_step` (net.train(), BCEWithLogitsLoss per slice,
+    non_prompt_loss.backward(retain_graph=True), optimizer2.step(), prompt_loss.backward(), optimizer1.step(), two torch.optim.Adam built
+    like train_3d.py:34-54): the `.grad`s equal the explicit BPTT of training_3d (which tests/test_bptt_gpu.py pins to the reference's own
+    autograd, tests/golden/grads_bptt_t256.npz) and are checked against that fixture directly; the Adam update equals train_step_3d's;
+  * the same loop through `SAM2VideoPredictor.train_init_state / train_add_new_bbox / train_propagate_in_video`;
+  * the 2-D loop's module calls (func_2d/function.py:70-259: forward_image -> memory_attention -> sam_mask_decoder -> losses.backward()).
+"""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from test_bptt_gpu import GROUP_OF, _case, rel_sub  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def reference_optimizers(net):
+    """train_3d.py:34-54"""
+    sam_layers = list(net.sam_mask_decoder.parameters())
+    mem_layers = (list(net.obj_ptr_proj.parameters()) + list(net.memory_encoder.parameters()) + list(net.memory_attention.parameters())
+                  + list(net.mask_downsample.parameters()))
+    optimizer1 = torch.optim.Adam(sam_layers, lr=1e-4, betas=(0.9, 0.999), eps=1e-08, weight_decay=0, amsgrad=False)
+    optimizer2 = torch.optim.Adam(mem_layers, lr=1e-8, betas=(0.9, 0.999), eps=1e-08, weight_decay=0, amsgrad=False)
+    return optimizer1, optimizer2
+
+
+def test_reference_shaped_3d_loop_on_track_step_matches_the_explicit_bptt():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import medical_sam2_amd.ops as ops
+    import medical_sam2_amd.training as tr
+    import medical_sam2_amd.training_3d as t3
+    from medical_sam2_amd.volume import box_point_inputs
+    net, G, meta, volume, prompts, targets = _case()                      # net.train(), every dropout 0 (the fixture's deterministic mode)
+    fp16 = ops.OP16 == torch.float16
+    twin = copy.deepcopy(net)                                             # the explicit path steps a copy of the same weights
+    T, S, n = meta["n_slices"], meta["image_size"], meta["n_objects"]
+    optimizer1, optimizer2 = reference_optimizers(net)
+    optimizer1.zero_grad()
+    optimizer2.zero_grad()
+    lossfunc = torch.nn.BCEWithLogitsLoss(pos_weight=torch.ones([1]).cuda(DEV) * meta["pos_weight"])
+    prompt_frame_id = sorted(prompts)
+    output_dict = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
+    video_segments = {}
+    for t in prompt_frame_id + [t for t in range(T) if t not in prompts]:
+        bo = net.forward_image(volume[t][None])
+        bo = {"backbone_fpn": [f.expand(n, -1, -1, -1) for f in bo["backbone_fpn"]], "vision_pos_enc": [q.expand(n, -1, -1, -1) for q in bo["vision_pos_enc"]]}
+        _, feats, pos, sizes = net._prepare_backbone_features(bo)
+        pin = None
+        if t in prompts:
+            pr = prompts[t]
+            pin = box_point_inputs(pr["boxes"]) if "boxes" in pr else {"point_coords": pr["point_coords"], "point_labels": pr["point_labels"]}
+        cur = net.track_step(frame_idx=t, is_init_cond_frame=t in prompts, current_vision_feats=feats, current_vision_pos_embeds=pos,
+                             feat_sizes=sizes, point_inputs=pin, mask_inputs=None, output_dict=output_dict, num_frames=T)
+        output_dict["cond_frame_outputs" if t in prompts else "non_cond_frame_outputs"][t] = cur
+        assert cur["pred_masks"].grad_fn is not None and cur["maskmem_features"].grad_fn is not None and cur["obj_ptr"].grad_fn is not None
+        video_segments[t] = F.interpolate(cur["pred_masks"], size=(S, S), mode="bilinear", align_corners=False)
+    prompt_loss = non_prompt_loss = 0
+    for t in range(T):
+        for o in range(n):
+            obj_loss = lossfunc(video_segments[t][o][None], targets[t][o][None])
+            if t in prompt_frame_id:
+                prompt_loss = prompt_loss + obj_loss
+            else:
+                non_prompt_loss = non_prompt_loss + obj_loss
+    non_prompt_loss = non_prompt_loss / (T - len(prompt_frame_id)) / n
+    prompt_loss = prompt_loss / len(prompt_frame_id) / n
+    assert abs(float(non_prompt_loss) - float(G["non_prompt_loss"][0])) < 1e-2 and abs(float(prompt_loss) - float(G["prompt_loss"][0])) < 1e-2
+    non_prompt_loss.backward(retain_graph=True)
+    # ---- `.grad` after the first backward = the non-prompt gradient of every group: against the explicit BPTT and the reference fixture
+    named = dict(net.named_parameters())
+    out = {}
+    with torch.no_grad():
+        opts = {"decoder": tr.DecoderAdam(twin.sam_mask_decoder, lr=1e-4), "memory_attention": tr.DecoderAdam(twin.memory_attention, lr=1e-8),
+                "memory_encoder": tr.DecoderAdam(twin.memory_encoder, lr=1e-8), "obj_ptr_proj": tr.DecoderAdam(twin.obj_ptr_proj, lr=1e-8)}
+        t3.train_step_3d(twin, opts, volume, prompts, targets, pos_weight=meta["pos_weight"], grads_out=out)
+    prefix = {v: k for k, v in GROUP_OF.items()}
+    worst_explicit, worst_fixture = {}, {}
+    for grp, gd in out["non_prompt"].items():
+        num = den = 0.0
+        for pname, g in gd.items():
+            if pname.startswith("conv_s"):
+                continue
+            got = named[f"{prefix[grp]}.{pname}"].grad
+            assert got is not None, (grp, pname)
+            num += float((got.double() - g.double()).pow(2).sum())
+            den += float(g.double().pow(2).sum())
+        worst_explicit[grp] = (num / max(den, 1e-60)) ** 0.5
+    for k in G:
+        if not k.startswith("non_prompt."):
+            continue
+        _, gname, pname = k.split(".", 2)
+        if gname == "sam_mask_decoder" or pname.endswith("k_proj.bias") or meta["grad_stats"][k]["abs_sum"] < 1e-7:
+            continue                                                       # (the decoder's chained gradient: compared with the explicit path above)
+        worst_fixture[gname + "." + pname] = rel_sub(named[f"{gname}.{pname}"].grad, G[k])
+    print("autograd loop vs explicit BPTT (relative L2 per group):", worst_explicit)
+    print("autograd loop vs the reference's own .grad fixture, memory groups, worst:", sorted(worst_fixture.items(), key=lambda kv: -kv[1])[:5])
+    assert all(v < (0.02 if fp16 else 0.1) for v in worst_explicit.values()), worst_explicit
+    assert len(worst_fixture) > 100 and max(worst_fixture.values()) < (0.06 if fp16 else 0.3)
+    # the image encoder is under grad in the reference's loop too (nothing steps it): its gradient arrived and is finite
+    enc_grads = [p.grad for p in net.image_encoder.parameters() if p.grad is not None]
+    assert len(enc_grads) > 100 and all(torch.isfinite(g).all() for g in enc_grads)
+    # ---- the rest of function.py:176-191
+    optimizer2.step()
+    prompt_loss.backward()
+    optimizer1.step()
+    optimizer1.zero_grad()
+    optimizer2.zero_grad()
+    # the update of every stepped parameter equals train_step_3d's (torch.optim.Adam vs the HIP Adam kernel, first step = +-lr per element
+    # wherever |g| >> eps): compared as the fraction of elements whose update has the same sign and size
+    before = dict(_case()[0].named_parameters())
+    agree = {}
+    for (k, p), (_, q) in zip(net.named_parameters(), twin.named_parameters()):
+        grp = k.split(".")[0]
+        if grp not in prefix.values() or ".conv_s" in k:
+            continue
+        d1, d2 = (p - before[k]).detach(), (q - before[k]).detach()
+        moved = d2 != 0
+        if moved.any():
+            agree.setdefault(grp, []).append(float(((d1 - d2).abs() <= 0.05 * d2.abs().max()).float()[moved].mean()))
+    print("fraction of elements with the same Adam update:", {g: min(v) for g, v in agree.items()})
+    assert set(agree) == {"sam_mask_decoder", "memory_attention", "memory_encoder", "obj_ptr_proj"}
+    assert all(np.mean(v) > 0.97 for v in agree.values()), {g: np.mean(v) for g, v in agree.items()}
+    assert all(torch.isfinite(p).all() for p in net.parameters())
+
+
+def test_func_3d_loop_through_the_video_predictor_train_entry_points():
+    """func_3d/function.py:58-191 against SAM2VideoPredictor: train_init_state, train_add_new_bbox per object, train_propagate_in_video,
+    the per-object loss sums, both backward passes and both optimisers; three iterations lower the loss and move exactly the four groups."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import medical_sam2_amd.build_sam as bs
+    import medical_sam2_amd.synthetic as syn
+    import medical_sam2_amd.weights as wts
+    from test_bptt_gpu import box_target
+    S, video_length, prompt_freq, n_obj = 256, 4, 2, 2
+    net = bs.build_sam2_video_predictor("sam2_hiera_t", device="cpu", hydra_overrides_extra=[f"++model.image_size={S}"])
+    net.load_state_dict(wts.init_weights("hiera_t", 0), strict=True)
+    net = net.to(DEV)
+    net.image_encoder.requires_grad_(False)          # (saves the encoder's backward; no optimiser of train_3d.py steps it)
+    optimizer1, optimizer2 = reference_optimizers(net)
+    lossfunc = torch.nn.BCEWithLogitsLoss(pos_weight=torch.ones([1]).cuda(DEV) * 2)
+    volume, boxes = syn.blob_volume(3, n_slices=video_length, size=S, n_objects=n_obj, normalised=False)
+    dflt = (S * 0.3, S * 0.3, S * 0.6, S * 0.6)
+    bbox_dict = {t: {o: torch.tensor([[float(v) for v in (boxes[o][t] or dflt)]]) for o in range(n_obj)} for t in range(video_length)}
+    mask_dict = {t: {o: box_target(boxes[o][t], S)[None] for o in range(n_obj)} for t in range(video_length)}
+    before = {k: p.detach().clone() for k, p in net.named_parameters()}
+    net.train()
+    optimizer1.zero_grad()
+    optimizer2.zero_grad()
+    history = []
+    for _ in range(3):
+        imgs_tensor = volume.to(dtype=torch.float32, device=DEV)
+        train_state = net.train_init_state(imgs_tensor=imgs_tensor)
+        prompt_frame_id = list(range(0, video_length, prompt_freq))
+        obj_list = list(range(n_obj))
+        for id in prompt_frame_id:
+            for ann_obj_id in obj_list:
+                _, _, _ = net.train_add_new_bbox(inference_state=train_state, frame_idx=id, obj_id=ann_obj_id,
+                                                 bbox=bbox_dict[id][ann_obj_id].to(device=DEV), clear_old_points=False)
+        video_segments = {}
+        for out_frame_idx, out_obj_ids, out_mask_logits in net.train_propagate_in_video(train_state, start_frame_idx=0):
+            video_segments[out_frame_idx] = {out_obj_id: out_mask_logits[i] for i, out_obj_id in enumerate(out_obj_ids)}
+        loss, non_prompt_loss, prompt_loss = 0, 0, 0
+        for id in range(video_length):
+            for ann_obj_id in obj_list:
+                pred = video_segments[id][ann_obj_id].unsqueeze(0)
+                assert pred.grad_fn is not None
+                mask = mask_dict[id][ann_obj_id].to(dtype=torch.float32, device=DEV)
+                obj_loss = lossfunc(pred, mask)
+                loss += obj_loss.item()
+                if id in prompt_frame_id:
+                    prompt_loss += obj_loss
+                else:
+                    non_prompt_loss += obj_loss
+        loss = loss / video_length / len(obj_list)
+        non_prompt_loss = non_prompt_loss / (video_length - len(prompt_frame_id)) / len(obj_list)
+        prompt_loss = prompt_loss / len(prompt_frame_id) / len(obj_list)
+        non_prompt_loss.backward(retain_graph=True)
+        optimizer2.step()
+        prompt_loss.backward()
+        optimizer1.step()
+        optimizer1.zero_grad()
+        optimizer2.zero_grad()
+        net.reset_state(train_state)
+        history.append(loss)
+    print("loss per iteration:", history)
+    assert history[-1] < history[0], history
+    moved = {k.split(".")[0] for k, p in net.named_parameters() if not torch.equal(p.detach(), before[k])}
+    assert moved == {"sam_mask_decoder", "memory_attention", "memory_encoder", "obj_ptr_proj"}, moved
+    assert all(torch.isfinite(p).all() for p in net.parameters())
+    # and the inference entry points are unchanged by all this: eval() + the public methods give graph-free tensors
+    net.eval()
+    st = net.val_init_state(volume.to(DEV))
+    _, _, masks = net.add_new_bbox(st, 0, 0, bbox_dict[0][0])
+    assert masks.grad_fn is None and not masks.requires_grad
+
+
+def test_func_2d_module_calls_carry_gradients_to_every_trained_group():
+    """func_2d/function.py:70-259: forward_image -> memory_attention -> (no_grad prompt encoder) -> sam_mask_decoder -> loss.backward() ->
+    AdamW over net.parameters() (train_2d.py:43-47); the `.grad`s equal the explicit train_step_2d gradients."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import medical_sam2_amd.build_sam as bs
+    import medical_sam2_amd.ops as ops
+    import medical_sam2_amd.synthetic as syn
+    import medical_sam2_amd.training as T
+    import medical_sam2_amd.weights as wts
+    fp16 = ops.OP16 == torch.float16
+    B, S, E = 2, 256, 16
+    net = bs.build_sam2("sam2_hiera_t", device="cpu", hydra_overrides_extra=[f"++model.image_size={S}"])
+    net.load_state_dict(wts.init_weights("hiera_t", 0), strict=True)
+    net = net.to(DEV).train()
+    for layer in net.memory_attention.layers:
+        layer.dropout_value = 0.0
+    for mod in net.modules():
+        if hasattr(mod, "dropout_p"):
+            mod.dropout_p = 0.0
+    g = torch.Generator().manual_seed(150)
+    imgs = torch.stack([syn.normalize_image(syn.blob_image(i, S)[0]) for i in range(B)]).to(DEV)
+    pts, labels = torch.tensor([[[100.0, 120.0]], [[60.0, 200.0]]]).to(DEV), torch.ones(B, 1, dtype=torch.int32).to(DEV)
+    memory, memory_pos = (torch.randn(2 * E * E, B, 64, generator=g) * 0.5).to(DEV), torch.randn(2 * E * E, B, 64, generator=g).to(DEV)
+    target = (torch.randn(B, 1, S // 4, S // 4, generator=g) > 0.3).float().to(DEV)
+    twin = copy.deepcopy(net)
+    optimizer = torch.optim.AdamW(net.parameters(), lr=1e-5)
+    feat_sizes = [(S // 4, S // 4), (S // 8, S // 8), (S // 16, S // 16)]
+    backbone_out = net.forward_image(imgs)
+    _, vision_feats, vision_pos_embeds, _ = net._prepare_backbone_features(backbone_out)
+    vision_feats[-1] = net.memory_attention(curr=[vision_feats[-1]], curr_pos=[vision_pos_embeds[-1]], memory=memory, memory_pos=memory_pos,
+                                            num_obj_ptr_tokens=0)
+    feats = [feat.permute(1, 2, 0).view(B, -1, *feat_size) for feat, feat_size in zip(vision_feats[::-1], feat_sizes[::-1])][::-1]
+    image_embed, high_res_feats = feats[-1], feats[:-1]
+    with torch.no_grad():
+        se, de = net.sam_prompt_encoder(points=(pts, labels), boxes=None, masks=None, batch_size=B)
+    low_res_multimasks, iou_predictions, sam_output_tokens, object_score_logits = net.sam_mask_decoder(
+        image_embeddings=image_embed, image_pe=net.sam_prompt_encoder.get_dense_pe(), sparse_prompt_embeddings=se, dense_prompt_embeddings=de,
+        multimask_output=False, repeat_image=False, high_res_features=high_res_feats)
+    assert low_res_multimasks.shape == (B, 1, S // 4, S // 4) and low_res_multimasks.grad_fn is not None
+    assert sam_output_tokens.shape == (B, 1, 256) and iou_predictions.shape == (B, 1) and object_score_logits.shape == (B, 1)
+    # the loss form of the explicit step (mean BCE over all four mask tokens' maps) so that the two gradient fields are comparable
+    masks4, _, _, _ = net.sam_mask_decoder.predict_masks(image_embed, net.sam_prompt_encoder.get_dense_pe(), se, de, False, None, high_res_feats)
+    tgt4 = (torch.randn(B, 4, S // 4, S // 4, generator=g) > 0.3).float().to(DEV)
+    losses = F.binary_cross_entropy_with_logits(masks4, tgt4)
+    optimizer.zero_grad()
+    losses.backward()
+    got: dict = {}
+    with torch.no_grad():
+        zero = [T.DecoderAdam(mod, lr=0.0) for mod in (twin.memory_attention, twin.sam_mask_decoder, twin.image_encoder)]
+        loss0, _ = T.train_step_2d(twin, zero[0], zero[1], imgs, pts, labels, memory, memory_pos, tgt4, opt_enc=zero[2], grads_out=got)
+    assert abs(float(losses) - loss0) < 2e-3 * abs(loss0), (float(losses), loss0)
+    named = dict(net.named_parameters())
+    errs = {}
+    for grp, pre in (("memory_attention", "memory_attention."), ("decoder", "sam_mask_decoder."), ("image_encoder", "image_encoder.")):
+        num = den = 0.0
+        for k, gexp in got[grp].items():
+            ga = named[pre + k].grad
+            assert ga is not None, (grp, k)
+            num += float((ga.double() - gexp.double()).pow(2).sum())
+            den += float(gexp.double().pow(2).sum())
+        errs[grp] = (num / max(den, 1e-60)) ** 0.5
+    print("2-D loop: autograd .grad vs explicit train_step_2d gradients (relative L2 per group):", errs)
+    assert all(v < (0.03 if fp16 else 0.15) for v in errs.values()), errs
+    optimizer.step()
+    assert all(torch.isfinite(p).all() for p in net.parameters())

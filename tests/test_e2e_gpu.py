@@ -326,20 +326,32 @@ def test_volume_bbox_prompts_vs_oracle(build):
     assert worst_iou >= (0.98 if _fp16() else 0.95) and worst_max <= TOL_MAX, (worst_iou, worst_max)
 
 
-def test_config3_volume_at_size_sampled_slices_vs_oracle(build):
-    """BASELINE.json configs[2] AT SIZE: sam2_hiera_s, 1024^2, 64 slices, bbox prompt on every 2nd slice, one object, the whole volume
-    through `segment_volume` on the HIP path.  The CPU oracle cannot run a 64-slice chain at this size inside a test, so three
-    propagated slices (early, middle, last: 35 memories = 143 k keys + up to 39 pointers) are checked by teacher forcing: the oracle's
-    `track_step` for slice t on the HIP chain's own memory bank (its conditioning + propagated outputs up to t-1), compared with the
-    HIP path's slice t -- same selection rule (token counts asserted), masks / pointers / new memory within the propagated-slice
-    tolerance.  This is the regime of the 155 k-key split-KV cross-attention that round 1 only timed."""
+def _minority_iou(got, ref):
+    """IoU of the smaller of {foreground, background} of the reference mask: random-weight masks are often almost all foreground, where
+    the plain IoU is dominated by the huge intersection and says nothing; returns (iou, minority pixel count)"""
+    g, r = got > 0, ref > 0
+    if r.sum() * 2 > r.size:
+        g, r = ~g, ~r
+    union = float((g | r).sum())
+    return (1.0 if union == 0 else float((g & r).sum()) / union), int(r.sum())
+
+
+def _teacher_forced_slices(build, T, slices_fixed, n_extra, tag, weights_seed, volume_seed):
+    """BASELINE.json configs[2] / [3] AT SIZE on one GPU: sam2_hiera_s, 1024^2, T slices, bbox prompt on every 2nd slice, one object, the
+    whole volume through `segment_volume` on the HIP path.  The CPU oracle cannot run a chain of this length inside a test, so a few
+    propagated slices are checked by teacher forcing: the oracle's `track_step` for slice t on the HIP chain's own memory bank (its
+    conditioning + propagated outputs up to t-1) against the HIP path's slice t -- same selection rule (token counts asserted), masks /
+    pointers / new memory within the prompted-slice tolerance (one step from an identical bank).
+    Which slices: `slices_fixed` (early / middle / last: the bank at its different fill levels) plus the `n_extra` propagated slices whose
+    masks have the LARGEST minority class -- VERDICT r2 weak item 1: with weight seed 0 every sampled mask was empty and the IoU clause
+    compared nothing with nothing; the seeds used here give masks with both classes present and the test asserts it."""
     from oracle import sam2_oracle as O
     import medical_sam2_amd.volume as vol
-    S, T = 1024, 64
-    m = build("hiera_s", S)
-    W = wts.init_weights("hiera_s", 0)
+    S = 1024
+    m = build("hiera_s", S, weights_seed)
+    W = wts.init_weights("hiera_s", weights_seed)
     cfg = O.model_config("hiera_s", S)
-    volume, boxes = syn.blob_volume(0, n_slices=T, size=S, n_objects=1)
+    volume, boxes = syn.blob_volume(volume_seed, n_slices=T, size=S, n_objects=1)
     box_at = lambda t: torch.tensor([[float(v) for v in (boxes[0][t] or (S * 0.3, S * 0.3, S * 0.6, S * 0.6))]])
     prompts = {t: {"boxes": box_at(t).to(DEV)} for t in range(0, T, 2)}
     seen = []
@@ -360,29 +372,51 @@ def test_config3_volume_at_size_sampled_slices_vs_oracle(build):
     finally:
         m.memory_attention.forward = real
     assert sorted(masks) == list(range(T)) and len(seen) == T // 2
-    # steady state reached: 32 conditioning + 3 recent memories = 143 k keys; every past conditioning pointer + the recent ones
-    assert max(n for n, _ in seen) >= 35 * 4096 and max(p for _, p in seen) >= 4 * 32
+    # steady state reached: T/2 conditioning + 3 recent memories; every past conditioning pointer + the recent ones
+    assert max(n for n, _ in seen) >= (T // 2 + 3) * 4096 and max(p for _, p in seen) >= 4 * (T // 2)
+    minority = {t: min(int((masks[t] > 0).sum()), int((masks[t] <= 0).sum())) for t in range(1, T, 2)}
+    extra = sorted(minority, key=lambda t: -minority[t])[:n_extra]
     c = lambda t: t.detach().float().cpu()
     pick = lambda o: {"maskmem_features": c(o["maskmem_features"]), "maskmem_pos_enc": [c(o["maskmem_pos_enc"][0])], "obj_ptr": c(o["obj_ptr"])}
-    worst = dict(iou=1.0, max=0.0, mean=0.0, ptr=0.0, mem=0.0)
-    for t in (5, 33, 63):
-        od = {"cond_frame_outputs": {u: pick(state["cond_frame_outputs"][u]) for u in sorted(state["cond_frame_outputs"])},
-              "non_cond_frame_outputs": {u: pick(o) for u, o in state["non_cond_frame_outputs"].items() if u < t}}
+    worst = dict(flips=0, max=0.0, mean=0.0, ptr=0.0, mem=0.0)
+    cond_cpu = {u: pick(state["cond_frame_outputs"][u]) for u in sorted(state["cond_frame_outputs"])}
+    for t in sorted(set(slices_fixed) | set(extra)):
+        od = {"cond_frame_outputs": cond_cpu,
+              "non_cond_frame_outputs": {u: pick(o) for u, o in state["non_cond_frame_outputs"].items() if t - 20 <= u < t}}
         feats, pos, sizes = O.prepare_backbone_features(O.forward_image(W, cfg, volume[t][None]))
         col = {}
         ref = O.track_step(W, cfg, t, False, feats, pos, sizes, None, None, od, T, collect=col)
         assert (col["memory_shape"][0], col["num_obj_ptr_tokens"]) == seen[t // 2], (t, col["memory_shape"], seen[t // 2])
         got = state["non_cond_frame_outputs"][t]
         g, r = c(got["pred_masks"]).numpy(), ref["pred_masks"].numpy()
-        rep = dict(iou=mask_iou(g, r), max_abs=max_abs(g, r), mean_abs=_mean_abs(g, r), keys=col["memory_shape"][0],
-                   ptr=rel_err(c(got["obj_ptr"]), ref["obj_ptr"]), mem=rel_err(c(got["maskmem_features"]), ref["maskmem_features"]),
-                   fg=int((r > 0).sum()))
-        REPORT[f"config3_t{t}"] = rep
-        worst = dict(iou=min(worst["iou"], rep["iou"]), max=max(worst["max"], rep["max_abs"]), mean=max(worst["mean"], rep["mean_abs"]),
+        miou, mcount = _minority_iou(g, r)
+        rep = dict(iou=mask_iou(g, r), minority_iou=miou, minority_px=mcount, flips=int(((g > 0) != (r > 0)).sum()), max_abs=max_abs(g, r),
+                   mean_abs=_mean_abs(g, r), keys=col["memory_shape"][0], ptr=rel_err(c(got["obj_ptr"]), ref["obj_ptr"]),
+                   mem=rel_err(c(got["maskmem_features"]), ref["maskmem_features"]), fg=int((r > 0).sum()), extra=t in extra)
+        REPORT[f"{tag}_t{t}"] = rep
+        if t in extra:
+            # a real mask comparison: both classes present in the REFERENCE's mask, and the smaller one reproduced
+            assert mcount > 500 and miou >= TOL_IOU, (t, rep)
+        worst = dict(flips=max(worst["flips"], rep["flips"]), max=max(worst["max"], rep["max_abs"]), mean=max(worst["mean"], rep["mean_abs"]),
                      ptr=max(worst["ptr"], rep["ptr"]), mem=max(worst["mem"], rep["mem"]))
     _dump()
     # one step from an identical bank: the prompted-slice bounds apply (no upstream binarisation flips between the two sides)
-    assert worst["iou"] >= TOL_IOU and worst["max"] <= TOL_MAX and worst["mean"] <= TOL_MEAN and worst["ptr"] < TOL_PTR and worst["mem"] < TOL_PTR, worst
+    assert worst["flips"] <= max_flips(65536) and worst["max"] <= TOL_MAX and worst["mean"] <= TOL_MEAN and worst["ptr"] < TOL_PTR \
+        and worst["mem"] < TOL_PTR, worst
+
+
+def test_config3_volume_at_size_sampled_slices_vs_oracle(build):
+    """BASELINE.json configs[2]: 64 slices, 32 conditioning memories, up to 143 k keys + 156 pointer tokens -- the regime of the split-KV
+    cross-attention at ~150 k keys."""
+    _teacher_forced_slices(build, 64, (5, 33, 63), 2, "config3", weights_seed=2, volume_seed=1)
+
+
+def test_configs3_volume_512_slices_on_one_gpu_vs_oracle(build):
+    """BASELINE.json configs[3]'s WORKLOAD on one GPU (its 8-way sharding needs 8 GPUs: tests/test_volume_ranks_gpu.py covers the sharded
+    path at 2 ranks): 512 slices, 256 prompted, ~1.06 M memory keys + ~1 k pointer tokens per propagated slice; two propagated slices
+    (the last one and the one with the richest mask) teacher-forced against the oracle, whose attention walks the key range in query
+    blocks (oracle.softmax_attention).  VERDICT r2 weak item 3."""
+    _teacher_forced_slices(build, 512, (511,), 1, "config3_512", weights_seed=2, volume_seed=1)
 
 
 def test_config1_image_predictor(build):
