@@ -78,6 +78,7 @@ SIGNATURES = {
     "msam2_gemm_tt": (c_i, [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_l, c_p]),
     "msam2_bilinear_upsample_bwd": (c_i, [c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_p]),
     "msam2_maxpool2x2_bwd": (c_i, [c_p, c_i, c_l, c_p, c_l, c_p, c_l, c_l, c_l, c_l, c_l, c_p]),
+    "msam2_window_move": (c_i, [c_p, c_l, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_l, c_i, c_i, c_p]),
     "msam2_sumpool2x2": (c_i, [c_p, c_p, c_l, c_l, c_l, c_l, c_p]),
     "msam2_hiera_pos_embed_bwd": (c_i, [c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_l, c_p, c_z, c_p]),
     "msam2_hiera_pos_embed_bwd_workspace_bytes": (c_z, [c_l, c_l, c_l, c_l]),

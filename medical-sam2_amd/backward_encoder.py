@@ -61,6 +61,25 @@ def _windows(img: torch.Tensor, ws: int, fill: Optional[torch.Tensor] = None) ->
     return win.reshape(B * (Hp // ws) * (Wp // ws), heads, ws * ws, D), Hp, Wp
 
 
+def window_partition(img: torch.Tensor, B: int, H: int, W: int, heads: int, D: int, ws: int, fill: Optional[torch.Tensor] = None):
+    """img: [B*H*W, >= heads*D] token rows (row stride free, 16-bit or fp32; a column slice of a wider buffer is fine) ->
+    (windows [B*nW, heads, ws*ws, D] contiguous, Hp, Wp): backbones/utils.py:16-38 by one 16-byte-chunk kernel (msam2_window_move);
+    padded tokens take `fill` [heads*D] (cast to img's type) or zero."""
+    assert img.dim() == 2 and img.stride(1) == 1 and img.shape[0] == B * H * W and img.shape[1] == heads * D
+    nwy, nwx = -(-H // ws), -(-W // ws)
+    win = torch.empty(B * nwy * nwx, heads, ws * ws, D, dtype=img.dtype, device=img.device)
+    f = None if fill is None else fill.to(img.dtype).contiguous()
+    check(lib().msam2_window_move(_p(img), img.stride(0), _p(win), _p(f), B, H, W, heads, D, ws, img.element_size(), 1, _stream()))
+    return win, nwy * ws, nwx * ws
+
+
+def window_unpartition_into(win: torch.Tensor, img: torch.Tensor, B: int, H: int, W: int, heads: int, D: int, ws: int) -> None:
+    """windows [B*nW, heads, ws*ws, D] contiguous -> the [B*H*W, heads*D] rows of `img` (a column slice of a wider buffer is fine),
+    padding cropped: backbones/utils.py:41-62."""
+    assert win.is_contiguous() and img.dim() == 2 and img.stride(1) == 1 and img.shape == (B * H * W, heads * D) and img.dtype == win.dtype
+    check(lib().msam2_window_move(_p(img), img.stride(0), _p(win), None, B, H, W, heads, D, ws, img.element_size(), 0, _stream()))
+
+
 def _unwindows(win: torch.Tensor, B: int, Hp: int, Wp: int, ws: int) -> torch.Tensor:
     """inverse of `_windows` (without the crop): [B*nW, heads, ws*ws, D] (any strides) -> [B, Hp, Wp, heads, D]"""
     _, heads, _, D = win.shape
@@ -100,10 +119,10 @@ def hiera_block_backward(blk, t: torch.Tensor, B: int, H: int, W: int, dy: torch
     kv5 = qkv.view(B, H, W, 3, heads, D)
     if ws > 0:
         ws_q = ws // 2 if pool else ws
-        bias3 = qkv_b.view(3, heads, D)
-        qw, Hqp, Wqp = _windows(q_src, ws_q)
-        kw, Hp, Wp = _windows(kv5[:, :, :, 1], ws, bias3[1])
-        vw, _, _ = _windows(kv5[:, :, :, 2], ws, bias3[2])
+        bias3 = qkv_b.view(3, width)
+        qw, Hqp, Wqp = window_partition(qp if pool else q_img, B, Hq, Wq, heads, D, ws_q)
+        kw, Hp, Wp = window_partition(qkv[:, width:2 * width], B, H, W, heads, D, ws, bias3[1])
+        vw, _, _ = window_partition(qkv[:, 2 * width:], B, H, W, heads, D, ws, bias3[2])
         q4, k4, v4 = qw, kw, vw                                                      # [B*nW, heads, L, D]
     else:
         q4 = q_src.reshape(B, Hq * Wq, heads, D).permute(0, 2, 1, 3)
@@ -111,11 +130,12 @@ def hiera_block_backward(blk, t: torch.Tensor, B: int, H: int, W: int, dy: torch
         v4 = kv5[:, :, :, 2].reshape(B, H * W, heads, D).permute(0, 2, 1, 3)
     o4, lse = bwd.attention_forward_lse(q4, k4, v4, scale)                           # o4: [.., heads, Lq, D] view of [.., Lq, heads, D]
     if ws > 0:
-        o_img = _unwindows(o4, B, Hqp, Wqp, ws_q)[:, :Hq, :Wq]
-        o = o_img.reshape(B * Hq * Wq, width)
+        o = torch.empty(B * Hq * Wq, width, dtype=o4.dtype, device=o4.device)
+        # (attention_forward_lse returns [.., heads, Lq, D] as a VIEW of a [.., Lq, heads, D] buffer: make the window layout explicit)
+        window_unpartition_into(o4.contiguous(), o, B, Hq, Wq, heads, D, ws_q)
     else:
         o = o4.permute(0, 2, 1, 3).reshape(B * Hq * Wq, width)
-    o = o if o.is_contiguous() else o.contiguous()
+        o = o if o.is_contiguous() else o.contiguous()
     if dim != dim_out:
         pw, pb = w_bf16(wc, "pw", blk.proj.weight), f("pb", blk.proj.bias)
         pre = ops.gemm(xn, pw, pb, out_dtype=F32)                                    # un-pooled projected shortcut [T, dim_out]
@@ -138,18 +158,28 @@ def hiera_block_backward(blk, t: torch.Tensor, B: int, H: int, W: int, dy: torch
         g["attn.proj.weight"] = g["attn.proj.weight"].view(dim_out, heads, Dp)[:, :, :Dt].reshape(dim_out, heads * Dt)
     # ---- attention core
     do_img = do.view(B, Hq, Wq, heads, D)
+    dqkv = None
     if ws > 0:
-        dow, _, _ = _windows(do_img, ws_q)                                           # padded queries: zero upstream gradient
+        dow, _, _ = window_partition(do, B, Hq, Wq, heads, D, ws_q)                   # padded queries: zero upstream gradient
         dq4, dk4, dv4 = bwd.attention_backward(q4, k4, v4, dow, scale, o_lse=(o4, lse))
-        dq_img = _unwindows(dq4, B, Hqp, Wqp, ws_q)[:, :Hq, :Wq].reshape(B * Hq * Wq, width)
-        dk_full, dv_full = _unwindows(dk4, B, Hp, Wp, ws), _unwindows(dv4, B, Hp, Wp, ws)
-        dk_img, dv_img = dk_full[:, :H, :W].reshape(T, width), dv_full[:, :H, :W].reshape(T, width)
+        dq4, dk4, dv4 = (x.to(F32).contiguous() for x in (dq4, dk4, dv4))
+        # the three gradients go straight into their column thirds of the fused-qkv gradient (no window -> image copies, no torch.cat)
+        dqkv = torch.empty(T, 3 * width, dtype=F32, device=t.device)
+        if pool:
+            dq_img = torch.empty(B * Hq * Wq, width, dtype=F32, device=t.device)
+            window_unpartition_into(dq4, dq_img, B, Hq, Wq, heads, D, ws_q)
+        else:
+            window_unpartition_into(dq4, dqkv[:, :width], B, Hq, Wq, heads, D, ws_q)
+            dq_img = None
+        window_unpartition_into(dk4, dqkv[:, width:2 * width], B, H, W, heads, D, ws)
+        window_unpartition_into(dv4, dqkv[:, 2 * width:], B, H, W, heads, D, ws)
         pad_bias = None
         if (Hp, Wp) != (H, W):
             # zero-padded tokens carry k = v = bias (the LayerNorm'ed map is padded BEFORE the qkv Linear, hieradet.py:143-150 +
-            # utils.py:28-31): their dk / dv flow into the qkv bias
-            cs = lambda m: bwd.colsum(m.reshape(-1, width).contiguous())
-            pad_bias = torch.cat([torch.zeros(width, dtype=F32, device=t.device), cs(dk_full) - cs(dk_img), cs(dv_full) - cs(dv_img)])
+            # utils.py:28-31): their dk / dv flow into the qkv bias = (sum over ALL window tokens) - (sum over the image's tokens)
+            allk, allv = dk4.sum(dim=(0, 2)).reshape(width), dv4.sum(dim=(0, 2)).reshape(width)
+            pad_bias = torch.cat([torch.zeros(width, dtype=F32, device=t.device), allk - bwd.colsum(dqkv[:, width:2 * width]),
+                                  allv - bwd.colsum(dqkv[:, 2 * width:])])
     else:
         do4 = do_img.reshape(B, Hq * Wq, heads, D).permute(0, 2, 1, 3)
         dq4, dk4, dv4 = bwd.attention_backward(q4, k4, v4, do4, scale, o_lse=(o4, lse))
@@ -158,7 +188,10 @@ def hiera_block_backward(blk, t: torch.Tensor, B: int, H: int, W: int, dy: torch
         pad_bias = None
     if pool:
         dq_img = maxpool2x2_backward(q_img, dq_img.contiguous(), B, H, W)            # routed to the arg-max of each 2x2 window
-    dqkv = torch.cat([dq_img, dk_img, dv_img], dim=1)                                # fp32 [T, 3*width] (data movement)
+    if dqkv is None:
+        dqkv = torch.cat([dq_img, dk_img, dv_img], dim=1)                            # fp32 [T, 3*width] (data movement)
+    elif dq_img is not None:
+        dqkv[:, :width].copy_(dq_img)
     dxn, g["attn.qkv.weight"], g["attn.qkv.bias"] = bwd.linear_backward(xn, qkv_w, dqkv)
     if pad_bias is not None:
         g["attn.qkv.bias"] = g["attn.qkv.bias"] + pad_bias

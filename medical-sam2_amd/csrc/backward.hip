@@ -1023,6 +1023,82 @@ extern "C" int msam2_maxpool2x2_bwd(const void* x, int x_is_16bit, int64_t ldx, 
   return msam2_check_launch("maxpool2x2_bwd");
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// window_partition / window_unpartition (backbones/utils.py:16-62) as ONE data-movement kernel each way, in 16-byte chunks, for the
+// attention BACKWARD of the Hiera trunk: its flash kernels take [batch, head, token, D] operands with one token stride, which a window
+// of an un-partitioned token image does not have.  The training iteration used to build the seven window tensors of a block (q, k, v,
+// dO in; dQ, dK, dV out) with torch's generic strided copies plus a torch.cat: 14 % of the whole iteration
+// (profiles/r02_train_iteration_kernel_stats.csv).  (The forward never partitions: its window kernel gathers.)
+//   partition:   img [B, H, W, heads * D] (row stride ld_img elements, any column offset folded into the pointer)
+//                -> win [B * nWy * nWx, heads, ws * ws, D] contiguous; bottom / right padding rows take `fill` [heads * D] (same type) or 0
+//   unpartition: the reverse, cropping the padding (every [B, H, W] row of img is written)
+// es = element size in bytes (2 or 4); D * es must be a multiple of 16.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool TO_WINDOWS>
+__global__ void window_move_kernel(unsigned char* __restrict__ img, int64_t ld_img_b, unsigned char* __restrict__ win,
+                                   const unsigned char* __restrict__ fill, int B, int H, int W, int heads, int cpd /* 16-byte chunks per D */,
+                                   int ws, int nwy, int nwx) {
+  const int L = ws * ws;
+  const int64_t total = TO_WINDOWS ? (int64_t)B * nwy * nwx * heads * L * cpd : (int64_t)B * H * W * heads * cpd;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c, head, y, x, b;
+    int64_t widx;
+    if (TO_WINDOWS) {
+      c = (int)(i % cpd);
+      int64_t t = i / cpd;
+      const int tok = (int)(t % L);
+      t /= L;
+      head = (int)(t % heads);
+      t /= heads;
+      const int wx = (int)(t % nwx);
+      t /= nwx;
+      const int wy = (int)(t % nwy);
+      b = (int)(t / nwy);
+      y = wy * ws + tok / ws;
+      x = wx * ws + tok % ws;
+      widx = i;
+    } else {
+      c = (int)(i % cpd);
+      int64_t t = i / cpd;
+      head = (int)(t % heads);
+      t /= heads;
+      x = (int)(t % W);
+      t /= W;
+      y = (int)(t % H);
+      b = (int)(t / H);
+      const int wy = y / ws, wx = x / ws, tok = (y % ws) * ws + (x % ws);
+      widx = ((((int64_t)(b * nwy + wy) * nwx + wx) * heads + head) * L + tok) * cpd + c;
+    }
+    uint4* wp = reinterpret_cast<uint4*>(win) + widx;
+    if (TO_WINDOWS) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (y < H && x < W) v = *reinterpret_cast<const uint4*>(img + (((int64_t)b * H + y) * W + x) * ld_img_b + ((int64_t)head * cpd + c) * 16);
+      else if (fill) v = *reinterpret_cast<const uint4*>(fill + ((int64_t)head * cpd + c) * 16);
+      *wp = v;
+    } else {
+      *reinterpret_cast<uint4*>(img + (((int64_t)b * H + y) * W + x) * ld_img_b + ((int64_t)head * cpd + c) * 16) = *wp;
+    }
+  }
+}
+
+extern "C" int msam2_window_move(void* img, int64_t ld_img, void* win, const void* fill, int64_t B, int64_t H, int64_t W, int64_t heads, int64_t D,
+                                 int64_t ws, int elem_bytes, int to_windows, void* stream) {
+  MSAM2_REQUIRE(img && win && B > 0 && H > 0 && W > 0 && heads > 0 && D > 0 && ws > 0, "window_move: bad arguments");
+  MSAM2_REQUIRE((elem_bytes == 2 || elem_bytes == 4) && (D * elem_bytes) % 16 == 0 && (ld_img * elem_bytes) % 16 == 0 &&
+                    (((uintptr_t)img | (uintptr_t)win | (uintptr_t)fill) & 15) == 0,
+                "window_move: 16-byte chunks (D * element size, row stride and pointers must be multiples of 16 bytes)");
+  const int nwy = (int)((H + ws - 1) / ws), nwx = (int)((W + ws - 1) / ws), cpd = (int)(D * elem_bytes / 16);
+  const int64_t total = to_windows ? B * nwy * nwx * heads * ws * ws * cpd : B * H * W * heads * cpd;
+  dim3 grid((unsigned)min((int64_t)16384, (total + 255) / 256)), block(256);
+  if (to_windows)
+    hipLaunchKernelGGL((window_move_kernel<true>), grid, block, 0, (hipStream_t)stream, (unsigned char*)img, ld_img * elem_bytes, (unsigned char*)win,
+                       (const unsigned char*)fill, (int)B, (int)H, (int)W, (int)heads, cpd, (int)ws, nwy, nwx);
+  else
+    hipLaunchKernelGGL((window_move_kernel<false>), grid, block, 0, (hipStream_t)stream, (unsigned char*)img, ld_img * elem_bytes, (unsigned char*)win,
+                       (const unsigned char*)fill, (int)B, (int)H, (int)W, (int)heads, cpd, (int)ws, nwy, nwx);
+  return msam2_check_launch("window_move");
+}
+
 // adjoint of the FPN's nearest-2x top-down step (msam2_upsample2x_add, image_encoder.py:113-124): out[b,i,j,c] = sum of the 2x2 block
 __global__ void sumpool2x2_kernel(const float* __restrict__ dy, float* __restrict__ out, int B, int H, int W, int C) {
   const int Ho = H / 2, Wo = W / 2;

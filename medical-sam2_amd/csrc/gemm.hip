@@ -296,7 +296,15 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x16
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const int e0 = 2 * k, ro = i * 32 + (e0 & 3) + 8 * (e0 >> 2);
-          const float x0 = fn(acc[i][j][e0], j), x1 = fn(acc[i][j][e0 + 1], j);
+          float x0, x1;
+          if constexpr (ACT == 1) {                       // GELU on the pair: packed fp32 arithmetic (common.h)
+            const f32x2 gp = gelu_erf2(f32x2{acc[i][j][e0] + bias_j[j], acc[i][j][e0 + 1] + bias_j[j]});
+            x0 = gp[0] * cs_j[j];
+            x1 = gp[1] * cs_j[j];
+          } else {
+            x0 = fn(acc[i][j][e0], j);
+            x1 = fn(acc[i][j][e0 + 1], j);
+          }
           if constexpr (!ROPE) {
             // convert first, then trade 16-bit halves: P = (x0 | x1 << 16), N = the neighbour lane's P;
             // even lanes keep (P.lo, N.lo) = row(e0) cols (r, r+1), odd lanes (N.hi, P.hi) = row(e0+1) cols (r-1, r)
@@ -960,6 +968,252 @@ __global__ __launch_bounds__(256, OCC) void gemm_wide_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// W-STATIONARY persistent variant for short reductions (K = 256 / 384: the qkv / fc1 projections of Hiera stage 3 and the
+// memory attention's linear1 -- 16384 token rows against a weight of a few hundred KB; round 3).
+//
+// Why.  With K = 384 a 128x128 output tile is only 6 k-steps of 64: the tiled kernels above spend their life in the prologue (first
+// DMA), the epilogue and at 2-stage-ring barriers (PMC of gemm_glds_kernel at 16384 x 1536 x 384: waves wait 50 % of their cycles,
+// MFMA-busy 19 %; profiles/r03_gemm_*), and every tile re-streams its 96 KB W panel from L2.  Here a workgroup KEEPS its 128-row W
+// panel (all of K: NK x 16 KB) in LDS for its whole life and walks a strided list of M tiles, streaming only A through a 4-stage
+// LDS-DMA ring that runs on ACROSS tile boundaries (prefetch distance 3 chunks = ~1.5k MFMA cycles), so there is one prologue per
+// workgroup instead of one per tile and half the L2 -> LDS traffic (A: N/128 re-reads, W: once per workgroup).
+// The epilogue of tile t (bias, activation, 16-bit conversion, 32 dword stores per wave straight from the accumulator layout) is
+// DEFERRED: the finished accumulators move to a second register set and one 32x32 block of them is retired inside each of the next
+// tile's first four k-chunks, between that chunk's MFMAs -- with one wave per SIMD nothing else could hide the GELU's VALU work.
+// vmcnt counts loads, LDS-DMA and stores together in issue order (MI355X_MICROARCH.md), so every wait is COUNTED: the ops younger than
+// chunk g's four DMA pieces are the pieces of chunks g+1, g+2 and the stores of the epilogue slices issued since.
+// One workgroup (4 waves, one per SIMD) per CU: 160 KB of LDS at K = 384.  Requires M % 128 == 0, N % 128 == 0, 16-bit output,
+// no residual / column scale / RoPE / pooling; grid = groups x panels <= 256.
+// ------------------------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wstat_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wstat_wait_dyn(int n) {      // n: multiple of 4, 0..40 (wave-uniform)
+  switch (n >> 2) {
+    case 0: wstat_wait<0>(); break;
+    case 1: wstat_wait<4>(); break;
+    case 2: wstat_wait<8>(); break;
+    case 3: wstat_wait<12>(); break;
+    case 4: wstat_wait<16>(); break;
+    case 5: wstat_wait<20>(); break;
+    case 6: wstat_wait<24>(); break;
+    case 7: wstat_wait<28>(); break;
+    case 8: wstat_wait<32>(); break;
+    case 9: wstat_wait<36>(); break;
+    default: wstat_wait<40>(); break;
+  }
+}
+
+template <int NK, int ACT, bool NT>
+__global__ __launch_bounds__(512, 1) void gemm_wstat_kernel(GemmParams p, int n_panels, int groups) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 128, BN = 128, BK = 64, NST = 4;
+  constexpr int KT_BYTES = BN * BK * 2;             // one k-tile of the W image / one A stage: 16 KiB
+  constexpr int W_BYTES = NK * KT_BYTES;
+  constexpr int LPC = 2;                            // DMA pieces per wave and chunk (16 pieces of 1 KiB over 8 waves)
+  constexpr int SPR = 8;                            // stores per retired 32x32 block
+  static_assert(NK >= 4, "the ring's prefetch distance (3 chunks) must stay inside one tile for the wait arithmetic below");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // [W image: NK k-tiles | A ring: NST stages]
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;          // 8 waves (two per SIMD): 4 row slabs of 32 x 2 column halves of 64
+  const int r = lane & 31, h = lane >> 5, odd = lane & 1;
+  const int panel = blockIdx.x % n_panels, grp = blockIdx.x / n_panels;
+  const int n_tiles_m = p.M / BM;
+  const int my_tiles = grp < n_tiles_m ? (n_tiles_m - grp + groups - 1) / groups : 0;     // tiles grp, grp + groups, ...
+  if (my_tiles == 0) return;
+  const int64_t n0 = (int64_t)panel * BN;
+  const int total = my_tiles * NK;
+
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+  // a piece = 8 rows x 128 B = one DMA instruction; 128-byte-row image, chunk c of row r in slot c ^ ((r >> 1) & 7) (as gemm_glds_kernel)
+  unsigned offsA[LPC], offsW[LPC];
+#pragma unroll
+  for (int i = 0; i < LPC; ++i) {
+    const int row = (wave * LPC + i) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    offsA[i] = (unsigned)((int64_t)row * p.lda * 2 + chunk * 16);
+    offsW[i] = (unsigned)((n0 + row) * p.ldw * 2 + chunk * 16);
+  }
+  unsigned char* const ring = lds + W_BYTES;
+  auto issue_a = [&](int g) {
+    const int ti = g / NK, kt = g - ti * NK;
+    const unsigned so = (unsigned)(((int64_t)(grp + ti * groups) * BM * p.lda + (int64_t)kt * BK) * 2);
+    unsigned char* base = ring + (g & (NST - 1)) * KT_BYTES + wave * (LPC * 1024);
+#pragma unroll
+    for (int i = 0; i < LPC; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(base + i * 1024), 16, offsA[i], so, 0, 0);
+  };
+  // this workgroup's columns never change: bias once, BEFORE any DMA is in flight (the compiler waits for these loads with vmcnt(0))
+  float bias_j[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bias_j[j] = p.bias ? p.bias[n0 + wn * 64 + j * 32 + r] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- prologue: the whole W panel, then the first three A chunks (W is older than chunk 0: waiting for chunk 0 covers it)
+#pragma unroll
+  for (int kt = 0; kt < NK; ++kt)
+#pragma unroll
+    for (int i = 0; i < LPC; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(lds + kt * KT_BYTES + (wave * LPC + i) * 1024), 16,
+                                               offsW[i], (unsigned)kt * BK * 2, 0, 0);
+#pragma unroll
+  for (int g = 0; g < NST - 1; ++g)
+    if (g < total) issue_a(g);
+
+  // fragment read offsets inside a 16 KiB k-tile image, without the k-substep term
+  const int ra = wm * 32 + r;
+  const int offA = ra * 128, swzA = (ra >> 1) & 7;
+  int offB[2], swzB[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rb = wn * 64 + j * 32 + r;
+    offB[j] = rb * 128;
+    swzB[j] = (rb >> 1) & 7;
+  }
+  const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((int64_t)p.M * p.ldc * 2), 0x00020000);
+  const int ldc_b = (int)p.ldc * 2;
+  const int vcol = (int)(n0 + wn * 64 + (r & ~1)) * 2;
+
+  // one 32x32 block of a finished tile: bias -> activation -> 16-bit pairs through DPP -> 8 dword stores (gemm_epilogue_direct's
+  // 16-bit form; rows past M cannot occur: M % 128 == 0)
+  auto retire = [&](const f32x16& blk, int j, int row0) {
+    const int vbase = (row0 + wm * 32 + 4 * h + odd) * ldc_b + vcol;
+#pragma unroll
+    for (int k = 0; k < SPR; ++k) {
+      const int e0 = 2 * k, ro = (e0 & 3) + 8 * (e0 >> 2);
+      float x0 = blk[e0] + bias_j[j], x1 = blk[e0 + 1] + bias_j[j];
+      if constexpr (ACT == 1) {
+        const f32x2 gp = gelu_erf2(f32x2{x0, x1});
+        x0 = gp[0];
+        x1 = gp[1];
+      } else if constexpr (ACT == 2) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
+      op16x2 own;
+      own[0] = f2op(x0);
+      own[1] = f2op(x1);
+      const unsigned P = __builtin_bit_cast(unsigned, own);
+      const unsigned Nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)P, 0xB1, 0xf, 0xf, false);
+      const unsigned outw = __builtin_amdgcn_perm(Nb, P, odd ? 0x03020706u : 0x05040100u);
+      __builtin_amdgcn_raw_buffer_store_b32(outw, c_rsrc, vbase + ro * ldc_b + j * 64, 0, NT ? 2 : 0);
+    }
+  };
+
+  // One tile: NK chunks, fully unrolled (kt is a compile-time constant).  `cur` accumulates; `prev` holds the PREVIOUS tile's finished
+  // accumulators, whose two 32x32 blocks are retired in chunks 0 and 1 -- the two accumulator sets swap roles from tile to tile, so
+  // nothing is ever copied.  Counted wait before chunk g: the ops younger than chunk g's LPC pieces are the pieces of chunks g+1, g+2
+  // and the SPR stores of every retire issued in iterations g-3 .. g-1 (kt 0 and 1 of a tile that has a predecessor).
+  auto tile = [&](f32x16 (&cur)[2], f32x16 (&prev)[2], int ti, bool has_prev, int prev_row0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) cur[j][e] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) {
+      const int g = ti * NK + kt;
+      // stores among the three previous iterations: this tile's kt-1, kt-2, kt-3 if they are 0 / 1 (need has_prev); for kt < 3 the
+      // window reaches into the previous tile, whose retiring chunks (its kt 0 / 1) are >= NK - 3 >= 1 chunks older only when NK - 3 + kt... 
+      int st = 0;
+#pragma unroll
+      for (int d = 1; d <= 3; ++d) {
+        const int k2 = kt - d;                       // >= 0: this tile (retires iff has_prev); < 0: previous tile's chunk NK + k2
+        if (k2 >= 0) st += (k2 < 2 && has_prev) ? SPR : 0;
+        else st += ((NK + k2) < 2 && ti >= 2) ? SPR : 0;
+      }
+      const int rem = total - 1 - g;
+      if (rem >= 2) {
+        if (st == 0) wstat_wait<2 * LPC>();
+        else if (st == SPR) wstat_wait<2 * LPC + SPR>();
+        else wstat_wait<2 * LPC + 2 * SPR>();
+      } else if (rem == 1) {
+        if (st == 0) wstat_wait<LPC>();
+        else if (st == SPR) wstat_wait<LPC + SPR>();
+        else wstat_wait<LPC + 2 * SPR>();
+      } else {
+        if (st == 0) wstat_wait<0>();
+        else if (st == SPR) wstat_wait<SPR>();
+        else wstat_wait<2 * SPR>();
+      }
+      __builtin_amdgcn_s_barrier();                   // chunk g is complete for every wave; stage (g-1) % NST is free again
+      if (g + NST - 1 < total) issue_a(g + NST - 1);
+      const unsigned char* sa = ring + (g & (NST - 1)) * KT_BYTES;
+      const unsigned char* sw = lds + kt * KT_BYTES;
+      op16x8 af[4], bfr[4][2];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int c = 2 * ks + h;
+        af[ks] = *reinterpret_cast<const op16x8*>(sa + offA + ((c ^ swzA) << 4));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bfr[ks][j] = *reinterpret_cast<const op16x8*>(sw + offB[j] + ((c ^ swzB[j]) << 4));
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) cur[j] = MSAM2_MFMA_32x32x16(af[ks], bfr[ks][j], cur[j], 0, 0, 0);
+      if (has_prev && kt < 2) retire(prev[kt], kt, prev_row0);
+    }
+  };
+
+  f32x16 accA[2], accB[2];
+  int row_prev = 0;
+  for (int ti = 0; ti < my_tiles; ti += 2) {
+    tile(accA, accB, ti, ti > 0, row_prev);
+    row_prev = (grp + ti * groups) * BM;
+    if (ti + 1 < my_tiles) {
+      tile(accB, accA, ti + 1, true, row_prev);
+      row_prev = (grp + (ti + 1) * groups) * BM;
+    }
+  }
+  // the last tile's epilogue
+  if (my_tiles & 1) {
+    retire(accA[0], 0, row_prev);
+    retire(accA[1], 1, row_prev);
+  } else {
+    retire(accB[0], 0, row_prev);
+    retire(accB[1], 1, row_prev);
+  }
+#endif
+}
+
+template <int NK, int ACT, bool NT>
+static void launch_wstat(const GemmParams& p, int n_panels, int groups, hipStream_t s) {
+  constexpr int LDS = (NK + 4) * 128 * 64 * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_wstat_kernel<NK, ACT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_wstat_kernel<NK, ACT, NT>), dim3((unsigned)(n_panels * groups)), dim3(512), LDS, s, p, n_panels, groups);
+}
+
+// the W-stationary kernel serves this problem: returns true after launching it
+static bool gemm_try_wstat(const GemmParams& p, hipStream_t s) {
+  if (!p.out_is_16bit || p.res || p.colscale || p.rope_cos || p.pool_W || p.Q2 || p.res_mod) return false;
+  if (!(p.K == 256 || p.K == 384) || p.N % 128 != 0 || p.M % 128 != 0 || p.M < 8192 || !(p.act == 0 || p.act == 1 || p.act == 2)) return false;
+  if ((p.ldc & 1) || ((uintptr_t)p.C & 3) || (int64_t)p.M * p.ldc * 2 >= (1ll << 31) || (int64_t)p.M * p.lda * 2 >= (1ll << 31) ||
+      (int64_t)p.N * p.ldw * 2 >= (1ll << 31)) return false;
+  const int n_panels = p.N / 128;
+  if (n_panels > 64) return false;
+  const int groups = min(256 / n_panels, p.M / 128);
+#define WSTAT2(NKV, NTV) \
+  do { \
+    if (p.act == 0) launch_wstat<NKV, 0, NTV>(p, n_panels, groups, s); \
+    else if (p.act == 1) launch_wstat<NKV, 1, NTV>(p, n_panels, groups, s); \
+    else launch_wstat<NKV, 2, NTV>(p, n_panels, groups, s); \
+  } while (0)
+#define WSTAT(NKV) \
+  do { \
+    if (p.store_nt) WSTAT2(NKV, true); \
+    else WSTAT2(NKV, false); \
+  } while (0)
+  if (p.K == 384) WSTAT(6);
+  else WSTAT(4);
+#undef WSTAT
+#undef WSTAT2
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Skinny GEMM for M <= 32 (decoder tokens, hyper-network / IoU / object-pointer MLPs: 4..32 rows): one workgroup per 32
 // output columns, its 4 waves split K, operand fragments come straight from global memory (row r, 8 consecutive k = one
 // 16-byte load per lane per operand per MFMA, all independent => the whole reduction is in flight at once), partial 32x32
@@ -1113,6 +1367,11 @@ static int gemm_launch(const void* A, int64_t lda, const void* W, int64_t ldw, c
       hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, p);
       return msam2_check_launch("gemm(split-K)");
     }
+  }
+  {
+    const char* ew = getenv("MSAM2_GEMM_WSTAT");
+    const int wstat_mode = ew ? atoi(ew) : 0;
+    if (wstat_mode && !var && dma_ok && gemm_try_wstat(p, s)) return msam2_check_launch("gemm(w-stationary)");
   }
   const int vv = var ? atoi(var) : (tiles <= 256 && K >= 1024 ? 8 : (K % 64 == 0 && K >= 384 ? 2 : 5));
   if (dma_ok && K % 32 == 0 && vv == 6) {

@@ -179,7 +179,11 @@ __global__ __launch_bounds__(256, OCC) void mlp_fused_kernel(MlpFusedParams p) {
 #ifdef MSAM2_MLP_NO_GELU   // timing experiment only: what the activation costs
           for (int e = 0; e < 16; ++e) hf[e >> 3][e & 7] = f2op(acch[e]);
 #else
-          for (int e = 0; e < 16; ++e) hf[e >> 3][e & 7] = f2op(gelu_erf(acch[e]));
+          for (int e = 0; e < 16; e += 2) {               // pairs: packed fp32 arithmetic (common.h)
+            const f32x2 gp = gelu_erf2(f32x2{acch[e], acch[e + 1]});
+            hf[e >> 3][e & 7] = f2op(gp[0]);
+            hf[e >> 3][(e & 7) + 1] = f2op(gp[1]);
+          }
 #endif
           // fc2: Y^T[d][token] += W2[d][hidden] H^T[hidden][token]; operand k order = the accumulator's register order (permuted W2)
 #pragma unroll

@@ -108,7 +108,12 @@ class GraphedPropagation:
             if n:
                 tail = bucket.memory[len(spatial) * HW:].view(self.cap, split, n_obj, m.mem_dim)
                 tail[:n].copy_(self.ptr_bank[:n].view(n, n_obj, split, m.mem_dim).permute(0, 2, 1, 3))
-        self.key_count.fill_(len(spatial) * HW + n * split)
+        valid = len(spatial) * HW + n * split
+        self.key_count.fill_(valid)
+        from . import parallel
+        kvs = parallel.current_kv_split()
+        if kvs is not None:
+            kvs.host_key_count = valid         # lets every rank project only the keys of its own splits (RoPEAttention.proj_rope_key_range)
 
     def _body(self, bucket: _Bucket) -> dict:
         """the prompt-free track_step on the static buffers (what is captured)"""

@@ -103,18 +103,38 @@ class RoPEAttention(Attention):
             self._tables[key] = ops.rope_table(side, self.internal_dim // self.num_heads, float(self.rope_theta), device)
         return self._tables[key]
 
-    def proj_rope(self, which: str, x_bf16: torch.Tensor, B: int, rows_per_batch: int, n_rope: int, tab) -> torch.Tensor:
+    def proj_rope(self, which: str, x_bf16: torch.Tensor, B: int, rows_per_batch: int, n_rope: int, tab, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """q/k projection + RoPE -> bf16 [B, rows_per_batch, internal]; the rotation rides in the GEMM's store when the problem
-        qualifies (ops.gemm_rope), otherwise it is applied in place after the projection."""
+        qualifies (ops.gemm_rope), otherwise it is applied in place after the projection.  out: write into this [B*rows, internal] view."""
         lin = getattr(self, which + "_proj")
         w, b = w_bf16(self._wc, which + "w", lin.weight), v_f32(self._wc, which + "b", lin.bias)
         M = x_bf16.shape[0]
         if _FUSED_ROPE and M >= 256 and rows_per_batch >= 128 and tab[0].shape[0] >= 128 and n_rope > 0 and M * self.internal_dim * 4 < 2 ** 31:
             return ops.gemm_rope(x_bf16, w, b, tab, rope_cols=self.internal_dim, head_dim=self.internal_dim // self.num_heads,
-                                 rows_per_batch=rows_per_batch, n_rope=n_rope).view(B, rows_per_batch, -1)
-        y = ops.gemm(x_bf16, w, b).view(B, rows_per_batch, -1)
+                                 rows_per_batch=rows_per_batch, n_rope=n_rope, out=out).view(B, rows_per_batch, -1)
+        y = ops.gemm(x_bf16, w, b, out=out).view(B, rows_per_batch, -1)
         ops.rope_(y, n_rope, tab)
         return y
+
+    def proj_rope_key_range(self, mem_k: torch.Tensor, n_ptr_tokens: int, tab, valid_keys: int, eff: int, share: Tuple[int, int]) -> torch.Tensor:
+        """The rotated key projection for ONE RANK of a cross-GPU key split (parallel.KVSplit): only the keys of this rank's splits
+        [share[0], share[1]) of an `eff`-way split over `valid_keys` keys are projected -- rounded out to whole position-table periods
+        (memory entries of n_pos tokens), so the rotation of a projected row is the one the full call applies to it.  The other rows of the
+        returned [B, Nk, internal] buffer are uninitialised: this rank's attention partials never read them.  (under
+        the key split every rank used to project and rotate the whole bank -- ~1 ms of the replicated 2.7 ms per propagated slice at 1.06 M keys.)"""
+        B, Nk, _ = mem_k.shape
+        n_pos = tab[0].shape[0]
+        tiles_total = -(-valid_keys // 32)                       # the kernels' split -> key-tile map (attention.hip: 32-key tiles)
+        tiles_per = -(-tiles_total // eff)
+        k0 = min(share[0] * tiles_per * 32, valid_keys)
+        k1 = min(share[1] * tiles_per * 32, valid_keys)
+        r0, r1 = (k0 // n_pos) * n_pos, min(-(-k1 // n_pos) * n_pos, Nk)
+        kk = torch.empty(B, Nk, self.internal_dim, dtype=OP16, device=mem_k.device)
+        if r1 > r0:
+            n_rope = max(0, min(Nk - n_ptr_tokens, r1) - r0)     # rows past the spatial memories (object pointers) are not rotated
+            for b in range(B):
+                self.proj_rope("k", mem_k[b, r0:r1], 1, r1 - r0, n_rope, tab, out=kk[b, r0:r1])
+        return kk
 
     def folds_values(self) -> bool:
         """True when the value projection can be folded out of the attention: P (M W_v^T + b_v) = (P M) W_v^T + b_v because the
@@ -220,7 +240,15 @@ class MemoryAttentionLayer(nn.Module):
         # cross attention to the memory bank (keys carry the position encoding, values do not)
         t = self._ln("norm2", x)
         q = ca.proj_rope("q", t, B, L, L, tab)
-        kk = ca.proj_rope("k", mem_k.reshape(B * Nk, -1), B, Nk, Nk - n_ptr_tokens, tab)
+        from .. import parallel
+        kvs = parallel.current_kv_split()
+        eff = ops.attention_effective_splits(Nk, attn_splits(B, 1, L, Nk)) if (kvs is not None and ca.folds_values()) else 1
+        valid = Nk if key_count is None else (kvs.host_key_count if kvs is not None else None)
+        if eff > 1 and valid is not None and (Nk - n_ptr_tokens) % tab[0].shape[0] == 0:
+            # cross-GPU key split: this rank projects + rotates only the keys its attention partials read
+            kk = ca.proj_rope_key_range(mem_k, n_ptr_tokens, tab, int(valid), eff, kvs.share(eff))
+        else:
+            kk = ca.proj_rope("k", mem_k.reshape(B * Nk, -1), B, Nk, Nk - n_ptr_tokens, tab)
         if ca.folds_values():
             # O' = softmax(q k^T) M on the 64-channel memory rows; v_proj is folded into the out-projection (5/8 of the MFMA work)
             x = ca.out_folded(ca.core_folded(q, kk, mem_v, key_count), x)

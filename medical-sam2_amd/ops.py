@@ -109,7 +109,7 @@ def gemm_qkv_pool2x2(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tens
 
 
 def gemm_rope(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], table: Tuple[torch.Tensor, torch.Tensor], *,
-              rope_cols: int, head_dim: int, rows_per_batch: int, n_rope: int) -> torch.Tensor:
+              rope_cols: int, head_dim: int, rows_per_batch: int, n_rope: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """16-bit out[M,N] = rope(a @ w^T + bias): columns < rope_cols (whole heads of head_dim channels) of rows whose position
     m % rows_per_batch is < n_rope are rotated with table row (m % rows_per_batch) % n_pos -- the q/k projections of RoPEAttention
     with the rotation applied to the fp32 accumulator in the store."""
@@ -120,7 +120,9 @@ def gemm_rope(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], ta
          "gemm_rope: table must be cos/sin fp32 [n_pos, head_dim/2]")
     M, K = a.shape
     N = w.shape[0]
-    out = torch.empty(M, N, dtype=OP16, device=a.device)
+    if out is None:
+        out = torch.empty(M, N, dtype=OP16, device=a.device)
+    _req(out.dtype == OP16 and out.shape == (M, N) and out.stride(1) == 1, "gemm_rope: out must be 16-bit [M, N] row-major")
     check(lib().msam2_gemm_rope(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, _p(cs), _p(sn),
                                 rope_cols, head_dim, rows_per_batch, n_rope, cs.shape[0], _stream()))
     return out

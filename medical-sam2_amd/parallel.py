@@ -179,6 +179,80 @@ def gather_slice_features(local: Dict[int, dict], slice_ids: List[int], owners: 
     return out
 
 
+class FeatureStream:
+    """PIPELINED exchange of the non-conditioning slices' backbone features: instead of one up-front all-gather of
+    every slice's features (4.3 GB per rank at 512 slices) that the propagation chain has to wait for, the slices travel in CHUNKS of
+    consecutive slices of one owner, each chunk as one asynchronous broadcast per feature level from the rank that encoded it, all
+    issued at once in slice order -- the order the chain consumes them in.  `get(t)` waits for the chunk of slice t only, so the chain
+    starts as soon as the first chunk has landed and the rest of the transfer runs under it (on RCCL's own stream).
+    local: this rank's {slice: {"backbone_fpn": [levels x [1,C,h,w]], "vision_pos_enc": [...]}}; slice_ids / owners: the global, ordered
+    list of slices to exchange and the rank that encoded each.  Features travel channels-last; the position tables stay local."""
+
+    def __init__(self, local: Dict[int, dict], slice_ids: List[int], owners: List[int], group=None, chunk: int = 8,
+                 pos_tables=None, device: Optional[torch.device] = None):
+        self.group, self.local, self.pos = group, dict(local), pos_tables
+        self.rank = dist.get_rank(group)
+        world = dist.get_world_size(group)
+        my_ids = [t for t, o in zip(slice_ids, owners) if o == self.rank]
+        assert sorted(my_ids) == sorted(local), "a rank must pass exactly the slices it encoded"
+        meta = None
+        if my_ids:
+            one = local[my_ids[0]]["backbone_fpn"]
+            meta = [[f.shape[2], f.shape[3], f.shape[1]] for f in one]              # (h, w, C) per level
+            device = one[0].device
+        objs = [None] * world
+        dist.all_gather_object(objs, meta, group=group)
+        self.meta = next((m for m in objs if m is not None), None)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        # chunks: runs of consecutive list entries with one owner, at most `chunk` slices each
+        self.chunks: List[dict] = []
+        self.where: Dict[int, tuple] = {}
+        i = 0
+        while i < len(slice_ids):
+            j = i
+            while j < len(slice_ids) and owners[j] == owners[i] and j - i < chunk:
+                j += 1
+            ids, owner = slice_ids[i:j], owners[i]
+            ck = {"ids": ids, "owner": owner, "bufs": None, "works": [], "left": len(ids)}
+            if owner != self.rank or world > 1:
+                bufs = []
+                for (h, w, c) in self.meta:
+                    buf = torch.empty(len(ids), h, w, c, dtype=torch.float32, device=device)
+                    if owner == self.rank:
+                        for k, t in enumerate(ids):
+                            buf[k].copy_(_to_nhwc(local[t]["backbone_fpn"][len(bufs)])[0])
+                    src = dist.get_global_rank(group, owner) if group is not None else owner
+                    ck["works"].append(dist.broadcast(buf, src=src, group=group, async_op=True))
+                    bufs.append(buf)
+                ck["bufs"] = bufs                  # (the owner serves its own tensors from `local`; its slabs live until the sends are done)
+            for k, t in enumerate(ids):
+                self.where[t] = (len(self.chunks), k)
+            self.chunks.append(ck)
+            i = j
+
+    def get(self, t: int) -> dict:
+        """features of slice t (waits for its chunk if it has not landed yet); call once per slice"""
+        ci, k = self.where[t]
+        ck = self.chunks[ci]
+        for w in ck["works"]:
+            w.wait()
+        ck["works"] = []
+        ck["left"] -= 1
+        if ck["owner"] == self.rank:
+            out = self.local.pop(t)
+        else:
+            out = {"backbone_fpn": [_from_nhwc(b[k: k + 1]) for b in ck["bufs"]], "vision_pos_enc": self.pos}
+        if out["vision_pos_enc"] is None:
+            out["vision_pos_enc"] = self.pos
+        if ck["left"] == 0:
+            ck["bufs"] = None                                                       # the views handed out keep their storage alive
+        return out
+
+    def pop(self, t: int) -> dict:
+        return self.get(t)
+
+
 def gather_object_shards(masks: Dict[int, torch.Tensor], slice_ids: List[int], n_obj: int, group=None) -> Dict[int, torch.Tensor]:
     """Object-sharded chain -> full object batch on every rank: masks[t] is this rank's [n_local, 1, h, w] share
     (`shard_range(n_obj, rank, world)`) for every t in slice_ids; one all-gather of a [len(slice_ids), cap, 1, h, w] slab."""
@@ -218,7 +292,8 @@ class KVSplit:
         assert _is_dist(group), "KVSplit needs an initialised process group with more than one rank"
         self.group, self.world, self.rank = group, dist.get_world_size(group), dist.get_rank(group)
         self.calls = 0
-        self._prev = _KV_SPLIT
+        self.host_key_count = None         # padded banks: the number of valid keys of the CURRENT slice as the host knows it (the device
+        self._prev = _KV_SPLIT             # scalar `key_count` holds the same value): graphs.GraphedPropagation._fill sets it
         _KV_SPLIT = self
 
     def close(self):

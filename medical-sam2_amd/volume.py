@@ -9,9 +9,10 @@ slices twice, sam2_video_predictor.py:1378-1380), and conditioning slices run th
 Multi-GPU (one process per GPU):
   1. image encoder of ALL slices + conditioning-slice heads / memory encoding: independent per slice -> every rank takes a contiguous
      share of the slices (`parallel.shard_range`), conditioning or not;
-  2. ONE exchange step: all-gather of the conditioning memories / pointers (`parallel.gather_cond_memories`; ranks without a
-     conditioning slice join with an empty slab) and of the non-conditioning slices' backbone features
-     (`parallel.gather_slice_features`: 16.8 MB per slice at 1024^2, a few large messages);
+  2. the exchange: all-gather of the conditioning memories / pointers (`parallel.gather_cond_memories`; ranks without a
+     conditioning slice join with an empty slab); the non-conditioning slices' backbone features (16.8 MB per slice at 1024^2) travel
+     as chunked asynchronous broadcasts from their owners, issued in slice order and waited for chunk by chunk by the chain
+     (`parallel.FeatureStream`), so the chain starts after the first chunk and the rest of the 4.3 GB (512 slices) moves under it;
   3. the propagation chain is sequential in the slice index: it is sharded over OBJECTS when there are at least as many objects as
      ranks (objects never interact: non_overlap_masks is off), otherwise every rank runs it with the memory cross-attention's KEY
      range split over the ranks (`parallel.KVSplit`: each rank's share of the split-KV partials, one all-gather of the (max, sum, O')
@@ -27,7 +28,7 @@ import torch.distributed as dist
 
 from . import ops
 from .graphs import GraphedPropagation, pointer_capacity
-from .parallel import KVSplit, _is_dist, gather_cond_memories, gather_object_shards, gather_slice_features, shard_range
+from .parallel import FeatureStream, KVSplit, _is_dist, gather_cond_memories, gather_object_shards, gather_slice_features, shard_range
 
 
 class _SliceEncoder:
@@ -71,7 +72,8 @@ def box_point_inputs(boxes: torch.Tensor) -> dict:
 @torch.no_grad()
 def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_hole_area: int = 0, group=None,
                    shard_objects: bool = True, encode_batch: int = 8, kv_split: bool = True, return_state: bool = False,
-                   graphs: bool = False, padded_bank: bool = True, stats: Optional[dict] = None, graph_cache: Optional[dict] = None):
+                   graphs: bool = False, padded_bank: bool = True, stats: Optional[dict] = None, graph_cache: Optional[dict] = None,
+                   pipelined_exchange: bool = True, exchange_chunk: int = 8):
     """volume: [T,3,S,S] normalised slices on the GPU; prompts: {slice_idx: {"boxes": [n,4]} | {"point_coords", "point_labels"}}
     for the conditioning slices (same n objects everywhere).  Returns {slice_idx: low-res mask logits [n,1,S/4,S/4]} for ALL slices
     and ALL objects on every rank.  encode_batch: slices per image-encoder call (results do not depend on it).  shard_objects /
@@ -85,7 +87,9 @@ def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_h
     hipGraphs, one per bucket -- bit-identical to the padded-bank launches; not combined with the cross-GPU key split, whose exchange
     runs between the partial pass and the merge (the padded bank itself is).  stats: filled with the replay / capture counts of this
     call.  graph_cache: a dict the caller keeps between volumes of the same shape (slices, objects, prompt schedule): the captured
-    graphs are reused, a later volume replays from its first steady-state slice on."""
+    graphs are reused, a later volume replays from its first steady-state slice on.
+    pipelined_exchange (multi-rank): the non-conditioning slices' features travel as chunked asynchronous broadcasts that the chain waits
+    for chunk by chunk (`parallel.FeatureStream`, `exchange_chunk` slices per message) instead of one all-gather before the chain starts."""
     T = volume.shape[0]
     cond_ids = sorted(prompts)
     assert cond_ids, "at least one conditioning slice is needed"
@@ -138,13 +142,18 @@ def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_h
         like = (n_obj, model.mem_dim, model.sam_image_embedding_size, model.hidden_dim, volume.device)
         cond = gather_cond_memories(local_cond, cond_ids, group, owners=[owner(t) for t in cond_ids], like=like)
         non_cond_ids = [t for t in range(T) if t not in cond_set]
-        feats_all = gather_slice_features(local_feats, non_cond_ids, [owner(t) for t in non_cond_ids], group)
         for o in cond.values():                       # remote entries: the position table of the memory encoder is a constant
             if o["maskmem_pos_enc"] is None:
                 o["maskmem_pos_enc"] = [model.memory_encoder.position_encoding(o["maskmem_features"]).to(o["maskmem_features"].dtype)]
-        for o in feats_all.values():
-            if o["vision_pos_enc"] is None:
-                o["vision_pos_enc"] = pos_tables
+        if pipelined_exchange and non_cond_ids:
+            # chunked asynchronous broadcasts in slice order: the chain below waits per chunk, the rest travels under it
+            feats_all = FeatureStream(local_feats, non_cond_ids, [owner(t) for t in non_cond_ids], group, chunk=exchange_chunk,
+                                      pos_tables=pos_tables, device=volume.device)
+        else:
+            feats_all = gather_slice_features(local_feats, non_cond_ids, [owner(t) for t in non_cond_ids], group)
+            for o in feats_all.values():
+                if o["vision_pos_enc"] is None:
+                    o["vision_pos_enc"] = pos_tables
     else:
         cond, feats_all = local_cond, local_feats
 

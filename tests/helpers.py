@@ -37,6 +37,19 @@ def max_abs(a, b) -> float:
     return float((a - b).abs().max())
 
 
+def op16_is_fp16() -> bool:
+    """operand type of the loaded library (fp16 by default; bf16 with MSAM2_LIB_PATH=libmsam2_hip_bf16.so)"""
+    import medical_sam2_amd.ops as ops
+    return ops.OP16 == torch.float16
+
+
+def btol(tol_fp16: float, factor: float = 4.0) -> float:
+    """The STATED bf16 tolerance of a bound written for the default fp16 operands: bf16 keeps 8 significand bits against fp16's 11, an 8x
+    coarser unit round-off per operand; through a few dozen independent roundings the measured error ratios are 2-3.5x (round 3:
+    gpurun_out/bf16_suite.log), so the bf16 bound is 4x the fp16 bound unless a test says otherwise."""
+    return tol_fp16 if op16_is_fp16() else tol_fp16 * factor
+
+
 def mask_iou(a, b) -> float:
     a = torch.as_tensor(np.asarray(a)) > 0
     b = torch.as_tensor(np.asarray(b)) > 0

@@ -6,6 +6,9 @@ import os
 import sys
 
 import pytest
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from helpers import btol, op16_is_fp16  # noqa: E402
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -104,7 +107,7 @@ def test_hiera_block_backward_variants():
             errs[k] = rel(v, P[pre + "." + k].grad)
         assert set(g) == {k[len(pre) + 1:] for k in P}, (i, sorted(set(g) ^ {k[len(pre) + 1:] for k in P}))
         worst[i] = max(errs.items(), key=lambda kv: kv[1])
-        assert worst[i][1] < 3e-2, (i, spec, sorted(errs.items(), key=lambda kv: -kv[1])[:5])
+        assert worst[i][1] < btol(3e-2), (i, spec, sorted(errs.items(), key=lambda kv: -kv[1])[:5])
     print("worst per block:", worst)
 
 
@@ -128,7 +131,7 @@ def test_image_encoder_backward_vs_autograd(name):
     with torch.no_grad():
         out, st = be.image_encoder_forward_saved(m, img.to(DEV))
         for l in range(3):
-            assert rel(out["backbone_fpn"][l], bo["backbone_fpn"][l]) < 3e-3
+            assert rel(out["backbone_fpn"][l], bo["backbone_fpn"][l]) < btol(3e-3)
         d_fpn = [d.permute(0, 2, 3, 1).reshape(-1, d.shape[1]).contiguous().to(DEV) for d in dys]
         grads = be.image_encoder_backward(m, st, d_fpn)
     want = {k for k in P if train(k) and P[k].grad is not None and not k.startswith("image_encoder.neck.convs.0.")}   # level 3 is scalped: no gradient... except through the top-down path

@@ -4,6 +4,9 @@ import os
 import sys
 
 import pytest
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from helpers import btol, op16_is_fp16  # noqa: E402
 import torch
 import torch.nn.functional as F
 
@@ -74,7 +77,7 @@ def test_act_backward(mods, act):
     dy = rnd(513, 96, seed=9)
     (O.gelu(pre) if act == 1 else torch.relu(pre)).backward(dy)
     out = B.act_backward(pre.detach().to(DEV), dy.to(DEV), act)
-    assert (out.float().cpu() - pre.grad).abs().max().item() < 4e-3             # 16-bit output rounding
+    assert (out.float().cpu() - pre.grad).abs().max().item() < btol(4e-3)       # 16-bit output rounding
 
 
 @pytest.mark.parametrize("K,M,N", [(16384, 256, 256), (65536, 128, 64), (300, 200, 40), (28, 8, 2048), (4097, 264, 136)])
@@ -207,7 +210,7 @@ def test_memory_attention_layer_backward(mods):
     d = lambda tns: tns.detach().to(DEV)
     dx, dmk, dmv, grads = B_.memory_attention_layer_backward(layer, d(x).reshape(B * L, C).contiguous(), d(mem_k).to(ops.OP16), d(mem_v).to(ops.OP16),
                                                              B, L, n_ptr, d(dy).reshape(B * L, C).contiguous())
-    tol = 2e-2
+    tol = btol(2e-2)
     report = {"dx": rel(dx.view(B, L, C), x.grad), "dmem_k": rel(dmk, mem_k.grad), "dmem_v": rel(dmv, mem_v.grad)}
     for name, gten in grads.items():
         ref = P[f"{pre}.{name}"].grad
@@ -246,7 +249,7 @@ def test_memory_attention_module_backward(mods):
     n_params = sum(1 for k in sd if k.startswith("memory_attention."))
     assert len(grads) == n_params == 106, (len(grads), n_params)
     worst = sorted(report.items(), key=lambda kv: -kv[1])[:5]
-    assert worst[0][1] < 3e-2, worst
+    assert worst[0][1] < btol(3e-2), worst
 
 
 def test_two_way_transformer_backward(mods):
@@ -288,7 +291,7 @@ def test_two_way_transformer_backward(mods):
     n_params = sum(1 for k in sd if k.startswith(pre + "."))
     assert len(grads) == n_params, (len(grads), n_params)
     worst = sorted(report.items(), key=lambda kv: -kv[1])[:6]
-    assert worst[0][1] < 3e-2, worst
+    assert worst[0][1] < btol(3e-2), worst
 
 
 @pytest.mark.parametrize("Pp,with_tokens", [(2, False), (3, False), (1, True), (3, True)])
@@ -336,7 +339,7 @@ def test_mask_decoder_backward(mods, Pp, with_tokens):
     assert expect <= set(grads), sorted(expect - set(grads))
     worst = sorted(report.items(), key=lambda kv: -kv[1])[:6]
     # (9 decoder tokens / the extra token gradient: the same 16-bit links, the worst single parameter sits at 5-7 % instead of < 4 %)
-    assert worst[0][1] < (4e-2 if (Pp, with_tokens) == (2, False) else 8e-2), worst
+    assert worst[0][1] < btol(4e-2 if (Pp, with_tokens) == (2, False) else 8e-2), worst
 
 
 def test_bce_and_adam_kernels(mods):
@@ -410,7 +413,7 @@ def test_decoder_finetune_step(mods):
         cos_min = min(cos_min, cos)
     # (the first Adam step is lr * g / (|g| + eps), i.e. nearly sign(g): an element whose gradient is small against the 1-4 % gradient
     # error can flip, so the bar is on the direction of each parameter's update, not on its elements)
-    assert touched >= 60 and cos_min > 0.9, (touched, cos_min)
+    assert touched >= 60 and cos_min > (0.9 if op16_is_fp16() else 0.85), (touched, cos_min)
     # second step runs on the updated weights (kernel-ready weight caches are invalidated by the update)
     loss2 = T.decoder_finetune_step(dec, optim, tm(emb), tm(pe), d(sparse), tm(f0).to(ops.OP16), tm(f1).to(ops.OP16), B, E, E, d(target))
     assert loss2 < loss
@@ -546,7 +549,7 @@ def test_memory_decoder_loss_grads(mods):
     with torch.no_grad():
         y_hip, _ = B_.memory_attention_forward_saved(mod, d(curr), d(curr_pos), d(memory), d(memory_pos), n_ptr)
     y_o = O.memory_attention(P, cfg, curr, memory, curr_pos, memory_pos, n_ptr)            # [L, B, C]
-    assert rel(y_hip, y_o) < 2e-3
+    assert rel(y_hip, y_o) < btol(2e-3)
     y_lin = y_hip.detach().cpu().float().contiguous().requires_grad_(True)               # the decoder is linearised at the HIP forward's point
     emb = y_lin.permute(1, 2, 0).reshape(B, C, E, E)
     masks, _, _, _ = O.mask_decoder_predict(P, emb, pe, sparse, dense.view(1, C, 1, 1).expand(B, C, E, E), [f0, f1])
@@ -685,7 +688,7 @@ def test_memory_bank_loss_grads(mods):
     ptr_o = O.mlp(P, "obj_ptr_proj", sam_tok, 3, torch.relu).view(B, 4, 64).transpose(0, 1)  # [4, B, 64]
     memory_o = torch.cat([mem_o.flatten(2).permute(2, 0, 1), ptr_o], 0)                      # [L + 4, B, 64]
     y_o = O.memory_attention(P, cfg, curr, memory_o, curr_pos, torch.cat([memory_pos, torch.zeros(4, B, 64)], 0), 4)
-    assert rel(y_hip, y_o) < 2e-3
+    assert rel(y_hip, y_o) < btol(2e-3)
     y_lin = y_hip.detach().cpu().float().contiguous().requires_grad_(True)
     emb = y_lin.permute(1, 2, 0).reshape(B, C, E, E)
     masks, _, _, _ = O.mask_decoder_predict(P, emb, pe, sparse, dense.view(1, C, 1, 1).expand(B, C, E, E), [f0, f1])
@@ -988,7 +991,7 @@ def test_memory_attention_train_mode_dropout(mods):
         y_ev_hip = ma(curr=[d(curr)], curr_pos=[d(curr_pos)], memory=d(memory), memory_pos=d(memory_pos), num_obj_ptr_tokens=n_ptr)
     assert rel(y, y_ref) < 5e-3, rel(y, y_ref)
     assert torch.equal(y_mod, y)                                                  # same (p, seed) -> same masks
-    assert rel(y_ev_hip, y_eval) < 3e-3 and rel(y, y_eval) > 0.05                 # and dropout really changed the output
+    assert rel(y_ev_hip, y_eval) < btol(3e-3) and rel(y, y_eval) > 0.05                 # and dropout really changed the output
     errs = {"dcurr": rel(dcurr, cr.grad), "dmemory": rel(dmem, mr.grad), "dmemory_pos": rel(dmem_pos, mpr.grad)}
     for k, v in grads.items():
         errs[k] = rel(v, P["memory_attention." + k].grad)

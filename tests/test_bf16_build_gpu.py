@@ -19,7 +19,7 @@ def test_bf16_build_passes_the_parity_suite():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     assert os.path.exists(LIB), "libmsam2_hip_bf16.so is built by __graft_entry__.build()"
-    env = dict(os.environ, MSAM2_LIB_PATH=LIB)
+    env = dict(os.environ, MSAM2_LIB_PATH=LIB, MSAM2_E2E_REPORT="gpurun_out/e2e_report_bf16.json")
     probe = subprocess.run([sys.executable, "-c", "import medical_sam2_amd.ops as o, torch; print(o.OP16)"], cwd=ROOT, env=env,
                            capture_output=True, text=True, timeout=300)
     assert "bfloat16" in probe.stdout, probe.stdout + probe.stderr

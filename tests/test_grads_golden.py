@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import sam2_oracle as O  # noqa: E402
 
 import medical_sam2_amd.weights as wts  # noqa: E402
-from helpers import load_meta, load_npz, sub  # noqa: E402
+from helpers import btol, load_meta, load_npz, sub  # noqa: E402
 
 DEV = "cuda"
 SUBN = 256
@@ -191,7 +191,7 @@ def test_hip_backward_matches_reference_gradients():
                 continue                                                # identically-zero reference gradient (softmax key bias)
             rep[name] = rel_sub(g, G[k])
         worst = sorted(rep.items(), key=lambda kv: -kv[1])[:5]
-        assert worst[0][1] < 4e-2, worst
+        assert worst[0][1] < btol(4e-2), worst
         # ---- mask decoder, loss = BCEWithLogitsLoss(pos_weight) from the HIP loss kernel
         dec = m.sam_mask_decoder.to(DEV).eval()
         emb, pe, sparse, f0, f1, target = dec_inputs(meta["dec"])
@@ -278,5 +278,5 @@ def test_hip_encoder_backward_matches_reference_grads():
     errs = sorted(((rel_sub(grads[k[len("enc_param."):]], gold[k]), k) for k in keys), reverse=True)
     stats = meta["grad_stats"]
     num = sum((float(grads[k[len("enc_param."):]].double().abs().sum()) - stats[k]["abs_sum"]) ** 2 for k in keys)
-    assert errs[0][0] < 8e-2, errs[:5]                      # 16-bit operands; the worst entries are the position tables (4 %)
+    assert errs[0][0] < btol(8e-2, 2.5), errs[:5]                      # 16-bit operands; the worst entries are the position tables (4 %)
     assert sum(e for e, _ in errs) / len(errs) < 2e-2, errs[:5]

@@ -8,6 +8,9 @@ import math
 
 import numpy as np
 import pytest
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from helpers import btol, op16_is_fp16  # noqa: E402
 import torch
 import torch.nn.functional as F
 
@@ -660,7 +663,7 @@ def test_ln_mlp_residual_fused(ops, dim, T):
                               d(P["m.layers.1.bias"]))
     assert out.shape == x.shape and out.dtype == torch.float32
     # two 16-bit roundings (normalised input, hidden activation) as in the three-launch path
-    close(out, ref, 6e-3, 4e-3, "fused LN+MLP")
+    close(out, ref, btol(6e-3), btol(4e-3), "fused LN+MLP")
     # against the three-launch path of the same library: same operand roundings, different summation order only
     xn = ops.layernorm(d(x), d(P["n.weight"]), d(P["n.bias"]), 1e-6)
     hid = ops.gemm(xn, bf(P["m.layers.0.weight"]).to(DEV), d(P["m.layers.0.bias"]), act=ops.ACT_GELU)

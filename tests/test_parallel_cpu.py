@@ -67,6 +67,14 @@ def _worker(rank, world, port, q):
     feats = par.gather_slice_features({t: mk(t) for t, o in zip(sl_ids, owners) if o == rank}, sl_ids, owners)
     ok &= sorted(feats) == sl_ids and all(bool((feats[t]["backbone_fpn"][0] == t).all()) and bool((feats[t]["backbone_fpn"][1] == 10.0 + t).all())
                                           and feats[t]["backbone_fpn"][0].shape == (1, 4, 8, 8) for t in sl_ids)
+    # the same exchange PIPELINED: chunked async broadcasts in slice order, waited for chunk by chunk (5 slices, chunks of 2, ragged owners)
+    sl2, own2 = [1, 3, 5, 7, 9], [0, 0, 0, 1, 1]
+    stream = par.FeatureStream({t: mk(t) for t, o in zip(sl2, own2) if o == rank}, sl2, own2, chunk=2, pos_tables=["pos"], device=dev)
+    ok &= [len(c["ids"]) for c in stream.chunks] == [2, 1, 2]
+    for t in sl2:
+        f = stream.pop(t)
+        ok &= bool((f["backbone_fpn"][0] == t).all()) and bool((f["backbone_fpn"][1] == 10.0 + t).all()) and f["backbone_fpn"][0].shape == (1, 4, 8, 8)
+        ok &= f["vision_pos_enc"] == ["pos"]
     # object shards -> full object batch (3 objects over 2 ranks: 2 + 1)
     ob, oe = par.shard_range(3, rank, world)
     sh = {t: torch.arange(ob, oe, dtype=torch.float32).reshape(-1, 1, 1, 1).expand(-1, 1, 2, 2).contiguous() + 10 * t for t in (0, 1)}

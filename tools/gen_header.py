@@ -58,6 +58,7 @@ DOC = {
     "msam2_gemm_tt": "Weight-gradient GEMM C[M,N] (fp32) = sum_k A[k][m] B[k][n] on k-major 16-bit operands: dW = dY^T X of nn.Linear under autograd\n(sam2_utils.py:127-131, memory_attention.py:96, transformer.py:241-261) straight from the token-major dY and X -- no transposed copies;\nthe token reduction is split over workgroups (fp32 atomics into the zeroed output).  a_colsum (optional, [M]) receives sum_k A[k][m]:\nthe bias gradient in the same pass over dY.",
     "msam2_bilinear_upsample_bwd": "Adjoint of msam2_bilinear_upsample: gradient of the video-resolution mask logits (sam2_video_predictor.py:724-744, the tensor the\ntraining loss of func_3d/function.py:137-170 is taken on) back to the decoder's low-resolution logits.",
     "msam2_maxpool2x2_bwd": "Backward of MaxPool2d(2, 2) on token-major maps (do_pool, hieradet.py:23-34, under autograd in the 2-D training loop,\nfunc_2d/function.py:70-72): dy is routed to the first maximum of each 2x2 window, every dx element is written.",
+    "msam2_window_move": "window_partition (to_windows = 1) / window_unpartition (0) of backbones/utils.py:16-62 on a projected token image, in 16-byte chunks:\nimg [B, H, W, heads * D] (row stride ld_img elements) <-> win [B * nW, heads, ws * ws, D] contiguous; padded window tokens take `fill`\n[heads * D] (or 0) on the way in and are cropped on the way out.  The operands of the attention backward of the Hiera trunk under\nautograd (hieradet.py:138-158 in the 2-D training loop, func_2d/function.py:70-72); the forward's window kernel gathers by itself.",
     "msam2_sumpool2x2": "Adjoint of msam2_upsample2x_add (FPN nearest-2x top-down step, image_encoder.py:113-124): sums of the 2x2 blocks.",
     "msam2_hiera_pos_embed_bwd": "Adjoint of msam2_hiera_pos_embed (hieradet.py:269-277): gradient of the position-token table -> d pos_embed (transposed bicubic\nresize) and d pos_embed_window (sum over the tiling).  Two gather passes through a caller-owned workspace, no atomics.",
     "msam2_hiera_pos_embed_bwd_workspace_bytes": "Scratch needed by msam2_hiera_pos_embed_bwd (per-row partial sums).",
