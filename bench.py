@@ -207,7 +207,9 @@ def pmc_traffic():
     here = os.path.dirname(os.path.abspath(__file__))
     tot = 0.0
     for name, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
-        path = os.path.join(here, "profiles", f"r02_attnkv64_pmc_{name}.csv")
+        path = os.path.join(here, "profiles", f"r03_attnkv64_pmc_{name}.csv")
+        if not os.path.exists(path):
+            path = os.path.join(here, "profiles", f"r02_attnkv64_pmc_{name}.csv")
         if not os.path.exists(path):
             return None
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
@@ -358,11 +360,11 @@ def time_gemm_family(m, imgs, pts, labels, memory, memory_pos, device):
     e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
     check(lib().msam2_event_create(ctypes.byref(e0)))
     check(lib().msam2_event_create(ctypes.byref(e1)))
-    rows, reps = [], 10
+    rows, reps = [], 20
     for key, g in groups.items():
         fn, a, kw = g["call"]
         kw = {k: v for k, v in kw.items() if k != "out"}        # never re-write a live buffer of the model (out= aliases)
-        for _ in range(2):
+        for _ in range(3):
             fn(*a, **kw)
         torch.cuda.synchronize()
         check(lib().msam2_event_record(e0, stream))
@@ -389,8 +391,9 @@ def time_gemm_family(m, imgs, pts, labels, memory, memory_pos, device):
             "traffic": None, "what": "all GEMM launches of one step (flop-weighted): sum of 2MNK over sum of launches x stand-alone average launch time",
             "gemm_ms_per_step": tot_t * 1e3, "flops_per_step": tot_f, "launches_per_step": sum(r["launches_per_step"] for r in rows),
             "distinct_shapes": len(rows), "top_shapes": rows[:8],
-            "pmc": "profiles/r03_gemm_16384x1536x384_pmc_*.csv, profiles/r03_gemm_16384x384x1536_pmc_*.csv (stage-3 fc1 / fc2: HBM bytes, L2 hit rate, "
-                   "MFMA-busy, LDS activity; summary in profiles/README.md)"}
+            "pmc": "profiles/r03_gemm_16384x1536x384_pmc_*.csv, profiles/r03_gemm_16384x384x1536_pmc_*.csv (stage-3 fc1 / fc2 on the tiled kernel), "
+                   "profiles/r03_gemm_qkv16384x1152x384_{wstat,tiled}_pmc_*.csv (the W-stationary kernel against the tiled one): HBM bytes, L2 "
+                   "requests / hit rate, MFMA-busy, wait cycles; summary in profiles/README.md"}
 
 
 # ---------------------------------------------------------------------------------------------------------------------

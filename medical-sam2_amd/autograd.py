@@ -207,6 +207,37 @@ class TokenMLPFn(torch.autograd.Function):
             return (None, d_tok.to(F32) * inv, *_param_grads(ctx.names, ctx.params, {k[2:]: v for k, v in g.items()}, inv))
 
 
+class BilinearUpsampleFn(torch.autograd.Function):
+    """F.interpolate(mode="bilinear", align_corners=False) on [n,1,h,w] fp32 maps (sam2_base.py:367-373, sam2_video_predictor.py:724-744)
+    by the library's kernel and its exact adjoint -- the same bits as the inference path produces, so a training forward and an
+    inference forward of the same weights agree bit for bit."""
+
+    @staticmethod
+    def forward(ctx, x, H, W):
+        ctx.shape = x.shape
+        ctx.set_materialize_grads(False)
+        with torch.no_grad():
+            return ops.bilinear_upsample(x.detach().to(F32).contiguous(), H, W)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return None, None, None
+        from ._lib import check, lib
+        n, c, h, w = ctx.shape
+        with torch.no_grad():
+            d = dy.to(F32).contiguous()
+            dx = torch.empty(n * c, h, w, dtype=F32, device=d.device)
+            check(lib().msam2_bilinear_upsample_bwd(ops._p(d), ops._p(dx), n * c, h, w, d.shape[-2], d.shape[-1], ops._stream()))
+        return dx.view(n, c, h, w), None, None
+
+
+def bilinear_upsample(x: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    if tuple(x.shape[-2:]) == (H, W):
+        return x
+    return BilinearUpsampleFn.apply(x, H, W)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 class ImageEncoderFn(torch.autograd.Function):
     """`SAM2Base.forward_image` (sam2_base.py:464-476: Hiera trunk + FPN neck + conv_s0 / conv_s1): outputs the feature levels."""
@@ -321,8 +352,8 @@ def forward_sam_heads(model, backbone_features, point_inputs=None, mask_inputs=N
         ious_out = ious[:, 1:]
     else:
         low_res_multimasks, ious_out = low_res_masks, iou_sel
-    high_res_masks = F.interpolate(low_res_masks, size=(S, S), mode="bilinear", align_corners=False)
-    high_res_multimasks = F.interpolate(low_res_multimasks, size=(S, S), mode="bilinear", align_corners=False) if multimask_output else high_res_masks
+    high_res_masks = bilinear_upsample(low_res_masks, S, S)
+    high_res_multimasks = bilinear_upsample(low_res_multimasks, S, S) if multimask_output else high_res_masks
     tok_sel = sel if (multimask_output and dec.use_multimask_token_for_obj_ptr) else torch.zeros(B, dtype=torch.long, device=dev)
     token = mask_tokens[ar, tok_sel]
     mlp = model.obj_ptr_proj

@@ -1005,7 +1005,7 @@ __device__ __forceinline__ void wstat_wait_dyn(int n) {      // n: multiple of 4
   }
 }
 
-template <int NK, int ACT, bool NT>
+template <int NK, int ACT, bool NT, bool APF>
 __global__ __launch_bounds__(512, 1) void gemm_wstat_kernel(GemmParams p, int n_panels, int groups) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = 128, BN = 128, BK = 64, NST = 4;
@@ -1019,9 +1019,25 @@ __global__ __launch_bounds__(512, 1) void gemm_wstat_kernel(GemmParams p, int n_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;          // 8 waves (two per SIMD): 4 row slabs of 32 x 2 column halves of 64
   const int r = lane & 31, h = lane >> 5, odd = lane & 1;
-  const int panel = blockIdx.x % n_panels, grp = blockIdx.x / n_panels;
+  // XCD-aware placement (grid = 256 workgroups, dealt round-robin over the 8 XCDs: id % 8 share an XCD and its private L2).  The
+  // n_panels workgroups of a GROUP stream the same A tiles at the same time, so a group sits on ONE XCD wherever it fits: each XCD's 32
+  // slots hold F = 32 / n_panels whole groups; the R left-over slots per XCD are pooled (XCD-major) into further groups that span two
+  // XCDs.  With id-order placement every A tile was fetched by all 8 L2s: ~100 MB through the fabric for a 12.6 MB operand.
+  int panel, grp;
+  {
+    const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+    const int F = 32 / n_panels, R = 32 - F * n_panels;
+    if (l < F * n_panels) {
+      grp = xcd * F + l / n_panels;
+      panel = l % n_panels;
+    } else {
+      const int q = (l - F * n_panels) + R * xcd;
+      grp = 8 * F + q / n_panels;
+      panel = q % n_panels;
+    }
+  }
   const int n_tiles_m = p.M / BM;
-  const int my_tiles = grp < n_tiles_m ? (n_tiles_m - grp + groups - 1) / groups : 0;     // tiles grp, grp + groups, ...
+  const int my_tiles = grp < min(groups, n_tiles_m) ? (n_tiles_m - grp + groups - 1) / groups : 0;     // tiles grp, grp + groups, ...
   if (my_tiles == 0) return;
   const int64_t n0 = (int64_t)panel * BN;
   const int total = my_tiles * NK;
@@ -1050,7 +1066,10 @@ __global__ __launch_bounds__(512, 1) void gemm_wstat_kernel(GemmParams p, int n_
   float bias_j[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) bias_j[j] = p.bias ? p.bias[n0 + wn * 64 + j * 32 + r] : 0.f;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // the values pass through an empty asm: the compiler waits for the two loads HERE (nothing else is in flight yet) and afterwards
+  // treats them as plain registers -- otherwise it puts its own conservative s_waitcnt vmcnt(N) in front of their first use, in the
+  // middle of the first retiring chunk, where it drains DMA pieces that are meant to stay in flight
+  asm volatile("" : "+v"(bias_j[0]), "+v"(bias_j[1])::"memory");
   // ---- prologue: the whole W panel, then the first three A chunks (W is older than chunk 0: waiting for chunk 0 covers it)
 #pragma unroll
   for (int kt = 0; kt < NK; ++kt)
@@ -1059,7 +1078,7 @@ __global__ __launch_bounds__(512, 1) void gemm_wstat_kernel(GemmParams p, int n_
       __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(lds + kt * KT_BYTES + (wave * LPC + i) * 1024), 16,
                                                offsW[i], (unsigned)kt * BK * 2, 0, 0);
 #pragma unroll
-  for (int g = 0; g < NST - 1; ++g)
+  for (int g = 0; g < (APF ? NST : NST - 1); ++g)
     if (g < total) issue_a(g);
 
   // fragment read offsets inside a 16 KiB k-tile image, without the k-substep term
@@ -1103,6 +1122,22 @@ __global__ __launch_bounds__(512, 1) void gemm_wstat_kernel(GemmParams p, int n_
   // accumulators, whose two 32x32 blocks are retired in chunks 0 and 1 -- the two accumulator sets swap roles from tile to tile, so
   // nothing is ever copied.  Counted wait before chunk g: the ops younger than chunk g's LPC pieces are the pieces of chunks g+1, g+2
   // and the SPR stores of every retire issued in iterations g-3 .. g-1 (kt 0 and 1 of a tile that has a predecessor).
+  // W fragments of k-tile kt (static image): 8 reads, issued a whole chunk ahead of the MFMAs that use them
+  auto load_b = [&](int kt, op16x8 (&bf)[4][2]) __attribute__((always_inline)) {
+    const unsigned char* sw = lds + kt * KT_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[ks][j] = *reinterpret_cast<const op16x8*>(sw + offB[j] + (((2 * ks + h) ^ swzB[j]) << 4));
+  };
+  auto load_a = [&](int stage, op16x8 (&af)[4]) __attribute__((always_inline)) {
+    const unsigned char* sa = ring + stage * KT_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) af[ks] = *reinterpret_cast<const op16x8*>(sa + offA + (((2 * ks + h) ^ swzA) << 4));
+  };
+  op16x8 afr[2][4];                                   // (APF) A fragments, double buffered like the W fragments
+  op16x8 bfr[2][4][2];                                // double buffer: chunk kt uses [kt & 1] (NK is even), loads [(kt + 1) & 1]
+  static_assert(NK % 2 == 0, "the W-fragment double buffer alternates with the chunk index");
   auto tile = [&](f32x16 (&cur)[2], f32x16 (&prev)[2], int ti, bool has_prev, int prev_row0) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -1111,8 +1146,7 @@ __global__ __launch_bounds__(512, 1) void gemm_wstat_kernel(GemmParams p, int n_
 #pragma unroll
     for (int kt = 0; kt < NK; ++kt) {
       const int g = ti * NK + kt;
-      // stores among the three previous iterations: this tile's kt-1, kt-2, kt-3 if they are 0 / 1 (need has_prev); for kt < 3 the
-      // window reaches into the previous tile, whose retiring chunks (its kt 0 / 1) are >= NK - 3 >= 1 chunks older only when NK - 3 + kt... 
+      // retire stores among the three previous iterations (chunks 0 / 1 of a tile that has a predecessor)
       int st = 0;
 #pragma unroll
       for (int d = 1; d <= 3; ++d) {
@@ -1120,40 +1154,73 @@ __global__ __launch_bounds__(512, 1) void gemm_wstat_kernel(GemmParams p, int n_
         if (k2 >= 0) st += (k2 < 2 && has_prev) ? SPR : 0;
         else st += ((NK + k2) < 2 && ti >= 2) ? SPR : 0;
       }
-      const int rem = total - 1 - g;
-      if (rem >= 2) {
-        if (st == 0) wstat_wait<2 * LPC>();
-        else if (st == SPR) wstat_wait<2 * LPC + SPR>();
-        else wstat_wait<2 * LPC + 2 * SPR>();
-      } else if (rem == 1) {
-        if (st == 0) wstat_wait<LPC>();
-        else if (st == SPR) wstat_wait<LPC + SPR>();
-        else wstat_wait<LPC + 2 * SPR>();
+      if constexpr (!APF) {
+        const int rem = total - 1 - g;
+        if (rem >= 2) {
+          if (st == 0) wstat_wait<2 * LPC>();
+          else if (st == SPR) wstat_wait<2 * LPC + SPR>();
+          else wstat_wait<2 * LPC + 2 * SPR>();
+        } else if (rem == 1) {
+          if (st == 0) wstat_wait<LPC>();
+          else if (st == SPR) wstat_wait<LPC + SPR>();
+          else wstat_wait<LPC + 2 * SPR>();
+        } else {
+          if (st == 0) wstat_wait<0>();
+          else if (st == SPR) wstat_wait<SPR>();
+          else wstat_wait<2 * SPR>();
+        }
+        __builtin_amdgcn_s_barrier();                   // chunk g is complete for every wave; stage (g-1) % NST is free again
+        if (g + NST - 1 < total) issue_a(g + NST - 1);
+        if (g == 0) load_b(0, bfr[0]);                  // the W image landed with chunk 0 (it is older): first fragments
+        const unsigned char* sa = ring + (g & (NST - 1)) * KT_BYTES;
+        op16x8 af[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) af[ks] = *reinterpret_cast<const op16x8*>(sa + offA + (((2 * ks + h) ^ swzA) << 4));
+        // next chunk's W fragments: in flight under this chunk's MFMAs (the phases of the eight waves are locked by the barrier, so
+        // without this every wave reads LDS, then every wave issues MFMAs)
+        load_b((kt + 1) % NK, bfr[(kt + 1) & 1]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) cur[j] = MSAM2_MFMA_32x32x16(af[ks], bfr[kt & 1][ks][j], cur[j], 0, 0, 0);
       } else {
-        if (st == 0) wstat_wait<0>();
-        else if (st == SPR) wstat_wait<SPR>();
-        else wstat_wait<2 * SPR>();
+        // A fragments one chunk ahead as well: this iteration waits for chunk g+1, reads its fragments under chunk g's MFMAs and streams
+        // chunk g+4 into the stage chunk g occupied (its fragments went to registers one iteration ago)
+        if (g + 1 < total) {
+          const int rem = total - 2 - g;                // chunks issued beyond g+1 (at most g+2, g+3)
+          if (rem >= 2) {
+            if (st == 0) wstat_wait<2 * LPC>();
+            else if (st == SPR) wstat_wait<2 * LPC + SPR>();
+            else wstat_wait<2 * LPC + 2 * SPR>();
+          } else if (rem == 1) {
+            if (st == 0) wstat_wait<LPC>();
+            else if (st == SPR) wstat_wait<LPC + SPR>();
+            else wstat_wait<LPC + 2 * SPR>();
+          } else {
+            if (st == 0) wstat_wait<0>();
+            else if (st == SPR) wstat_wait<SPR>();
+            else wstat_wait<2 * SPR>();
+          }
+        }
+        __builtin_amdgcn_s_barrier();
+        if (g + NST < total) issue_a(g + NST);
+        if (g + 1 < total) load_a((g + 1) & (NST - 1), afr[(kt + 1) & 1]);
+        load_b((kt + 1) % NK, bfr[(kt + 1) & 1]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) cur[j] = MSAM2_MFMA_32x32x16(afr[kt & 1][ks], bfr[kt & 1][ks][j], cur[j], 0, 0, 0);
       }
-      __builtin_amdgcn_s_barrier();                   // chunk g is complete for every wave; stage (g-1) % NST is free again
-      if (g + NST - 1 < total) issue_a(g + NST - 1);
-      const unsigned char* sa = ring + (g & (NST - 1)) * KT_BYTES;
-      const unsigned char* sw = lds + kt * KT_BYTES;
-      op16x8 af[4], bfr[4][2];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int c = 2 * ks + h;
-        af[ks] = *reinterpret_cast<const op16x8*>(sa + offA + ((c ^ swzA) << 4));
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bfr[ks][j] = *reinterpret_cast<const op16x8*>(sw + offB[j] + ((c ^ swzB[j]) << 4));
-      }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) cur[j] = MSAM2_MFMA_32x32x16(af[ks], bfr[ks][j], cur[j], 0, 0, 0);
       if (has_prev && kt < 2) retire(prev[kt], kt, prev_row0);
     }
   };
 
+  if constexpr (APF) {
+    wstat_wait_dyn(LPC * min(total - 1, NST - 1));    // chunk 0 (and the W panel before it) has landed; chunks 1..3 may still fly
+    __builtin_amdgcn_s_barrier();
+    load_a(0, afr[0]);
+    load_b(0, bfr[0]);
+  }
   f32x16 accA[2], accB[2];
   int row_prev = 0;
   for (int ti = 0; ti < my_tiles; ti += 2) {
@@ -1175,31 +1242,35 @@ __global__ __launch_bounds__(512, 1) void gemm_wstat_kernel(GemmParams p, int n_
 #endif
 }
 
-template <int NK, int ACT, bool NT>
+template <int NK, int ACT, bool NT, bool APF>
 static void launch_wstat(const GemmParams& p, int n_panels, int groups, hipStream_t s) {
   constexpr int LDS = (NK + 4) * 128 * 64 * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_wstat_kernel<NK, ACT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_wstat_kernel<NK, ACT, NT, APF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_wstat_kernel<NK, ACT, NT>), dim3((unsigned)(n_panels * groups)), dim3(512), LDS, s, p, n_panels, groups);
+  hipLaunchKernelGGL((gemm_wstat_kernel<NK, ACT, NT, APF>), dim3(256), dim3(512), LDS, s, p, n_panels, groups);
 }
 
 // the W-stationary kernel serves this problem: returns true after launching it
-static bool gemm_try_wstat(const GemmParams& p, hipStream_t s) {
+static bool gemm_try_wstat(const GemmParams& p, hipStream_t s, bool apf) {
   if (!p.out_is_16bit || p.res || p.colscale || p.rope_cos || p.pool_W || p.Q2 || p.res_mod) return false;
   if (!(p.K == 256 || p.K == 384) || p.N % 128 != 0 || p.M % 128 != 0 || p.M < 8192 || !(p.act == 0 || p.act == 1 || p.act == 2)) return false;
   if ((p.ldc & 1) || ((uintptr_t)p.C & 3) || (int64_t)p.M * p.ldc * 2 >= (1ll << 31) || (int64_t)p.M * p.lda * 2 >= (1ll << 31) ||
       (int64_t)p.N * p.ldw * 2 >= (1ll << 31)) return false;
   const int n_panels = p.N / 128;
-  if (n_panels > 64) return false;
+  if (n_panels > 32) return false;                    // a group has to fit the 32 slots of an XCD
   const int groups = min(256 / n_panels, p.M / 128);
 #define WSTAT2(NKV, NTV) \
   do { \
-    if (p.act == 0) launch_wstat<NKV, 0, NTV>(p, n_panels, groups, s); \
-    else if (p.act == 1) launch_wstat<NKV, 1, NTV>(p, n_panels, groups, s); \
-    else launch_wstat<NKV, 2, NTV>(p, n_panels, groups, s); \
+    if (apf) { \
+      if (p.act == 0) launch_wstat<NKV, 0, NTV, true>(p, n_panels, groups, s); \
+      else if (p.act == 1) launch_wstat<NKV, 1, NTV, true>(p, n_panels, groups, s); \
+      else launch_wstat<NKV, 2, NTV, true>(p, n_panels, groups, s); \
+    } else if (p.act == 0) launch_wstat<NKV, 0, NTV, false>(p, n_panels, groups, s); \
+    else if (p.act == 1) launch_wstat<NKV, 1, NTV, false>(p, n_panels, groups, s); \
+    else launch_wstat<NKV, 2, NTV, false>(p, n_panels, groups, s); \
   } while (0)
 #define WSTAT(NKV) \
   do { \
@@ -1369,9 +1440,14 @@ static int gemm_launch(const void* A, int64_t lda, const void* W, int64_t ldw, c
     }
   }
   {
+    // W-stationary persistent kernel for the short-reduction 16-bit projections (measured, tools/wstat_sweep.py: qkv 16384 x 1152 x 384
+    // 28.6 -> 23-25 us, memory-attention linear1 16384 x 2048 x 256 34 -> 30 us, 16384 x 768 x 256 16.6 -> 13.6 us); not for GELU
+    // epilogues, whose VALU work the tiled kernel hides better behind a second workgroup (fc1: 42 vs 45 us).
+    // MSAM2_GEMM_WSTAT = 0 never, 1 every shape it supports, 2 with A-fragment prefetch (experiments); default: act 0 / 2 only.
     const char* ew = getenv("MSAM2_GEMM_WSTAT");
-    const int wstat_mode = ew ? atoi(ew) : 0;
-    if (wstat_mode && !var && dma_ok && gemm_try_wstat(p, s)) return msam2_check_launch("gemm(w-stationary)");
+    const int wstat_mode = ew ? atoi(ew) : -1;
+    const bool want = wstat_mode > 0 || (wstat_mode < 0 && (act == 0 || act == 2));
+    if (want && !var && dma_ok && gemm_try_wstat(p, s, wstat_mode == 2)) return msam2_check_launch("gemm(w-stationary)");
   }
   const int vv = var ? atoi(var) : (tiles <= 256 && K >= 1024 ? 8 : (K % 64 == 0 && K >= 384 ? 2 : 5));
   if (dma_ok && K % 32 == 0 && vv == 6) {

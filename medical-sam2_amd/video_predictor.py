@@ -250,8 +250,9 @@ class SAM2VideoPredictor(SAM2Base):
         """F.interpolate(mode="bilinear", align_corners=False) on [n,1,h,w] fp32 (HIP kernel)."""
         if masks.shape[-2:] == (H, W):
             return masks
-        if torch.is_grad_enabled() and masks.requires_grad:      # train_* twins: keep the graph (same arithmetic, torch's kernel)
-            return torch.nn.functional.interpolate(masks.to(F32), size=(H, W), mode="bilinear", align_corners=False)
+        if torch.is_grad_enabled() and masks.requires_grad:      # train_* twins: keep the graph (the same kernel behind an autograd Function)
+            from .autograd import bilinear_upsample
+            return bilinear_upsample(masks, H, W)
         return ops.bilinear_upsample(masks.to(F32).contiguous(), H, W)
 
     def _get_orig_video_res_output(self, inference_state, any_res_masks):

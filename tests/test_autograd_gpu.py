@@ -131,9 +131,9 @@ def test_reference_shaped_3d_loop_on_track_step_matches_the_explicit_bptt():
     before = dict(_case()[0].named_parameters())
     agree = {}
     for (k, p), (_, q) in zip(net.named_parameters(), twin.named_parameters()):
+        if "." not in k or k.split(".")[0] not in prefix.values() or ".conv_s" in k or k.endswith("k_proj.bias"):
+            continue       # (top-level tables, untrained modules, the neck's folded convs; softmax is invariant to a key bias: its gradient is round-off)
         grp, pname = k.split(".")[0], k.split(".", 1)[1]
-        if grp not in prefix.values() or ".conv_s" in k:
-            continue
         g_exp = out["non_prompt"][GROUP_OF[grp]].get(pname)
         if grp == "sam_mask_decoder" and pname in out["prompt"]["decoder"]:
             g_exp = out["prompt"]["decoder"][pname] + (g_exp if g_exp is not None else 0)
@@ -143,6 +143,8 @@ def test_reference_shaped_3d_loop_on_track_step_matches_the_explicit_bptt():
         strong = g_exp.abs() > 1e-2 * g_exp.abs().max()
         if strong.any():
             agree.setdefault(grp, []).append(float(((d1 - d2).abs() <= 0.1 * d2.abs().max()).float()[strong].mean()))
+            if agree[grp][-1] < 0.9:
+                print("  update disagreement:", k, agree[grp][-1], "max|g|", float(g_exp.abs().max()))
     print("fraction of gradient-carrying elements with the same Adam update (mean, min per tensor):", {g: (float(np.mean(v)), min(v)) for g, v in agree.items()})
     assert set(agree) == {"sam_mask_decoder", "memory_attention", "memory_encoder", "obj_ptr_proj"}
     assert all(np.mean(v) > (0.98 if fp16 else 0.9) for v in agree.values()), {g: np.mean(v) for g, v in agree.items()}
