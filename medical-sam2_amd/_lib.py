@@ -32,6 +32,8 @@ SIGNATURES = {
     "msam2_attention_workspace_bytes": (c_z, [c_l, c_l, c_l, c_l, c_i]),
     "msam2_attention_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_f, c_i, c_p, c_z, c_p]),
     "msam2_attention_fwd_lse": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_f, c_i, c_p, c_z, c_p, c_p]),
+    "msam2_attention_fwd_lse_dropout": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_f, c_i, c_p, c_z, c_p, c_f,
+                                              ctypes.c_uint64, ctypes.c_uint64, c_p, c_p]),
     "msam2_attention_kv64_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_f, c_i, c_p, c_z, c_p]),
     "msam2_attention_kv64_partial": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_f, c_i, c_i, c_i, c_p, c_z, c_p]),
     "msam2_attention_kv64_dyn_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_p, c_f, c_i, c_p, c_z, c_p]),
@@ -72,6 +74,8 @@ SIGNATURES = {
     "msam2_attention_bwd_workspace_bytes": (c_z, [c_l, c_l, c_l, c_l]),
     "msam2_attention_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_z,
                                   c_l, c_l, c_l, c_l, c_l, c_f, c_p]),
+    "msam2_attention_bwd_dropout": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_z,
+                                          c_l, c_l, c_l, c_l, c_l, c_f, c_f, ctypes.c_uint64, ctypes.c_uint64, c_p, c_p]),
     "msam2_dwconv7x7": (c_i, [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_i, c_p]),
     "msam2_dwconv7x7_wgrad": (c_i, [c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_p]),
     "msam2_col2im3x3s2": (c_i, [c_p, c_l, c_p, c_l, c_l, c_l, c_l, c_p]),

@@ -102,17 +102,24 @@ def mlp_backward(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.
     return dx, dw1, db1, dw2, db2
 
 
-def attention_forward_lse(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None):
+def attention_forward_lse(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None, dropout: Optional[tuple] = None):
     """Forward attention on [B,H,L,D] 16-bit views that keeps what the flash-style backward needs: (o 16-bit [B,H,Lq,D] view of a
-    [B,Lq,H,D] buffer, lse fp32 [B,H,Lq] in the log2 domain).  Hand both to `attention_backward(..., o_lse=...)`."""
+    [B,Lq,H,D] buffer, lse fp32 [B,H,Lq] in the log2 domain).  Hand both to `attention_backward(..., o_lse=...)`.
+    dropout = (p, seed, offset): dropout on the probabilities inside the kernel (pass the same triple to `attention_backward`)."""
     from .modeling.common import attn_splits
     B, H, Lq, D = q.shape
     lse = torch.empty(B, H, Lq, dtype=F32, device=q.device)
-    o = ops.attention(q, k, v, scale=scale if scale is not None else D ** -0.5, splits=attn_splits(B, H, Lq, k.shape[2]), lse=lse)
+    o = ops.attention(q, k, v, scale=scale if scale is not None else D ** -0.5, splits=attn_splits(B, H, Lq, k.shape[2]), lse=lse, dropout=dropout)
     return o, lse
 
 
-def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: torch.Tensor, scale: Optional[float] = None, o_lse=None):
+def flash_dropout_supported(D: int, Lq: int) -> bool:
+    """the flash kernels carry the dropout mask generator for head dims 96 / 128 / 256 and more than 64 queries"""
+    return D in (96, 128, 256) and Lq > 64 and not os.environ.get("MSAM2_MATERIALISED_DROPOUT") and not os.environ.get("MSAM2_MATERIALISED_BWD")
+
+
+def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: torch.Tensor, scale: Optional[float] = None, o_lse=None,
+                       dropout: Optional[tuple] = None):
     """Gradients of o = softmax(q k^T * scale) v for 16-bit q [B,H,Lq,D], k/v [B,H,Lk,D], upstream do [B,H,Lq,D] (any float type).
     Returns (dq, dk, dv) in fp32, shaped like q / k / v.
     Head dims 64 / 96 / 128 / 256: FLASH-STYLE (`msam2_attention_bwd`, csrc/attention_bwd.hip) -- the forward is re-run for O and the log-sum-exp rows,
@@ -120,7 +127,8 @@ def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: to
     Other head dims (D % 8 == 0), or MSAM2_MATERIALISED_BWD=1: MATERIALISED form -- per (batch, head) the [Lq, Lk] scores live in
     HBM (fp32 S, 16-bit P / dS), the five products run on the forward GEMM kernel and the softmax and its Jacobian on two row
     kernels (reduction dims zero-padded to multiples of 8).
-    o_lse: the (o, lse) pair of `attention_forward_lse` on the same q, k, v when the caller has already run it (saves the re-run)."""
+    o_lse: the (o, lse) pair of `attention_forward_lse` on the same q, k, v when the caller has already run it (saves the re-run).
+    dropout = (p, seed, offset): the forward ran with dropout on the probabilities (`attention_forward_lse(..., dropout=...)`); flash path only."""
     B, H, Lq, D = q.shape
     Lk = k.shape[2]
     _req(q.dtype == OP16 and k.dtype == OP16 and v.dtype == OP16, "attention_backward: 16-bit q, k, v")
@@ -131,15 +139,26 @@ def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: to
     dv = torch.empty(B, H, Lk, D, dtype=F32, device=q.device)
     if D in (64, 96, 128, 256) and not os.environ.get("MSAM2_MATERIALISED_BWD"):
         q, k, v = (t if t.stride(3) == 1 and all(st % 8 == 0 for st in t.stride()[:3]) else t.contiguous() for t in (q, k, v))
-        o, lse = o_lse if o_lse is not None else attention_forward_lse(q, k, v, scale)
+        o, lse = o_lse if o_lse is not None else attention_forward_lse(q, k, v, scale, dropout=dropout)
         g = do.to(F32)
         g = g if g.stride(3) == 1 and all(st % 4 == 0 for st in g.stride()[:3]) else g.contiguous()
         nbytes = lib().msam2_attention_bwd_workspace_bytes(B, H, Lq, D)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+        if dropout is not None and dropout[0] > 0:
+            pd, seed, offset = dropout
+            seed_dev = None
+            if isinstance(seed, ops.DeviceSeed):
+                seed, seed_dev = seed.base, seed.dev
+            check(lib().msam2_attention_bwd_dropout(_p(q), ops._strides3(q), _p(k), ops._strides3(k), _p(v), ops._strides3(v), _p(o), ops._strides3(o),
+                                                    _p(lse), _p(g), ops._strides3(g), _p(dq), ops._strides3(dq), _p(dk), ops._strides3(dk), _p(dv),
+                                                    ops._strides3(dv), _p(ws), nbytes, B, H, Lq, Lk, D, float(scale), float(pd),
+                                                    int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), _p(seed_dev), _stream()))
+            return dq, dk, dv
         check(lib().msam2_attention_bwd(_p(q), ops._strides3(q), _p(k), ops._strides3(k), _p(v), ops._strides3(v), _p(o), ops._strides3(o),
                                         _p(lse), _p(g), ops._strides3(g), _p(dq), ops._strides3(dq), _p(dk), ops._strides3(dk), _p(dv),
                                         ops._strides3(dv), _p(ws), nbytes, B, H, Lq, Lk, D, float(scale), _stream()))
         return dq, dk, dv
+    _req(dropout is None or dropout[0] == 0, "attention_backward: dropout needs the flash path (attention_dropout_backward is the materialised form)")
     # P / dS are GEMM operands with the keys as reduction dim: rows padded to a multiple of 8 keys with zeros (memory banks hold
     # 4 tokens per object pointer, so Lk is only a multiple of 4)
     Lkp = -(-Lk // 8) * 8
@@ -253,9 +272,14 @@ def _memory_attention_layer_forward_saved(layer, x: torch.Tensor, mem_k: torch.T
     u4 = lambda t: t.unsqueeze(1)                                                 # [B, N, C] -> [B, 1, N, C]
     flash = C in (64, 96, 128, 256) and not os.environ.get("MSAM2_MATERIALISED_BWD")
     dp, dseed, dl = (drop["p"], drop["seed"], drop["layer"]) if drop else (0.0, 0, 0)
+    fdrop = bool(drop) and flash and flash_dropout_supported(C, L)     # dropout on the probabilities inside the flash kernels (round 3)
     if drop:
-        flash, ol1 = False, None
-        a1 = attention_dropout_forward(q1, k1, v1, dp, dseed, drop_offset(dl, "sa_attn"))
+        if fdrop:
+            ol1 = attention_forward_lse(u4(q1), u4(k1), u4(v1), dropout=(dp, dseed, drop_offset(dl, "sa_attn")))
+            a1 = ol1[0].permute(0, 2, 1, 3).reshape(B * L, C)
+        else:
+            ol1 = None
+            a1 = attention_dropout_forward(q1, k1, v1, dp, dseed, drop_offset(dl, "sa_attn"))
         x1 = ops.dropout(sa.out(a1, None), dp, dseed, drop_offset(dl, "drop1"), residual=x)
     else:
         ol1 = attention_forward_lse(u4(q1), u4(k1), u4(v1)) if flash else None
@@ -270,8 +294,12 @@ def _memory_attention_layer_forward_saved(layer, x: torch.Tensor, mem_k: torch.T
     ops.rope_(kk, Nk - n_ptr_tokens, tab)
     vv = ops.gemm(mv2, wv, Bv("vb", ca.v_proj.bias)).view(B, Nk, C)
     if drop:
-        ol2 = None
-        a2 = attention_dropout_forward(q2, kk, vv, dp, dseed, drop_offset(dl, "ca_attn"))
+        if fdrop:
+            ol2 = attention_forward_lse(u4(q2), u4(kk), u4(vv), dropout=(dp, dseed, drop_offset(dl, "ca_attn")))
+            a2 = ol2[0].permute(0, 2, 1, 3).reshape(B * L, C)
+        else:
+            ol2 = None
+            a2 = attention_dropout_forward(q2, kk, vv, dp, dseed, drop_offset(dl, "ca_attn"))
         x2 = ops.dropout(ca.out(a2, None), dp, dseed, drop_offset(dl, "drop2"), residual=x1)
     else:
         ol2 = attention_forward_lse(u4(q2), u4(kk), u4(vv)) if flash else None
@@ -320,7 +348,9 @@ def _memory_attention_layer_backward_saved(layer, ctx: dict, dy: torch.Tensor):
     # cross attention
     d_ca = ops.dropout(dx2, dp, dseed, drop_offset(dl, "drop2")) if drop else dx2
     da2, g["cross_attn_image.out_proj.weight"], g["cross_attn_image.out_proj.bias"] = linear_backward(a2, W("ow", ca.out_proj.weight), d_ca)
-    if drop:
+    if drop and ol2 is not None:
+        dq2, dkk, dvv = attention_backward(u4(q2), u4(kk), u4(vv), u4(da2.view(B, L, C)), o_lse=ol2, dropout=(dp, dseed, drop_offset(dl, "ca_attn")))
+    elif drop:
         dq2, dkk, dvv = attention_dropout_backward(q2, kk, vv, da2, dp, dseed, drop_offset(dl, "ca_attn"))
     else:
         dq2, dkk, dvv = attention_backward(u4(q2), u4(kk), u4(vv), u4(da2.view(B, L, C)), o_lse=ol2)
@@ -334,7 +364,9 @@ def _memory_attention_layer_backward_saved(layer, ctx: dict, dy: torch.Tensor):
     # self attention
     d_sa = ops.dropout(dx1, dp, dseed, drop_offset(dl, "drop1")) if drop else dx1
     da1, g["self_attn.out_proj.weight"], g["self_attn.out_proj.bias"] = linear_backward(a1, W("ow_s", sa.out_proj.weight), d_sa)
-    if drop:
+    if drop and ol1 is not None:
+        dq1, dk1, dv1 = attention_backward(u4(q1), u4(k1), u4(v1), u4(da1.view(B, L, C)), o_lse=ol1, dropout=(dp, dseed, drop_offset(dl, "sa_attn")))
+    elif drop:
         dq1, dk1, dv1 = attention_dropout_backward(q1, k1, v1, da1, dp, dseed, drop_offset(dl, "sa_attn"))
     else:
         dq1, dk1, dv1 = attention_backward(u4(q1), u4(k1), u4(v1), u4(da1.view(B, L, C)), o_lse=ol1)

@@ -60,6 +60,8 @@ struct AttnParams {
   // log-sum-exp rows [Bz][H][Lq] (log2 domain) for the backward; written by the merge kernel (split path) or by the
   // register-staged kernel (single pass); null = not wanted
   float* lse;
+  // attention-probability dropout (train mode; attn_glds_kernel only): thr == 0 = off
+  AttnDropout drop;
 };
 
 template <int D>
@@ -341,7 +343,7 @@ __global__ void attn_merge_kernel(AttnParams p, int Bz) {
 // DP = LDS row pitch in elements (power of two >= D).  D = 96 (Hiera global blocks) runs with DP = 128: each 192-byte K/V row is
 // DMA'd into a 256-byte LDS row slot (12 of every 16 lanes carry data, the other 4 re-read the row start), so the same
 // power-of-two swizzles apply.
-template <int D, int DP, int NW, int OCC>
+template <int D, int DP, int NW, int OCC, bool DROP = false>
 __global__ __launch_bounds__(NW * 64, OCC) void attn_glds_kernel(AttnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor builtins exist only in the device pass; the host pass just needs the launch stub
   constexpr int BK = 32, RB = DP * 2, CPR = DP / 8, GCPR = D / 8;  // LDS row bytes, chunks per LDS row, valid chunks per global row
@@ -382,6 +384,14 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_glds_kernel(AttnParams p) {
     uint4 v = make_uint4(0, 0, 0, 0);
     if (qvalid) v = *reinterpret_cast<const uint4*>(qb + (int64_t)qi * p.q_ts + s * 16 + h * 8);
     qf[s] = __builtin_bit_cast(op16x8, v);
+  }
+
+  // dropout stream position of this lane's query row (element index of key 0) and the effective seed
+  // (DROP instances only: the inference instances carry none of this -- the D = 256 one sits exactly at its 256-register budget)
+  uint64_t drop_base = 0, drop_seed = 0;
+  if constexpr (DROP) {
+    drop_base = p.drop.offset + (((uint64_t)z * p.H + head) * p.Lq + (qvalid ? qi : 0)) * (uint64_t)p.Lk;
+    drop_seed = p.drop.seed + (p.drop.seed_dev ? *p.drop.seed_dev : 0ull);
   }
 
   const int tiles_total = (p.Lk + BK - 1) / BK;
@@ -501,14 +511,26 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_glds_kernel(AttnParams p) {
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
     const f32x2_t sc2 = {p.scale_log2, p.scale_log2}, nm2 = {-m_run, -m_run};   // -m_run finite: every tile holds >= 1 valid key
     f32x2_t psum2 = {0.f, 0.f};
+    if constexpr (DROP) {
+      // train mode: the row sum (the softmax denominator) takes every probability, the P V product only the kept ones / (1 - p)
+      const uint64_t ebase = drop_base + (uint64_t)(key0 + 4 * h);
 #pragma unroll
-    for (int e = 0; e < 16; e += 2) {
-      const f32x2_t sv = {s[e], s[e + 1]};
-      const f32x2_t t = __builtin_elementwise_fma(sv, sc2, nm2);
-      const f32x2_t pe = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-      psum2 += pe;
-      pf[e >> 3][e & 7] = f2op_fast(pe[0]);
-      pf[e >> 3][(e & 7) + 1] = f2op_fast(pe[1]);
+      for (int e = 0; e < 16; ++e) {
+        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], p.scale_log2, -m_run));
+        psum2[e & 1] += pe;
+        const bool keep = dropout_keep(drop_seed, ebase + (uint64_t)((e & 3) + 8 * (e >> 2)), p.drop.thr);
+        pf[e >> 3][e & 7] = f2op_fast(keep ? pe * p.drop.inv_keep : 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        const f32x2_t sv = {s[e], s[e + 1]};
+        const f32x2_t t = __builtin_elementwise_fma(sv, sc2, nm2);
+        const f32x2_t pe = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+        psum2 += pe;
+        pf[e >> 3][e & 7] = f2op_fast(pe[0]);
+        pf[e >> 3][(e & 7) + 1] = f2op_fast(pe[1]);
+      }
     }
     l_run += psum2[0] + psum2[1];
     STAMP(t3_);
@@ -1272,7 +1294,11 @@ static int launch_attn_kv64(const AttnParams& p, int Bz, hipStream_t s) {
 template <int D>
 static int launch_attn_glds(const AttnParams& p, int Bz, hipStream_t s) {
   dim3 grid(cdiv(p.Lq, 128), p.H, Bz * p.splits);
-  if constexpr (D == 96) hipLaunchKernelGGL((attn_glds_kernel<96, 128, 4, 3>), grid, dim3(256), 0, s, p);
+  if (p.drop.thr) {
+    // train-mode instances (mask generator in the softmax): one workgroup per CU, registers to spare
+    if constexpr (D == 96) hipLaunchKernelGGL((attn_glds_kernel<96, 128, 4, 1, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_glds_kernel<D, D, 4, 1, true>), grid, dim3(256), 0, s, p);
+  } else if constexpr (D == 96) hipLaunchKernelGGL((attn_glds_kernel<96, 128, 4, 3>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((attn_glds_kernel<D, D, 4, 2>), grid, dim3(256), 0, s, p);
   if (p.splits > 1 && !p.defer_merge) {
     const int64_t rows = (int64_t)Bz * p.H * p.Lq;
@@ -1354,7 +1380,7 @@ extern "C" int msam2_attention_merge(void* o, const int64_t* o_strides, int64_t 
 static int attention_fwd_impl(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
                               const void* v, const int64_t* v_strides, void* o, const int64_t* o_strides, int64_t B,
                               int64_t H, int64_t Lq, int64_t Lk, int64_t D, float scale, int splits, void* workspace,
-                              size_t workspace_bytes, float* lse, void* stream) {
+                              size_t workspace_bytes, float* lse, void* stream, const AttnDropout* drop = nullptr) {
   MSAM2_REQUIRE(q && k && v && o, "attention: null tensor");
   MSAM2_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attention: empty problem");
   MSAM2_REQUIRE(D == 96 || D == 256 || D == 64 || D == 128, "attention: head dim %lld not built (96/256/64/128)", (long long)D);
@@ -1389,6 +1415,11 @@ static int attention_fwd_impl(const void* q, const int64_t* q_strides, const voi
   hipStream_t s = (hipStream_t)stream;
   const char* force = getenv("MSAM2_ATTN_V1");
   const bool v2 = !(force && force[0] == '1') && Lq > 64 && !(lse && splits == 1);
+  if (drop && drop->thr) {
+    p.drop = *drop;
+    MSAM2_REQUIRE(v2 && (D == 96 || D == 128 || D == 256) && (D != 96 || k_strides[2] * 2 * 32 < (1ll << 31)),
+                  "attention: dropout runs on the LDS-DMA kernel only (head dim 96 / 128 / 256, more than 64 queries)");
+  }
   switch (D) {
     case 96: return (v2 && k_strides[2] * 2 * 32 < (1ll << 31)) ? launch_attn_glds<96>(p, (int)B, s) : dispatch_nw<96, false>(p, (int)B, s);
     case 256: return v2 ? launch_attn_glds<256>(p, (int)B, s) : dispatch_nw<256, false>(p, (int)B, s);
@@ -1414,6 +1445,23 @@ extern "C" int msam2_attention_fwd_lse(const void* q, const int64_t* q_strides, 
   MSAM2_REQUIRE(lse, "attention_fwd_lse: null lse");
   return attention_fwd_impl(q, q_strides, k, k_strides, v, v_strides, o, o_strides, B, H, Lq, Lk, D, scale, splits, workspace, workspace_bytes,
                             lse, stream);
+}
+
+// msam2_attention_fwd_lse with dropout on the attention probabilities (F.scaled_dot_product_attention(dropout_p = p) as RoPEAttention
+// calls it in train mode, transformer.py:317-318): probability (b, h, q, k) is kept iff element offset + ((b*H + h)*Lq + q)*Lk + k of the
+// counter-based stream `seed` (+ *seed_dev, optional: msam2_counter_bump) says so, kept ones are scaled by 1 / (1 - p); the softmax
+// denominator and the returned log-sum-exp rows are those of the UN-dropped probabilities.  msam2_attention_bwd_dropout with the same
+// (p, seed, offset) re-creates the mask.  Head dim 96 / 128 / 256, Lq > 64.  No [Lq, Lk] tensor anywhere.
+extern "C" int msam2_attention_fwd_lse_dropout(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
+                                               const void* v, const int64_t* v_strides, void* o, const int64_t* o_strides, int64_t B,
+                                               int64_t H, int64_t Lq, int64_t Lk, int64_t D, float scale, int splits, void* workspace,
+                                               size_t workspace_bytes, float* lse, float p, uint64_t seed, uint64_t offset,
+                                               const void* seed_dev, void* stream) {
+  MSAM2_REQUIRE(lse, "attention_fwd_lse_dropout: null lse");
+  MSAM2_REQUIRE(p >= 0.f && p < 1.f, "attention_fwd_lse_dropout: p must be in [0, 1)");
+  AttnDropout d = {(unsigned)fmin(4294967295.0, (double)p * 4294967296.0), 1.f / (1.f - p), seed, offset, (const uint64_t*)seed_dev};
+  return attention_fwd_impl(q, q_strides, k, k_strides, v, v_strides, o, o_strides, B, H, Lq, Lk, D, scale, splits, workspace, workspace_bytes,
+                            lse, stream, &d);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -36,6 +36,7 @@ struct AttnBwdParams {
   int64_t dq_bs, dq_hs, dq_ts, dk_bs, dk_hs, dk_ts, dv_bs, dv_hs, dv_ts;
   int B, H, Lq, Lk;
   float scale_log2, scale;
+  AttnDropout drop;                                   // attention-probability dropout of the forward (thr == 0: none)
 };
 
 constexpr int ROLE_DQ = 0, ROLE_DK = 1, ROLE_DV = 2;
@@ -141,6 +142,10 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
   }
   const float delta_own = (ROLE == ROLE_DQ && ovalid) ? p.delta[bh * p.Lq + oi] : 0.f;
   const float lse_own = (ROLE == ROLE_DQ && ovalid) ? p.lse[bh * p.Lq + oi] : 0.f;
+  // dropout stream: DQ owns a query row (element index of key 0 of that row), DK / DV own a key (element index of query 0, that key)
+  const uint64_t drop_seed = p.drop.seed + ((p.drop.thr && p.drop.seed_dev) ? *p.drop.seed_dev : 0ull);
+  const uint64_t drop_own = p.drop.offset + (uint64_t)bh * p.Lq * (uint64_t)p.Lk +
+                            (ROLE == ROLE_DQ ? (uint64_t)(ovalid ? oi : 0) * (uint64_t)p.Lk : (uint64_t)(ovalid ? oi : 0));
 
   const int tiles_all = (n_str + C::BK - 1) / C::BK;
   const int tiles_per = (tiles_all + nsplit - 1) / nsplit;
@@ -226,12 +231,16 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
     }
     // streamed row of register e: (e&3) + 8*(e>>2) + 4*h
     op16x8 wf[2];
+    const int row0 = tile * C::BK;
     if constexpr (ROLE == ROLE_DQ) {
       // (rows past the end of the keys hold zeros in LDS: whatever weight they get multiplies a zero K^T column)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const float pe = __builtin_amdgcn_exp2f(s[e] * p.scale_log2 - lse_own);
-        wf[e >> 3][e & 7] = f2op(pe * (dp[e] - delta_own));
+        float dpe = dp[e];
+        if (p.drop.thr)                                  // owner = query oi, streamed row = key: the forward's mask on dP
+          dpe = dropout_keep(drop_seed, drop_own + (uint64_t)(row0 + (e & 3) + 8 * (e >> 2) + 4 * h), p.drop.thr) ? dpe * p.drop.inv_keep : 0.f;
+        wf[e >> 3][e & 7] = f2op(pe * (dpe - delta_own));
       }
     } else {
       const float* st_lse = stats + cur * 2 * C::BK;
@@ -240,7 +249,10 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
       for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
         const float pe = __builtin_amdgcn_exp2f(s[e] * p.scale_log2 - st_lse[row]);
-        wf[e >> 3][e & 7] = f2op(ROLE == ROLE_DV ? pe : pe * (dp[e] - st_del[row]));
+        float m = 1.f;
+        if (p.drop.thr)                                  // owner = key oi, streamed row = query
+          m = dropout_keep(drop_seed, drop_own + (uint64_t)(row0 + row) * (uint64_t)p.Lk, p.drop.thr) ? p.drop.inv_keep : 0.f;
+        wf[e >> 3][e & 7] = f2op(ROLE == ROLE_DV ? pe * m : pe * (dp[e] * m - st_del[row]));
       }
     }
     // out^T[d][owner] += tile^T[d][row] w[row][owner]
@@ -354,6 +366,10 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dma_kernel(AttnBwdParams 
   }
   const float delta_own = (ROLE == ROLE_DQ && ovalid) ? p.delta[bh * p.Lq + oi] : 0.f;
   const float lse_own = (ROLE == ROLE_DQ && ovalid) ? p.lse[bh * p.Lq + oi] : 0.f;
+  // dropout stream: DQ owns a query row (element index of key 0 of that row), DK / DV own a key (element index of query 0, that key)
+  const uint64_t drop_seed = p.drop.seed + ((p.drop.thr && p.drop.seed_dev) ? *p.drop.seed_dev : 0ull);
+  const uint64_t drop_own = p.drop.offset + (uint64_t)bh * p.Lq * (uint64_t)p.Lk +
+                            (ROLE == ROLE_DQ ? (uint64_t)(ovalid ? oi : 0) * (uint64_t)p.Lk : (uint64_t)(ovalid ? oi : 0));
 
   const int tiles_all = (n_str + BK - 1) / BK;
   const int tiles_per = (tiles_all + nsplit - 1) / nsplit;
@@ -455,7 +471,10 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dma_kernel(AttnBwdParams 
       for (int e = 0; e < 16; ++e) {
         float pe = __builtin_amdgcn_exp2f(s[e] * p.scale_log2 - lse_own);
         if (masked && row0 + (e & 3) + 8 * (e >> 2) + 4 * h >= n_str) pe = 0.f;   // tail tile: clamped duplicates of the last key
-        wf[e >> 3][e & 7] = f2op(pe * (dp[e] - delta_own));
+        float dpe = dp[e];
+        if (p.drop.thr)                                  // owner = query oi, streamed row = key: the forward's mask on dP
+          dpe = dropout_keep(drop_seed, drop_own + (uint64_t)(row0 + (e & 3) + 8 * (e >> 2) + 4 * h), p.drop.thr) ? dpe * p.drop.inv_keep : 0.f;
+        wf[e >> 3][e & 7] = f2op(pe * (dpe - delta_own));
       }
     } else {
       const float* st_lse = stats + (stage & 1) * 2 * BK;
@@ -464,7 +483,10 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dma_kernel(AttnBwdParams 
       for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
         const float pe = __builtin_amdgcn_exp2f(s[e] * p.scale_log2 - st_lse[row]);   // lse = +inf past the end: weight 0
-        wf[e >> 3][e & 7] = f2op(ROLE == ROLE_DV ? pe : pe * (dp[e] - st_del[row]));
+        float m = 1.f;
+        if (p.drop.thr)                                  // owner = key oi, streamed row = query
+          m = dropout_keep(drop_seed, drop_own + (uint64_t)(row0 + row) * (uint64_t)p.Lk, p.drop.thr) ? p.drop.inv_keep : 0.f;
+        wf[e >> 3][e & 7] = f2op(ROLE == ROLE_DV ? pe * m : pe * (dp[e] * m - st_del[row]));
       }
     }
 #pragma unroll
@@ -638,11 +660,11 @@ extern "C" size_t msam2_attention_bwd_workspace_bytes(int64_t B, int64_t H, int6
 // q / k / v / o: 16-bit, element strides {batch, head, token}, channels contiguous; d_o fp32 with its own strides; dq / dk / dv fp32
 // outputs with their own strides (token stride a multiple of 4 elements, 16-byte aligned rows).  o is the forward's output for the
 // same q, k, v and lse [B, H, Lq] its log-sum-exp rows (msam2_attention_fwd_lse).  workspace: msam2_attention_bwd_workspace_bytes.
-extern "C" int msam2_attention_bwd(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides, const void* v,
-                                   const int64_t* v_strides, const void* o, const int64_t* o_strides, const float* lse,
-                                   const float* d_o, const int64_t* do_strides, float* dq, const int64_t* dq_strides, float* dk, const int64_t* dk_strides,
-                                   float* dv, const int64_t* dv_strides, void* workspace, size_t workspace_bytes, int64_t B, int64_t H,
-                                   int64_t Lq, int64_t Lk, int64_t D, float scale, void* stream) {
+static int attention_bwd_impl(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides, const void* v,
+                              const int64_t* v_strides, const void* o, const int64_t* o_strides, const float* lse,
+                              const float* d_o, const int64_t* do_strides, float* dq, const int64_t* dq_strides, float* dk, const int64_t* dk_strides,
+                              float* dv, const int64_t* dv_strides, void* workspace, size_t workspace_bytes, int64_t B, int64_t H,
+                              int64_t Lq, int64_t Lk, int64_t D, float scale, void* stream, const AttnDropout* drop) {
   MSAM2_REQUIRE(q && k && v && o && lse && d_o && dq && dk && dv && workspace, "attention_bwd: null pointer");
   MSAM2_REQUIRE(q_strides && k_strides && v_strides && o_strides && do_strides && dq_strides && dk_strides && dv_strides,
                 "attention_bwd: null strides");
@@ -675,6 +697,7 @@ extern "C" int msam2_attention_bwd(const void* q, const int64_t* q_strides, cons
   p.dv_bs = dv_strides[0]; p.dv_hs = dv_strides[1]; p.dv_ts = dv_strides[2];
   p.B = (int)B; p.H = (int)H; p.Lq = (int)Lq; p.Lk = (int)Lk;
   p.scale = scale; p.scale_log2 = scale * 1.4426950408889634f;
+  p.drop = drop ? *drop : AttnDropout{0u, 1.f, 0ull, 0ull, nullptr};
   hipStream_t s = (hipStream_t)stream;
   switch (D) {
     case 64: return launch_all<64>(p, d_o, do_strides, (const op16*)o, o_strides, do16, delta, s);
@@ -682,4 +705,29 @@ extern "C" int msam2_attention_bwd(const void* q, const int64_t* q_strides, cons
     case 128: return launch_all<128>(p, d_o, do_strides, (const op16*)o, o_strides, do16, delta, s);
     default: return launch_all<256>(p, d_o, do_strides, (const op16*)o, o_strides, do16, delta, s);
   }
+}
+
+extern "C" int msam2_attention_bwd(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides, const void* v,
+                                   const int64_t* v_strides, const void* o, const int64_t* o_strides, const float* lse,
+                                   const float* d_o, const int64_t* do_strides, float* dq, const int64_t* dq_strides, float* dk, const int64_t* dk_strides,
+                                   float* dv, const int64_t* dv_strides, void* workspace, size_t workspace_bytes, int64_t B, int64_t H,
+                                   int64_t Lq, int64_t Lk, int64_t D, float scale, void* stream) {
+  return attention_bwd_impl(q, q_strides, k, k_strides, v, v_strides, o, o_strides, lse, d_o, do_strides, dq, dq_strides, dk, dk_strides, dv,
+                            dv_strides, workspace, workspace_bytes, B, H, Lq, Lk, D, scale, stream, nullptr);
+}
+
+// msam2_attention_bwd for a forward that ran with dropout on the attention probabilities (msam2_attention_fwd_lse_dropout with the same
+// p / seed / offset / seed_dev): every pass re-creates the mask from the counter stream -- dV takes the kept probabilities / (1 - p),
+// dQ / dK take dS = P o (mask o dP / (1 - p) - delta) with delta = rowsum(dO o O) of the dropped forward's output.  o and lse are the
+// forward's outputs (lse: of the un-dropped probabilities).
+extern "C" int msam2_attention_bwd_dropout(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides, const void* v,
+                                           const int64_t* v_strides, const void* o, const int64_t* o_strides, const float* lse,
+                                           const float* d_o, const int64_t* do_strides, float* dq, const int64_t* dq_strides, float* dk,
+                                           const int64_t* dk_strides, float* dv, const int64_t* dv_strides, void* workspace, size_t workspace_bytes,
+                                           int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t D, float scale, float p, uint64_t seed,
+                                           uint64_t offset, const void* seed_dev, void* stream) {
+  MSAM2_REQUIRE(p >= 0.f && p < 1.f, "attention_bwd_dropout: p must be in [0, 1)");
+  AttnDropout d = {(unsigned)fmin(4294967295.0, (double)p * 4294967296.0), 1.f / (1.f - p), seed, offset, (const uint64_t*)seed_dev};
+  return attention_bwd_impl(q, q_strides, k, k_strides, v, v_strides, o, o_strides, lse, d_o, do_strides, dq, dq_strides, dk, dk_strides, dv,
+                            dv_strides, workspace, workspace_bytes, B, H, Lq, Lk, D, scale, stream, &d);
 }

@@ -1240,14 +1240,6 @@ extern "C" int msam2_hiera_pos_embed_bwd(const float* d_table, float* d_pos_embe
 // hipGraph bakes its by-value arguments in, so the per-forward sub-stream counter has to live in device memory and be advanced by a
 // kernel of the step itself (msam2_counter_bump) for a replay to draw fresh masks.
 // ------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, unsigned thr) {
-  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (unsigned)(z >> 32) >= thr;
-}
-
 template <typename TI, typename TO>
 __global__ void dropout_kernel(const TI* __restrict__ x, int64_t ldx, const float* __restrict__ res, int64_t ldr, TO* __restrict__ y, int64_t ldy,
                                int64_t rows, int64_t cols, unsigned thr, float inv_keep, uint64_t seed, uint64_t offset,

@@ -107,6 +107,24 @@ __device__ __forceinline__ float fast_erf(float x) {
   return copysignf(e, x);
 }
 
+// Counter-based dropout mask shared by the element-wise dropout kernel (backward.hip) and the flash attention kernels (attention.hip,
+// attention_bwd.hip): element idx of stream seed is KEPT iff the upper half of splitmix64(seed + idx * golden) is >= thr = p * 2^32.
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, unsigned thr) {
+  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (unsigned)(z >> 32) >= thr;
+}
+// attention-probability dropout of a flash kernel (F.scaled_dot_product_attention(dropout_p) in train mode, transformer.py:317-318):
+// probability (b, h, q, k) uses element offset + ((b * H + h) * Lq + q) * Lk + k of the stream; thr == 0 switches it off.
+struct AttnDropout {
+  unsigned thr;
+  float inv_keep;
+  uint64_t seed, offset;
+  const uint64_t* seed_dev;      // optional: added to seed on the device (msam2_counter_bump)
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

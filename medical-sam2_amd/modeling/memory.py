@@ -22,6 +22,7 @@ from .encoder import MLP  # noqa: F401  (re-export for the registry)
 import os as _os
 _FUSED_ROPE = _os.environ.get("MSAM2_NO_FUSED_ROPE") is None   # experiment switch: rotate in a separate in-place kernel instead
 _FOLD_V = _os.environ.get("MSAM2_NO_VALUE_FOLD") is None       # experiment switch: 256-wide values through v_proj instead
+_BATCH_K_PROJ = _os.environ.get("MSAM2_BATCHED_KPROJ") is not None   # experiment switch (OFF: measured slower, see _project_all_keys)
 
 
 class LayerNorm2d(nn.Module):
@@ -217,8 +218,10 @@ class MemoryAttentionLayer(nn.Module):
         return ops.layernorm(x, v_f32(self._wc, name + "w", n.weight), v_f32(self._wc, name + "b", n.bias), n.eps)
 
     def run(self, x: torch.Tensor, mem_k: torch.Tensor, mem_v: torch.Tensor, B: int, L: int, n_ptr_tokens: int,
-            key_count: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """x fp32 [B*L, C]; mem_k (= memory + pos) / mem_v (= memory) bf16 [B, Nk, 64]; key_count: see RoPEAttention.core_folded."""
+            key_count: Optional[torch.Tensor] = None, kk: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x fp32 [B*L, C]; mem_k (= memory + pos) / mem_v (= memory) bf16 [B, Nk, 64]; key_count: see RoPEAttention.core_folded.
+        kk: this layer's rotated key projection [B, Nk, 256] (row stride free) when the caller projected all layers' keys in one GEMM
+        (MemoryAttention.forward)."""
         wc, sa, ca = self._wc, self.self_attn, self.cross_attn_image
         C = self.d_model
         Nk = mem_k.shape[1]
@@ -244,7 +247,9 @@ class MemoryAttentionLayer(nn.Module):
         kvs = parallel.current_kv_split()
         eff = ops.attention_effective_splits(Nk, attn_splits(B, 1, L, Nk)) if (kvs is not None and ca.folds_values()) else 1
         valid = Nk if key_count is None else (kvs.host_key_count if kvs is not None else None)
-        if eff > 1 and valid is not None and (Nk - n_ptr_tokens) % tab[0].shape[0] == 0:
+        if kk is not None:
+            pass                                            # projected for all layers at once by the caller
+        elif eff > 1 and valid is not None and (Nk - n_ptr_tokens) % tab[0].shape[0] == 0:
             # cross-GPU key split: this rank projects + rotates only the keys its attention partials read
             kk = ca.proj_rope_key_range(mem_k, n_ptr_tokens, tab, int(valid), eff, kvs.share(eff))
         else:
@@ -312,6 +317,31 @@ class MemoryAttention(nn.Module):
         self._drop_ctr_host = self._dropout_calls
         return p, ops.DeviceSeed(int(self.dropout_seed) << 32, snap)
 
+    def _project_all_keys(self, mem_k: torch.Tensor, B: int, L: int, n_ptr_tokens: int) -> Optional[torch.Tensor]:
+        """The rotated key projections of ALL layers' cross-attentions as ONE GEMM: the four layers project the same 64-channel bank rows
+        (memory + position) with their own k_proj, i.e. one [layers * 256, 64] weight, and each layer then reads its 256 columns as a
+        strided view.  MEASURED AND SWITCHED OFF (round 3, MSAM2_BATCHED_KPROJ=1 enables it): one launch instead of four, but the step
+        got slower (6.67 -> 6.75 ms, twice, alternating runs) and the 64-slice volume much slower (294 -> 259 slices/s) -- the attention's
+        K tiles then come from rows 2 KB apart in a buffer four times the size, which costs more than three launches save.  Not under the cross-GPU key split (each rank projects only its own key range there) and not when the
+        fused output would pass the 32-bit offsets of the RoPE store (banks beyond ~500 k keys keep the per-layer launches)."""
+        from .. import parallel
+        n = len(self.layers)
+        Nk = mem_k.shape[1]
+        cas = [l.cross_attn_image for l in self.layers]
+        if not (_BATCH_K_PROJ and n > 1 and parallel.current_kv_split() is None and all(isinstance(c, RoPEAttention) and c.folds_values() for c in cas)):
+            return None
+        C = cas[0].internal_dim
+        tab = cas[0].table(L, mem_k.device)
+        M = B * Nk
+        if not (_FUSED_ROPE and M >= 256 and Nk >= 128 and tab[0].shape[0] >= 128 and Nk - n_ptr_tokens > 0 and M * n * C * 4 < 2 ** 31
+                and len({(c.rope_theta, c.num_heads) for c in cas}) == 1):
+            return None
+        w = w_bf16(self._wc, "kall", *[c.k_proj.weight for c in cas])
+        b = v_f32(self._wc, "kallb", *[c.k_proj.bias for c in cas])
+        out = ops.gemm_rope(mem_k.reshape(M, -1), w, b, tab, rope_cols=n * C, head_dim=C // cas[0].num_heads, rows_per_batch=Nk,
+                            n_rope=Nk - n_ptr_tokens)
+        return out.view(B, Nk, n, C)
+
     def forward(self, curr: torch.Tensor, memory: torch.Tensor, curr_pos: Optional[torch.Tensor] = None,
                 memory_pos: Optional[torch.Tensor] = None, num_obj_ptr_tokens: int = 0, key_count: Optional[torch.Tensor] = None):
         """key_count (not in the reference's signature): int32 device scalar, number of valid leading rows of a `memory` padded to a
@@ -339,8 +369,9 @@ class MemoryAttention(nn.Module):
         mem_bf = memory.transpose(0, 1)
         mem_k = ops.add_cast(mem_bf, memory_pos.transpose(0, 1), 1.0, OP16)
         mem_v = ops.add_cast(mem_bf, None, 1.0, OP16)
-        for layer in self.layers:
-            x = layer.run(x, mem_k, mem_v, B, L, num_obj_ptr_tokens, key_count)
+        kk_all = self._project_all_keys(mem_k, B, L, num_obj_ptr_tokens)
+        for i, layer in enumerate(self.layers):
+            x = layer.run(x, mem_k, mem_v, B, L, num_obj_ptr_tokens, key_count, None if kk_all is None else kk_all[:, :, i])
         y = ops.layernorm(x, v_f32(self._wc, "nw", self.norm.weight), v_f32(self._wc, "nb", self.norm.bias), self.norm.eps,
                           out_dtype=F32)
         return y.view(B, L, C).transpose(0, 1)

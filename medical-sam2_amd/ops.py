@@ -169,11 +169,14 @@ def _strides3(t: torch.Tensor) -> "ctypes.Array":
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, splits: int = 1,
               out: Optional[torch.Tensor] = None, scale: Optional[float] = None, workspace: Optional[torch.Tensor] = None,
-              defer_merge: bool = False, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+              defer_merge: bool = False, lse: Optional[torch.Tensor] = None, dropout: Optional[tuple] = None) -> torch.Tensor:
     """softmax(q k^T / sqrt(D)) v.  q [B,H,Lq,D], k/v [B,H,Lk,D] as (possibly strided) bf16 views with D contiguous.
     Returns [B,H,Lq,D] view of a [B,Lq,H,D] buffer (heads recombined for the following out-projection).
     defer_merge (needs a caller-owned `workspace`): run the split-KV pass only; finish with attention_merge().
-    lse (fp32 [B,H,Lq] contiguous): also return the log-sum-exp rows (log2 domain) the backward needs; runs with >= 2 splits."""
+    lse (fp32 [B,H,Lq] contiguous): also return the log-sum-exp rows (log2 domain) the backward needs; runs with >= 2 splits.
+    dropout = (p, seed, offset) with lse: train-mode dropout on the attention probabilities inside the flash kernel (seed: int or
+    DeviceSeed; probability (b,h,q,k) = element offset + ((b*H+h)*Lq+q)*Lk+k of the stream); `backward.attention_backward(...,
+    dropout=...)` re-creates the mask."""
     B, H, Lq, D = q.shape
     Lk = k.shape[2]
     for t in (q, k, v):
@@ -188,6 +191,16 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, splits: int 
     _req(not defer_merge or (workspace is not None and splits > 1), "defer_merge needs splits > 1 and a caller-owned workspace")
     _req(ws is None or ws.numel() * ws.element_size() >= ws_bytes, "attention workspace too small")
     sc = scale if scale is not None else 1.0 / math.sqrt(D)
+    if dropout is not None and dropout[0] > 0:
+        _req(lse is not None, "attention: dropout is a training feature (pass lse)")
+        pd, seed, offset = dropout
+        seed_dev = None
+        if isinstance(seed, DeviceSeed):
+            seed, seed_dev = seed.base, seed.dev
+        check(lib().msam2_attention_fwd_lse_dropout(_p(q), _strides3(q), _p(k), _strides3(k), _p(v), _strides3(v), _p(out), _strides3(out),
+                                                    B, H, Lq, Lk, D, sc, splits, _p(ws), ws_bytes if ws is not None else 0, _p(lse), float(pd),
+                                                    int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), _p(seed_dev), _stream()))
+        return out
     if lse is not None:
         check(lib().msam2_attention_fwd_lse(_p(q), _strides3(q), _p(k), _strides3(k), _p(v), _strides3(v), _p(out), _strides3(out),
                                             B, H, Lq, Lk, D, sc, splits, _p(ws), ws_bytes if ws is not None else 0, _p(lse), _stream()))

@@ -222,8 +222,8 @@ def test_hip_backward_matches_reference_gradients():
         scale = 2.0 ** (math.floor(math.log2(masks.numel() / meta["dec"]["pos_weight"])) - 4)
         scaled = report(*bwd.mask_decoder_backward(dec, tm(emb), tm(pe), d(sparse), f0t, f1t, B, E, E, d_masks * scale), 1.0 / scale)
         print("worst relative gradient errors, unscaled:", plain[:3], " loss-scaled:", scaled[:3])
-        assert plain[0][1] < 5e-2, plain
-        assert scaled[0][1] < 4e-2, scaled
+        assert plain[0][1] < btol(5e-2), plain
+        assert scaled[0][1] < btol(4e-2, 5.0), scaled
         # ---- memory encoder
         enc = m.memory_encoder.to(DEV).eval()
         pix, mask, dyo = memenc_inputs(meta["memenc"])

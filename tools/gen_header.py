@@ -50,6 +50,8 @@ DOC = {
     "msam2_convt2x2_scatter_grad": "Adjoint of the 2x2 pixel shuffle: the gradient of the ConvTranspose GEMM output as a 16-bit operand.",
     "msam2_bce_logits": "BCEWithLogitsLoss(pos_weight) value (accumulated into a zeroed scalar) and its gradient w.r.t. the logits, mean reduction\n(func_3d/function.py:69 criterion_G).",
     "msam2_attention_fwd_lse": "msam2_attention_fwd that also writes the log-sum-exp of every query row (log2 domain, fp32 [B, H, Lq]) for msam2_attention_bwd.",
+    "msam2_attention_fwd_lse_dropout": "msam2_attention_fwd_lse with dropout on the attention probabilities INSIDE the flash kernel (F.scaled_dot_product_attention(dropout_p)\nas RoPEAttention calls it in train mode, transformer.py:317-318): counter-based mask, element offset + ((b*H + h)*Lq + q)*Lk + k of\nstream seed (+ *seed_dev, optional, see msam2_counter_bump); the softmax denominator and lse are those of the un-dropped probabilities.\nHead dim 96 / 128 / 256, Lq > 64.",
+    "msam2_attention_bwd_dropout": "msam2_attention_bwd for a forward run by msam2_attention_fwd_lse_dropout with the same (p, seed, offset, seed_dev): every pass re-creates\nthe mask; O(L) memory -- the train-mode attention backward of the memory attention no longer materialises [Lq, Lk] tensors.",
     "msam2_attention_bwd_workspace_bytes": "Scratch needed by msam2_attention_bwd (16-bit copy of dO and the delta rows).",
     "msam2_attention_bwd": "Flash-style dQ / dK / dV of softmax(Q K^T * scale) V (torch.autograd of F.scaled_dot_product_attention at transformer.py:318 and\nhieradet.py:72-76 in the training loops func_3d/function.py:182-191, func_2d/function.py:246-259): head dim 64 / 96 / 128 / 256,\n16-bit q / k / v / o and lse (the outputs of msam2_attention_fwd_lse), fp32 dO in, fp32 gradients out, O(L) memory (no [Lq, Lk] tensor).",
     "msam2_dwconv7x7": "Plain depthwise 7x7 convolution (pad 3) on fp32 NHWC tokens, taps [49, C]; flip = 1 gives the input gradient of CXBlock.dwconv\n(memory_encoder.py:83-90) -- the forward uses the fused msam2_dwconv7x7_ln.",

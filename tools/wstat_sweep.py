@@ -4,7 +4,7 @@ import medical_sam2_amd.ops as ops
 from tools.kernel_bench import timeit
 g = torch.Generator().manual_seed(0)
 for (M, N, K, act) in [(16384, 1152, 384, 0), (16384, 1536, 384, 1), (16384, 1536, 384, 0), (16384, 2048, 256, 2), (16384, 1024, 256, 1), (16384, 768, 256, 0), (16384, 384, 384, 0),
-                       (8192, 1152, 384, 0), (32768, 1152, 384, 0), (65536, 768, 256, 0), (4096, 2304, 768, 0), (128, 128, 256, 0), (384, 256, 384, 1)]:
+                       (8192, 1152, 384, 0), (8192, 1536, 384, 1), (32768, 1152, 384, 0), (32768, 1536, 384, 1), (65536, 768, 256, 0)]:
     a = torch.randn(M, K, generator=g).to(ops.OP16).cuda(); w = (torch.randn(N, K, generator=g) * 0.05).to(ops.OP16).cuda(); b = torch.randn(N, generator=g).cuda()
     out = torch.empty(M, N, dtype=ops.OP16, device="cuda")
     res = []
