@@ -152,7 +152,7 @@ def time_dominant_kernel(device, batch):
 def time_hiera_attention(device, batch):
     """north_star's second figure: the Hiera attention kernels of this workload timed alone (HIP events on the launch stream, graph-free:
     20 back-to-back launches), at the two shapes that carry the trunk's attention time:
-      * global blocks 7 / 10 / 13: attn_glds_kernel<96,128,4,3>, B x 4 heads x 4096 x 4096 x 96 -- MFMA-bound (AI ~ 2000);
+      * global blocks 7 / 10 / 13: attn_g96x2_kernel<1,8> (round 2: attn_glds_kernel<96,128,4,3>), B x 4 heads x 4096 x 4096 x 96 -- MFMA-bound (AI ~ 2000);
       * stage-3 windowed blocks (x7): attn_win_kernel<96>, 25 windows of 14x14 per image x 4 heads, 196 x 196 x 96 -- HBM-bound stand-alone
         (AI ~ 98): priced on the algorithmic bytes q, k, v, o once in 16 bits.
     Returns the `roofline_hiera_attention` object."""
@@ -190,7 +190,7 @@ def time_hiera_attention(device, batch):
     fl_win = 4.0 * B * 25 * heads * 196 * 196 * D
     lib().msam2_event_destroy(e0)
     lib().msam2_event_destroy(e1)
-    return {"global": {"kernel": f"attn_glds_kernel<96,128,4,3> at B={B} heads=4 Lq=Lk=4096 D=96", "bound": "mfma", "avg_launch_us": t_glob * 1e6,
+    return {"global": {"kernel": f"attn_g96x2_kernel<1,8> at B={B} heads=4 Lq=Lk=4096 D=96", "bound": "mfma", "avg_launch_us": t_glob * 1e6,
                        "achieved": fl_glob / t_glob / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl_glob / t_glob / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                        "flops_per_launch": fl_glob},
             "windowed": {"kernel": f"attn_win_kernel<96> at B={B} 25 windows x 4 heads, 196 x 196 x 96 (stage-3 blocks)", "bound": "hbm",

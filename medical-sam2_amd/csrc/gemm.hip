@@ -1441,12 +1441,13 @@ static int gemm_launch(const void* A, int64_t lda, const void* W, int64_t ldw, c
   }
   {
     // W-stationary persistent kernel for the short-reduction 16-bit projections (measured, tools/wstat_sweep.py: qkv 16384 x 1152 x 384
-    // 28.6 -> 23-25 us, memory-attention linear1 16384 x 2048 x 256 34 -> 30 us, 16384 x 768 x 256 16.6 -> 13.6 us); not for GELU
-    // epilogues, whose VALU work the tiled kernel hides better behind a second workgroup (fc1: 42 vs 45 us).
-    // MSAM2_GEMM_WSTAT = 0 never, 1 every shape it supports, 2 with A-fragment prefetch (experiments); default: act 0 / 2 only.
+    // 28.6 -> 21-25 us, memory-attention linear1 16384 x 2048 x 256 34 -> 25-30 us, 16384 x 768 x 256 16.6 -> 13.6 us).  GELU epilogues
+    // too since the activation became a polynomial (common.h): with the erf form the tiled kernel hid the epilogue's VALU work better
+    // behind its second workgroup (fc1 16384 x 1536 x 384: 42 vs 45 us); now 38.2 vs 37.8, and 16384 x 1024 x 256 21.1 vs 17.6.
+    // MSAM2_GEMM_WSTAT = 0 never, 1 every shape it supports, 2 with A-fragment prefetch, 3 act 0 / 2 only (the round-3 default before).
     const char* ew = getenv("MSAM2_GEMM_WSTAT");
     const int wstat_mode = ew ? atoi(ew) : -1;
-    const bool want = wstat_mode > 0 || (wstat_mode < 0 && (act == 0 || act == 2));
+    const bool want = wstat_mode == 1 || wstat_mode == 2 || wstat_mode < 0 || (wstat_mode == 3 && (act == 0 || act == 2));
     if (want && !var && dma_ok && gemm_try_wstat(p, s, wstat_mode == 2)) return msam2_check_launch("gemm(w-stationary)");
   }
   const int vv = var ? atoi(var) : (tiles <= 256 && K >= 1024 ? 8 : (K % 64 == 0 && K >= 384 ? 2 : 5));

@@ -1,13 +1,12 @@
 #!/bin/bash
 # Where the D = 96 global attention kernel's time goes: the same kernel with pieces removed (diagnostic builds -DMSAM2_G96_PROBE=n in
-# build_ab/, see attn_g96x2_kernel), both workgroup shapes.
+# build_ab/, see attn_g96_kernel): 2 no softmax, 3 + fragments read once, 4 + no DMA / barrier (MFMAs only).
 mkdir -p gpurun_out/g96probe
 timeout -k 10 400 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "attention_vs_oracle" > gpurun_out/g96probe/tests.log 2>&1
 echo "tests rc=$?"; tail -2 gpurun_out/g96probe/tests.log
-MSAM2_G96_X2=1 timeout -k 10 400 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "attention_vs_oracle" > gpurun_out/g96probe/tests_x2.log 2>&1
-echo "tests x2 rc=$?"; tail -2 gpurun_out/g96probe/tests_x2.log
-for lib in medical-sam2_amd/libmsam2_hip.so build_ab/libmsam2_hip_dmabuiltin.so build_ab/libprobe2.so build_ab/libprobe3.so build_ab/libprobe4.so; do
-  echo "== $lib: 8 waves x 32 queries | 4 waves x 64 queries"
+for lib in medical-sam2_amd/libmsam2_hip.so build_ab/libprobe2.so build_ab/libprobe3.so build_ab/libprobe4.so; do
+  echo "== $lib"
   timeout -k 10 120 python tools/attn_ab.py $lib 2>&1 | grep global
-  MSAM2_G96_X2=1 timeout -k 10 120 python tools/attn_ab.py $lib 2>&1 | grep global
 done
+echo "== old kernel"
+MSAM2_G96_V1=1 timeout -k 10 120 python tools/attn_ab.py medical-sam2_amd/libmsam2_hip.so 2>&1 | grep global
