@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const float* __restr
   if (lane == 0) delta[row] = acc;
 }
 
-template <int D, int NW, int ROLE>
+template <int D, int NW, int ROLE, bool DROP>
 __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
   using C = BwdCfg<D>;
   constexpr int NT = NW * 64;
@@ -143,9 +143,14 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
   const float delta_own = (ROLE == ROLE_DQ && ovalid) ? p.delta[bh * p.Lq + oi] : 0.f;
   const float lse_own = (ROLE == ROLE_DQ && ovalid) ? p.lse[bh * p.Lq + oi] : 0.f;
   // dropout stream: DQ owns a query row (element index of key 0 of that row), DK / DV own a key (element index of query 0, that key)
-  const uint64_t drop_seed = p.drop.seed + ((p.drop.thr && p.drop.seed_dev) ? *p.drop.seed_dev : 0ull);
-  const uint64_t drop_own = p.drop.offset + (uint64_t)bh * p.Lq * (uint64_t)p.Lk +
-                            (ROLE == ROLE_DQ ? (uint64_t)(ovalid ? oi : 0) * (uint64_t)p.Lk : (uint64_t)(ovalid ? oi : 0));
+  // (DROP instances only: as a run-time branch the mask generator cost every instance 12-90 registers -- the D = 96 dK pass went from
+  //  200 to 288 and lost its second wave per SIMD, 3.5 ms of the 2-D training iteration)
+  uint64_t drop_seed = 0, drop_own = 0;
+  if constexpr (DROP) {
+    drop_seed = p.drop.seed + (p.drop.seed_dev ? *p.drop.seed_dev : 0ull);
+    drop_own = p.drop.offset + (uint64_t)bh * p.Lq * (uint64_t)p.Lk +
+               (ROLE == ROLE_DQ ? (uint64_t)(ovalid ? oi : 0) * (uint64_t)p.Lk : (uint64_t)(ovalid ? oi : 0));
+  }
 
   const int tiles_all = (n_str + C::BK - 1) / C::BK;
   const int tiles_per = (tiles_all + nsplit - 1) / nsplit;
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
       for (int e = 0; e < 16; ++e) {
         const float pe = __builtin_amdgcn_exp2f(s[e] * p.scale_log2 - lse_own);
         float dpe = dp[e];
-        if (p.drop.thr)                                  // owner = query oi, streamed row = key: the forward's mask on dP
+        if constexpr (DROP)                              // owner = query oi, streamed row = key: the forward's mask on dP
           dpe = dropout_keep(drop_seed, drop_own + (uint64_t)(row0 + (e & 3) + 8 * (e >> 2) + 4 * h), p.drop.thr) ? dpe * p.drop.inv_keep : 0.f;
         wf[e >> 3][e & 7] = f2op(pe * (dpe - delta_own));
       }
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
         const float pe = __builtin_amdgcn_exp2f(s[e] * p.scale_log2 - st_lse[row]);
         float m = 1.f;
-        if (p.drop.thr)                                  // owner = key oi, streamed row = query
+        if constexpr (DROP)                              // owner = key oi, streamed row = query
           m = dropout_keep(drop_seed, drop_own + (uint64_t)(row0 + row) * (uint64_t)p.Lk, p.drop.thr) ? p.drop.inv_keep : 0.f;
         wf[e >> 3][e & 7] = f2op(ROLE == ROLE_DV ? pe * m : pe * (dp[e] * m - st_del[row]));
       }
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(AttnBwdParams p) {
 // a row image for DQ / DK and a tr image for DV.  One barrier per tile: tile t+1 is issued right after the barrier that says
 // "tile t has landed and everybody is done with tile t-1".
 // ------------------------------------------------------------------------------------------------------------------
-template <int D, int NW, int ROLE>
+template <int D, int NW, int ROLE, bool DROP>
 __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dma_kernel(AttnBwdParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BK = 32, RB = D * 2, CPR = D / 8;
@@ -367,9 +372,14 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dma_kernel(AttnBwdParams 
   const float delta_own = (ROLE == ROLE_DQ && ovalid) ? p.delta[bh * p.Lq + oi] : 0.f;
   const float lse_own = (ROLE == ROLE_DQ && ovalid) ? p.lse[bh * p.Lq + oi] : 0.f;
   // dropout stream: DQ owns a query row (element index of key 0 of that row), DK / DV own a key (element index of query 0, that key)
-  const uint64_t drop_seed = p.drop.seed + ((p.drop.thr && p.drop.seed_dev) ? *p.drop.seed_dev : 0ull);
-  const uint64_t drop_own = p.drop.offset + (uint64_t)bh * p.Lq * (uint64_t)p.Lk +
-                            (ROLE == ROLE_DQ ? (uint64_t)(ovalid ? oi : 0) * (uint64_t)p.Lk : (uint64_t)(ovalid ? oi : 0));
+  // (DROP instances only: as a run-time branch the mask generator cost every instance 12-90 registers -- the D = 96 dK pass went from
+  //  200 to 288 and lost its second wave per SIMD, 3.5 ms of the 2-D training iteration)
+  uint64_t drop_seed = 0, drop_own = 0;
+  if constexpr (DROP) {
+    drop_seed = p.drop.seed + (p.drop.seed_dev ? *p.drop.seed_dev : 0ull);
+    drop_own = p.drop.offset + (uint64_t)bh * p.Lq * (uint64_t)p.Lk +
+               (ROLE == ROLE_DQ ? (uint64_t)(ovalid ? oi : 0) * (uint64_t)p.Lk : (uint64_t)(ovalid ? oi : 0));
+  }
 
   const int tiles_all = (n_str + BK - 1) / BK;
   const int tiles_per = (tiles_all + nsplit - 1) / nsplit;
@@ -472,7 +482,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dma_kernel(AttnBwdParams 
         float pe = __builtin_amdgcn_exp2f(s[e] * p.scale_log2 - lse_own);
         if (masked && row0 + (e & 3) + 8 * (e >> 2) + 4 * h >= n_str) pe = 0.f;   // tail tile: clamped duplicates of the last key
         float dpe = dp[e];
-        if (p.drop.thr)                                  // owner = query oi, streamed row = key: the forward's mask on dP
+        if constexpr (DROP)                              // owner = query oi, streamed row = key: the forward's mask on dP
           dpe = dropout_keep(drop_seed, drop_own + (uint64_t)(row0 + (e & 3) + 8 * (e >> 2) + 4 * h), p.drop.thr) ? dpe * p.drop.inv_keep : 0.f;
         wf[e >> 3][e & 7] = f2op(pe * (dpe - delta_own));
       }
@@ -484,7 +494,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dma_kernel(AttnBwdParams 
         const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
         const float pe = __builtin_amdgcn_exp2f(s[e] * p.scale_log2 - st_lse[row]);   // lse = +inf past the end: weight 0
         float m = 1.f;
-        if (p.drop.thr)                                  // owner = key oi, streamed row = query
+        if constexpr (DROP)                              // owner = key oi, streamed row = query
           m = dropout_keep(drop_seed, drop_own + (uint64_t)(row0 + row) * (uint64_t)p.Lk, p.drop.thr) ? p.drop.inv_keep : 0.f;
         wf[e >> 3][e & 7] = f2op(ROLE == ROLE_DV ? pe * m : pe * (dp[e] * m - st_del[row]));
       }
@@ -583,8 +593,8 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(const float* __res
   }
 }
 
-template <int D, int NW, int ROLE>
-void launch_role(const AttnBwdParams& p, hipStream_t s) {
+template <int D, int NW, int ROLE, bool DROP>
+void launch_role_t(const AttnBwdParams& p, hipStream_t s) {
   using C = BwdCfg<D>;
   const int n_own = ROLE == ROLE_DQ ? p.Lq : p.Lk;
   dim3 grid(cdiv(n_own, NW * 32) * (ROLE == ROLE_DQ ? p.ksplit : 1), p.H, p.B);
@@ -596,19 +606,25 @@ void launch_role(const AttnBwdParams& p, hipStream_t s) {
       constexpr int LDSB = 2 * (ROLE == ROLE_DV ? 2 : 3) * 32 * D * 2 + BwdCfg<D>::STATS;
       static bool attr_dma = false;
       if (!attr_dma) {
-        hipFuncSetAttribute((const void*)attn_bwd_dma_kernel<D, NW, ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+        hipFuncSetAttribute((const void*)attn_bwd_dma_kernel<D, NW, ROLE, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
         attr_dma = true;
       }
-      hipLaunchKernelGGL((attn_bwd_dma_kernel<D, NW, ROLE>), grid, dim3(NW * 64), LDSB, s, p);
+      hipLaunchKernelGGL((attn_bwd_dma_kernel<D, NW, ROLE, DROP>), grid, dim3(NW * 64), LDSB, s, p);
       return;
     }
   }
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)attn_bwd_kernel<D, NW, ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    hipFuncSetAttribute((const void*)attn_bwd_kernel<D, NW, ROLE, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_bwd_kernel<D, NW, ROLE>), grid, dim3(NW * 64), C::LDS_BYTES, s, p);
+  hipLaunchKernelGGL((attn_bwd_kernel<D, NW, ROLE, DROP>), grid, dim3(NW * 64), C::LDS_BYTES, s, p);
+}
+
+template <int D, int NW, int ROLE>
+void launch_role(const AttnBwdParams& p, hipStream_t s) {
+  if (p.drop.thr) launch_role_t<D, NW, ROLE, true>(p, s);
+  else launch_role_t<D, NW, ROLE, false>(p, s);
 }
 
 // DQ role: key splits per owner block -- until there are ~2 workgroups per CU, each split keeping at least 8 key tiles, at most
