@@ -167,6 +167,144 @@ __global__ __launch_bounds__(256) void gemm_tt_kernel(GemmTTParams p) {
   }
 }
 
+// LDS-DMA form of gemm_tt_kernel (round 3): the register-staged kernel above runs 8 MFMAs per wave and barrier behind a global-load
+// round trip (150 TFLOP/s over the training iteration's weight gradients -- 13.6 % of the iteration, profiles/r03_train_*); this one is
+// gemm_glds_kernel's structure on k-major operands: 128 x 128 x 64 tiles, both 64-row x 256-byte slabs streamed global -> LDS by DMA
+// (one 1-KiB piece = 4 k-rows; 8 pieces per wave and tile), two stages, one barrier per 64 k; all 16 operand fragments of a tile are
+// read in one burst (transposed reads, the V^T pattern of attn_glds_kernel<128>: 16-byte chunk c of row k sits at c ^ ((k & 3) << 2),
+// applied on the DMA's source address) and the 16 MFMAs run with the next tile's DMA pieces issued in their shadow.
+// K % 64 == 0 (rows past K cannot be zero-filled by a DMA); columns past M / N re-read chunk 0 of their row (results not stored).
+__global__ __launch_bounds__(256, 2) void gemm_tt_dma_kernel(GemmTTParams p) {
+  constexpr int BK = 64, RB = 256, SLAB = BK * RB, STAGE = 2 * SLAB;   // 32 KiB per stage
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5, li = lane & 15;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  const int nk_all = p.K / BK;
+  const int kt0 = blockIdx.z * p.ktiles_per_split, kt1 = min(nk_all, kt0 + p.ktiles_per_split);
+  if (kt0 >= kt1) return;
+  const bool want_cs = p.a_colsum != nullptr && blockIdx.x == 0;      // (workgroup-uniform)
+
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+  const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0x7fffffff, 0x00020000);
+  // piece i of this wave: k-rows 4 (4 wave + i) .. +3 of the slab; lane -> (row, LDS chunk slot), source chunk = slot ^ ((row & 3) << 2)
+  unsigned offA[4], offB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 4 * (4 * wave + i) + (lane >> 4);
+    const int col = (((lane & 15) ^ ((row & 3) << 2))) * 8;
+    offA[i] = (unsigned)(row * p.lda * 2 + (m0 + (m0 + col < p.M ? col : 0)) * 2);
+    offB[i] = (unsigned)(row * p.ldb * 2 + (n0 + (n0 + col < p.N ? col : 0)) * 2);
+  }
+  auto issue_piece = [&](int kt, int stage, int i) {
+    unsigned char* base = lds + stage * STAGE + (4 * wave) * 1024;
+    if (i < 4)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(base + i * 1024), 16, offA[i],
+                                               (unsigned)kt * BK * (unsigned)p.lda * 2u, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (__attribute__((address_space(3))) void*)(base + SLAB + (i - 4) * 1024), 16, offB[i - 4],
+                                               (unsigned)kt * BK * (unsigned)p.ldb * 2u, 0, 0);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  float cs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+
+  // transposed fragment of 32 columns (block cb of the slab) x 16 k-rows (step ks): rows 16 ks + 4 h + vq (+ 8), see attn_glds_kernel
+  const int vq = li >> 2, vp = li & 3, cgrp = (lane >> 4) & 1;
+  const int t_row = (4 * h + vq) * RB + ((vp & 1) << 3);
+  const int t_sw = vq << 2, t_c0 = 2 * cgrp + (vp >> 1);
+  typedef __attribute__((ext_vector_type(8))) short short8_t;
+  auto frag = [&](const unsigned char* slab, int ks, int cb) -> op16x8 {
+    const unsigned char* a0 = slab + t_row + (16 * ks) * RB + (((cb * 4 + t_c0) ^ t_sw) << 4);
+    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0));
+    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0 + 8 * RB));
+    short8_t t8;
+    t8[0] = lo[0]; t8[1] = lo[1]; t8[2] = lo[2]; t8[3] = lo[3];
+    t8[4] = hi[0]; t8[5] = hi[1]; t8[6] = hi[2]; t8[7] = hi[3];
+    return __builtin_bit_cast(op16x8, t8);
+  };
+
+#pragma unroll
+  for (int i = 0; i < 8; ++i) issue_piece(kt0, 0, i);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int st = (kt - kt0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of tile kt have landed
+    __builtin_amdgcn_s_barrier();                        // ... and so have every other wave's; stage st^1 is free again
+    const unsigned char* sa = lds + st * STAGE;
+    const unsigned char* sb = sa + SLAB;
+    op16x8 af[4][2], bfr[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[ks][i] = frag(sa, ks, wm * 2 + i);
+        bfr[ks][i] = frag(sb, ks, wn * 2 + i);
+      }
+    if (want_cs) {
+      // bias gradient: thread t adds rows (t >> 4) + 16 u of column chunk t & 15 of the A slab
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = (tid >> 4) + 16 * u;
+        const op16x8 av = *reinterpret_cast<const op16x8*>(sa + row * RB + ((((tid & 15) ^ ((row & 3) << 2))) << 4));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] += op2f(av[e]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = MSAM2_MFMA_32x32x16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+      if (kt + 1 < kt1) {
+        issue_piece(kt + 1, st ^ 1, 2 * ks);
+        issue_piece(kt + 1, st ^ 1, 2 * ks + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (want_cs) {
+    __builtin_amdgcn_s_barrier();                        // every wave is past its last fragment read
+    float* red = reinterpret_cast<float*>(lds);          // [16][128]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(tid >> 4) * 128 + (tid & 15) * 8 + e] = cs[e];
+    __syncthreads();
+    if (tid < 128 && m0 + tid < p.M) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t += red[g * 128 + tid];
+      atomicAdd(p.a_colsum + m0 + tid, t);
+    }
+  }
+  const bool atomic = gridDim.z > 1;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + r;
+    if (n >= p.N) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m < p.M) {
+          if (atomic) atomicAdd(p.C + (int64_t)m * p.ldc + n, acc[i][j][e]);
+          else p.C[(int64_t)m * p.ldc + n] = acc[i][j][e];
+        }
+      }
+  }
+}
+
 __global__ __launch_bounds__(256) void gemm_tt_zero_kernel(float* __restrict__ C, int64_t ldc, int M, int N, float* __restrict__ colsum, int zero_c) {
   const int64_t total = zero_c ? (int64_t)M * N : 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) C[(i / N) * ldc + i % N] = 0.f;
@@ -183,16 +321,25 @@ extern "C" int msam2_gemm_tt(const void* A, int64_t lda, const void* B, int64_t 
   GemmTTParams p;
   p.A = (const op16*)A; p.B = (const op16*)B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.a_colsum = a_colsum;
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
-  const int64_t tiles = (int64_t)cdiv(M, 128) * cdiv(N, 128), nk = cdiv(K, 32);
-  // ~2 workgroups per CU, each split at least 16 k-tiles long (swept on the training step's shapes: tools/gemm_tt_bench.py)
-  int64_t splits = max((int64_t)1, min(min((int64_t)128, cdiv(512, tiles)), nk / 16));
+  // LDS-DMA kernel: 64-row k-tiles, 32-bit DMA offsets (the whole operand within 2 GiB)
+  static const bool no_dma = getenv("MSAM2_GEMM_TT_V1") != nullptr;
+  const bool dma = !no_dma && K % 64 == 0 && K * lda * 2 < (1ll << 31) && K * ldb * 2 < (1ll << 31);
+  const int64_t tiles = (int64_t)cdiv(M, 128) * cdiv(N, 128), nk = dma ? K / 64 : cdiv(K, 32);
+  // splits: ~1 workgroup per CU (2 for the register-staged kernel), each split at least 8 (16) k-tiles long -- swept on the training
+  // iteration's 20 shapes (tools/gemm_tt_bench.py, ms per iteration): register-staged 6.04; DMA kernel 4.85 / 4.07 / 3.92 / 3.96 / 4.39
+  // / 5.38 at 128 / 192 / 256 / 320 / 512 / 1024 workgroups aimed at (more splits = more fp32 atomics per output element)
+  static const int64_t env_mink = getenv("MSAM2_TT_MINK") ? atoll(getenv("MSAM2_TT_MINK")) : 0;   // sweeps (tools/gemm_tt_bench.py)
+  static const int64_t env_wgs = getenv("MSAM2_TT_WGS") ? atoll(getenv("MSAM2_TT_WGS")) : 0;
+  const int64_t mink = env_mink > 0 ? env_mink : (dma ? 8 : 16), wgs = env_wgs > 0 ? env_wgs : (dma ? 256 : 512);
+  int64_t splits = max((int64_t)1, min(min((int64_t)128, cdiv(wgs, tiles)), nk / mink));
   p.ktiles_per_split = (int)cdiv(nk, splits);
   splits = cdiv(nk, p.ktiles_per_split);
   hipStream_t s = (hipStream_t)stream;
   if (splits > 1 || a_colsum)
     hipLaunchKernelGGL(gemm_tt_zero_kernel, dim3((unsigned)min((int64_t)1024, (M * N + 255) / 256)), dim3(256), 0, s, C, ldc, (int)M, (int)N, a_colsum,
                        splits > 1 ? 1 : 0);
-  hipLaunchKernelGGL(gemm_tt_kernel, dim3(cdiv(N, 128), cdiv(M, 128), (unsigned)splits), dim3(256), 0, s, p);
+  if (dma) hipLaunchKernelGGL(gemm_tt_dma_kernel, dim3(cdiv(N, 128), cdiv(M, 128), (unsigned)splits), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(gemm_tt_kernel, dim3(cdiv(N, 128), cdiv(M, 128), (unsigned)splits), dim3(256), 0, s, p);
   return msam2_check_launch("gemm_tt");
 }
 

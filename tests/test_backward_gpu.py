@@ -80,7 +80,9 @@ def test_act_backward(mods, act):
     assert (out.float().cpu() - pre.grad).abs().max().item() < btol(4e-3)       # 16-bit output rounding
 
 
-@pytest.mark.parametrize("K,M,N", [(16384, 256, 256), (65536, 128, 64), (300, 200, 40), (28, 8, 2048), (4097, 264, 136)])
+@pytest.mark.parametrize("K,M,N", [(16384, 256, 256), (65536, 128, 64), (300, 200, 40), (28, 8, 2048), (4097, 264, 136),
+                                   # K % 64 == 0: the LDS-DMA kernel, ragged M / N tiles, a single k-tile, an odd number of k-tiles per split
+                                   (8192, 200, 40), (4096, 384, 1160), (64, 136, 8), (4928, 96, 96)])
 def test_gemm_tt(mods, K, M, N):
     """dW-shaped product on k-major operands (a^T b): integer operands make every partial sum exact, so the split-K atomics must
     reproduce the fp64 result bit for bit; strided rows (column slices of wider buffers)."""
