@@ -94,9 +94,12 @@ def mlp_backward(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.
                  act: int):
     """y = W2 act(W1 x + b1) + b2 (two-layer MLP of hieradet / memory attention / two-way blocks).  The hidden activations are
     recomputed (one extra forward GEMM pair) instead of being saved by the forward.  Returns (dx fp32, dW1, db1, dW2, db2)."""
-    pre = ops.gemm(x, w1, b1, out_dtype=F32)
     h = ops.gemm(x, w1, b1, act=act)
-    dh, dw2, db2 = linear_backward(h, w2, dy, dx_dtype=F32)
+    # act'(pre): ReLU's is the sign of h itself; GELU's needs the pre-activations -- recomputed into 16 bits (the W-stationary kernel takes
+    # the shape; an fp32 [tokens, hidden] map is 100 MB per stage-3 block).  The hidden gradient likewise stays in 16 bits: it is
+    # multiplied by act' and rounded to the GEMM operand type right behind it.
+    pre = h if act == ops.ACT_RELU else ops.gemm(x, w1, b1)
+    dh, dw2, db2 = linear_backward(h, w2, dy, dx_dtype=OP16)
     dpre = act_backward(pre, dh, act)
     dx, dw1, db1 = linear_backward(x, w1, dpre)
     return dx, dw1, db1, dw2, db2
@@ -334,8 +337,8 @@ def _memory_attention_layer_backward_saved(layer, ctx: dict, dy: torch.Tensor):
     if drop:
         # FFN with its two dropouts: y = x2 + drop3(linear2(drop_ffn(relu(linear1(t3)))))
         b1v = Bv("f1b", layer.linear1.bias)
-        pre = ops.gemm(t3, w1, b1v, out_dtype=F32)
-        hid_d = ops.dropout(ops.gemm(t3, w1, b1v, act=ops.ACT_RELU), dp, dseed, drop_offset(dl, "ffn"))
+        pre = ops.gemm(t3, w1, b1v, act=ops.ACT_RELU)                                # ReLU'(pre) is the sign of relu(pre)
+        hid_d = ops.dropout(pre, dp, dseed, drop_offset(dl, "ffn"))
         d_ffn = ops.dropout(dy.to(F32).contiguous(), dp, dseed, drop_offset(dl, "drop3"))
         dhid_d, g["linear2.weight"], g["linear2.bias"] = linear_backward(hid_d, w2, d_ffn)
         dpre = act_backward(pre, ops.dropout(dhid_d, dp, dseed, drop_offset(dl, "ffn")), ops.ACT_RELU)
