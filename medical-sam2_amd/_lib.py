@@ -79,6 +79,7 @@ SIGNATURES = {
     "msam2_dwconv7x7": (c_i, [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_i, c_p]),
     "msam2_dwconv7x7_wgrad": (c_i, [c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_p]),
     "msam2_col2im3x3s2": (c_i, [c_p, c_l, c_p, c_l, c_l, c_l, c_l, c_p]),
+    "msam2_gemm_nt": (c_i, [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_i, c_l, c_l, c_l, c_p]),
     "msam2_gemm_tt": (c_i, [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_l, c_p]),
     "msam2_bilinear_upsample_bwd": (c_i, [c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_p]),
     "msam2_maxpool2x2_bwd": (c_i, [c_p, c_i, c_l, c_p, c_l, c_p, c_l, c_l, c_l, c_l, c_l, c_p]),

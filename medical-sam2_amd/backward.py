@@ -73,9 +73,27 @@ def linear_backward(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, need_dx:
     db fp32 [N])."""
     dy16 = _op16(dy)
     _req(w.shape[0] % 8 == 0, "linear_backward: out_features must be a multiple of 8 (GEMM reduction length of dX)")
-    dx = ops.gemm(dy16, transpose16(w), out_dtype=dx_dtype) if need_dx else None          # [M,N] @ (W^T [K,N])^T
+    dx = gemm_nt(dy16, w, out_dtype=dx_dtype) if need_dx else None                       # [M, N] @ W [N, K], W as the forward stores it
     dw, db = gemm_tt(dy16, x, a_colsum=True)
     return dx, dw, db
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, out_dtype: torch.dtype = F32, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[M, N] = residual + a [M, K] @ b [K, N] with b k-major (16-bit operands, rows possibly strided): the input gradient dX = dY W of a
+    linear layer straight from its weight [out, in] (`msam2_gemm_nt`) -- no transposed weight copy.  Reductions that are not a multiple of
+    64 (the 96-wide layers of Hiera's first stage) go through the transposed copy and the forward GEMM."""
+    _req(a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[0] and a.dtype == OP16 and b.dtype == OP16, "gemm_nt: 16-bit [M, K], [K, N]")
+    _req(a.stride(1) == 1 and b.stride(1) == 1, "gemm_nt: row-major operands")
+    M, K = a.shape
+    N = b.shape[1]
+    if K % 64 or N % 8 or a.stride(0) % 8 or b.stride(0) % 8 or a.data_ptr() % 16 or b.data_ptr() % 16:
+        return ops.gemm(a, transpose16(b), residual=residual, out_dtype=out_dtype)
+    out = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    if residual is not None:
+        _req(residual.dtype == F32 and residual.shape == (M, N) and residual.stride(1) == 1, "gemm_nt: residual must be fp32 [M, N]")
+    check(lib().msam2_gemm_nt(_p(a), a.stride(0), _p(b), b.stride(0), None, _p(residual), residual.stride(0) if residual is not None else 0,
+                              _p(out), out.stride(0), _is_bf16(out), M, N, K, _stream()))
+    return out
 
 
 def gemm_tt(a: torch.Tensor, b: torch.Tensor, a_colsum: bool = False):

@@ -1474,6 +1474,139 @@ static int gemm_launch(const void* A, int64_t lda, const void* W, int64_t ldw, c
   return msam2_check_launch("gemm");
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// C[M, N] = A[M, K] B[K, N] with B stored k-MAJOR (row k holds the N outputs): the input-gradient GEMM dX = dY W of a linear layer takes
+// the layer's weight W [out, in] exactly as the forward stores it -- no transposed weight copy (161 of them per training iteration at
+// ~8.7 us each, latency not bytes: profiles/r03_train_iteration_kernel_stats.csv).  gemm_glds_kernel's structure with the second operand
+// handled like gemm_tt_dma_kernel's slabs: a 64-row x 256-byte slab per k-tile by DMA (chunk c of row k at c ^ ((k & 3) << 2), applied on
+// the source address), fragments by ds_read_b64_tr_b16 -- here with rows 8 h + q (+ 4) so that the transposed fragment carries the same
+// k order as the ds_read_b128 fragment of A (k = 8 h + e).  K % 64 == 0 (slab rows past K cannot be zero-filled by a DMA).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
+  constexpr int BM = 128, BN = 128, BK = 64, A_BYTES = BM * BK * 2, STAGE_BYTES = A_BYTES + BK * BN * 2;  // 16 + 16 KiB
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE_BYTES];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5, li = lane & 15;
+  const int n_tiles_n = (p.N + BN - 1) / BN, n_tiles_m = (p.M + BM - 1) / BM;
+  const int nwg = n_tiles_n * n_tiles_m;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8;
+    bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + bid / 8;
+  }
+  const int64_t m0 = (int64_t)(bid / n_tiles_n) * BM;
+  const int n0 = (bid % n_tiles_n) * BN;
+
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+  // A: 4 pieces per wave of 8 rows x 128 B (as gemm_glds_kernel); B: 4 pieces per wave of 4 k-rows x 256 B (as gemm_tt_dma_kernel)
+  unsigned offsA[4], offsW[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    offsA[i] = (unsigned)(min(m0 + row, (int64_t)p.M - 1) * p.lda * 2 + chunk * 16);
+    const int krow = 4 * (4 * wave + i) + (lane >> 4);
+    const int col = ((lane & 15) ^ ((krow & 3) << 2)) * 8;
+    offsW[i] = (unsigned)(krow * p.ldw * 2 + (n0 + (n0 + col < p.N ? col : 0)) * 2);
+  }
+  auto issue_piece = [&](int kt, int stage, int i) {
+    unsigned char* base = lds + stage * STAGE_BYTES + wave * 4096;
+    if (i < 4)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(base + i * 1024), 16, offsA[i],
+                                               (unsigned)kt * BK * 2, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(base + A_BYTES + (i - 4) * 1024), 16, offsW[i - 4],
+                                               (unsigned)kt * BK * (unsigned)p.ldw * 2u, 0, 0);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  int offA[2], swzA[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ra = wm * 64 + i * 32 + r;
+    offA[i] = ra * 128;
+    swzA[i] = (ra >> 1) & 7;
+  }
+  // transposed fragment of column block cb (32 columns) x k-step ks (16 rows) of the slab: lane 4 q + p of a 16-lane group addresses row
+  // q of the block, columns 4 p .. 4 p + 3; the group of lanes (16 cgrp .. +15) of half h takes rows 8 h + q (elements 0..3) and
+  // 8 h + 4 + q (elements 4..7) of columns 16 cgrp .. +15  ==  B[k = 8 h + e][n = lane & 31]
+  const int vq = li >> 2, vp = li & 3, cgrp = (lane >> 4) & 1;
+  const int t_row = (8 * h + vq) * 256 + ((vp & 1) << 3);
+  const int t_sw = vq << 2, t_c0 = 2 * cgrp + (vp >> 1);
+  typedef __attribute__((ext_vector_type(8))) short short8_t;
+  auto bfrag = [&](const unsigned char* slab, int ks, int cb) -> op16x8 {
+    const unsigned char* a0 = slab + t_row + (16 * ks) * 256 + (((cb * 4 + t_c0) ^ t_sw) << 4);
+    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0));
+    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0 + 4 * 256));
+    short8_t t8;
+    t8[0] = lo[0]; t8[1] = lo[1]; t8[2] = lo[2]; t8[3] = lo[3];
+    t8[4] = hi[0]; t8[5] = hi[1]; t8[6] = hi[2]; t8[7] = hi[3];
+    return __builtin_bit_cast(op16x8, t8);
+  };
+
+  const int nk = p.K / BK;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) issue_piece(0, 0, i);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int st = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of tile kt have landed
+    __builtin_amdgcn_s_barrier();                        // ... and so have every other wave's; stage st^1 is free again
+    const unsigned char* sa = lds + st * STAGE_BYTES;
+    const unsigned char* sb = sa + A_BYTES;
+    op16x8 af[4][2], bfr[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = 2 * ks + h;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[ks][i] = *reinterpret_cast<const op16x8*>(sa + offA[i] + ((c ^ swzA[i]) << 4));
+        bfr[ks][i] = bfrag(sb, ks, wn * 2 + i);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = MSAM2_MFMA_32x32x16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+      if (kt + 1 < nk) {
+        issue_piece(kt + 1, st ^ 1, 2 * ks);
+        issue_piece(kt + 1, st ^ 1, 2 * ks + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __builtin_amdgcn_s_barrier();
+  gemm_epilogue<2, 2>(p, acc, reinterpret_cast<float*>(lds) + wave * 32 * 68, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+// out[M, N] = residual + a[M, K] b[K, N] (+ bias), b k-major (row pitch ldb); K % 64 == 0, N % 8 == 0; out fp32 or 16-bit.
+extern "C" int msam2_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, const float* bias, const void* residual, int64_t ldr,
+                             void* C, int64_t ldc, int out_is_16bit, int64_t M, int64_t N, int64_t K, void* stream) {
+  MSAM2_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "gemm_nt: bad arguments");
+  MSAM2_REQUIRE(K % 64 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0,
+                "gemm_nt: K %% 64 == 0, N / lda / ldb multiples of 8 and 16-byte aligned operands");
+  MSAM2_REQUIRE(M * lda * 2 < (1ll << 31) && K * ldb * 2 < (1ll << 31) && lda >= K && ldb >= N && ldc >= N, "gemm_nt: bad sizes");
+  GemmParams p = {};
+  p.A = (const op16*)A; p.W = (const op16*)B; p.bias = bias; p.res = residual; p.C = C;
+  p.lda = lda; p.ldw = ldb; p.ldr = ldr; p.ldc = ldc;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.out_is_16bit = out_is_16bit;
+  p.rope_period = 1; p.rope_npos = 1;
+  hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(cdiv(N, 128) * cdiv(M, 128))), dim3(256), 0, (hipStream_t)stream, p);
+  return msam2_check_launch("gemm_nt");
+}
+
 extern "C" int msam2_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* colscale,
                           const void* residual, int64_t ldr, int res_is_16bit, int64_t res_mod, void* C, int64_t ldc, int out_is_16bit,
                           int64_t M, int64_t N, int64_t K, int act, void* stream) {

@@ -100,6 +100,26 @@ def test_gemm_tt(mods, K, M, N):
     assert torch.equal(out2, out) and torch.equal(cs.cpu().double(), a[:, 8:].double().sum(0))
 
 
+@pytest.mark.parametrize("M,K,N", [(300, 128, 200), (16384, 1152, 384), (4096, 64, 256), (1000, 1536, 392), (130, 192, 8), (257, 96, 64)])
+def test_gemm_nt(mods, M, K, N):
+    """dX-shaped product a @ b with b k-major (the layer's weight [out, in] as stored): integer operands make the result exact; ragged
+    row / column tiles, a single k-tile, strided rows, fp32 residual, 16-bit output; K = 96 takes the transposed-copy fallback."""
+    B_, ops = mods
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randint(-2, 3, (M, K + 8), generator=g).float()
+    b = torch.randint(-2, 3, (K, N + 16), generator=g).float()
+    b[:, 16] += torch.arange(K).float() % 3
+    res = torch.randint(-4, 5, (M, N), generator=g).float()
+    ref = a[:, 8:].double() @ b[:, 16:].double()
+    ad, bd = a.to(ops.OP16).to(DEV), b.to(ops.OP16).to(DEV)
+    out = B_.gemm_nt(ad[:, 8:], bd[:, 16:])
+    assert out.shape == ref.shape and torch.equal(out.cpu().double(), ref), (out.cpu().double() - ref).abs().max()
+    out_r = B_.gemm_nt(ad[:, 8:], bd[:, 16:], residual=res.to(DEV))
+    assert torch.equal(out_r.cpu().double(), ref + res.double())
+    out16 = B_.gemm_nt(ad[:, 8:], bd[:, 16:], out_dtype=ops.OP16)
+    assert out16.dtype == ops.OP16 and torch.equal(out16.float().cpu(), ref.float().to(ops.OP16).float())
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 384, 96), (4096, 96, 384), (1000, 256, 2048), (64, 32, 64)])
 def test_linear_backward(mods, M, N, K):
     B, ops = mods
