@@ -102,10 +102,48 @@ def gemm_tt(a: torch.Tensor, b: torch.Tensor, a_colsum: bool = False):
     returns the column sums of a (fp32 [Ma]: the bias gradient when a = dY) from the same pass."""
     _req(a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0] and a.dtype == OP16 and b.dtype == OP16, "gemm_tt: 16-bit [K, M], [K, N]")
     _req(a.stride(1) == 1 and b.stride(1) == 1, "gemm_tt: row-major operands")
+    arena = _ARENA[0]
+    if arena is not None:
+        # outputs carved from a buffer zeroed once for the whole backward pass: the library adds into them, no zeroing launch per call
+        out = arena.take(a.shape[1] * b.shape[1], a.device).view(a.shape[1], b.shape[1])
+        cs = arena.take(a.shape[1], a.device) if a_colsum else None
+        check(lib().msam2_gemm_tt_acc(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), _p(cs), a.shape[1], b.shape[1], a.shape[0],
+                                      _stream()))
+        return (out, cs) if a_colsum else out
     out = torch.empty(a.shape[1], b.shape[1], dtype=F32, device=a.device)
     cs = torch.empty(a.shape[1], dtype=F32, device=a.device) if a_colsum else None     # (zeroed by the library)
     check(lib().msam2_gemm_tt(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), _p(cs), a.shape[1], b.shape[1], a.shape[0], _stream()))
     return (out, cs) if a_colsum else out
+
+
+class ZeroArena:
+    """fp32 outputs of the weight-gradient GEMMs carved from large buffers that are zeroed ONCE (one fill per 64 MB instead of one
+    zeroing launch per GEMM).  `with zero_arena():` around a backward pass; the gradients are views that keep their buffer alive."""
+    CHUNK = 16 << 20                                   # elements (64 MB)
+
+    def __init__(self):
+        self.buf, self.off = None, 0
+
+    def take(self, numel: int, device) -> torch.Tensor:
+        if self.buf is None or self.off + numel > self.buf.numel() or self.buf.device != device:
+            self.buf, self.off = torch.zeros(max(numel, self.CHUNK), dtype=F32, device=device), 0
+        v = self.buf[self.off:self.off + numel]
+        self.off += -(-numel // 64) * 64               # 256-byte aligned slices
+        return v
+
+
+_ARENA = [None]
+
+
+class zero_arena:
+    def __enter__(self):
+        import os
+        self._prev, _ARENA[0] = _ARENA[0], (None if os.environ.get("MSAM2_NO_ARENA") else ZeroArena())
+        return _ARENA[0]
+
+    def __exit__(self, *exc):
+        _ARENA[0] = self._prev
+        return False
 
 
 def mlp_backward(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: Optional[torch.Tensor], dy: torch.Tensor,

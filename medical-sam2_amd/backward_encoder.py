@@ -313,6 +313,16 @@ def image_encoder_backward(model, state: dict, d_fpn: List[Optional[torch.Tensor
     scales = scales if scales is not None else {}
     calibrate = not scales.get("done", False)
 
+    pending_t, pending_s = [], []
+
+    def unscale(name: str, g: torch.Tensor, inv: float):
+        """registers a parameter gradient that still carries its link's loss scale (fp32, owned by this call: scaled in place at the end)"""
+        g = g if g.dtype == F32 else g.to(F32)
+        grads[name] = g
+        if inv != 1.0:
+            pending_t.append(g)
+            pending_s.append(float(inv))
+
     def rescaled(key: str, parts):
         """sum of (tensor, scale) pairs brought to the cached / calibrated power-of-two scale of `key`; returns (tensor, scale)"""
         if calibrate:
@@ -348,10 +358,12 @@ def image_encoder_backward(model, state: dict, d_fpn: List[Optional[torch.Tensor
         assert pc is None or folded, "a post conv on a top-down level is not folded in the forward either"
         dx, g_lat, g_post = _lateral_backward(tok, conv, g_lvl, pc if folded else None)
         inv = 1.0 / s_lvl
-        grads[f"image_encoder.neck.convs.{n - lvl}.conv.weight"], grads[f"image_encoder.neck.convs.{n - lvl}.conv.bias"] = g_lat["w"] * inv, g_lat["b"] * inv
+        unscale(f"image_encoder.neck.convs.{n - lvl}.conv.weight", g_lat["w"], inv)
+        unscale(f"image_encoder.neck.convs.{n - lvl}.conv.bias", g_lat["b"], inv)
         if g_post is not None:
             name = "conv_s0" if lvl == 0 else "conv_s1"
-            grads[f"sam_mask_decoder.{name}.weight"], grads[f"sam_mask_decoder.{name}.bias"] = g_post["w"] * inv, g_post["b"] * inv
+            unscale(f"sam_mask_decoder.{name}.weight", g_post["w"], inv)
+            unscale(f"sam_mask_decoder.{name}.bias", g_post["b"], inv)
         d_stage[bi] = (dx, s_lvl)
     # ---- trunk blocks in reverse
     run: Optional[Tuple[torch.Tensor, float]] = None
@@ -364,7 +376,7 @@ def image_encoder_backward(model, state: dict, d_fpn: List[Optional[torch.Tensor
         dt, g = hiera_block_backward(trunk.blocks[i], t_in, B, hh, ww, dt)
         inv = 1.0 / s_blk
         for k, v in g.items():
-            grads[f"image_encoder.trunk.blocks.{i}.{k}"] = v * inv
+            unscale(f"image_encoder.trunk.blocks.{i}.{k}", v, inv)
         run = (dt, s_blk)
     # ---- patch embedding + position embedding
     if run is not None:
@@ -374,8 +386,8 @@ def image_encoder_backward(model, state: dict, d_fpn: List[Optional[torch.Tensor
         E = pe.proj.weight.shape[0]
         dt16 = bwd._op16(dt)
         dW, db = bwd.gemm_tt(dt16, state["cols"], a_colsum=True)                       # [E, 160] (147 real columns)
-        grads["image_encoder.trunk.patch_embed.proj.weight"] = dW[:, :147].reshape(pe.proj.weight.shape) * inv
-        grads["image_encoder.trunk.patch_embed.proj.bias"] = db * inv
+        unscale("image_encoder.trunk.patch_embed.proj.weight", dW[:, :147].reshape(pe.proj.weight.shape), inv)
+        unscale("image_encoder.trunk.patch_embed.proj.bias", db, inv)
         h = w = state["S"] // 4
         d_table = bwd.colsum(dt.view(B, h * w * E)).view(h * w, E)                     # the table is broadcast over the batch
         dpe, dpw = torch.empty_like(trunk.pos_embed, dtype=F32), torch.empty_like(trunk.pos_embed_window, dtype=F32)
@@ -384,6 +396,10 @@ def image_encoder_backward(model, state: dict, d_fpn: List[Optional[torch.Tensor
         ws = torch.empty(nb, dtype=torch.uint8, device=d_table.device)
         check(lib().msam2_hiera_pos_embed_bwd(_p(d_table), _p(dpe), _p(dpw), E, trunk.pos_embed.shape[2], trunk.pos_embed.shape[3], h, w,
                                               wsz, _p(ws), nb, _stream()))
-        grads["image_encoder.trunk.pos_embed"], grads["image_encoder.trunk.pos_embed_window"] = dpe * inv, dpw * inv
+        unscale("image_encoder.trunk.pos_embed", dpe, inv)
+        unscale("image_encoder.trunk.pos_embed_window", dpw, inv)
+    # every parameter gradient leaves its link's power-of-two scale in ONE multi-tensor launch (166 tensors: was a torch kernel each)
+    if pending_t:
+        torch._foreach_mul_(pending_t, pending_s)
     scales["done"] = True
     return grads

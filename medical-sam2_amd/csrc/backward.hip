@@ -45,6 +45,7 @@ struct GemmTTParams {
   float* a_colsum;   // optional [M]: sum_k A[k][m] (the bias gradient when A = dY), accumulated by the n-tile-0 workgroups into a zeroed vector
   int64_t lda, ldb, ldc;
   int M, N, K, ktiles_per_split;
+  int accumulate;    // C and a_colsum already hold values to add to (msam2_gemm_tt_acc): no zeroing pass, every store is an atomic add
 };
 
 constexpr int TT_PITCH = 320;                 // bytes per LDS row (128 op16 + 64 B pad)
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void gemm_tt_kernel(GemmTTParams p) {
       atomicAdd(p.a_colsum + m0 + tid, t);
     }
   }
-  const bool atomic = gridDim.z > 1;
+  const bool atomic = gridDim.z > 1 || p.accumulate;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + wn * 64 + j * 32 + r;
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_dma_kernel(GemmTTParams p) {
       atomicAdd(p.a_colsum + m0 + tid, t);
     }
   }
-  const bool atomic = gridDim.z > 1;
+  const bool atomic = gridDim.z > 1 || p.accumulate;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + wn * 64 + j * 32 + r;
@@ -312,8 +313,8 @@ __global__ __launch_bounds__(256) void gemm_tt_zero_kernel(float* __restrict__ C
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256) colsum[i] = 0.f;
 }
 
-extern "C" int msam2_gemm_tt(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* a_colsum, int64_t M, int64_t N,
-                             int64_t K, void* stream) {
+static int gemm_tt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* a_colsum, int64_t M, int64_t N,
+                        int64_t K, int accumulate, void* stream) {
   MSAM2_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "gemm_tt: bad arguments");
   MSAM2_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0,
                 "gemm_tt: M, N, lda, ldb must be multiples of 8 and the operands 16-byte aligned");
@@ -321,6 +322,7 @@ extern "C" int msam2_gemm_tt(const void* A, int64_t lda, const void* B, int64_t 
   GemmTTParams p;
   p.A = (const op16*)A; p.B = (const op16*)B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.a_colsum = a_colsum;
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.accumulate = accumulate;
   // LDS-DMA kernel: 64-row k-tiles, 32-bit DMA offsets (the whole operand within 2 GiB)
   static const bool no_dma = getenv("MSAM2_GEMM_TT_V1") != nullptr;
   const bool dma = !no_dma && K % 64 == 0 && K * lda * 2 < (1ll << 31) && K * ldb * 2 < (1ll << 31);
@@ -335,12 +337,24 @@ extern "C" int msam2_gemm_tt(const void* A, int64_t lda, const void* B, int64_t 
   p.ktiles_per_split = (int)cdiv(nk, splits);
   splits = cdiv(nk, p.ktiles_per_split);
   hipStream_t s = (hipStream_t)stream;
-  if (splits > 1 || a_colsum)
+  if (!accumulate && (splits > 1 || a_colsum))
     hipLaunchKernelGGL(gemm_tt_zero_kernel, dim3((unsigned)min((int64_t)1024, (M * N + 255) / 256)), dim3(256), 0, s, C, ldc, (int)M, (int)N, a_colsum,
                        splits > 1 ? 1 : 0);
   if (dma) hipLaunchKernelGGL(gemm_tt_dma_kernel, dim3(cdiv(N, 128), cdiv(M, 128), (unsigned)splits), dim3(256), 0, s, p);
   else hipLaunchKernelGGL(gemm_tt_kernel, dim3(cdiv(N, 128), cdiv(M, 128), (unsigned)splits), dim3(256), 0, s, p);
   return msam2_check_launch("gemm_tt");
+}
+
+extern "C" int msam2_gemm_tt(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* a_colsum, int64_t M, int64_t N,
+                             int64_t K, void* stream) {
+  return gemm_tt_impl(A, lda, B, ldb, C, ldc, a_colsum, M, N, K, 0, stream);
+}
+
+// msam2_gemm_tt that ADDS into C (and a_colsum): gradient accumulation, or outputs carved from a buffer that was zeroed once for a whole
+// backward pass (the per-call zeroing launch of msam2_gemm_tt is 150 launches per training iteration).
+extern "C" int msam2_gemm_tt_acc(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* a_colsum, int64_t M,
+                                 int64_t N, int64_t K, void* stream) {
+  return gemm_tt_impl(A, lda, B, ldb, C, ldc, a_colsum, M, N, K, 1, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -18,25 +18,64 @@ class WeightCache:
 
     def __init__(self):
         self._c: Dict[str, Tuple[tuple, object]] = {}
+        self._casts: Dict[str, torch.Tensor] = {}      # key -> the single parameter a plain 16-bit cast was built from (refresh_casts)
 
-    def get(self, key: str, params: Sequence[torch.Tensor], build: Callable[[], object]):
-        sig = tuple((p.data_ptr(), p._version, str(p.device), p.dtype) for p in params)
+    @staticmethod
+    def _sig(params: Sequence[torch.Tensor]) -> tuple:
+        return tuple((p.data_ptr(), p._version, str(p.device), p.dtype) for p in params)
+
+    def get(self, key: str, params: Sequence[torch.Tensor], build: Callable[[], object], cast_of: torch.Tensor = None):
+        sig = self._sig(params)
         hit = self._c.get(key)
         if hit is None or hit[0] != sig:
             with torch.no_grad():
                 hit = (sig, build())
             self._c[key] = hit
+            if cast_of is not None:
+                self._casts[key] = cast_of
         return hit[1]
 
     def clear(self):
         self._c.clear()
+        self._casts.clear()
+
+
+def refresh_casts(model: torch.nn.Module) -> int:
+    """After an optimiser step every plain 16-bit weight copy (`w_bf16` of one parameter) of every module is stale; rebuilt lazily that is
+    one conversion kernel per weight (141 per training iteration, ~6 us each: latency, not bytes).  This refreshes all stale ones IN
+    PLACE with one multi-tensor copy and re-stamps their cache entries; fused / permuted layouts still rebuild lazily.  Returns the number
+    of copies refreshed.  Safe to call at any time (e.g. at the head of a training step, inside a captured graph)."""
+    import os
+    if os.environ.get("MSAM2_NO_REFRESH"):
+        return 0
+    dsts, srcs, stamp = [], [], []
+    for mod in model.modules():
+        wc = getattr(mod, "_wc", None)
+        if not isinstance(wc, WeightCache):
+            continue
+        for key, src in wc._casts.items():
+            hit = wc._c.get(key)
+            if hit is None:
+                continue
+            sig = WeightCache._sig((src,))
+            if hit[0] == sig or hit[0][0][0] != sig[0][0] or hit[1].numel() != src.numel():
+                continue                                  # fresh, or the parameter was re-allocated: the lazy path handles that
+            dsts.append(hit[1])
+            srcs.append(src.detach().reshape(hit[1].shape))
+            stamp.append((wc, key, sig, hit[1]))
+    if dsts:
+        with torch.no_grad():
+            torch._foreach_copy_(dsts, srcs)
+        for wc, key, sig, val in stamp:
+            wc._c[key] = (sig, val)
+    return len(dsts)
 
 
 def w_bf16(cache: WeightCache, key: str, *weights: torch.Tensor) -> torch.Tensor:
     """bf16 [sum(out_i), in] matrix from one or more nn.Linear / 1x1-conv weights stacked along the output dim."""
     if len(weights) == 1:                                  # one conversion pass, no concatenation copy (re-done after every optimiser step)
         w0 = weights[0]
-        return cache.get(key, weights, lambda: w0.detach().reshape(w0.shape[0], -1).to(OP16).contiguous())
+        return cache.get(key, weights, lambda: w0.detach().reshape(w0.shape[0], -1).to(OP16).contiguous(), cast_of=w0)
     return cache.get(key, weights, lambda: torch.cat([w.detach().reshape(w.shape[0], -1) for w in weights], 0).to(OP16).contiguous())
 
 

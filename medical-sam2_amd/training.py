@@ -351,9 +351,11 @@ def train_step_2d(model, opt_mem: DecoderAdam, opt_dec: DecoderAdam, imgs, pts, 
     by `parallel.allreduce_gradients_async`, started as soon as the group's backward is done so that the transfer runs under the next
     group's backward (decoder under memory attention, memory attention under image encoder), and averaged inside Adam (grad_scale).
     Returns (loss, maskmem_features [B,64,S/16,S/16])."""
+    from . import backward as bwd_mod
     from . import backward_encoder as be
-    from .modeling.common import to_bf16, tokens_of
+    from .modeling.common import refresh_casts, to_bf16, tokens_of
     B = imgs.shape[0]
+    refresh_casts(model)                               # the previous step's Adam left every 16-bit weight copy stale: one multi-tensor copy
     if opt_enc is not None:
         backbone_out, enc_state = be.image_encoder_forward_saved(model, imgs)
     else:
@@ -373,42 +375,44 @@ def train_step_2d(model, opt_mem: DecoderAdam, opt_dec: DecoderAdam, imgs, pts, 
         mon = opt_mem.scale_monitor = {}
     kwargs = dict(dense_tokens=dense, aux=aux, mem_scale=cal.get(mask_index), mask_index=mask_index, data_parallel=data_parallel, monitor=mon,
                   on_decoder_grads=(lambda g: pend.__setitem__("dec", parallel.allreduce_gradients_async(g))) if data_parallel else None)
-    loss, scale, scale_mem, g_dec, g_mem, dcurr = memory_decoder_loss_grads(
-        model.memory_attention, model.sam_mask_decoder, vision_feats[-1], vision_pos_embeds[-1], memory, memory_pos, 0, pe, se.to(torch.float32),
-        f0, f1, B, h, w, target_masks, **kwargs)
-    cal[mask_index] = scale_mem / scale
-    opt_mem.calibrated_loss_scales = cal
-    inv_world = 1.0
-    if data_parallel:
-        pend["mem"] = parallel.allreduce_gradients_async(g_mem)
-    if opt_enc is not None:
-        # the encoder's three outputs received: level 0 / 1 through the decoder's up-scaling adds (loss scale `scale`), level 2 through
-        # the memory attention's query stream (`scale_mem`); the encoder backward runs every block under its own cached scale
-        C = dcurr.shape[-1]
-        d_top = dcurr.transpose(0, 1).reshape(B * h * w, C).contiguous()
-        enc_scales = getattr(opt_enc, "calibrated_block_scales", None)
-        if enc_scales is None:
-            enc_scales = opt_enc.calibrated_block_scales = {}
-        g_all = be.image_encoder_backward(model, enc_state, [aux["d_feat_s0"], aux["d_feat_s1"], d_top], [scale, scale, scale_mem],
-                                          enc_scales.setdefault(mask_index, {}))
+    # weight-gradient outputs of this backward pass come from buffers zeroed once (backward.ZeroArena): no zeroing launch per GEMM
+    with bwd_mod.zero_arena():
+        loss, scale, scale_mem, g_dec, g_mem, dcurr = memory_decoder_loss_grads(
+            model.memory_attention, model.sam_mask_decoder, vision_feats[-1], vision_pos_embeds[-1], memory, memory_pos, 0, pe, se.to(torch.float32),
+            f0, f1, B, h, w, target_masks, **kwargs)
+        cal[mask_index] = scale_mem / scale
+        opt_mem.calibrated_loss_scales = cal
+        inv_world = 1.0
         if data_parallel:
-            g_all, inv_world = parallel.allreduce_gradients(g_all)
-        g_enc = {k[len("image_encoder."):]: v for k, v in g_all.items() if k.startswith("image_encoder.")}
-        g_convs = {k[len("sam_mask_decoder."):]: v * scale for k, v in g_all.items() if k.startswith("sam_mask_decoder.")}
-    if data_parallel:
-        g_dec, inv_world = pend["dec"].wait()
-        g_mem, _ = pend["mem"].wait()
-    if opt_enc is not None:
-        g_dec = dict(g_dec)
-        g_dec.update(g_convs)                                                    # conv_s0 / conv_s1 live in the decoder's group
-        opt_enc.step(g_enc, grad_scale=inv_world)
+            pend["mem"] = parallel.allreduce_gradients_async(g_mem)
+        if opt_enc is not None:
+            # the encoder's three outputs received: level 0 / 1 through the decoder's up-scaling adds (loss scale `scale`), level 2 through
+            # the memory attention's query stream (`scale_mem`); the encoder backward runs every block under its own cached scale
+            C = dcurr.shape[-1]
+            d_top = dcurr.transpose(0, 1).reshape(B * h * w, C).contiguous()
+            enc_scales = getattr(opt_enc, "calibrated_block_scales", None)
+            if enc_scales is None:
+                enc_scales = opt_enc.calibrated_block_scales = {}
+            g_all = be.image_encoder_backward(model, enc_state, [aux["d_feat_s0"], aux["d_feat_s1"], d_top], [scale, scale, scale_mem],
+                                              enc_scales.setdefault(mask_index, {}))
+            if data_parallel:
+                g_all, inv_world = parallel.allreduce_gradients(g_all)
+            g_enc = {k[len("image_encoder."):]: v for k, v in g_all.items() if k.startswith("image_encoder.")}
+            g_convs = {k[len("sam_mask_decoder."):]: v * scale for k, v in g_all.items() if k.startswith("sam_mask_decoder.")}
+        if data_parallel:
+            g_dec, inv_world = pend["dec"].wait()
+            g_mem, _ = pend["mem"].wait()
+        if opt_enc is not None:
+            g_dec = dict(g_dec)
+            g_dec.update(g_convs)                                                    # conv_s0 / conv_s1 live in the decoder's group
+            opt_enc.step(g_enc, grad_scale=inv_world)
+            if grads_out is not None:
+                grads_out["image_encoder"] = g_enc
         if grads_out is not None:
-            grads_out["image_encoder"] = g_enc
-    if grads_out is not None:
-        grads_out["decoder"] = {k: v / scale for k, v in g_dec.items()}
-        grads_out["memory_attention"] = {k: v / scale_mem for k, v in g_mem.items()}
-    opt_dec.step(g_dec, grad_scale=inv_world / scale)
-    opt_mem.step(g_mem, grad_scale=inv_world / scale_mem)
+            grads_out["decoder"] = {k: v / scale for k, v in g_dec.items()}
+            grads_out["memory_attention"] = {k: v / scale_mem for k, v in g_mem.items()}
+        opt_dec.step(g_dec, grad_scale=inv_world / scale)
+        opt_mem.step(g_mem, grad_scale=inv_world / scale_mem)
     low_res = aux["masks"][:, :1].contiguous()                                   # single-mask output token (multimask_output=False)
     high_res = ops.bilinear_upsample(low_res, model.image_size, model.image_size)
     maskmem_features, _ = model._encode_new_memory(current_vision_feats=vision_feats, feat_sizes=feat_sizes, pred_masks_high_res=high_res,
