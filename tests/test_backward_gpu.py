@@ -98,6 +98,12 @@ def test_gemm_tt(mods, K, M, N):
     assert out.shape == ref.shape and torch.equal(out.cpu().double(), ref), (out.cpu().double() - ref).abs().max()
     out2, cs = B_.gemm_tt(ad[:, 8:], bd[:, 16:], a_colsum=True)
     assert torch.equal(out2, out) and torch.equal(cs.cpu().double(), a[:, 8:].double().sum(0))
+    # inside a zero_arena the outputs are slices of a buffer zeroed once and the library ADDS into them (msam2_gemm_tt_acc)
+    with B_.zero_arena() as arena:
+        o1, c1 = B_.gemm_tt(ad[:, 8:], bd[:, 16:], a_colsum=True)
+        o2 = B_.gemm_tt(ad[:, 8:], bd[:, 16:])
+        assert o1.data_ptr() != o2.data_ptr() and arena.buf is not None
+    assert torch.equal(o1, out) and torch.equal(o2, out) and torch.equal(c1, cs)
 
 
 @pytest.mark.parametrize("M,K,N", [(300, 128, 200), (16384, 1152, 384), (4096, 64, 256), (1000, 1536, 392), (130, 192, 8), (257, 96, 64)])

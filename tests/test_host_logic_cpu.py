@@ -1,0 +1,53 @@
+"""Host-side pieces of the training path that need no GPU: the in-place refresh of 16-bit weight copies and the zeroed-once arena the
+weight-gradient GEMMs carve their outputs from."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_refresh_casts_rewrites_stale_16bit_copies_in_place():
+    from medical_sam2_amd.modeling.common import OP16, WeightCache, refresh_casts, w_bf16
+
+    class Lin(torch.nn.Module):
+        def __init__(self, n, k):
+            super().__init__()
+            self.weight = torch.nn.Parameter(torch.randn(n, k))
+            self._wc = WeightCache()
+
+    net = torch.nn.Sequential(Lin(8, 4), Lin(3, 8))
+    copies = [w_bf16(m._wc, "w", m.weight) for m in net]
+    assert all(c.dtype == OP16 for c in copies)
+    assert refresh_casts(net) == 0                                   # nothing stale
+    with torch.no_grad():
+        net[0].weight.add_(1.0)                                      # an optimiser step bumps the version counter
+    assert refresh_casts(net) == 1
+    again = w_bf16(net[0]._wc, "w", net[0].weight)
+    assert again.data_ptr() == copies[0].data_ptr()                  # same buffer, re-stamped: no lazy rebuild behind it
+    assert torch.equal(again.float(), net[0].weight.detach().to(OP16).float())
+    assert w_bf16(net[1]._wc, "w", net[1].weight).data_ptr() == copies[1].data_ptr()
+    # a re-allocated parameter is left to the lazy path
+    net[1].weight = torch.nn.Parameter(torch.randn(3, 8))
+    assert refresh_casts(net) == 0
+    fresh = w_bf16(net[1]._wc, "w", net[1].weight)
+    assert torch.equal(fresh.float(), net[1].weight.detach().to(OP16).float())
+
+
+def test_zero_arena_hands_out_disjoint_zeroed_slices():
+    from medical_sam2_amd.backward import ZeroArena
+    a = ZeroArena()
+    ZeroArena.CHUNK, keep = 1000, ZeroArena.CHUNK
+    try:
+        x = a.take(100, torch.device("cpu"))
+        y = a.take(300, torch.device("cpu"))
+        assert x.numel() == 100 and y.numel() == 300 and float(x.abs().sum() + y.abs().sum()) == 0.0
+        x.fill_(1.0)
+        assert float(y.abs().sum()) == 0.0                            # disjoint
+        assert (y.data_ptr() - x.data_ptr()) % 256 == 0               # 256-byte aligned slices
+        big = a.take(5000, torch.device("cpu"))                       # larger than a chunk: its own buffer
+        assert big.numel() == 5000 and float(big.abs().sum()) == 0.0 and float(x.sum()) == 100.0
+    finally:
+        ZeroArena.CHUNK = keep

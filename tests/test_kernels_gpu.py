@@ -271,6 +271,17 @@ def test_attention_vs_oracle(ops, B, H, Lq, Lk, D, splits):
     close(out, ref, 0.02, 0.01, "attention")
 
 
+def test_attention_d96_four_wave_shape_in_a_child_process():
+    """attn_g96x2_kernel<2, 4> (64 queries per wave, one wave per SIMD: MSAM2_G96_X2=1, read once per process) on the same cases as the
+    default 8-wave shape."""
+    import subprocess, sys
+    env = dict(_os.environ)
+    env["MSAM2_G96_X2"] = "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", _os.path.abspath(__file__), "-q", "-m", "gpu", "-k", "test_attention_vs_oracle and 96"],
+                       env=env, capture_output=True, text=True, cwd=_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("B,H,Lq,Lk,splits", [(1, 1, 32, 32, 1), (2, 1, 200, 520, 1), (1, 1, 130, 2100, 4), (2, 1, 64, 4096 + 8, 8),
                                               (1, 2, 256, 1000, 3), (1, 1, 1024, 33, 1),
                                               # 64-queries-per-wave kernel (Lq >= 256): ragged query tile, a single full tile, a single
