@@ -558,10 +558,8 @@ def attention_module_backward(att, q_in16, k_in16, v_in16, B: int, d_out: torch.
             x16, w_bf16(wc, nm + "w", getattr(att, nm + "_proj").weight), rows(g))
         outs.append(dx)
     if amax is not None:
-        for k in ("out_proj", "q_proj", "k_proj", "v_proj"):
-            for wb in ("weight", "bias"):
-                grads[f"{prefix}.{k}.{wb}"] = grads[f"{prefix}.{k}.{wb}"] * amax
-        outs = [o * amax for o in outs]
+        # back from the unit-max normalisation: one multi-tensor launch for the 8 parameter gradients + 3 input gradients
+        torch._foreach_mul_([grads[f"{prefix}.{k}.{wb}"] for k in ("out_proj", "q_proj", "k_proj", "v_proj") for wb in ("weight", "bias")] + outs, amax)
     return outs
 
 
@@ -681,10 +679,12 @@ def mlp_layers_backward(mlp, x16: torch.Tensor, dy: torch.Tensor, prefix: str, g
     d, a = _unit_max(dy.to(F32))
     for i in range(n - 1, -1, -1):
         d, gw, gb = linear_backward(hs[i], Ws[i], d)
-        grads[f"{prefix}.layers.{i}.weight"], grads[f"{prefix}.layers.{i}.bias"] = gw * a, gb * a
+        grads[f"{prefix}.layers.{i}.weight"], grads[f"{prefix}.layers.{i}.bias"] = gw, gb
         if i > 0:
             d = act_backward(pres[i - 1], d, mlp._act_code)
-    return d * a
+    d = d if d.dtype == F32 else d.to(F32)
+    torch._foreach_mul_([grads[f"{prefix}.layers.{i}.{wb}"] for i in range(n) for wb in ("weight", "bias")] + [d], a)   # one launch
+    return d
 
 
 def _convt_gather(g, bias, skip, B, h, w):

@@ -266,7 +266,11 @@ def record_scaled_amax(scales: dict, key: str, scaled: torch.Tensor, calibrating
     once and then frozen for every replay: as gradient magnitudes drift over training, a frozen scale lets 16-bit operands
     saturate or flush to zero without any visible sign -- `scale_drift` reads these slots and says when to calibrate again."""
     slots = scales.setdefault("_amax", {})
-    a = scaled.detach().abs().max().reshape(1).to(F32)
+    t = scaled.detach()
+    if t.dim() == 2 and t.shape[0] >= 4096:
+        t = t[::4]                                         # a monitor, not a norm: every 4th row of the large token maps (order of magnitude)
+    mn, mx = torch.aminmax(t)                              # one pass, no |t| temporary
+    a = torch.maximum(mx, -mn).reshape(1).to(F32)
     if calibrating or key not in slots:
         slots[key] = a.clone()
     else:
