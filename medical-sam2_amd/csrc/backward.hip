@@ -487,10 +487,145 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
 }
 
+// Vector form (round 3): 16 lanes per row, four rows per wave in flight, 16-byte loads / stores (a 16-lane group covers 256 contiguous
+// bytes per instruction), ALL of a row's loads (x, dy, the by-pass gradient) issued before the first reduction -- the kernel above walks
+// one row per wave with three dependent 64-lane reductions per row and 4-byte accesses (48.8 us for 16384 x 384: 2 TB/s; it was
+// 5.3 % of the training iteration).  dgamma / dbeta stay in registers per lane (its own 4-column chunks), are folded over the four
+// row groups of a wave by two shuffles, over the four waves through LDS, and leave as one atomic per column and workgroup.
+// C % 4 == 0, 16-byte aligned rows; CHUNKS = ceil(C / 64).
+template <typename TD, int CHUNKS>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ x, int64_t ldx, const TD* __restrict__ dy, int64_t ldd,
+                                                                const float* __restrict__ gamma, float* __restrict__ dx, int64_t ldo,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int C,
+                                                                float eps, const float* __restrict__ add, int64_t lda) {
+  __shared__ float sg[4][CHUNKS * 64], sb[4][CHUNKS * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;   // 16 groups per workgroup
+  const int nch = C >> 2;
+  const int64_t rows_per_block = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r_begin = blockIdx.x * rows_per_block, r_end = min(rows, r_begin + rows_per_block);
+  f32x4 gam[CHUNKS], ag[CHUNKS], ab[CHUNKS];
+#pragma unroll
+  for (int j = 0; j < CHUNKS; ++j) {
+    const int ch = l16 + 16 * j;
+    gam[j] = ch < nch ? *reinterpret_cast<const f32x4*>(gamma + ch * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    ag[j] = ab[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float inv_c = 1.f / (float)C;
+  auto sum16 = [](float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+  for (int64_t row = r_begin + grp; row < r_end; row += 16) {
+    const float* xr = x + row * ldx;
+    const TD* dr = dy + row * ldd;
+    const float* ar = add ? add + row * lda : nullptr;     // gradient of the residual branch that by-passes the LayerNorm
+    f32x4 xv[CHUNKS], gv[CHUNKS], av[CHUNKS];
+#pragma unroll
+    for (int j = 0; j < CHUNKS; ++j) {
+      const int ch = l16 + 16 * j;
+      xv[j] = gv[j] = av[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ch < nch) {
+        xv[j] = *reinterpret_cast<const f32x4*>(xr + ch * 4);
+        if constexpr (sizeof(TD) == 4) {
+          gv[j] = *reinterpret_cast<const f32x4*>(dr + ch * 4);
+        } else {
+          const op16x4 t = *reinterpret_cast<const op16x4*>(dr + ch * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gv[j][e] = op2f(t[e]);
+        }
+        if (ar) av[j] = *reinterpret_cast<const f32x4*>(ar + ch * 4);
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CHUNKS; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += xv[j][e];
+    const float mean = sum16(s) * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < CHUNKS; ++j)
+      if (l16 + 16 * j < nch) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = xv[j][e] - mean;
+          q += d * d;
+        }
+      }
+    const float rstd = 1.f / sqrtf(sum16(q) * inv_c + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < CHUNKS; ++j) {
+      const bool in = l16 + 16 * j < nch;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = in ? (xv[j][e] - mean) * rstd : 0.f, g = gv[j][e] * gam[j][e];
+        s1 += g;
+        s2 += g * xh;
+        ag[j][e] += gv[j][e] * xh;
+        ab[j][e] += gv[j][e];
+        xv[j][e] = xh;
+        gv[j][e] = g;
+      }
+    }
+    const float m1 = sum16(s1) * inv_c, m2 = sum16(s2) * inv_c;
+    float* o = dx + row * ldo;
+#pragma unroll
+    for (int j = 0; j < CHUNKS; ++j) {
+      const int ch = l16 + 16 * j;
+      if (ch < nch) {
+        f32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = rstd * (gv[j][e] - m1 - xv[j][e] * m2) + av[j][e];
+        *reinterpret_cast<f32x4*>(o + ch * 4) = w;
+      }
+    }
+  }
+  // fold the four row groups of a wave (lanes l16, l16 + 16, + 32, + 48 hold the same columns), then the four waves through LDS
+#pragma unroll
+  for (int j = 0; j < CHUNKS; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = ag[j][e], b = ab[j][e];
+      a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+      b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+      if (lane < 16) {
+        sg[wave][(l16 + 16 * j) * 4 + e] = a;
+        sb[wave][(l16 + 16 * j) * 4 + e] = b;
+      }
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(dgamma + c, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
+    atomicAdd(dbeta + c, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
+  }
+}
+
 template <typename TD>
 static void layernorm_bwd_launch(const float* x, int64_t ldx, const TD* dy, int64_t ldd, const float* gamma, float* dx, int64_t ldo, float* dgamma,
                                  float* dbeta, int64_t rows, int C, float eps, const float* add, int64_t lda, hipStream_t s) {
-  const dim3 grid((unsigned)min((int64_t)1024, cdiv(rows, 16))), block(256);
+  static const int64_t env_grid = getenv("MSAM2_LNB_GRID") ? atoll(getenv("MSAM2_LNB_GRID")) : 0;
+  // every workgroup ends with one atomic per column on the SAME 2 C addresses: at 1024 workgroups that serialisation is the kernel
+  // (16384 x 384: 45 us at 1024, 33 at 512, 30 at 256, 37 at 128; 262144 x 96: 90 / 85 / 107 / 187) -> 256 for the short maps, 512 beyond
+  const dim3 grid((unsigned)min(env_grid > 0 ? env_grid : (int64_t)(rows <= 32768 ? 256 : 512), cdiv(rows, 16))), block(256);
+  {
+    static const bool v1 = getenv("MSAM2_LN_BWD_V1") != nullptr;
+    const bool vec = !v1 && C % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldd % 4 == 0 && (!add || lda % 4 == 0) && ((uintptr_t)x & 15) == 0 &&
+                     ((uintptr_t)dx & 15) == 0 && ((uintptr_t)dy & (sizeof(TD) == 4 ? 15 : 7)) == 0 && (!add || ((uintptr_t)add & 15) == 0) &&
+                     ((uintptr_t)gamma & 15) == 0 && C <= 384;   // <= 6 chunks per lane: beyond that the six per-lane arrays cost the second wave per SIMD
+    if (vec) {
+      const int chunks = cdiv(C / 4, 16);
+#define LNV(CH) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<TD, CH>), grid, block, 0, s, x, ldx, dy, ldd, gamma, dx, ldo, dgamma, dbeta, rows, C, eps, add, lda)
+      if (chunks <= 1) LNV(1);
+      else if (chunks <= 2) LNV(2);
+      else if (chunks <= 3) LNV(3);
+      else if (chunks <= 4) LNV(4);
+      else LNV(6);
+#undef LNV
+      return;
+    }
+  }
 #define LNB(NI) hipLaunchKernelGGL((layernorm_bwd_kernel<TD, NI>), grid, block, 0, s, x, ldx, dy, ldd, gamma, dx, ldo, dgamma, dbeta, rows, C, eps, add, lda)
   const int ni = cdiv(C, 64);
   if (ni <= 1) LNB(1);

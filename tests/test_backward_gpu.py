@@ -53,7 +53,8 @@ def test_transpose_and_colsum(mods, R, C):
     assert torch.equal(B.colsum(xi.to(ops.OP16).to(DEV)).cpu(), xi.sum(0))
 
 
-@pytest.mark.parametrize("rows,C,eps", [(300, 96, 1e-6), (1000, 384, 1e-6), (64, 256, 1e-5), (7, 768, 1e-6)])
+@pytest.mark.parametrize("rows,C,eps", [(300, 96, 1e-6), (1000, 384, 1e-6), (64, 256, 1e-5), (7, 768, 1e-6), (20000, 192, 1e-6), (33, 100, 1e-6),
+                                          (17, 98, 1e-6)])   # C % 4 != 0 / C > 384: the one-row-per-wave kernel; else 16 lanes per row
 def test_layernorm_backward(mods, rows, C, eps):
     B, ops = mods
     x = (rnd(rows, C, seed=4) * 2 + 0.5).requires_grad_(True)
