@@ -74,11 +74,19 @@ def test_layernorm_backward(mods, rows, C, eps):
 @pytest.mark.parametrize("act", [1, 2])
 def test_act_backward(mods, act):
     B, ops = mods
-    pre = rnd(513, 96, seed=8, scale=2.0).requires_grad_(True)
+    pre = rnd(513, 96, seed=8, scale=2.5).requires_grad_(True)
     dy = rnd(513, 96, seed=9)
     (O.gelu(pre) if act == 1 else torch.relu(pre)).backward(dy)
     out = B.act_backward(pre.detach().to(DEV), dy.to(DEV), act)
     assert (out.float().cpu() - pre.grad).abs().max().item() < btol(4e-3)       # 16-bit output rounding
+    # 513 x 96 is a multiple of 8: the 8-elements-per-thread kernel; an odd count takes the scalar one; 16-bit inputs both
+    out_odd = B.act_backward(pre.detach()[:511, :95].contiguous().to(DEV), dy[:511, :95].contiguous().to(DEV), act)
+    assert (out_odd.float().cpu() - pre.grad[:511, :95]).abs().max().item() < btol(4e-3)
+    p16, d16 = pre.detach().to(ops.OP16), dy.to(ops.OP16)
+    p16r = p16.float().requires_grad_(True)
+    (O.gelu(p16r) if act == 1 else torch.relu(p16r)).backward(d16.float())
+    out16 = B.act_backward(p16.to(DEV), d16.to(DEV), act)
+    assert (out16.float().cpu() - p16r.grad).abs().max().item() < btol(4e-3)
 
 
 @pytest.mark.parametrize("K,M,N", [(16384, 256, 256), (65536, 128, 64), (300, 200, 40), (28, 8, 2048), (4097, 264, 136),
