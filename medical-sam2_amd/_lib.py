@@ -81,6 +81,7 @@ SIGNATURES = {
     "msam2_col2im3x3s2": (c_i, [c_p, c_l, c_p, c_l, c_l, c_l, c_l, c_p]),
     "msam2_gemm_nt": (c_i, [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_i, c_l, c_l, c_l, c_p]),
     "msam2_gemm_tt": (c_i, [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_l, c_p]),
+    "msam2_window_unpartition_cvt": (c_i, [c_p, c_l, c_p, c_l, c_l, c_l, c_l, c_l, c_l, c_p]),
     "msam2_gemm_tt_acc": (c_i, [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_l, c_p]),
     "msam2_bilinear_upsample_bwd": (c_i, [c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_p]),
     "msam2_maxpool2x2_bwd": (c_i, [c_p, c_i, c_l, c_p, c_l, c_p, c_l, c_l, c_l, c_l, c_l, c_p]),

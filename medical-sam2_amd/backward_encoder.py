@@ -80,6 +80,14 @@ def window_unpartition_into(win: torch.Tensor, img: torch.Tensor, B: int, H: int
     check(lib().msam2_window_move(_p(img), img.stride(0), _p(win), None, B, H, W, heads, D, ws, img.element_size(), 0, _stream()))
 
 
+def window_unpartition_cvt_into(win: torch.Tensor, img16: torch.Tensor, B: int, H: int, W: int, heads: int, D: int, ws: int) -> None:
+    """fp32 windows [B*nW, heads, ws*ws, D] contiguous -> the 16-bit [B*H*W, heads*D] rows of `img16` (a column slice of a wider buffer is
+    fine), padding cropped: un-partition and conversion to the GEMM operand type in one pass (`msam2_window_unpartition_cvt`)."""
+    assert win.is_contiguous() and win.dtype == F32 and img16.dim() == 2 and img16.stride(1) == 1 and img16.shape == (B * H * W, heads * D)
+    assert img16.dtype == ops.OP16
+    check(lib().msam2_window_unpartition_cvt(_p(img16), img16.stride(0), _p(win), B, H, W, heads, D, ws, _stream()))
+
+
 def _unwindows(win: torch.Tensor, B: int, Hp: int, Wp: int, ws: int) -> torch.Tensor:
     """inverse of `_windows` (without the crop): [B*nW, heads, ws*ws, D] (any strides) -> [B, Hp, Wp, heads, D]"""
     _, heads, _, D = win.shape
@@ -163,23 +171,23 @@ def hiera_block_backward(blk, t: torch.Tensor, B: int, H: int, W: int, dy: torch
         dow, _, _ = window_partition(do, B, Hq, Wq, heads, D, ws_q)                   # padded queries: zero upstream gradient
         dq4, dk4, dv4 = bwd.attention_backward(q4, k4, v4, dow, scale, o_lse=(o4, lse))
         dq4, dk4, dv4 = (x.to(F32).contiguous() for x in (dq4, dk4, dv4))
-        # the three gradients go straight into their column thirds of the fused-qkv gradient (no window -> image copies, no torch.cat)
-        dqkv = torch.empty(T, 3 * width, dtype=F32, device=t.device)
+        # the three gradients go straight into their column thirds of the fused-qkv gradient (no window -> image copies, no torch.cat),
+        # un-partitioned AND converted to the 16-bit GEMM operand type in one pass: the fused-qkv gradient is never an fp32 map
+        dqkv = torch.empty(T, 3 * width, dtype=ops.OP16, device=t.device)
         if pool:
             dq_img = torch.empty(B * Hq * Wq, width, dtype=F32, device=t.device)
             window_unpartition_into(dq4, dq_img, B, Hq, Wq, heads, D, ws_q)
         else:
-            window_unpartition_into(dq4, dqkv[:, :width], B, Hq, Wq, heads, D, ws_q)
+            window_unpartition_cvt_into(dq4, dqkv[:, :width], B, Hq, Wq, heads, D, ws_q)
             dq_img = None
-        window_unpartition_into(dk4, dqkv[:, width:2 * width], B, H, W, heads, D, ws)
-        window_unpartition_into(dv4, dqkv[:, 2 * width:], B, H, W, heads, D, ws)
+        window_unpartition_cvt_into(dk4, dqkv[:, width:2 * width], B, H, W, heads, D, ws)
+        window_unpartition_cvt_into(dv4, dqkv[:, 2 * width:], B, H, W, heads, D, ws)
         pad_bias = None
         if (Hp, Wp) != (H, W):
             # zero-padded tokens carry k = v = bias (the LayerNorm'ed map is padded BEFORE the qkv Linear, hieradet.py:143-150 +
-            # utils.py:28-31): their dk / dv flow into the qkv bias = (sum over ALL window tokens) - (sum over the image's tokens)
-            allk, allv = dk4.sum(dim=(0, 2)).reshape(width), dv4.sum(dim=(0, 2)).reshape(width)
-            pad_bias = torch.cat([torch.zeros(width, dtype=F32, device=t.device), allk - bwd.colsum(dqkv[:, width:2 * width]),
-                                  allv - bwd.colsum(dqkv[:, 2 * width:])])
+            # utils.py:28-31): their dk / dv flow into the qkv bias, whose k / v thirds are therefore the sums over ALL window tokens
+            # (image tokens + padded ones) -- they REPLACE the column sums over the image's tokens that linear_backward returns
+            pad_bias = (dk4.sum(dim=(0, 2)).reshape(width), dv4.sum(dim=(0, 2)).reshape(width))
     else:
         do4 = do_img.reshape(B, Hq * Wq, heads, D).permute(0, 2, 1, 3)
         dq4, dk4, dv4 = bwd.attention_backward(q4, k4, v4, do4, scale, o_lse=(o4, lse))
@@ -194,7 +202,8 @@ def hiera_block_backward(blk, t: torch.Tensor, B: int, H: int, W: int, dy: torch
         dqkv[:, :width].copy_(dq_img)
     dxn, g["attn.qkv.weight"], g["attn.qkv.bias"] = bwd.linear_backward(xn, qkv_w, dqkv)
     if pad_bias is not None:
-        g["attn.qkv.bias"] = g["attn.qkv.bias"] + pad_bias
+        g["attn.qkv.bias"][width:2 * width].copy_(pad_bias[0])
+        g["attn.qkv.bias"][2 * width:].copy_(pad_bias[1])
     if Dp != Dt:
         g["attn.qkv.weight"] = g["attn.qkv.weight"].view(3, heads, Dp, dim)[:, :, :Dt].reshape(3 * heads * Dt, dim)
         g["attn.qkv.bias"] = g["attn.qkv.bias"].view(3, heads, Dp)[:, :, :Dt].reshape(3 * heads * Dt)

@@ -1459,6 +1459,47 @@ extern "C" int msam2_window_move(void* img, int64_t ld_img, void* win, const voi
   return msam2_check_launch("window_move");
 }
 
+// window_unpartition of fp32 windows into a 16-BIT token image (the gradients dq / dk / dv of the trunk's windowed attention leave the flash
+// backward in fp32 window order and are consumed as the 16-bit operand of the fused-qkv weight / input gradient GEMMs): one pass instead
+// of an fp32 un-partition (4 B read + 4 B written per element) followed by a cast (4 read + 2 written).  8 elements per thread.
+__global__ void window_unpartition_cvt_kernel(op16* __restrict__ img, int64_t ld_img, const float* __restrict__ win, int B, int H, int W, int heads,
+                                              int c8pd /* 8-element chunks per D */, int ws, int nwy, int nwx) {
+  const int L = ws * ws;
+  const unsigned total = (unsigned)B * H * W * heads * c8pd;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int c = (int)(i % c8pd);
+    unsigned t = i / c8pd;
+    const int head = (int)(t % heads);
+    t /= heads;
+    const int x = (int)(t % W);
+    t /= W;
+    const int y = (int)(t % H), b = (int)(t / H);
+    const int wy = y / ws, wx = x / ws, tok = (y % ws) * ws + (x % ws);
+    const float* src = win + (((((int64_t)(b * nwy + wy) * nwx + wx) * heads + head) * L + tok) * c8pd + c) * 8;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src), bb = *reinterpret_cast<const f32x4*>(src + 4);
+    op16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = f2op(a[e]);
+      o[4 + e] = f2op(bb[e]);
+    }
+    *reinterpret_cast<op16x8*>(img + (((int64_t)b * H + y) * W + x) * ld_img + ((int64_t)head * c8pd + c) * 8) = o;
+  }
+}
+
+extern "C" int msam2_window_unpartition_cvt(void* img16, int64_t ld_img, const float* win, int64_t B, int64_t H, int64_t W, int64_t heads, int64_t D,
+                                            int64_t ws, void* stream) {
+  MSAM2_REQUIRE(img16 && win && B > 0 && H > 0 && W > 0 && heads > 0 && D > 0 && ws > 0, "window_unpartition_cvt: bad arguments");
+  MSAM2_REQUIRE(D % 8 == 0 && ld_img % 8 == 0 && (((uintptr_t)img16 | (uintptr_t)win) & 15) == 0,
+                "window_unpartition_cvt: D and the row stride must be multiples of 8 elements, pointers 16-byte aligned");
+  const int64_t total = B * H * W * heads * (D / 8);
+  MSAM2_REQUIRE(total + 16384ll * 256 < (1ll << 32), "window_unpartition_cvt: volume beyond 32-bit chunk indices");
+  const int nwy = (int)((H + ws - 1) / ws), nwx = (int)((W + ws - 1) / ws);
+  hipLaunchKernelGGL(window_unpartition_cvt_kernel, dim3((unsigned)min((int64_t)16384, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (op16*)img16, ld_img, win, (int)B, (int)H, (int)W, (int)heads, (int)(D / 8), (int)ws, nwy, nwx);
+  return msam2_check_launch("window_unpartition_cvt");
+}
+
 // adjoint of the FPN's nearest-2x top-down step (msam2_upsample2x_add, image_encoder.py:113-124): out[b,i,j,c] = sum of the 2x2 block
 __global__ void sumpool2x2_kernel(const float* __restrict__ dy, float* __restrict__ out, int B, int H, int W, int C) {
   const int Ho = H / 2, Wo = W / 2;
