@@ -178,7 +178,7 @@ def flash_dropout_supported(D: int, Lq: int) -> bool:
 
 
 def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: torch.Tensor, scale: Optional[float] = None, o_lse=None,
-                       dropout: Optional[tuple] = None):
+                       dropout: Optional[tuple] = None, out: Optional[tuple] = None):
     """Gradients of o = softmax(q k^T * scale) v for 16-bit q [B,H,Lq,D], k/v [B,H,Lk,D], upstream do [B,H,Lq,D] (any float type).
     Returns (dq, dk, dv) in fp32, shaped like q / k / v.
     Head dims 64 / 96 / 128 / 256: FLASH-STYLE (`msam2_attention_bwd`, csrc/attention_bwd.hip) -- the forward is re-run for O and the log-sum-exp rows,
@@ -193,9 +193,16 @@ def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: to
     _req(q.dtype == OP16 and k.dtype == OP16 and v.dtype == OP16, "attention_backward: 16-bit q, k, v")
     _req(D % 8 == 0, "attention_backward: head dim must be a multiple of 8")
     scale = scale if scale is not None else D ** -0.5
-    dq = torch.empty(B, H, Lq, D, dtype=F32, device=q.device)
-    dk = torch.empty(B, H, Lk, D, dtype=F32, device=q.device)
-    dv = torch.empty(B, H, Lk, D, dtype=F32, device=q.device)
+    if out is not None:
+        # fp32 [B,H,L,D] VIEWS to write into (e.g. the column thirds of a fused-qkv gradient buffer): any batch / head / token strides
+        # that are multiples of 4 elements, channels contiguous
+        dq, dk, dv = out
+        _req(all(t.dtype == F32 and t.stride(3) == 1 and all(st % 4 == 0 for st in t.stride()[:3]) for t in out) and
+             dq.shape == q.shape and dk.shape == k.shape and dv.shape == v.shape, "attention_backward: out must be fp32 views shaped like q, k, v")
+    else:
+        dq = torch.empty(B, H, Lq, D, dtype=F32, device=q.device)
+        dk = torch.empty(B, H, Lk, D, dtype=F32, device=q.device)
+        dv = torch.empty(B, H, Lk, D, dtype=F32, device=q.device)
     if D in (64, 96, 128, 256) and not os.environ.get("MSAM2_MATERIALISED_BWD"):
         q, k, v = (t if t.stride(3) == 1 and all(st % 8 == 0 for st in t.stride()[:3]) else t.contiguous() for t in (q, k, v))
         o, lse = o_lse if o_lse is not None else attention_forward_lse(q, k, v, scale, dropout=dropout)

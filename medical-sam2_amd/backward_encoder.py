@@ -190,9 +190,16 @@ def hiera_block_backward(blk, t: torch.Tensor, B: int, H: int, W: int, dy: torch
             pad_bias = (dk4.sum(dim=(0, 2)).reshape(width), dv4.sum(dim=(0, 2)).reshape(width))
     else:
         do4 = do_img.reshape(B, Hq * Wq, heads, D).permute(0, 2, 1, 3)
-        dq4, dk4, dv4 = bwd.attention_backward(q4, k4, v4, do4, scale, o_lse=(o4, lse))
-        dq_img = dq4.permute(0, 2, 1, 3).reshape(B * Hq * Wq, width)
-        dk_img, dv_img = dk4.permute(0, 2, 1, 3).reshape(T, width), dv4.permute(0, 2, 1, 3).reshape(T, width)
+        if not pool and D in (64, 96, 128, 256):
+            # global block: the flash backward writes dq / dk / dv straight into the column thirds of the fused-qkv gradient
+            dqkv = torch.empty(T, 3 * width, dtype=F32, device=t.device)
+            third = lambda i: dqkv[:, i * width:(i + 1) * width].view(B, H * W, heads, D).permute(0, 2, 1, 3)
+            bwd.attention_backward(q4, k4, v4, do4, scale, o_lse=(o4, lse), out=(third(0), third(1), third(2)))
+            dq_img = None
+        else:
+            dq4, dk4, dv4 = bwd.attention_backward(q4, k4, v4, do4, scale, o_lse=(o4, lse))
+            dq_img = dq4.permute(0, 2, 1, 3).reshape(B * Hq * Wq, width)
+            dk_img, dv_img = dk4.permute(0, 2, 1, 3).reshape(T, width), dv4.permute(0, 2, 1, 3).reshape(T, width)
         pad_bias = None
     if pool:
         dq_img = maxpool2x2_backward(q_img, dq_img.contiguous(), B, H, W)            # routed to the arg-max of each 2x2 window
