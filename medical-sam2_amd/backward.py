@@ -161,14 +161,16 @@ def mlp_backward(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.
     return dx, dw1, db1, dw2, db2
 
 
-def attention_forward_lse(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None, dropout: Optional[tuple] = None):
+def attention_forward_lse(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None, dropout: Optional[tuple] = None,
+                          out: Optional[torch.Tensor] = None):
     """Forward attention on [B,H,L,D] 16-bit views that keeps what the flash-style backward needs: (o 16-bit [B,H,Lq,D] view of a
     [B,Lq,H,D] buffer, lse fp32 [B,H,Lq] in the log2 domain).  Hand both to `attention_backward(..., o_lse=...)`.
     dropout = (p, seed, offset): dropout on the probabilities inside the kernel (pass the same triple to `attention_backward`)."""
     from .modeling.common import attn_splits
     B, H, Lq, D = q.shape
     lse = torch.empty(B, H, Lq, dtype=F32, device=q.device)
-    o = ops.attention(q, k, v, scale=scale if scale is not None else D ** -0.5, splits=attn_splits(B, H, Lq, k.shape[2]), lse=lse, dropout=dropout)
+    o = ops.attention(q, k, v, scale=scale if scale is not None else D ** -0.5, splits=attn_splits(B, H, Lq, k.shape[2]), lse=lse, dropout=dropout,
+                      out=out)                                   # out: a 16-bit [B,H,Lq,D] view to write into (any strides ops.attention takes)
     return o, lse
 
 

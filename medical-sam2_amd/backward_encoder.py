@@ -136,11 +136,13 @@ def hiera_block_backward(blk, t: torch.Tensor, B: int, H: int, W: int, dy: torch
         q4 = q_src.reshape(B, Hq * Wq, heads, D).permute(0, 2, 1, 3)
         k4 = kv5[:, :, :, 1].reshape(B, H * W, heads, D).permute(0, 2, 1, 3)
         v4 = kv5[:, :, :, 2].reshape(B, H * W, heads, D).permute(0, 2, 1, 3)
-    o4, lse = bwd.attention_forward_lse(q4, k4, v4, scale)                           # o4: [.., heads, Lq, D] view of [.., Lq, heads, D]
+    # windowed blocks: the output is written in the [windows, heads, Lq, D] order window_unpartition reads (no re-layout copy behind it);
+    # global blocks: attention_forward_lse's default, a [.., heads, Lq, D] view of a token-major [.., Lq, heads, D] buffer
+    o4_buf = torch.empty(q4.shape, dtype=q4.dtype, device=q4.device) if ws > 0 else None
+    o4, lse = bwd.attention_forward_lse(q4, k4, v4, scale, out=o4_buf)
     if ws > 0:
         o = torch.empty(B * Hq * Wq, width, dtype=o4.dtype, device=o4.device)
-        # (attention_forward_lse returns [.., heads, Lq, D] as a VIEW of a [.., Lq, heads, D] buffer: make the window layout explicit)
-        window_unpartition_into(o4.contiguous(), o, B, Hq, Wq, heads, D, ws_q)
+        window_unpartition_into(o4, o, B, Hq, Wq, heads, D, ws_q)
     else:
         o = o4.permute(0, 2, 1, 3).reshape(B * Hq * Wq, width)
         o = o if o.is_contiguous() else o.contiguous()
@@ -351,7 +353,9 @@ def image_encoder_backward(model, state: dict, d_fpn: List[Optional[torch.Tensor
         s_new = scales[key]
         acc = None
         for t, s in parts:
-            u = t.to(F32) * (s_new / s)                    # fp32, exact power-of-two factors
+            u = t if t.dtype == F32 else t.to(F32)
+            if s_new != s:
+                u = u * (s_new / s)                        # fp32, exact power-of-two factors (neighbouring links mostly share a scale: no pass)
             acc = u if acc is None else acc + u
         record_scaled_amax(scales, key, acc, calibrate)
         return acc, s_new

@@ -15,19 +15,30 @@ target = (torch.randn(4, 4, 256, 256, generator=torch.Generator().manual_seed(3)
 om, od, oe = T.DecoderAdam(mt.memory_attention, lr=1e-6), T.DecoderAdam(mt.sam_mask_decoder, lr=1e-4), T.DecoderAdam(mt.image_encoder, lr=1e-6)
 run = lambda: T.train_step_2d(mt, om, od, imgs, pts, labels, memory, memory_pos, target, sync=False, opt_enc=oe)
 run(); run(); torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True) as prof:
+import traceback
+from torch.utils._python_dispatch import TorchDispatchMode
+sites = collections.Counter(); elems = collections.Counter()
+WATCH = ("copy_", "fill_", "cat", "add", "mul", "zero_", "index", "index_put_", "_to_copy", "div", "neg", "sub", "clone", "abs", "sum", "amax", "aminmax", "max", "zeros", "maximum")
+
+
+class Sites(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = func.__name__.split(".")[0]
+        if name in WATCH:
+            st = [f for f in traceback.extract_stack() if "sam2_amd" in f.filename]
+            key = (name, " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in st[-2:][::-1]) if st else "?")
+            n = 1
+            for a in args:
+                if isinstance(a, torch.Tensor):
+                    n = a.numel(); break
+                if isinstance(a, (list, tuple)) and a and isinstance(a[0], torch.Tensor):
+                    n = sum(t.numel() for t in a); break
+            sites[key] += 1; elems[key] += n
+        return func(*args, **(kwargs or {}))
+
+
+with Sites():
     run()
 torch.cuda.synchronize()
-sites = collections.Counter(); elems = collections.Counter()
-names = ("aten::copy_", "aten::fill_", "aten::cat", "aten::add", "aten::mul", "aten::zero_", "aten::index", "aten::index_put_", "aten::_to_copy", "aten::div", "aten::neg", "aten::sub", "aten::clone", "aten::contiguous")
-for ev in prof.events():
-    if ev.name in names:
-        st = [f for f in ev.stack if "medical-sam2_amd" in f or "medical_sam2_amd" in f]
-        key = (ev.name, st[0][-100:] if st else "?")
-        n = 1
-        try:
-            for d in (ev.input_shapes[0] or []): n *= d
-        except Exception: pass
-        sites[key] += 1; elems[key] += n
-for key, e in elems.most_common(45):
-    print(f"{e/1e6:9.1f} Melem {sites[key]:4d} calls {key[0]:16s} {key[1]}")
+for key, c in sites.most_common(40):
+    print(f"{c:4d} calls {elems[key]/1e6:9.1f} Melem {key[0]:12s} {key[1]}")
