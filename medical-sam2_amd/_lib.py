@@ -82,6 +82,7 @@ SIGNATURES = {
     "msam2_gemm_nt": (c_i, [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_i, c_l, c_l, c_l, c_p]),
     "msam2_gemm_tt": (c_i, [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_l, c_p]),
     "msam2_window_unpartition_cvt": (c_i, [c_p, c_l, c_p, c_l, c_l, c_l, c_l, c_l, c_l, c_p]),
+    "msam2_window_pad_colsum": (c_i, [c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_l, c_p]),
     "msam2_gemm_tt_acc": (c_i, [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_l, c_p]),
     "msam2_bilinear_upsample_bwd": (c_i, [c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_p]),
     "msam2_maxpool2x2_bwd": (c_i, [c_p, c_i, c_l, c_p, c_l, c_p, c_l, c_l, c_l, c_l, c_l, c_p]),

@@ -187,9 +187,12 @@ def hiera_block_backward(blk, t: torch.Tensor, B: int, H: int, W: int, dy: torch
         pad_bias = None
         if (Hp, Wp) != (H, W):
             # zero-padded tokens carry k = v = bias (the LayerNorm'ed map is padded BEFORE the qkv Linear, hieradet.py:143-150 +
-            # utils.py:28-31): their dk / dv flow into the qkv bias, whose k / v thirds are therefore the sums over ALL window tokens
-            # (image tokens + padded ones) -- they REPLACE the column sums over the image's tokens that linear_backward returns
-            pad_bias = (dk4.sum(dim=(0, 2)).reshape(width), dv4.sum(dim=(0, 2)).reshape(width))
+            # utils.py:28-31): their dk / dv flow into the qkv bias, whose k / v thirds are the sums over ALL window tokens = the column
+            # sums over the image's tokens that linear_backward returns + the sums over the padded tokens (16 % of a 14 x 14 window
+            # grid on 64 x 64 tokens: a small gather-sum instead of two reductions over the whole fp32 window tensors)
+            pad_bias = torch.zeros(2, width, dtype=F32, device=t.device)
+            check(lib().msam2_window_pad_colsum(_p(dk4), _p(pad_bias[0]), B, H, W, heads, D, ws, _stream()))
+            check(lib().msam2_window_pad_colsum(_p(dv4), _p(pad_bias[1]), B, H, W, heads, D, ws, _stream()))
     else:
         do4 = do_img.reshape(B, Hq * Wq, heads, D).permute(0, 2, 1, 3)
         if not pool and D in (64, 96, 128, 256):
@@ -211,8 +214,7 @@ def hiera_block_backward(blk, t: torch.Tensor, B: int, H: int, W: int, dy: torch
         dqkv[:, :width].copy_(dq_img)
     dxn, g["attn.qkv.weight"], g["attn.qkv.bias"] = bwd.linear_backward(xn, qkv_w, dqkv)
     if pad_bias is not None:
-        g["attn.qkv.bias"][width:2 * width].copy_(pad_bias[0])
-        g["attn.qkv.bias"][2 * width:].copy_(pad_bias[1])
+        g["attn.qkv.bias"][width:].add_(pad_bias.view(-1))      # image tokens (the GEMM's column sums) + padded tokens
     if Dp != Dt:
         g["attn.qkv.weight"] = g["attn.qkv.weight"].view(3, heads, Dp, dim)[:, :, :Dt].reshape(3 * heads * Dt, dim)
         g["attn.qkv.bias"] = g["attn.qkv.bias"].view(3, heads, Dp)[:, :, :Dt].reshape(3 * heads * Dt)

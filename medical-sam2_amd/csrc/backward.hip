@@ -1500,6 +1500,34 @@ extern "C" int msam2_window_unpartition_cvt(void* img16, int64_t ld_img, const f
   return msam2_check_launch("window_unpartition_cvt");
 }
 
+// out[head * D + d] += sum of win[w][head][tok][d] over the window tokens that lie OUTSIDE the [H, W] image (the zero-padded tokens of
+// window_partition): their dk / dv belong to the qkv bias (the LayerNorm'ed map is padded before the qkv Linear, hieradet.py:143-150).
+// One workgroup per window; windows without padding leave at once.  out must be zeroed by the caller.
+__global__ __launch_bounds__(256) void window_pad_colsum_kernel(const float* __restrict__ win, float* __restrict__ out, int H, int W, int heads, int D,
+                                                                int ws, int nwy, int nwx) {
+  const int w = blockIdx.x, wx = w % nwx, wy = (w / nwx) % nwy;
+  const int y_in = min(ws, H - wy * ws), x_in = min(ws, W - wx * ws);       // tokens (ty < y_in && tx < x_in) are inside the image
+  if (y_in == ws && x_in == ws) return;
+  const int L = ws * ws, width = heads * D;
+  for (int c = threadIdx.x; c < width; c += 256) {
+    const int head = c / D, d = c - head * D;
+    const float* base = win + (((int64_t)w * heads + head) * L) * D + d;
+    float acc = 0.f;
+    for (int ty = 0; ty < ws; ++ty)
+      for (int tx = (ty < y_in ? x_in : 0); tx < ws; ++tx) acc += base[(int64_t)(ty * ws + tx) * D];
+    atomicAdd(out + c, acc);
+  }
+}
+
+extern "C" int msam2_window_pad_colsum(const float* win, float* out, int64_t B, int64_t H, int64_t W, int64_t heads, int64_t D, int64_t ws,
+                                       void* stream) {
+  MSAM2_REQUIRE(win && out && B > 0 && H > 0 && W > 0 && heads > 0 && D > 0 && ws > 0, "window_pad_colsum: bad arguments");
+  const int nwy = (int)((H + ws - 1) / ws), nwx = (int)((W + ws - 1) / ws);
+  hipLaunchKernelGGL(window_pad_colsum_kernel, dim3((unsigned)(B * nwy * nwx)), dim3(256), 0, (hipStream_t)stream, win, out, (int)H, (int)W, (int)heads,
+                     (int)D, (int)ws, nwy, nwx);
+  return msam2_check_launch("window_pad_colsum");
+}
+
 // adjoint of the FPN's nearest-2x top-down step (msam2_upsample2x_add, image_encoder.py:113-124): out[b,i,j,c] = sum of the 2x2 block
 __global__ void sumpool2x2_kernel(const float* __restrict__ dy, float* __restrict__ out, int B, int H, int W, int C) {
   const int Ho = H / 2, Wo = W / 2;

@@ -59,6 +59,7 @@ DOC = {
     "msam2_col2im3x3s2": "Adjoint of msam2_im2col3x3s2: input gradient of the mask down-sampler's k3 s2 p1 convolutions (memory_encoder.py:38-47) from the\ncolumn gradient of their GEMM form.",
     "msam2_gemm_nt": "Input-gradient GEMM C[M,N] = residual + A[M,K] B[K,N] (+ bias) with B k-major: dX = dY W of nn.Linear under autograd (sam2_utils.py:127-131,\nmemory_attention.py:96, transformer.py:241-261, hieradet.py:61,79) with W [out, in] exactly as the forward stores it -- no transposed weight\ncopy.  K % 64 == 0 (the layer's out_features), N % 8 == 0.",
     "msam2_window_unpartition_cvt": "window_unpartition (backbones/utils.py:41-62) of fp32 windows [B*nW, heads, ws*ws, D] into a 16-bit token image in one pass: the\nwindowed attention's dq / dk / dv (fp32, window order) become the 16-bit operand of the fused-qkv gradient GEMMs.",
+    "msam2_window_pad_colsum": "Sum of fp32 window rows [B*nW, heads, ws*ws, D] over the zero-padded window tokens (outside the [H, W] image), added into out [heads*D]:\nthe part of the windowed attention's dk / dv that belongs to the qkv bias (backbones/utils.py:28-31 pads AFTER the LayerNorm, so padded\ntokens carry k = v = bias).",
     "msam2_gemm_tt_acc": "msam2_gemm_tt that adds into C and a_colsum instead of overwriting them (torch.autograd's .grad accumulation; or outputs carved from a\nbuffer zeroed once per backward pass).",
     "msam2_gemm_tt": "Weight-gradient GEMM C[M,N] (fp32) = sum_k A[k][m] B[k][n] on k-major 16-bit operands: dW = dY^T X of nn.Linear under autograd\n(sam2_utils.py:127-131, memory_attention.py:96, transformer.py:241-261) straight from the token-major dY and X -- no transposed copies;\nthe token reduction is split over workgroups (fp32 atomics into the zeroed output).  a_colsum (optional, [M]) receives sum_k A[k][m]:\nthe bias gradient in the same pass over dY.",
     "msam2_bilinear_upsample_bwd": "Adjoint of msam2_bilinear_upsample: gradient of the video-resolution mask logits (sam2_video_predictor.py:724-744, the tensor the\ntraining loss of func_3d/function.py:137-170 is taken on) back to the decoder's low-resolution logits.",
