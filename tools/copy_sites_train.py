@@ -42,3 +42,29 @@ with Sites():
 torch.cuda.synchronize()
 for key, c in sites.most_common(40):
     print(f"{c:4d} calls {elems[key]/1e6:9.1f} Melem {key[0]:12s} {key[1]}")
+
+# the library's own cast / add kernel (msam2_add_cast) by call site
+import medical_sam2_amd.ops as _ops
+_orig = _ops.add_cast
+ac_sites = collections.Counter(); ac_bytes = collections.Counter()
+
+
+def _spy(a, b=None, alpha=1.0, out_dtype=None, out=None, *args, **kw):
+    st = [f for f in traceback.extract_stack()[:-1] if "sam2_amd" in f.filename]
+    key = " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in st[-3:][::-1])
+    r = _orig(a, b, alpha, out_dtype, out, *args, **kw) if out is not None or out_dtype is not None else _orig(a, b, alpha)
+    ac_sites[key] += 1
+    ac_bytes[key] += a.numel() * a.element_size() + (b.numel() * b.element_size() if b is not None else 0) + r.numel() * r.element_size()
+    return r
+
+
+_ops.add_cast = _spy
+import medical_sam2_amd.backward as _B, medical_sam2_amd.backward_encoder as _BE, medical_sam2_amd.modeling.common as _C
+for mod in (_B, _BE, _C):
+    if hasattr(mod, "ops"):
+        mod.ops.add_cast = _spy
+run()
+torch.cuda.synchronize()
+print("add_cast calls per iteration:", sum(ac_sites.values()), " MB moved:", round(sum(ac_bytes.values()) / 1e6))
+for key, by in ac_bytes.most_common(16):
+    print(f"{ac_sites[key]:4d} calls {by/1e6:8.1f} MB  {key}")
