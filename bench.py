@@ -433,6 +433,9 @@ def volume_workload(device, T):
     return volume, prompts
 
 
+LIVE_VOLUME_STATS: dict = {}       # the running pass's `stats` (phases done so far): what the watchdog reports when the pass hangs
+
+
 def run_volume(m, device, T, world, sync_dev, steps, warmup):
     """`steps` timed passes of the whole T-slice volume through segment_volume (all ranks, strong scaling).  Returns (seconds for all
     steps = max over ranks, phase seconds of the last pass on this rank, how the chain used the ranks, foreground fraction)."""
@@ -450,6 +453,8 @@ def run_volume(m, device, T, world, sync_dev, steps, warmup):
     t0 = time.perf_counter()
     for i in range(steps):
         st = {"time_phases": i == steps - 1}
+        LIVE_VOLUME_STATS.clear()
+        LIVE_VOLUME_STATS["stats"] = st
         masks = vol.segment_volume(m, volume, prompts, fill_hole_area=8, stats=st)
     torch.cuda.synchronize()
     par.barrier(sync_dev)
@@ -532,21 +537,29 @@ def launch_ranks(n: int, argv) -> int:
 
 
 class Watchdog:
-    """Side legs that talk to other ranks run under a deadline: when it passes, rank 0 prints the line it has (with the reason recorded
-    in `key`) and every rank leaves -- a hung exchange must not cost the headline figure."""
+    """Side legs that talk to other ranks run under a deadline.  When it passes, the process has given up on a hung collective or a
+    stuck kernel: rank 0 prints the line it has (the reason recorded under `key`), every rank dumps the stacks of all its threads and
+    what it was doing (`note`: e.g. the phase of the volume pass) to stderr, and EXITS NON-ZERO (3) -- a hang must surface as a failed
+    run, not as rc 0 with an error string inside an otherwise valid-looking line."""
+    EXIT_CODE = 3
 
-    def __init__(self, seconds, rank, line, key):
+    def __init__(self, seconds, rank, line, key, note=None):
         import threading
-        self.rank, self.line, self.key, self.seconds = rank, line, key, seconds
+        self.rank, self.line, self.key, self.seconds, self.note = rank, line, key, seconds, note
         self.timer = threading.Timer(seconds, self.fire)
         self.timer.daemon = True
         self.timer.start()
 
     def fire(self):
+        import faulthandler
+        what = self.note() if callable(self.note) else self.note
+        sys.stderr.write(f"[bench watchdog] rank {self.rank}: '{self.key or 'shutdown'}' gave no result within {self.seconds} s; state: {what}\n")
+        faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+        sys.stderr.flush()
         if self.rank == 0 and self.line is not None:
-            self.line[self.key] = {"error": f"no result within {self.seconds} s (stuck exchange?); the other figures of this line are unaffected"}
+            self.line[self.key] = {"error": f"no result within {self.seconds} s (stuck exchange or kernel); state: {what}; exit code {self.EXIT_CODE}"}
             print(json.dumps(self.line), flush=True)
-        os._exit(0)
+        os._exit(self.EXIT_CODE)
 
     def cancel(self):
         self.timer.cancel()
@@ -719,7 +732,8 @@ def main():
                 line["bf16"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if not args.no_volume:
         # all ranks: the 3-D path at configs[3]'s size (strong scaling), after the timed region; never part of `value`
-        dog = Watchdog(420, rank, line, "volume_3d")
+        dog = Watchdog(420, rank, line, "volume_3d",
+                       note=lambda: f"volume pass, phases completed so far: {LIVE_VOLUME_STATS.get('stats', {}).get('phases_done', 'none (warm-up pass)')}")
         try:
             side_obj = volume_side_object(m, device, args.slices, world, sync_dev)
         except Exception as e:  # noqa: BLE001 -- a side figure: report, do not fail the benchmark line
@@ -730,7 +744,7 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
-        dog = Watchdog(120, rank, None, "")
+        dog = Watchdog(120, rank, None, "", note="final barrier / destroy_process_group")
         par.barrier(sync_dev)
         dist.destroy_process_group()
         dog.cancel()

@@ -1502,20 +1502,32 @@ extern "C" int msam2_window_unpartition_cvt(void* img16, int64_t ld_img, const f
 
 // out[head * D + d] += sum of win[w][head][tok][d] over the window tokens that lie OUTSIDE the [H, W] image (the zero-padded tokens of
 // window_partition): their dk / dv belong to the qkv bias (the LayerNorm'ed map is padded before the qkv Linear, hieradet.py:143-150).
-// One workgroup per window; windows without padding leave at once.  out must be zeroed by the caller.
-__global__ __launch_bounds__(256) void window_pad_colsum_kernel(const float* __restrict__ win, float* __restrict__ out, int H, int W, int heads, int D,
-                                                                int ws, int nwy, int nwx) {
-  const int w = blockIdx.x, wx = w % nwx, wy = (w / nwx) % nwy;
-  const int y_in = min(ws, H - wy * ws), x_in = min(ws, W - wx * ws);       // tokens (ty < y_in && tx < x_in) are inside the image
-  if (y_in == ws && x_in == ws) return;
-  const int L = ws * ws, width = heads * D;
-  for (int c = threadIdx.x; c < width; c += 256) {
-    const int head = c / D, d = c - head * D;
-    const float* base = win + (((int64_t)w * heads + head) * L) * D + d;
-    float acc = 0.f;
-    for (int ty = 0; ty < ws; ++ty)
-      for (int tx = (ty < y_in ? x_in : 0); tx < ws; ++tx) acc += base[(int64_t)(ty * ws + tx) * D];
-    atomicAdd(out + c, acc);
+// DETERMINISTIC (round 4; the first form added one fp32 atomic per window and column, so the qkv-bias gradient -- and through Adam the
+// whole encoder -- changed in the last bits from run to run): a workgroup owns 16 columns, its 64 thread groups walk the (window, token
+// row) pairs in a fixed round-robin, and the 64 partial sums are added in index order by one thread per column.  `out` is accumulated
+// into (single writer per column), as before.
+__global__ __launch_bounds__(1024) void window_pad_colsum_kernel(const float* __restrict__ win, float* __restrict__ out, int H, int W, int heads, int D,
+                                                                 int ws, int nwy, int nwx, int n_win) {
+  __shared__ float red[64][17];
+  const int cl = threadIdx.x & 15, sub = threadIdx.x >> 4, width = heads * D;
+  const int c = blockIdx.x * 16 + cl;
+  float acc = 0.f;
+  if (c < width) {
+    const int head = c / D, d = c - head * D, L = ws * ws;
+    for (int item = sub; item < n_win * ws; item += 64) {
+      const int w = item / ws, ty = item - w * ws, wx = w % nwx, wy = (w / nwx) % nwy;
+      const int y_in = min(ws, H - wy * ws), x_in = min(ws, W - wx * ws);     // tokens (ty < y_in && tx < x_in) are inside the image
+      const int tx0 = ty < y_in ? x_in : 0;
+      const float* base = win + (((int64_t)w * heads + head) * L + ty * ws) * D + d;
+      for (int tx = tx0; tx < ws; ++tx) acc += base[(int64_t)tx * D];
+    }
+  }
+  red[sub][cl] = acc;
+  __syncthreads();
+  if (sub == 0 && c < width) {
+    float s = 0.f;
+    for (int i = 0; i < 64; ++i) s += red[i][cl];
+    out[c] += s;
   }
 }
 
@@ -1523,8 +1535,10 @@ extern "C" int msam2_window_pad_colsum(const float* win, float* out, int64_t B, 
                                        void* stream) {
   MSAM2_REQUIRE(win && out && B > 0 && H > 0 && W > 0 && heads > 0 && D > 0 && ws > 0, "window_pad_colsum: bad arguments");
   const int nwy = (int)((H + ws - 1) / ws), nwx = (int)((W + ws - 1) / ws);
-  hipLaunchKernelGGL(window_pad_colsum_kernel, dim3((unsigned)(B * nwy * nwx)), dim3(256), 0, (hipStream_t)stream, win, out, (int)H, (int)W, (int)heads,
-                     (int)D, (int)ws, nwy, nwx);
+  MSAM2_REQUIRE(B * nwy * nwx * ws < (1ll << 31), "window_pad_colsum: window count beyond 32-bit indices");
+  if (H % ws == 0 && W % ws == 0) return 0;                                   // no padded token anywhere
+  hipLaunchKernelGGL(window_pad_colsum_kernel, dim3((unsigned)((heads * D + 15) / 16)), dim3(1024), 0, (hipStream_t)stream, win, out, (int)H, (int)W,
+                     (int)heads, (int)D, (int)ws, nwy, nwx, (int)(B * nwy * nwx));
   return msam2_check_launch("window_pad_colsum");
 }
 

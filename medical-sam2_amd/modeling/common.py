@@ -28,16 +28,44 @@ class WeightCache:
         sig = self._sig(params)
         hit = self._c.get(key)
         if hit is None or hit[0] != sig:
-            with torch.no_grad():
-                hit = (sig, build())
+            old = None if hit is None else hit[1]
+            if cast_of is not None and key in self._casts and isinstance(old, torch.Tensor) and old.numel() == cast_of.numel() \
+                    and old.device == cast_of.device:
+                # A plain 16-bit cast is refreshed IN PLACE: its storage is stable for the life of the cache entry.  `refresh_casts`
+                # inside a captured training step bakes these pointers into the hipGraph; replacing the tensor here (an eager reader
+                # between two replays, after `mark_updated`) would hand the old block back to the allocator while the graph still
+                # writes weights into it and runs GEMMs out of it.
+                with torch.no_grad():
+                    old.copy_(cast_of.detach().reshape(old.shape))
+                hit = (sig, old)
+            else:
+                with torch.no_grad():
+                    hit = (sig, build())
             self._c[key] = hit
             if cast_of is not None:
                 self._casts[key] = cast_of
         return hit[1]
 
+    def tensors(self):
+        """every cached kernel-ready tensor (GraphedStep pins them for the life of its graph)"""
+        for _, val in self._c.values():
+            for t in (val if isinstance(val, (tuple, list)) else (val,)):
+                if isinstance(t, torch.Tensor):
+                    yield t
+
     def clear(self):
         self._c.clear()
         self._casts.clear()
+
+
+def cached_weight_tensors(model: torch.nn.Module) -> list:
+    """every kernel-ready weight tensor the modules of `model` currently hold in their caches"""
+    out = []
+    for mod in model.modules():
+        wc = getattr(mod, "_wc", None)
+        if isinstance(wc, WeightCache):
+            out.extend(wc.tensors())
+    return out
 
 
 def refresh_casts(model: torch.nn.Module) -> int:

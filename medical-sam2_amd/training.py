@@ -135,8 +135,10 @@ class GraphedStep:
     synchronisation), `check_every=N` does so every N replays, and when anything left the safe band and an `eager_fn` (the same step with
     sync=True) was given, the calibrations are dropped, the step runs eagerly once (re-calibrating) and the graph is captured again."""
 
-    def __init__(self, step_fn, optimizers, eager_fn=None, check_every: int = 0):
+    def __init__(self, step_fn, optimizers, eager_fn=None, check_every: int = 0, model=None):
+        """model (optional): the whole network -- its frozen modules' kernel-ready weights are pinned with the trained ones (below)."""
         self.optimizers, self.step_fn, self.eager_fn, self.check_every = list(optimizers), step_fn, eager_fn, int(check_every)
+        self.model = model
         self.replays = self.recalibrations = 0
         self._skipped = 0
         self._capture()
@@ -151,6 +153,17 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = self.step_fn()
+        # The graph holds raw pointers to the kernel-ready weight copies it read or refreshed (`refresh_casts` copies in place into tensors
+        # that were allocated eagerly and are owned by the modules' WeightCache only).  Plain casts are refreshed in place by every
+        # reader (`WeightCache.get`), so an eager forward between two replays keeps the pointers valid; the references held here keep
+        # the blocks alive even if a cache is cleared or an entry replaced while this graph exists.
+        from .modeling.common import cached_weight_tensors
+        mods = ([self.model] if self.model is not None else []) + [o.decoder for o in self.optimizers]
+        self._pinned = [t for mod in mods for t in cached_weight_tensors(mod)]
+        # capture RECORDED the weight refreshes without running them, but the host side stamped the cache entries as fresh: bump the
+        # versions so that an eager reader before the first replay converts the current weights instead of trusting those stamps
+        for o in self.optimizers:
+            o.mark_updated()
 
     def replay(self):
         self.graph.replay()

@@ -105,6 +105,8 @@ def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_h
 
     def _phase(name: str):
         """wall seconds of the phase that just ended (device drained first): only when the caller asked for `time_phases`"""
+        if stats is not None:
+            stats["phases_done"] = stats.get("phases_done", []) + [name]      # live: what a watchdog reports when the pass hangs
         if phase_s is not None:
             torch.cuda.synchronize(volume.device)
             now = _time.perf_counter()

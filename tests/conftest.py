@@ -8,9 +8,34 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Collection order of the GPU run (`pytest -m gpu -x`): the parity tests proper first -- kernels, modules, end to end, properties, graphs --
+# then the backward / training files, then the at-size runs, then the files that start child processes, the bf16 child suite last.  With
+# `-x` one fragile at-size or multi-process test can then never hide the kernel / e2e parity tests behind it.
+# Files not listed (the CPU files) keep their alphabetical order in front.
+ORDER = ["test_kernels_gpu", "test_modules_gpu", "test_e2e_gpu", "test_operand_rounding_gpu", "test_properties_gpu", "test_graphs_gpu",
+         "test_eval_seg", "test_data_contract", "test_backward_gpu", "test_backward_encoder_gpu", "test_grads_golden", "test_bptt_gpu",
+         "test_autograd_gpu", "test_train_graph_gpu", "test_rccl_gpu", "test_volume_ranks_gpu", "test_dp_training_gpu", "test_multigpu_gpu",
+         "test_config4_at_size_gpu", "test_bf16_build_gpu"]
+# the long at-size volume tests of test_e2e_gpu.py run with the other at-size test, after every parity file
+AT_SIZE = ("512_slices", "config3_volume_at_size")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(session, config, items):
+    rank = {name: i for i, name in enumerate(ORDER)}
+
+    def key(pair):
+        i, item = pair
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        r = rank.get(mod, -1)
+        if any(s in item.name for s in AT_SIZE):
+            r = rank["test_config4_at_size_gpu"] - 0.5
+        return (r, i)
+
+    items[:] = [it for _, it in sorted(enumerate(items), key=key)]
 
 
 @pytest.fixture(scope="session")

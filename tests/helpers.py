@@ -55,3 +55,24 @@ def mask_iou(a, b) -> float:
     b = torch.as_tensor(np.asarray(b)) > 0
     u = (a | b).sum().item()
     return 1.0 if u == 0 else (a & b).sum().item() / u
+
+
+def gradient_step_drops(loss_fn, groups: dict, grads: dict, loss0: float, frac: float = 0.02) -> dict:
+    """The loss-goes-down statement that the arithmetic guarantees ("the loss is lower after n Adam steps at lr x" is
+    not one: Adam's first update moves every parameter by +-lr whatever the gradient's size).  Per group {name: module} with TRUE
+    gradients grads[name] = {parameter: tensor}: the plain step p <- p - eta g with eta = frac * loss0 / |g|^2 has a first-order drop of
+    frac * loss0.  Returns {name: measured relative drop}; the parameters are restored (loss_fn must rebuild stale weight copies itself,
+    which the modules' version-checked caches do)."""
+    out = {}
+    with torch.no_grad():
+        for name, mod in groups.items():
+            g = grads[name]
+            params = dict(mod.named_parameters())
+            g2 = sum(float(v.double().pow(2).sum()) for v in g.values())
+            eta = frac * loss0 / g2
+            for k in g:
+                params[k].add_(g[k].to(params[k].dtype), alpha=-eta)
+            out[name] = (loss0 - loss_fn()) / loss0
+            for k in g:
+                params[k].add_(g[k].to(params[k].dtype), alpha=eta)
+    return out

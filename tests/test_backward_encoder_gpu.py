@@ -8,7 +8,7 @@ import sys
 import pytest
 import os as _os, sys as _sys
 _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
-from helpers import btol, op16_is_fp16  # noqa: E402
+from helpers import btol, gradient_step_drops, op16_is_fp16  # noqa: E402
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -79,6 +79,33 @@ def test_adjoint_kernels():
     ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
     check(lib().msam2_hiera_pos_embed_bwd(ops._p(d.to(DEV)), ops._p(dpe), ops._p(dpw), 24, 7, 7, h, w, 8, ops._p(ws), nb, ops._stream()))
     assert rel(dpw, pw.grad) < 1e-5 and rel(dpe, pe.grad) < 1e-4
+
+
+def test_window_pad_colsum_is_exact_and_deterministic():
+    """msam2_window_pad_colsum (the qkv-bias share of the zero-padded window tokens, hieradet.py:143-150 + utils.py:28-31): equals the masked
+    sum over the padded tokens, accumulates into its output, and -- round 4, VERDICT r3 item 1a -- repeated launches give the SAME BITS
+    (the first form added one fp32 atomic per window, so the encoder gradient changed in its last bits from run to run)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from medical_sam2_amd._lib import check, lib
+    import medical_sam2_amd.ops as ops
+    for (B, H, W, heads, D, ws) in ((4, 64, 64, 4, 96, 14), (2, 32, 32, 8, 96, 7), (1, 16, 20, 2, 56, 14), (2, 16, 16, 2, 24, 8)):
+        nwy, nwx = -(-H // ws), -(-W // ws)
+        win = rnd(B * nwy * nwx, heads, ws * ws, D, seed=ws + D).to(DEV)
+        ty, tx = torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")
+        ref = torch.zeros(heads * D, dtype=torch.float64)
+        for w in range(B * nwy * nwx):
+            wx, wy = w % nwx, (w // nwx) % nwy
+            pad = ((wy * ws + ty >= H) | (wx * ws + tx >= W)).reshape(-1)
+            ref += win[w].double().cpu()[:, pad].sum(1).reshape(-1)
+        outs = []
+        for rep in range(3):
+            out = torch.full((heads * D,), 1.5, dtype=torch.float32, device=DEV)          # accumulates into its output
+            check(lib().msam2_window_pad_colsum(win.data_ptr(), out.data_ptr(), B, H, W, heads, D, ws, torch.cuda.current_stream().cuda_stream))
+            outs.append(out.cpu())
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        err = (outs[0].double() - 1.5 - ref).abs().max().item()
+        assert err <= 1e-4 * max(1.0, ref.abs().max().item()), (B, H, W, heads, D, ws, err)
 
 
 def test_hiera_block_backward_variants():
@@ -198,13 +225,20 @@ def test_train_step_2d_with_image_encoder():
         by_stage[key] = max(by_stage.get(key, 0.0), e)
     print("worst per block / part:", by_stage)
     with torch.no_grad():
+        # sign and scale of every group's gradient: a plain step p <- p - eta g sized for a first-order drop of 2 % lowers the loss by
+        # about that (curvature takes some of it)
+        drops = gradient_step_drops(lambda: T.train_step_2d(m, zero[0], zero[1], *args, opt_enc=zero[2])[0],
+                                    {"decoder": m.sam_mask_decoder, "memory_attention": m.memory_attention, "image_encoder": m.image_encoder}, got, loss0)
+        print("relative loss drop of a plain gradient step per group (predicted 0.02):", drops)
+        assert all(0.005 < d < 0.03 for d in drops.values()), drops
         before = {k: v.detach().clone() for k, v in m.state_dict().items()}
         opts = [T.DecoderAdam(m.memory_attention, lr=1e-5), T.DecoderAdam(m.sam_mask_decoder, lr=1e-4), T.DecoderAdam(m.image_encoder, lr=1e-5)]
         losses = [T.train_step_2d(m, opts[0], opts[1], *args, opt_enc=opts[2])[0] for _ in range(4)]
         moved = {k.split(".")[0] for k, v in m.state_dict().items() if not torch.equal(v, before[k])}
     assert moved == {"memory_attention", "sam_mask_decoder", "image_encoder"}, moved
-    assert min(losses[1:]) < losses[0], losses
+    assert all(x == x and abs(x) < 1e6 for x in losses), losses
     assert all(torch.isfinite(v).all() for v in m.state_dict().values())
+    assert all(o.skipped_elements == 0 for o in opts)
 
 
 def test_graphed_step_detects_scale_drift_and_recalibrates():
@@ -252,7 +286,7 @@ def test_graphed_step_detects_scale_drift_and_recalibrates():
 def test_train_step_2d_hiera_bplus():
     """BASELINE configs[4]'s model through the whole 2-D training iteration (train_2d.py:43-47 trains every parameter): Hiera-B+ -- 24 blocks,
     head dim 56 zero-padded to 64 in the attention forward AND backward, 14 x 14 position embedding -- runs, moves the three groups, stays
-    finite and lowers the loss (its encoder gradients are pinned above against autograd)."""
+    finite, and a plain gradient step of every group lowers the loss by the predicted amount (its encoder gradients are pinned above against autograd)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import medical_sam2_amd.synthetic as syn
@@ -265,10 +299,20 @@ def test_train_step_2d_hiera_bplus():
     target = (rnd(B, 4, S // 4, S // 4, seed=152) > 0.3).float()
     args = tuple(t.to(DEV) for t in (imgs, pts, labels, memory, memory_pos, target))
     with torch.no_grad():
+        zero = [T.DecoderAdam(mod, lr=0.0) for mod in (m.memory_attention, m.sam_mask_decoder, m.image_encoder)]
+        got: dict = {}
+        loss0, _ = T.train_step_2d(m, zero[0], zero[1], *args, opt_enc=zero[2], grads_out=got)
+        # sign and scale of every group's gradient: a plain step p <- p - eta g sized for a first-order drop of 2 % lowers the loss by
+        # about that (curvature takes some of it)
+        drops = gradient_step_drops(lambda: T.train_step_2d(m, zero[0], zero[1], *args, opt_enc=zero[2])[0],
+                                    {"decoder": m.sam_mask_decoder, "memory_attention": m.memory_attention, "image_encoder": m.image_encoder}, got, loss0)
+        print("relative loss drop of a plain gradient step per group (predicted 0.02):", drops)
+        assert all(0.005 < d < 0.03 for d in drops.values()), drops
         before = {k: v.detach().clone() for k, v in m.state_dict().items()}
         opts = [T.DecoderAdam(m.memory_attention, lr=1e-5), T.DecoderAdam(m.sam_mask_decoder, lr=1e-4), T.DecoderAdam(m.image_encoder, lr=1e-5)]
         losses = [T.train_step_2d(m, opts[0], opts[1], *args, opt_enc=opts[2])[0] for _ in range(4)]
         moved = {k.split(".")[0] for k, v in m.state_dict().items() if not torch.equal(v, before[k])}
     assert moved == {"memory_attention", "sam_mask_decoder", "image_encoder"}, moved
-    assert min(losses[1:]) < losses[0], losses
+    assert all(x == x and abs(x) < 1e6 for x in losses), losses
     assert all(torch.isfinite(v).all() for v in m.state_dict().values())
+    assert all(o.skipped_elements == 0 for o in opts)

@@ -3,9 +3,15 @@
 (24-block Hiera-B+ trunk, FPN neck), memory attention and mask decoder forward / backward / Adam, memory encoding.  Its 8-GPU gradient
 all-reduce is covered by tests/test_dp_training_gpu.py (2 ranks) and tests/test_rccl_gpu.py (RCCL).
 
-Checked: every loss / parameter finite, the three trained groups move, the loss goes down over four iterations, and the image-encoder
-gradient -- 250 tensors through decoder -> memory attention -> FPN -> 24 blocks -- is spot-checked by a central finite difference of the
-loss ALONG the gradient itself (predicted change 2 eps |g|^2; a wrong scale or a wrong direction shows up as a ratio away from 1).
+Checked (VERDICT r3 item 1a -- every clause is something the arithmetic guarantees, none depends on where four Adam steps at some
+learning rate happen to land on a random-weight model):
+  * every loss / gradient / parameter finite, no gradient element skipped;
+  * per trained group (mask decoder, memory attention, image encoder): a central finite difference of the loss ALONG the group's own
+    gradient (predicted change 2 eps |g|^2 = 2 % of the loss; a wrong scale or direction shows up as a ratio away from 1), and a plain
+    gradient step p <- p - eta g of the same size must LOWER the loss by about the predicted 1 % (bar 0.5-1.5 %);
+  * the optimiser: `DecoderAdam` steps on all three groups equal `torch.optim.Adam` run on the same parameters with the step's own
+    gradients (two consecutive iterations, so the moment estimates and the bias correction are exercised), and exactly the three
+    groups move.
 
 The operand type is a property of the loaded library, so the fp16 parent process runs this file again in a child with MSAM2_LIB_PATH."""
 import os
@@ -18,6 +24,7 @@ import torch
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "medical-sam2_amd", "libmsam2_hip_bf16.so")
+FD_LO, FD_HI = 0.85, 1.10          # central finite difference / prediction; measured 0.977 on the encoder gradient (round 3)
 sys.path.insert(0, ROOT)
 
 
@@ -36,41 +43,61 @@ def _run_at_size():
     g = torch.Generator().manual_seed(3)
     target = (torch.randn(B, 4, 256, 256, generator=g) > 0.5).float().to(dev)
     args = (imgs, pts, labels, memory, memory_pos, target)
+    groups = {"decoder": m.sam_mask_decoder, "memory_attention": m.memory_attention, "image_encoder": m.image_encoder}
     with torch.no_grad():
-        # ---- gradients at the initial point (lr 0), then the finite difference along the encoder gradient
+        # ---- gradients at the initial point (lr 0)
         zero = [T.DecoderAdam(mod, lr=0.0) for mod in (m.memory_attention, m.sam_mask_decoder, m.image_encoder)]
         got: dict = {}
         loss0, _ = T.train_step_2d(m, zero[0], zero[1], *args, opt_enc=zero[2], grads_out=got)
-        g_enc = got["image_encoder"]
-        assert len(g_enc) > 240 and all(torch.isfinite(v).all() for v in g_enc.values())
-        assert all(torch.isfinite(v).all() for grp in ("decoder", "memory_attention") for v in got[grp].values())
-        params = dict(m.image_encoder.named_parameters())
-        g2 = sum(float(v.double().pow(2).sum()) for v in g_enc.values())
-        eps = 0.02 * loss0 / (2.0 * g2)                   # predicted central difference: 2 eps |g|^2 = 2 % of the loss
-        step = lambda sgn: [params[k].add_(g_enc[k].to(params[k].dtype), alpha=sgn * eps) for k in g_enc]
+        assert len(got["image_encoder"]) > 240
+        assert all(torch.isfinite(v).all() for grp in groups for v in got[grp].values())
 
         def loss_only():
             # parameters moved through raw tensor ops bump their version counters, so the kernel-ready 16-bit copies are rebuilt
             return T.train_step_2d(m, zero[0], zero[1], *args, opt_enc=zero[2])[0]
-        step(+1.0)
-        lp = loss_only()
-        step(-2.0)
-        lm = loss_only()
-        step(+1.0)
-        ratio = (lp - lm) / (2.0 * eps * g2)
-        print(f"configs[4] at size: loss {loss0:.5f}; finite difference along the encoder gradient: measured {lp - lm:.6f} vs predicted "
-              f"{2 * eps * g2:.6f} (ratio {ratio:.3f}), |g_enc| {g2 ** 0.5:.4e}")
-        assert 0.7 < ratio < 1.3, ratio
-        # ---- four real iterations
+        assert abs(loss_only() - loss0) <= 1e-6 * abs(loss0), "the forward + loss is run-to-run reproducible at fixed parameters"
+        for grp, mod in groups.items():
+            g = got[grp]
+            params = dict(mod.named_parameters())
+            g2 = sum(float(v.double().pow(2).sum()) for v in g.values())
+            eps = 0.02 * loss0 / (2.0 * g2)               # predicted central difference: 2 eps |g|^2 = 2 % of the loss
+            step = lambda sgn: [params[k].add_(g[k].to(params[k].dtype), alpha=sgn * eps) for k in g]
+            step(+1.0)
+            lp = loss_only()
+            step(-2.0)
+            lm = loss_only()                              # = one plain gradient step of size eta = eps from the initial point
+            step(+1.0)
+            ratio = (lp - lm) / (2.0 * eps * g2)
+            drop = (loss0 - lm) / loss0
+            print(f"configs[4] at size, {grp}: loss {loss0:.5f}; finite difference along the gradient: measured {lp - lm:.6f} vs predicted "
+                  f"{2 * eps * g2:.6f} (ratio {ratio:.3f}); plain gradient step lowers the loss by {100 * drop:.3f} % (predicted 1 %), "
+                  f"|g| {g2 ** 0.5:.4e}")
+            assert FD_LO < ratio < FD_HI, (grp, ratio)
+            assert 0.005 < drop < 0.015, (grp, drop)
+        # ---- two real iterations: DecoderAdam against torch.optim.Adam on the step's own gradients
+        lrs = {"memory_attention": 1e-5, "decoder": 1e-4, "image_encoder": 1e-5}
+        opts = {grp: T.DecoderAdam(groups[grp], lr=lrs[grp]) for grp in groups}
+        twins = {grp: {k: torch.nn.Parameter(p.detach().clone()) for k, p in groups[grp].named_parameters()} for grp in groups}
+        t_opts = {grp: torch.optim.Adam(list(twins[grp].values()), lr=lrs[grp], betas=(0.9, 0.999), eps=1e-8) for grp in groups}
         before = {k: v.detach().clone() for k, v in m.state_dict().items()}
-        opts = [T.DecoderAdam(m.memory_attention, lr=1e-5), T.DecoderAdam(m.sam_mask_decoder, lr=1e-4), T.DecoderAdam(m.image_encoder, lr=1e-5)]
-        losses = [T.train_step_2d(m, opts[0], opts[1], *args, opt_enc=opts[2])[0] for _ in range(4)]
+        losses = []
+        for it in range(2):
+            got = {}
+            losses.append(T.train_step_2d(m, opts["memory_attention"], opts["decoder"], *args, opt_enc=opts["image_encoder"], grads_out=got)[0])
+            for grp in groups:
+                for k, p in twins[grp].items():
+                    p.grad = got[grp][k].to(p.dtype).clone() if k in got[grp] else None
+                t_opts[grp].step()
+                worst = max(float((dict(groups[grp].named_parameters())[k].detach() - p.detach()).abs().max()) for k, p in twins[grp].items())
+                print(f"iteration {it}, {grp}: max |DecoderAdam - torch.optim.Adam| per element {worst:.3e} (lr {lrs[grp]:g})")
+                # |update| <= lr per element and step; the two agree to fp32 rounding of the update (1 % of lr covers v-hat ~ eps^2 corners)
+                assert worst <= 0.01 * lrs[grp], (it, grp, worst)
         moved = {k.split(".")[0] for k, v in m.state_dict().items() if not torch.equal(v, before[k])}
-    print("losses:", losses)
+    print("losses:", [loss0] + losses)
     assert moved == {"memory_attention", "sam_mask_decoder", "image_encoder"}, moved
-    assert all(map(lambda x: x == x and abs(x) < 1e6, losses)) and min(losses[1:]) < losses[0], losses
+    assert all(map(lambda x: x == x and abs(x) < 1e6, losses)), losses
     assert all(torch.isfinite(v).all() for v in m.state_dict().values())
-    assert all(o.skipped_elements == 0 for o in opts)
+    assert all(o.skipped_elements == 0 for o in opts.values())
 
 
 def test_configs4_hiera_bplus_train_iteration_at_1024_b4_bf16():
