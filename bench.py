@@ -2,7 +2,7 @@
 """Benchmark of the MI355X hot path: BASELINE.json metric "slices/sec @1024^2 (Hiera-S ...)".
 
 Workload at N=1 (BASELINE.json configs[1], the 2D `train_2d.py` SAM2 sub-sequence, func_2d/function.py:70-191, forward only):
-  4 synthetic 1024x1024 slices, 16-bit MFMA operands (fp16 by default; fp32 accumulate / residual streams) ->  forward_image -> _prepare_backbone_features -> memory_attention against a
+  4 synthetic 1024x1024 slices, 16-bit MFMA operands (bf16 as configs[1] states, `--dtype f16` for the fp16 build; fp32 accumulate / residual streams) ->  forward_image -> _prepare_backbone_features -> memory_attention against a
   pre-filled 16-entry memory bank (4 sampled memories per slice, fixed indices instead of torch.multinomial) -> prompt encoder
   (one click per slice) -> mask decoder (+ high-res features) -> bilinear x4 -> _encode_new_memory.
 One "step" = that sequence for the batch of 4 slices; value = slices / second with inputs resident in HBM.
@@ -387,6 +387,9 @@ def time_gemm_family(m, imgs, pts, labels, memory, memory_pos, device):
     for r in rows:
         r["share_of_gemm_time"] = r["step_us"] * 1e-6 / tot_t
     ach = tot_f / tot_t / 1e12
+    if os.environ.get("MSAM2_BENCH_GEMM_TABLE"):          # the whole table (every distinct shape of the step) for the profiles/ directory
+        with open(os.environ["MSAM2_BENCH_GEMM_TABLE"], "w") as f:
+            json.dump(rows, f, indent=1)
     return {"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
             "traffic": None, "what": "all GEMM launches of one step (flop-weighted): sum of 2MNK over sum of launches x stand-alone average launch time",
             "gemm_ms_per_step": tot_t * 1e3, "flops_per_step": tot_f, "launches_per_step": sum(r["launches_per_step"] for r in rows),
@@ -477,15 +480,17 @@ def volume_side_object(m, device, T, world, sync_dev):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def bf16_side_object(steps, warmup, oracle_low):
-    """BASELINE.json configs[1] names bf16; the default library computes on fp16 operands.  The same benchmark
-    step through libmsam2_hip_bf16.so in a CHILD process (the operand type is fixed when the library is loaded): its slices/s and the
-    parity of its slice-0 mask against the oracle mask of `cpu_baseline`."""
+def other_dtype_side_object(other, steps, warmup, oracle_low):
+    """The headline line runs on bf16 operands (BASELINE.json configs[1] states bf16; `--dtype`).  The library also builds on IEEE fp16
+    operands (11-bit significand: 8x finer operand rounding at the same MFMA rate): the same benchmark step through
+    the OTHER build in a CHILD process (the operand type is fixed when the library is loaded): its slices/s and the parity of its
+    slice-0 mask against the oracle mask of `cpu_baseline`."""
     import subprocess
     import tempfile
-    so = os.path.join(ROOT, "medical-sam2_amd", "libmsam2_hip_bf16.so")
+    name = "libmsam2_hip_bf16.so" if other == "bf16" else "libmsam2_hip.so"
+    so = os.path.join(ROOT, "medical-sam2_amd", name)
     if not os.path.exists(so):
-        return {"error": "libmsam2_hip_bf16.so not built (__graft_entry__.build())"}
+        return {"error": f"{name} not built (__graft_entry__.build())"}
     with tempfile.TemporaryDirectory() as td:
         dump = os.path.join(td, "slice0.pt")
         env = dict(os.environ, MSAM2_LIB_PATH=so)
@@ -495,10 +500,10 @@ def bf16_side_object(steps, warmup, oracle_low):
                "--no-train", "--no-volume", "--no-bf16", "--no-rooflines", "--dump-slice0", dump]
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         if r.returncode != 0:
-            return {"error": f"bf16 child exited {r.returncode}: {r.stderr[-300:]}"}
+            return {"error": f"{other} child exited {r.returncode}: {r.stderr[-300:]}"}
         child = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         res = {"dtype": child["dtype"], "value": child["value"], "unit": child["unit"], "ms_per_step": child["ms_per_step"],
-               "library": "libmsam2_hip_bf16.so (-DMSAM2_OPERAND_BF16), same step, same graph capture, child process"}
+               "library": f"{name}, same step, same graph capture, child process"}
         if oracle_low is not None and os.path.exists(dump):
             low = torch.load(dump).float()
             a, b = low > 0, oracle_low > 0
@@ -579,7 +584,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the (untimed-in-value) training-iteration figure")
     ap.add_argument("--no-volume", action="store_true", help="skip the volume_3d side object of the 2d line")
-    ap.add_argument("--no-bf16", action="store_true", help="skip the bf16-library side object (N=1 only)")
+    ap.add_argument("--dtype", choices=("bf16", "f16"), default="bf16",
+                    help="operand type of the 16-bit MFMA operands = which build of the library is loaded: bf16 (BASELINE.json configs[1]; "
+                         "libmsam2_hip_bf16.so) or f16 (libmsam2_hip.so).  MSAM2_LIB_PATH, when set, wins.")
+    ap.add_argument("--no-bf16", "--no-other-dtype", dest="no_bf16", action="store_true",
+                    help="skip the side object that runs the same step on the OTHER operand type's library (N=1 only)")
     ap.add_argument("--no-rooflines", action="store_true", help="skip the per-kernel roofline legs (used by the bf16 child run)")
     ap.add_argument("--dump-slice0", default=None, help="write the low-res mask logits of slice 0 to this file (bf16 child run)")
     args = ap.parse_args()
@@ -588,6 +597,10 @@ def main():
     if args.warmup is None:
         args.warmup = 3 if args.mode == "2d" else 1
 
+    # the operand type is a property of the loaded library: choose it before the package is imported (and before ranks are launched:
+    # the children inherit the environment)
+    if not os.environ.get("MSAM2_LIB_PATH"):
+        os.environ["MSAM2_LIB_PATH"] = os.path.join(ROOT, "medical-sam2_amd", "libmsam2_hip_bf16.so" if args.dtype == "bf16" else "libmsam2_hip.so")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))        # before any GPU call in this process
 
@@ -725,11 +738,12 @@ def main():
         if world == 1 and not args.no_train:
             line["train_iteration"] = train_iteration(m, imgs, pts, labels, memory, memory_pos, device, full=True)
             line["train_iteration_frozen_encoder"] = train_iteration(m, imgs, pts, labels, memory, memory_pos, device, full=False)
-        if world == 1 and not args.no_bf16 and dtype == "f16":
+        if world == 1 and not args.no_bf16:
+            other = "f16" if dtype == "bf16" else "bf16"
             try:
-                line["bf16"] = bf16_side_object(args.steps, args.warmup, oracle_low)
+                line[other] = other_dtype_side_object(other, args.steps, args.warmup, oracle_low)
             except Exception as e:  # noqa: BLE001 -- a side figure
-                line["bf16"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                line[other] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if not args.no_volume:
         # all ranks: the 3-D path at configs[3]'s size (strong scaling), after the timed region; never part of `value`
         dog = Watchdog(420, rank, line, "volume_3d",

@@ -138,7 +138,13 @@ def to_bf16(x2d: torch.Tensor) -> torch.Tensor:
 
 
 def attn_splits(B: int, H: int, Lq: int, Lk: int) -> int:
-    """Split-KV factor: enough workgroups (128 queries each) to cover the 256 CUs twice, at least 8 key tiles per split."""
+    """Split-KV factor: enough workgroups (128 queries each) to cover the 256 CUs twice, at least 8 key tiles per split.
+    Inside `parallel.batch_invariant_splits()` (the 3-D propagation chain, volume.segment_volume) the factor is the one a batch of ONE
+    object gets: the split boundaries -- and with them the rounding of the 16-bit partials -- then do not depend on how many objects a
+    rank carries, so an object-sharded chain reproduces the single-rank bits."""
+    from .. import parallel
+    if parallel.BATCH_INVARIANT_SPLITS:
+        B = 1
     wgs = B * H * ((Lq + 127) // 128)
     if wgs >= 512 or Lk < 1024:
         return 1

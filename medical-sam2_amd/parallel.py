@@ -182,14 +182,19 @@ def gather_slice_features(local: Dict[int, dict], slice_ids: List[int], owners: 
 class FeatureStream:
     """PIPELINED exchange of the non-conditioning slices' backbone features: instead of one up-front all-gather of
     every slice's features (4.3 GB per rank at 512 slices) that the propagation chain has to wait for, the slices travel in CHUNKS of
-    consecutive slices of one owner, each chunk as one asynchronous broadcast per feature level from the rank that encoded it, all
-    issued at once in slice order -- the order the chain consumes them in.  `get(t)` waits for the chunk of slice t only, so the chain
-    starts as soon as the first chunk has landed and the rest of the transfer runs under it (on RCCL's own stream).
+    consecutive slices of one owner, each chunk as one asynchronous broadcast per feature level from the rank that encoded it, issued
+    in slice order -- the order the chain consumes them in.  `get(t)` waits for the chunk of slice t only, so the chain starts as soon
+    as the first chunk has landed and the rest of the transfer runs under it (on RCCL's own stream).
+    BOUNDED: at most `window` chunks are allocated and in flight at any time -- chunk i + window is issued when chunk i has
+    been consumed -- so the peak is window x chunk slices (4 x 8 x 16.8 MB = 0.5 GB at 1024^2) instead of the whole volume's features;
+    every rank consumes the slices in the same order (the chain is sequential), so every rank issues the broadcasts in the same order.
+    `close()` (also the context-manager exit) waits for whatever is still in flight: a rank that stops consuming early leaves no
+    outstanding collective behind.
     local: this rank's {slice: {"backbone_fpn": [levels x [1,C,h,w]], "vision_pos_enc": [...]}}; slice_ids / owners: the global, ordered
     list of slices to exchange and the rank that encoded each.  Features travel channels-last; the position tables stay local."""
 
     def __init__(self, local: Dict[int, dict], slice_ids: List[int], owners: List[int], group=None, chunk: int = 8,
-                 pos_tables=None, device: Optional[torch.device] = None):
+                 pos_tables=None, device: Optional[torch.device] = None, window: int = 4):
         self.group, self.local, self.pos = group, dict(local), pos_tables
         self.rank = dist.get_rank(group)
         world = dist.get_world_size(group)
@@ -205,6 +210,7 @@ class FeatureStream:
         self.meta = next((m for m in objs if m is not None), None)
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        self.device = device
         # chunks: runs of consecutive list entries with one owner, at most `chunk` slices each
         self.chunks: List[dict] = []
         self.where: Dict[int, tuple] = {}
@@ -213,28 +219,40 @@ class FeatureStream:
             j = i
             while j < len(slice_ids) and owners[j] == owners[i] and j - i < chunk:
                 j += 1
-            ids, owner = slice_ids[i:j], owners[i]
-            ck = {"ids": ids, "owner": owner, "bufs": None, "works": [], "left": len(ids)}
-            if owner != self.rank or world > 1:
-                bufs = []
-                for (h, w, c) in self.meta:
-                    buf = torch.empty(len(ids), h, w, c, dtype=torch.float32, device=device)
-                    if owner == self.rank:
-                        for k, t in enumerate(ids):
-                            buf[k].copy_(_to_nhwc(local[t]["backbone_fpn"][len(bufs)])[0])
-                    src = dist.get_global_rank(group, owner) if group is not None else owner
-                    ck["works"].append(dist.broadcast(buf, src=src, group=group, async_op=True))
-                    bufs.append(buf)
-                ck["bufs"] = bufs                  # (the owner serves its own tensors from `local`; its slabs live until the sends are done)
+            ids = slice_ids[i:j]
             for k, t in enumerate(ids):
                 self.where[t] = (len(self.chunks), k)
-            self.chunks.append(ck)
+            self.chunks.append({"ids": ids, "owner": owners[i], "bufs": None, "works": [], "left": len(ids)})
             i = j
+        self.issued = 0
+        self.peak_chunks_alive = 0
+        for _ in range(max(1, int(window))):
+            self._issue_next()
+
+    def _issue_next(self):
+        """allocate the next chunk's slabs and start its broadcasts (the owner fills its slabs from `local` first)"""
+        if self.issued >= len(self.chunks):
+            return
+        ck = self.chunks[self.issued]
+        self.issued += 1
+        bufs = []
+        for lvl, (h, w, c) in enumerate(self.meta):
+            buf = torch.empty(len(ck["ids"]), h, w, c, dtype=torch.float32, device=self.device)
+            if ck["owner"] == self.rank:
+                for k, t in enumerate(ck["ids"]):
+                    buf[k].copy_(_to_nhwc(self.local[t]["backbone_fpn"][lvl])[0])
+            src = dist.get_global_rank(self.group, ck["owner"]) if self.group is not None else ck["owner"]
+            ck["works"].append(dist.broadcast(buf, src=src, group=self.group, async_op=True))
+            bufs.append(buf)
+        ck["bufs"] = bufs                      # (the owner serves its own tensors from `local`; its slabs live until the sends are done)
+        self.peak_chunks_alive = max(self.peak_chunks_alive, sum(1 for c in self.chunks if c["bufs"] is not None))
 
     def get(self, t: int) -> dict:
-        """features of slice t (waits for its chunk if it has not landed yet); call once per slice"""
+        """features of slice t (waits for its chunk if it has not landed yet); call once per slice, in the announced order"""
         ci, k = self.where[t]
         ck = self.chunks[ci]
+        while self.issued <= ci:               # (a consumer that skipped slices: catch up, in order)
+            self._issue_next()
         for w in ck["works"]:
             w.wait()
         ck["works"] = []
@@ -247,20 +265,40 @@ class FeatureStream:
             out["vision_pos_enc"] = self.pos
         if ck["left"] == 0:
             ck["bufs"] = None                                                       # the views handed out keep their storage alive
+            self._issue_next()                                                      # keep `window` chunks in flight
         return out
 
     def pop(self, t: int) -> dict:
         return self.get(t)
 
+    def close(self):
+        """wait for every broadcast that is in flight (every rank issued the same ones) and drop the slabs"""
+        for ck in self.chunks[: self.issued]:
+            for w in ck["works"]:
+                w.wait()
+            ck["works"] = []
+            ck["bufs"] = None
 
-def gather_object_shards(masks: Dict[int, torch.Tensor], slice_ids: List[int], n_obj: int, group=None) -> Dict[int, torch.Tensor]:
-    """Object-sharded chain -> full object batch on every rank: masks[t] is this rank's [n_local, 1, h, w] share
-    (`shard_range(n_obj, rank, world)`) for every t in slice_ids; one all-gather of a [len(slice_ids), cap, 1, h, w] slab."""
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+        return False
+
+
+def gather_object_shards(masks: Dict[int, torch.Tensor], slice_ids: List[int], n_obj: int, group=None, layout=None) -> Dict[int, torch.Tensor]:
+    """Object-sharded chain -> full object batch on every rank: masks[t] is this rank's [n_local, 1, h, w] share for every t in
+    slice_ids; one all-gather of a [len(slice_ids), cap, 1, h, w] slab.  layout (`chain_layout`): the object range of every rank; the
+    ranks of one chain group hold identical copies and the group's FIRST rank's copy is taken (default: one rank per group,
+    `shard_range(n_obj, rank, world)`)."""
     if not _is_dist(group):
         return dict(masks)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    shares = [shard_range(n_obj, r, world) for r in range(world)]
-    cap = max(e - b for b, e in shares)
+    if layout is None:
+        layout = [(shard_range(n_obj, r, world), (r, r + 1)) for r in range(world)]
+    shares = [objs if r == span[0] else (0, 0) for r, (objs, span) in enumerate(layout)]      # (begin, end) taken from rank r
+    cap = max(e - b for (b, e), _ in layout)
     if not slice_ids:
         return {}
     m0 = masks[slice_ids[0]]
@@ -269,7 +307,66 @@ def gather_object_shards(masks: Dict[int, torch.Tensor], slice_ids: List[int], n
         slab[i, : masks[t].shape[0]].copy_(masks[t])
     out = [torch.empty_like(slab) for _ in range(world)]
     dist.all_gather(out, slab, group=group)
-    return {t: torch.cat([out[r][i, : e - b] for r, (b, e) in enumerate(shares)], dim=0) for i, t in enumerate(slice_ids)}
+    return {t: torch.cat([out[r][i, : e - b] for r, (b, e) in enumerate(shares) if e > b], dim=0) for i, t in enumerate(slice_ids)}
+
+
+# set by `batch_invariant_splits()`: modeling.common.attn_splits then sizes the split-KV factor for a batch of one object
+BATCH_INVARIANT_SPLITS = False
+
+
+class batch_invariant_splits:
+    """context: the attention kernels' split-KV factor does not depend on the object batch (see modeling.common.attn_splits)"""
+
+    def __enter__(self):
+        global BATCH_INVARIANT_SPLITS
+        self.prev, BATCH_INVARIANT_SPLITS = BATCH_INVARIANT_SPLITS, True
+        return self
+
+    def __exit__(self, *a):
+        global BATCH_INVARIANT_SPLITS
+        BATCH_INVARIANT_SPLITS = self.prev
+        return False
+
+
+def chain_layout(n_obj: int, world: int, shard_objects: bool = True) -> List[Tuple[Tuple[int, int], Tuple[int, int]]]:
+    """How the sequential propagation chain uses `world` ranks for `n_obj` objects: G = min(n_obj, world) GROUPS
+    of consecutive ranks; group g carries the objects shard_range(n_obj, g, G) and owns the ranks shard_range(world, g, G), which split
+    the memory cross-attention's KEY range among themselves (`KVSplit` on the group's sub-communicator).
+      n_obj >= world : G = world, one rank per group -> pure object sharding (no key split);
+      n_obj == 1     : G = 1, all ranks in one group -> pure key split;
+      1 < n_obj < world (configs[2]'s n = 2..7 objects on 8 GPUs): one object per group, 8 // n or 8 // n + 1 ranks per object --
+      the HYBRID the round-3 build lacked (it fell back to the pure key split and carried every object on every rank).
+    Returns, per rank, ((object begin, end), (first rank, one past the last rank of its group)).  shard_objects=False: one group."""
+    G = min(n_obj, world) if shard_objects else 1
+    out = []
+    for g in range(G):
+        rb, re = shard_range(world, g, G)
+        out += [(shard_range(n_obj, g, G), (rb, re))] * (re - rb)
+    return out
+
+
+_SUBGROUPS: Dict[tuple, object] = {}
+
+
+def chain_subgroup(layout, group=None):
+    """The sub-communicator of this rank's chain group (None for a group of one rank; `group` itself when one group spans the world).
+    `dist.new_group` is collective over the parent -- every rank creates EVERY group of the layout, in the same order -- and RCCL
+    communicators are expensive to build, so they are cached per (parent, member ranks) for the life of the process."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    spans = sorted({span for _, span in layout})
+    if len(spans) == 1 and spans[0] == (0, world):
+        return group
+    mine = None
+    for (rb, re) in spans:
+        if re - rb < 2:
+            continue
+        members = tuple(dist.get_global_rank(group, r) if group is not None else r for r in range(rb, re))
+        key = (id(group) if group is not None else None, members)
+        if key not in _SUBGROUPS:
+            _SUBGROUPS[key] = dist.new_group(ranks=list(members))
+        if rb <= rank < re:
+            mine = _SUBGROUPS[key]
+    return mine
 
 
 _KV_SPLIT = None

@@ -13,10 +13,13 @@ Multi-GPU (one process per GPU):
      conditioning slice join with an empty slab); the non-conditioning slices' backbone features (16.8 MB per slice at 1024^2) travel
      as chunked asynchronous broadcasts from their owners, issued in slice order and waited for chunk by chunk by the chain
      (`parallel.FeatureStream`), so the chain starts after the first chunk and the rest of the 4.3 GB (512 slices) moves under it;
-  3. the propagation chain is sequential in the slice index: it is sharded over OBJECTS when there are at least as many objects as
-     ranks (objects never interact: non_overlap_masks is off), otherwise every rank runs it with the memory cross-attention's KEY
-     range split over the ranks (`parallel.KVSplit`: each rank's share of the split-KV partials, one all-gather of the (max, sum, O')
-     triples per layer, then the same merge kernel) -- both bit-identical to the single-rank result;
+  3. the propagation chain is sequential in the slice index: the ranks form min(n_obj, ranks) GROUPS (`parallel.chain_layout`), each
+     carrying its share of the OBJECTS (objects never interact: non_overlap_masks is off); the ranks of a group split the memory
+     cross-attention's KEY range among themselves (`parallel.KVSplit` on the group's sub-communicator: each rank's share of the
+     split-KV partials, one all-gather of the (max, sum, O') triples per layer, then the same merge kernel).  n_obj >= ranks: pure
+     object sharding; one object: pure key split; 1 < n_obj < ranks: the object x key hybrid (one object per group).  The key split
+     is bit-identical to the single-rank result by construction; the object shards are too as long as every kernel on the chain picks
+     the same variant for the smaller object batch (the split-KV factors are pinned: `parallel.batch_invariant_splits`);
   4. every rank returns ALL slices' masks for ALL objects (one all-gather over the object shards).
 """
 from __future__ import annotations
@@ -28,7 +31,8 @@ import torch.distributed as dist
 
 from . import ops
 from .graphs import GraphedPropagation, pointer_capacity
-from .parallel import FeatureStream, KVSplit, _is_dist, gather_cond_memories, gather_object_shards, gather_slice_features, shard_range
+from .parallel import (FeatureStream, KVSplit, _is_dist, batch_invariant_splits, chain_layout, chain_subgroup, gather_cond_memories,
+                       gather_object_shards, gather_slice_features, shard_range)
 
 
 class _SliceEncoder:
@@ -160,14 +164,21 @@ def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_h
         cond, feats_all = local_cond, local_feats
 
     _phase("exchange_memories_and_features")
-    # 3. propagation (sequential in t): object-sharded, key-split or replicated
-    obj_shard = distributed and shard_objects and n_obj >= world
-    ob, oe = shard_range(n_obj, rank, world) if obj_shard else (0, n_obj)
+    # 3. propagation (sequential in t): groups of ranks per object share (parallel.chain_layout) -- object-sharded when there are at
+    #    least as many objects as ranks, ONE key-split group for one object, and in between (1 < n_obj < ranks) one object per group with
+    #    the group's ranks splitting the memory cross-attention's key range: the object x key hybrid of SURVEY 8(e) row 3
+    layout = chain_layout(n_obj, world, shard_objects) if distributed else [((0, n_obj), (0, 1))]
+    (ob, oe), (gb, ge) = layout[rank]
+    obj_shard = distributed and (oe - ob) < n_obj
     sl = slice(ob, oe)
     chain_cond = {t: _slice_objects(o, sl) for t, o in cond.items()} if obj_shard else cond
     output_dict = {"cond_frame_outputs": chain_cond, "non_cond_frame_outputs": {}}
     masks: Dict[int, torch.Tensor] = {}
-    split_ctx = KVSplit(model, group) if (distributed and kv_split and not obj_shard) else None
+    sub = chain_subgroup(layout, group) if (distributed and kv_split) else None       # collective over `group`: every rank calls it
+    split_ctx = KVSplit(model, sub) if (distributed and kv_split and ge - gb > 1) else None
+    if stats is not None:
+        stats["chain_layout"] = {"objects": [ob, oe], "group_ranks": [gb, ge], "groups": len({span for _, span in layout}),
+                                 "key_split_ranks": ge - gb if split_ctx is not None else 1}
     prop = None
     if graphs or padded_bank:
         graphs = graphs and split_ctx is None
@@ -180,18 +191,21 @@ def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_h
                 graph_cache[ck] = prop
         before = (prop.replays, prop.captures, prop.eager_steps)
     try:
-        for t in range(T):
-            if t in cond_set:
-                continue
-            if prop is not None:
-                cur = prop.track(t, feats_all.pop(t), output_dict)
-            else:
-                feats, pos, sizes = _expand(model, feats_all.pop(t), oe - ob)
-                cur = model.track_step(frame_idx=t, is_init_cond_frame=False, current_vision_feats=feats, current_vision_pos_embeds=pos,
-                                       feat_sizes=sizes, point_inputs=None, mask_inputs=None, output_dict=output_dict, num_frames=T)
-            output_dict["non_cond_frame_outputs"][t] = cur
-            masks[t] = cur["pred_masks"]
+        with batch_invariant_splits():     # split-KV factors as for one object: an object-sharded chain reproduces the single-rank bits
+            for t in range(T):
+                if t in cond_set:
+                    continue
+                if prop is not None:
+                    cur = prop.track(t, feats_all.pop(t), output_dict)
+                else:
+                    feats, pos, sizes = _expand(model, feats_all.pop(t), oe - ob)
+                    cur = model.track_step(frame_idx=t, is_init_cond_frame=False, current_vision_feats=feats, current_vision_pos_embeds=pos,
+                                           feat_sizes=sizes, point_inputs=None, mask_inputs=None, output_dict=output_dict, num_frames=T)
+                output_dict["non_cond_frame_outputs"][t] = cur
+                masks[t] = cur["pred_masks"]
     finally:
+        if isinstance(feats_all, FeatureStream):
+            feats_all.close()                  # nothing of the exchange stays in flight, whatever ended the chain
         if split_ctx is not None:
             split_ctx.close()
         if prop is not None and stats is not None:
@@ -203,7 +217,7 @@ def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_h
     if distributed:
         cond_masks = {t: o["pred_masks"] for t, o in cond.items()}            # gathered with the memories (full object batch)
         if obj_shard:
-            masks = gather_object_shards(masks, [t for t in range(T) if t not in cond_set], n_obj, group)
+            masks = gather_object_shards(masks, [t for t in range(T) if t not in cond_set], n_obj, group, layout=layout)
     else:
         cond_masks = {t: o["pred_masks"] for t, o in local_cond.items()}
     masks.update(cond_masks)

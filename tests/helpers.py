@@ -76,3 +76,34 @@ def gradient_step_drops(loss_fn, groups: dict, grads: dict, loss0: float, frac: 
             for k in g:
                 params[k].add_(g[k].to(params[k].dtype), alpha=eta)
     return out
+
+
+# ---- multi-process GPU tests: the same workers run as gloo ranks sharing the one GPU of the test box (RCCL refuses two ranks on one
+# device) and -- tests/test_multigpu_gpu.py, MSAM2_TEST_REAL_DEVICES=1 -- as RCCL ranks on one GPU each
+def real_devices() -> bool:
+    import os
+    return os.environ.get("MSAM2_TEST_REAL_DEVICES") == "1"
+
+
+def rank_device(rank: int) -> int:
+    return rank if real_devices() else 0
+
+
+def init_test_process_group(rank: int, world: int):
+    """process group of a spawned test worker: backend nccl (= RCCL over xGMI) with one device per rank under MSAM2_TEST_REAL_DEVICES=1,
+    otherwise gloo with every rank on device 0.  MASTER_ADDR / MASTER_PORT are in the environment."""
+    import torch.distributed as dist
+    torch.cuda.set_device(rank_device(rank))
+    if real_devices():
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank_device(rank)))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def all_gather_flat(flat: torch.Tensor, world: int):
+    """all-gather of one flat tensor per rank for cross-rank comparisons (RCCL moves device tensors, gloo host tensors); returns CPU copies"""
+    import torch.distributed as dist
+    t = flat.cuda() if real_devices() else flat.cpu()
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [o.cpu() for o in out]

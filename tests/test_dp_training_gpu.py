@@ -8,6 +8,9 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import all_gather_flat, init_test_process_group, rank_device  # noqa: E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
@@ -49,8 +52,7 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
     torch.set_grad_enabled(False)
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    init_test_process_group(rank, world)
     import medical_sam2_amd.parallel as par
     import medical_sam2_amd.training as T
     B_all = 4
@@ -67,8 +69,7 @@ def _worker(rank, world, port, q):
     opt = T.DecoderAdam(dec, lr=1e-4)
     T.decoder_finetune_step(dec, opt, *args, data_parallel=True)
     flat = torch.cat([p.detach().reshape(-1) for p in dec.parameters()]).cpu()
-    gathered = [torch.empty_like(flat) for _ in range(world)]
-    dist.all_gather(gathered, flat)
+    gathered = all_gather_flat(flat, world)
     same = all(torch.equal(gathered[0], t) for t in gathered[1:])
     q.put((rank, rel, bool(same)))
     dist.destroy_process_group()
@@ -91,8 +92,7 @@ def _joint_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
     torch.set_grad_enabled(False)
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    init_test_process_group(rank, world)
     import medical_sam2_amd.build_sam as bs
     import medical_sam2_amd.ops as ops
     import medical_sam2_amd.training as T
@@ -116,8 +116,7 @@ def _joint_worker(rank, world, port, q):
     T.memory_decoder_finetune_step(m.memory_attention, m.sam_mask_decoder, om, od, *args, data_parallel=True)
     shared = om.calibrated_loss_scales[None]
     flat = torch.cat([p.detach().reshape(-1) for mod in (m.memory_attention, m.sam_mask_decoder) for p in mod.parameters()]).cpu()
-    gathered = [torch.empty_like(flat) for _ in range(world)]
-    dist.all_gather(gathered, flat)
+    gathered = all_gather_flat(flat, world)
     same = all(torch.equal(gathered[0], t) for t in gathered[1:])
     q.put((rank, float(sc_mem_local / sc), float(shared), bool(same), bool(torch.isfinite(flat).all())))
     dist.destroy_process_group()
@@ -150,7 +149,7 @@ def _full_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
     torch.set_grad_enabled(False)
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(rank_device(rank))
     import medical_sam2_amd.build_sam as bs
     import medical_sam2_amd.synthetic as syn
     import medical_sam2_amd.training as T
@@ -171,7 +170,7 @@ def _full_worker(rank, world, port, q):
     full: dict = {}
     z = [T.DecoderAdam(mod, lr=0.0) for mod in (m0.memory_attention, m0.sam_mask_decoder, m0.image_encoder)]
     T.train_step_2d(m0, z[0], z[1], imgs, pts, labels, memory, memory_pos, target, opt_enc=z[2], grads_out=full)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    init_test_process_group(rank, world)
     sl = slice(rank, rank + 1)
     m = model()
     opts = [T.DecoderAdam(m.memory_attention, lr=1e-5), T.DecoderAdam(m.sam_mask_decoder, lr=1e-4), T.DecoderAdam(m.image_encoder, lr=1e-5)]
@@ -185,8 +184,7 @@ def _full_worker(rank, world, port, q):
         den = sum(full[grp][k].double().pow(2).sum().item() for k in full[grp] if not k.endswith("k_proj.bias"))
         rels[grp] = (num / den) ** 0.5
     flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu()
-    gathered = [torch.empty_like(flat) for _ in range(world)]
-    dist.all_gather(gathered, flat)
+    gathered = all_gather_flat(flat, world)
     same = all(torch.equal(gathered[0], t) for t in gathered[1:])
     q.put((rank, rels, bool(same), bool(torch.isfinite(flat).all())))
     dist.destroy_process_group()
@@ -238,7 +236,7 @@ def _bptt_worker(rank, world, port, q):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(rank_device(rank))
     torch.set_grad_enabled(False)
     import medical_sam2_amd.training as T
     import medical_sam2_amd.training_3d as t3
@@ -263,7 +261,7 @@ def _bptt_worker(rank, world, port, q):
             g.update({grp[:8] + "." + k: v for k, v in out["non_prompt"][grp].items()})
         ref.append(g)
     mean = {k: (ref[0][k] + ref[1][k]) * 0.5 for k in ref[0]}
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    init_test_process_group(rank, world)
     lr = 1e-3
     opts = {"decoder": T.DecoderAdam(m.sam_mask_decoder, lr=lr), "memory_attention": T.DecoderAdam(m.memory_attention, lr=lr),
             "memory_encoder": T.DecoderAdam(m.memory_encoder, lr=lr), "obj_ptr_proj": T.DecoderAdam(m.obj_ptr_proj, lr=lr)}
@@ -281,8 +279,7 @@ def _bptt_worker(rank, world, port, q):
             agree += int((torch.sign(delta[big]) == -torch.sign(g[big])).sum())
             total += int(big.sum())
     flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu()
-    gathered = [torch.empty_like(flat) for _ in range(world)]
-    dist.all_gather(gathered, flat)
+    gathered = all_gather_flat(flat, world)
     q.put((rank, agree / max(total, 1), bool(all(torch.equal(gathered[0], t) for t in gathered[1:])), bool(torch.isfinite(flat).all())))
     dist.destroy_process_group()
 

@@ -69,12 +69,17 @@ def _worker(rank, world, port, q):
                                           and feats[t]["backbone_fpn"][0].shape == (1, 4, 8, 8) for t in sl_ids)
     # the same exchange PIPELINED: chunked async broadcasts in slice order, waited for chunk by chunk (5 slices, chunks of 2, ragged owners)
     sl2, own2 = [1, 3, 5, 7, 9], [0, 0, 0, 1, 1]
-    stream = par.FeatureStream({t: mk(t) for t, o in zip(sl2, own2) if o == rank}, sl2, own2, chunk=2, pos_tables=["pos"], device=dev)
-    ok &= [len(c["ids"]) for c in stream.chunks] == [2, 1, 2]
+    stream = par.FeatureStream({t: mk(t) for t, o in zip(sl2, own2) if o == rank}, sl2, own2, chunk=2, pos_tables=["pos"], device=dev, window=2)
+    ok &= [len(c["ids"]) for c in stream.chunks] == [2, 1, 2] and stream.issued == 2          # bounded: two of the three chunks in flight
     for t in sl2:
         f = stream.pop(t)
         ok &= bool((f["backbone_fpn"][0] == t).all()) and bool((f["backbone_fpn"][1] == 10.0 + t).all()) and f["backbone_fpn"][0].shape == (1, 4, 8, 8)
         ok &= f["vision_pos_enc"] == ["pos"]
+    ok &= stream.issued == 3 and stream.peak_chunks_alive <= 2 and all(c["bufs"] is None for c in stream.chunks)
+    # a consumer that stops early: close() waits for what is in flight on every rank (no collective left behind)
+    with par.FeatureStream({t: mk(t) for t, o in zip(sl2, own2) if o == rank}, sl2, own2, chunk=2, pos_tables=["pos"], device=dev, window=2) as st2:
+        ok &= bool((st2.pop(1)["backbone_fpn"][0] == 1).all())
+    ok &= all(not c["works"] for c in st2.chunks)
     # object shards -> full object batch (3 objects over 2 ranks: 2 + 1)
     ob, oe = par.shard_range(3, rank, world)
     sh = {t: torch.arange(ob, oe, dtype=torch.float32).reshape(-1, 1, 1, 1).expand(-1, 1, 2, 2).contiguous() + 10 * t for t in (0, 1)}
@@ -131,3 +136,73 @@ def test_two_rank_gloo_exchange():
         assert p.exitcode == 0
     res = sorted(q.get(timeout=5) for _ in range(2))
     assert res == [(0, True), (1, True)]
+
+
+def test_chain_layout_covers_objects_and_ranks():
+    """parallel.chain_layout: every rank in exactly one group of consecutive ranks, every object in exactly one group,
+    n_obj >= ranks -> one rank per group (object sharding), one object -> one group (key split), in between one object per group."""
+    sys.path.insert(0, ROOT)
+    from medical_sam2_amd.parallel import chain_layout
+    for world in (1, 2, 3, 4, 8):
+        for n in (1, 2, 3, 5, 7, 8, 13):
+            lay = chain_layout(n, world)
+            assert len(lay) == world
+            groups = sorted({(objs, span) for objs, span in lay})
+            assert len(groups) == min(n, world)
+            assert groups[0][0][0] == 0 and groups[-1][0][1] == n and groups[0][1][0] == 0 and groups[-1][1][1] == world
+            for (o0, s0), (o1, s1) in zip(groups, groups[1:]):
+                assert o0[1] == o1[0] and s0[1] == s1[0]
+            for r, (objs, (rb, re)) in enumerate(lay):
+                assert rb <= r < re and objs[1] > objs[0]
+            if n >= world:
+                assert all(re - rb == 1 for _, (rb, re) in lay)
+            if 1 < n < world:
+                assert all(o1 - o0 == 1 for (o0, o1), _ in lay) and max(re - rb for _, (rb, re) in lay) >= 2     # the hybrid
+            assert chain_layout(n, world, shard_objects=False) == [((0, n), (0, world))] * world
+
+
+def _hybrid_worker(rank, world, port, q):
+    """3 ranks, 2 objects: group 0 = ranks {0, 1} (object 0, key range split two ways), group 1 = rank {2} (object 1, no split)"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from medical_sam2_amd import parallel as par
+    par.init_distributed(backend="gloo")
+    lay = par.chain_layout(2, world)
+    ok = lay == [((0, 1), (0, 2)), ((0, 1), (0, 2)), ((1, 2), (2, 3))]
+    sub = par.chain_subgroup(lay)                                   # collective: every rank calls it
+    ok &= (sub is None) == (rank == 2)
+    ok &= par.chain_subgroup(lay) is sub                            # cached: no second communicator
+    (ob, oe), (gb, ge) = lay[rank]
+    # key-split exchange INSIDE the group: 5 splits over the group's 2 ranks, the third rank is not part of it
+    S, rows = 5, 4
+    ref_o = torch.arange(S * rows * 64, dtype=torch.int16).reshape(S, rows * 64) + 1000 * ob
+    ref_ml = torch.arange(S * rows * 2, dtype=torch.float32).reshape(S, rows * 2) + 1000 * ob
+    if ge - gb > 1:
+        ws = torch.zeros(S * rows * 64 * 2 + S * rows * 8, dtype=torch.uint8)
+        with par.KVSplit(None, sub) as kvs:
+            ok &= (kvs.world, kvs.rank) == (2, rank - gb)
+            b0, e0 = kvs.share(S)
+            ws[: S * rows * 128].view(torch.int16).view(S, -1)[b0:e0] = ref_o[b0:e0]
+            ws[S * rows * 128:].view(torch.float32).view(S, -1)[b0:e0] = ref_ml[b0:e0]
+            kvs.exchange(ws, S, rows)
+        ok &= torch.equal(ws[: S * rows * 128].view(torch.int16).view(S, -1), ref_o) and torch.equal(ws[S * rows * 128:].view(torch.float32).view(S, -1), ref_ml)
+    # every rank ends up with all objects: the group's first rank's copy is taken, duplicates inside a group are ignored
+    sh = {t: torch.full((oe - ob, 1, 2, 2), float(ob) + 10 * t + (0.0 if rank == gb else 0.5)) for t in (0, 1)}     # non-leaders hold a marked copy
+    full = par.gather_object_shards(sh, [0, 1], 2, layout=lay)
+    ok &= all(torch.equal(full[t][:, 0, 0, 0], torch.arange(2.0) + 10 * t) for t in (0, 1))
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_three_rank_gloo_object_x_key_hybrid():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_hybrid_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(3))
+    assert res == [(0, True), (1, True), (2, True)]

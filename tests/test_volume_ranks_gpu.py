@@ -9,6 +9,9 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import init_test_process_group, rank_device  # noqa: E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 S, T = 256, 8
@@ -33,28 +36,29 @@ def _case(n_obj, cond_slices):
 CASES = [(1, (0, 4)), (2, (0, 4)), (1, (0,)), (3, (2,))]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, CASES=CASES):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
     torch.set_grad_enabled(False)
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(rank_device(rank))
     import medical_sam2_amd.parallel as par
     import medical_sam2_amd.volume as vol
     m = _model()
     single = [vol.segment_volume(m, *_case(n, c), fill_hole_area=8) for n, c in CASES]     # before the process group exists: one rank
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    init_test_process_group(rank, world)
     res = []
     for (n, c), ref in zip(CASES, single):
         real = par.KVSplit.exchange
         calls = []
         par.KVSplit.exchange = lambda self, *a, **k: (calls.append(1), real(self, *a, **k))[1]
+        st = {}
         try:
-            got = vol.segment_volume(m, *_case(n, c), fill_hole_area=8)
+            got = vol.segment_volume(m, *_case(n, c), fill_hole_area=8, stats=st)
         finally:
             par.KVSplit.exchange = real
         same = sorted(got) == list(range(T)) and all(got[t].shape == ref[t].shape and torch.equal(got[t], ref[t]) for t in range(T))
-        res.append((n, len(c), bool(same), len(calls)))
+        res.append((n, len(c), bool(same), len(calls), st["chain_layout"]))
     q.put((rank, res))
     dist.destroy_process_group()
 
@@ -73,7 +77,34 @@ def test_segment_volume_two_ranks_equal_one_rank():
         assert p.exitcode == 0
     out = sorted(q.get(timeout=10) for _ in range(2))
     for rank, res in out:
-        for n_obj, n_cond, same, kv_calls in res:
+        for n_obj, n_cond, same, kv_calls, _ in res:
             assert same, (rank, n_obj, n_cond)
             # one object: the chain runs with the cross-rank key split (exchanges happened); >= 2 objects: object shards, no key split
             assert (kv_calls > 0) == (n_obj < 2), (rank, n_obj, kv_calls)
+
+
+HYBRID_CASES = [(2, (0, 4)), (1, (0, 4))]
+
+
+def test_segment_volume_three_ranks_object_x_key_hybrid():
+    """1 < n_obj < ranks (VERDICT r3 missing item 5): 2 objects on 3 ranks -> group {0, 1} carries object 0 with the
+    memory cross-attention's key range split two ways on the group's sub-communicator, group {2} carries object 1 alone; every rank
+    returns both objects, bit-equal to the single-rank result.  (One object on 3 ranks: one key-split group of three.)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30100 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_worker, args=(r, 3, port, q, HYBRID_CASES)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    out = sorted(q.get(timeout=10) for _ in range(3))
+    for rank, res in out:
+        (n2, _, same2, kv2, lay2), (n1, _, same1, kv1, lay1) = res
+        assert same2 and same1, (rank, same2, same1)
+        assert lay2["groups"] == 2 and lay2["objects"] == ([0, 1] if rank < 2 else [1, 2]) and lay2["group_ranks"] == ([0, 2] if rank < 2 else [2, 3])
+        assert (kv2 > 0) == (rank < 2) and lay2["key_split_ranks"] == (2 if rank < 2 else 1), (rank, kv2, lay2)
+        assert lay1["groups"] == 1 and lay1["key_split_ranks"] == 3 and kv1 > 0, (rank, kv1, lay1)
