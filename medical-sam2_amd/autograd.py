@@ -18,7 +18,7 @@ module and call -- this path is eager, not graph-captured) and are un-scaled in 
 
 Not differentiated (as on the explicit path): the prompt encoder (no optimiser of the reference's 3-D loop trains it; it
 runs under `torch.no_grad()` in the 2-D loop), the IoU / object-score heads (no loss of either loop reaches them through the mask
-logits: a gradient arriving there raises), a mask PROMPT's pointer path (`_use_mask_as_output` is evaluated as a constant).
+logits: a gradient arriving there RAISES -- `_RaiseOnGrad` -- instead of being dropped), a mask PROMPT's pointer path (`_use_mask_as_output` is evaluated as a constant).
 """
 from __future__ import annotations
 
@@ -50,6 +50,37 @@ def _named(module) -> List[str]:
     return [n for n, _ in module.named_parameters()]
 
 
+def _stamp(ctx, params):
+    """remember the in-place version of every parameter at forward time (see `_check`)"""
+    ctx.param_versions = tuple(p._version for p in params)
+
+
+def _check(ctx, params, what: str):
+    """The explicit backward passes re-read the module's CURRENT weights (the decoder's even recomputes its forward from them).  torch's
+    own autograd raises when a tensor saved for backward was modified in place; this bridge does the same instead of silently
+    differentiating a different function: an optimiser step between a module's forward and its backward is an error."""
+    now = tuple(p._version for p in params)
+    if now != ctx.param_versions:
+        n = sum(1 for a, b in zip(now, ctx.param_versions) if a != b)
+        raise RuntimeError(f"{what}: {n} parameter(s) were modified in place (an optimiser step?) between this module's forward and its "
+                           "backward; the HIP backward reads the current weights, so the gradient would belong to a different function")
+
+
+class _RaiseOnGrad(torch.autograd.Function):
+    """identity whose backward raises: outputs that the HIP path does not differentiate (`mark_non_differentiable` dropped a
+    gradient arriving there silently, so a loss term on the IoU prediction trained its head with zero gradient and no diagnostic)"""
+
+    @staticmethod
+    def forward(ctx, x, what):
+        ctx.what = what
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        raise RuntimeError(f"a gradient reached {ctx.what}, which the HIP backward does not differentiate (DESIGN.md 7.4): no loss of the "
+                           "reference's 2-D / 3-D training loops does; detach() the value if the term is meant as a constant")
+
+
 def _param_grads(names: List[str], params, grads: Dict[str, torch.Tensor], inv: float):
     out = []
     for n, p in zip(names, params):
@@ -68,6 +99,7 @@ class MemoryAttentionFn(torch.autograd.Function):
             y, state = bwd.memory_attention_forward_saved(module, curr.detach(), curr_pos.detach(), memory.detach().to(F32),
                                                           memory_pos.detach().to(F32), int(n_ptr_tok), dropout=module.next_dropout())
         ctx.module, ctx.state, ctx.names, ctx.params = module, state, _named(module), params
+        _stamp(ctx, params)
         ctx.set_materialize_grads(False)
         return y
 
@@ -75,6 +107,7 @@ class MemoryAttentionFn(torch.autograd.Function):
     def backward(ctx, dy):
         if dy is None:
             return (None,) * (6 + len(ctx.params))
+        _check(ctx, ctx.params, "MemoryAttention")
         with torch.no_grad():
             s = _pow2(dy)
             st = dict(ctx.state)
@@ -103,16 +136,19 @@ class MaskDecoderFn(torch.autograd.Function):
             masks, ious, tokens, obj = dec.predict_masks_tokens(src_c, pe.detach(), sp, f0_16, f1_16, B, h, w)
         ctx.args = (dec, src_c, pe.detach(), sp, f0_16, f1_16, B, h, w)
         ctx.names, ctx.params = _named(dec), params
+        _stamp(ctx, params)
         ctx.need_hr = f0.requires_grad or f1.requires_grad
         ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(ious, obj)
         return masks, ious, tokens.contiguous(), obj
 
     @staticmethod
     def backward(ctx, d_masks, d_ious, d_tokens, d_obj):
         n_in = 9 + len(ctx.params)
+        if d_ious is not None or d_obj is not None:     # (`mask_decoder` below wraps both outputs so that this is reported at the source)
+            raise RuntimeError("MaskDecoder: a gradient reached the IoU prediction / object-score logits, which the HIP backward does not differentiate")
         if d_masks is None and d_tokens is None:
             return (None,) * n_in
+        _check(ctx, ctx.params, "MaskDecoder")
         dec = ctx.args[0]
         with torch.no_grad():
             dev = ctx.args[1].device
@@ -148,7 +184,10 @@ class MaskDecoderFn(torch.autograd.Function):
 
 
 def mask_decoder(dec, src_tokens, pe_tokens, sparse, f0_tokens, f1_tokens, B: int, h: int, w: int):
-    return MaskDecoderFn.apply(dec, B, h, w, src_tokens, pe_tokens, sparse, f0_tokens, f1_tokens, *tuple(dec.parameters()))
+    masks, ious, tokens, obj = MaskDecoderFn.apply(dec, B, h, w, src_tokens, pe_tokens, sparse, f0_tokens, f1_tokens, *tuple(dec.parameters()))
+    # the two heads the HIP backward does not differentiate: usable as values (comparisons, selection, logging, .detach()), an error as
+    # soon as a loss back-propagates into them
+    return masks, _RaiseOnGrad.apply(ious, "the IoU prediction head"), tokens, _RaiseOnGrad.apply(obj, "the object-score head")
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -164,6 +203,7 @@ class MemoryEncoderFn(torch.autograd.Function):
             y = enc.run(pix, m, mode, sc, bi, B, H, W)
         ctx.args = (enc, pix, m, mode, sc, bi, B, H, W)
         ctx.names, ctx.params = _named(enc), params
+        _stamp(ctx, params)
         ctx.set_materialize_grads(False)
         return nchw_view(y, B, H, W)
 
@@ -171,6 +211,7 @@ class MemoryEncoderFn(torch.autograd.Function):
     def backward(ctx, dy):
         if dy is None:
             return (None,) * (9 + len(ctx.params))
+        _check(ctx, ctx.params, "MemoryEncoder")
         from .modeling.common import tokens_of
         enc, pix, m, mode, sc, bi, B, H, W = ctx.args
         with torch.no_grad():
@@ -192,6 +233,7 @@ class TokenMLPFn(torch.autograd.Function):
             y = mlp.run_tokens(t)
             ctx.tok16 = ops.add_cast(t.unsqueeze(0), None, 1.0, OP16)[0]
         ctx.mlp, ctx.names, ctx.params = mlp, _named(mlp), params
+        _stamp(ctx, params)
         ctx.set_materialize_grads(False)
         return y
 
@@ -199,6 +241,7 @@ class TokenMLPFn(torch.autograd.Function):
     def backward(ctx, dy):
         if dy is None:
             return (None,) * (2 + len(ctx.params))
+        _check(ctx, ctx.params, "obj_ptr_proj")
         with torch.no_grad():
             s = _pow2(dy)
             g: dict = {}
@@ -251,6 +294,7 @@ class ImageEncoderFn(torch.autograd.Function):
         ctx.names = ["image_encoder." + n for n in _named(model.image_encoder)]
         if model.use_high_res_features_in_sam:
             ctx.names += [f"sam_mask_decoder.{c}.{k}" for c in ("conv_s0", "conv_s1") for k in ("weight", "bias")]
+        _stamp(ctx, params)
         ctx.set_materialize_grads(False)
         return tuple(out["backbone_fpn"])
 
@@ -260,10 +304,30 @@ class ImageEncoderFn(torch.autograd.Function):
         from .modeling.common import tokens_of
         if all(d is None for d in d_levels):
             return (None,) * (2 + len(ctx.params))
+        _check(ctx, ctx.params, "ImageEncoder")
         with torch.no_grad():
             d_fpn = [None if d is None else tokens_of(d.to(F32)) for d in d_levels]
-            g = be.image_encoder_backward(ctx.model, ctx.state, d_fpn, [1.0] * len(d_fpn), None)
+            # a frozen trunk (`freeze_untrained`; only conv_s0 / conv_s1, which live in the decoder's optimiser group, still need gradients):
+            # the neck level of the backward is all there is to do
+            need_trunk = any(p.requires_grad for p in ctx.model.image_encoder.trunk.parameters())
+            g = be.image_encoder_backward(ctx.model, ctx.state, d_fpn, [1.0] * len(d_fpn), None, trunk_grads=need_trunk)
             return (None, None, *_param_grads(ctx.names, ctx.params, g, 1.0))
+
+
+def freeze_untrained(model, optimizers) -> int:
+    """`requires_grad_(False)` on every parameter of `model` that none of `optimizers` (torch.optim objects) owns; returns how many
+    were frozen.  The reference's 3-D loop (train_3d.py:34-54) builds its two optimisers over the memory / SAM layers only but never
+    clears `requires_grad` on the rest, so autograd -- there and through this bridge -- differentiates the image encoder for every
+    slice and throws the result away.  Calling this once after the optimisers are built stops the encoder's backward behind the FPN neck
+    (conv_s0 / conv_s1 sit in the decoder's group and still get their gradients; with those frozen too `forward_image` is a plain
+    graph-free forward): same updates, a fraction of the work."""
+    owned = {id(p) for opt in optimizers for grp in opt.param_groups for p in grp["params"]}
+    n = 0
+    for p in model.parameters():
+        if id(p) not in owned and p.requires_grad:
+            p.requires_grad_(False)
+            n += 1
+    return n
 
 
 def forward_image(model, imgs: torch.Tensor) -> dict:

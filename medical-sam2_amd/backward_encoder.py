@@ -313,7 +313,7 @@ def scale_drift(scales: dict, lo: float = 2.0 ** -11, hi: float = 2.0 ** 3, rese
 
 
 def image_encoder_backward(model, state: dict, d_fpn: List[Optional[torch.Tensor]], d_fpn_scales: Optional[List[float]] = None,
-                           scales: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+                           scales: Optional[dict] = None, trunk_grads: bool = True) -> Dict[str, torch.Tensor]:
     """d_fpn: gradients of `backbone_fpn` levels 0, 1, 2 as token-major maps ([B*256^2, 32], [B*128^2, 64], [B*64^2, 256] at 1024^2;
     None = no gradient), each multiplied by d_fpn_scales[l] (the loss scale it was computed under; default 1).  Returns
     {parameter name relative to the MODEL: TRUE gradient (loss scales removed)} for `image_encoder.*` and, when the high-res convs are
@@ -323,7 +323,9 @@ def image_encoder_backward(model, state: dict, d_fpn: List[Optional[torch.Tensor
     magnitude changes by orders of magnitude along the trunk (and between the three entry points), so every block -- and every neck
     level -- runs under its own power-of-two scale that brings max|gradient| to 2^-3.  `scales` (a dict, filled on the first call) caches
     them: the first call calibrates with one host read per block, later calls -- and a hipGraph captured after it -- reuse the cached
-    values without any synchronisation."""
+    values without any synchronisation.
+    trunk_grads=False: stop behind the neck (lateral convs + the folded conv_s0 / conv_s1) -- what is left to do when an optimiser owns the
+    mask decoder's high-resolution convs but not the encoder (train_3d.py:34-37)."""
     enc = model.image_encoder
     trunk, neck = enc.trunk, enc.neck
     B = state["B"]
@@ -393,7 +395,7 @@ def image_encoder_backward(model, state: dict, d_fpn: List[Optional[torch.Tensor
         d_stage[bi] = (dx, s_lvl)
     # ---- trunk blocks in reverse
     run: Optional[Tuple[torch.Tensor, float]] = None
-    for i in range(len(trunk.blocks) - 1, -1, -1):
+    for i in (range(len(trunk.blocks) - 1, -1, -1) if trunk_grads else ()):
         parts = ([run] if run is not None else []) + ([d_stage[i]] if i in d_stage else [])
         if not parts:
             continue                                       # blocks behind the coarsest level that received a gradient

@@ -1312,10 +1312,21 @@ static int launch_attn_kv64(const AttnParams& p, int Bz, hipStream_t s) {
 #ifndef MSAM2_G96_PROBE
 #define MSAM2_G96_PROBE 0
 #endif
+// MREF (round 4): the softmax reference rides in the MFMA.  Q is pre-multiplied by scale * log2(e) when its fragments are loaded, and every
+// score tile starts with one extra MFMA whose A operand is the constant "1 in k-slot 0" and whose B operand holds -m~ of the lane's
+// query (m~: the running reference, kept exactly representable in the 16-bit operand type), so the accumulator IS the exponent:
+// p = exp2(acc) -- one VALU op per score instead of fma + exp, no multiply in the row maximum (16 of ~80 vector instructions per 32 x 32
+// tile and wave gone for one MFMA more: the kernel is vector-issue-bound).  When the reference moves (rare: lazy rescale)
+// the pending score tile is shifted by m~_old - m~_new in the same branch that rescales O.  Any reference works for the softmax as long
+// as the SAME one enters the probabilities and the row sum, so the rounding of m~ costs nothing; the merge of split partials reads m~.
+#ifndef MSAM2_G96_MREF
+#define MSAM2_G96_MREF 1
+#endif
 template <int QB, int NW>
 __global__ __launch_bounds__(NW * 64, 1) void attn_g96x2_kernel(AttnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int D = 96, BK = 32, SK = 64;
+  constexpr bool MREF = MSAM2_G96_MREF != 0 && MSAM2_G96_PROBE == 0;
   constexpr int PROBE = MSAM2_G96_PROBE;   // diagnostic builds only (tools/g96_probe.sh): 1 no exp2, 2 no softmax, 3 + fragments read once, 4 + no DMA / barrier
   static_assert(QB * NW == 8, "256 queries per workgroup");
   constexpr int RB = D * 2, CPR = D / 8;                   // row bytes, 16-byte chunks per row
@@ -1355,8 +1366,21 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_g96x2_kernel(AttnParams p) {
       uint4 v = make_uint4(0, 0, 0, 0);
       if (qvalid[b]) v = *reinterpret_cast<const uint4*>(qb + (int64_t)qi[b] * p.q_ts + s * 16 + h * 8);
       qf[b][s] = __builtin_bit_cast(op16x8, v);
+      if constexpr (MREF) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qf[b][s][i] = f2op((float)qf[b][s][i] * p.scale_log2);
+      }
     }
   }
+  // the reference MFMA's operands: A = 1 in k-slot 0 (lanes of the first k half), B = -m~ of this lane's query in k-slot 0
+  op16x8 ones_a, mref[QB];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones_a[i] = (op16)0.f;
+  if (h == 0) ones_a[0] = (op16)1.f;
+#pragma unroll
+  for (int b = 0; b < QB; ++b)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mref[b][i] = (op16)0.f;
 
   const int Lk = p.Lk;
   const int stages_total = (Lk + SK - 1) / SK;
@@ -1437,6 +1461,10 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_g96x2_kernel(AttnParams p) {
     for (int b = 0; b < QB; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[b][e] = 0.f;
+    if constexpr (MREF) {
+#pragma unroll
+      for (int b = 0; b < QB; ++b) s[b] = MSAM2_MFMA_32x32x16(ones_a, mref[b], s[b], 0, 0, 0);     // every score starts at -m~(query)
+    }
 #pragma unroll
     for (int g = 0; g < DSTEPS; ++g)
 #pragma unroll
@@ -1449,15 +1477,33 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_g96x2_kernel(AttnParams p) {
       float m = -INFINITY;
 #pragma unroll
       for (int e = 0; e < 16; ++e) m = fmaxf(m, s[b][e]);
-      mx[b] = half_max(m) * p.scale_log2;
+      mx[b] = MREF ? half_max(m) : half_max(m) * p.scale_log2;     // MREF: already in log2 units, RELATIVE to the current reference
     }
   };
-  auto move_reference = [&](const float (&mx)[QB]) __attribute__((always_inline)) {
+  auto move_reference = [&](const float (&mx)[QB], f32x16 (&s_pend)[QB]) __attribute__((always_inline)) {
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-      const float m_new = fmaxf(m_run[b], mx[b]);
-      if (__any(m_new > m_run[b] + MSAM2_RESCALE_SLACK)) {
-        const float alpha = (m_run[b] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run[b] - m_new);
+      float m_new, alpha;
+      bool moved;
+      if constexpr (MREF) {
+        // mx is relative to m~ (0 before the first tile: m_run = -inf marks "no reference yet")
+        const bool first = m_run[b] == -INFINITY;
+        moved = __any(first || mx[b] > MSAM2_RESCALE_SLACK);
+        const float m_old = first ? 0.f : m_run[b];
+        m_new = (float)f2op(m_old + fmaxf(mx[b], first ? -INFINITY : 0.f));      // exactly representable: it re-enters as an MFMA operand
+        alpha = first ? 0.f : __builtin_amdgcn_exp2f(m_old - m_new);
+        if (moved) {
+          const float shift = m_old - m_new;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s_pend[b][e] += shift;                    // the pending tile was computed against the old reference
+          mref[b][0] = h == 0 ? f2op(-m_new) : (op16)0.f;
+        }
+      } else {
+        m_new = fmaxf(m_run[b], mx[b]);
+        moved = __any(m_new > m_run[b] + MSAM2_RESCALE_SLACK);
+        alpha = (m_run[b] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run[b] - m_new);
+      }
+      if (moved) {
         l_run[b] *= alpha;
         if constexpr (QB == 1) {
           // 256-register budget (two waves per SIMD), no inline asm naming AGPRs: hipcc then selects the VGPR form of every MFMA (O and S
@@ -1493,6 +1539,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_g96x2_kernel(AttnParams p) {
       for (int e = 0; e < 16; ++e) {
         float pe;
         if constexpr (PROBE >= 1) pe = s[b][e] * p.scale_log2 + nm;
+        else if constexpr (MREF) pe = __builtin_amdgcn_exp2f(s[b][e]);          // the accumulator is the exponent
         else pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[b][e], p.scale_log2, nm));
         if (masked) {
           const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -1561,7 +1608,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_g96x2_kernel(AttnParams p) {
       pv_phase(vf, pf);
       if constexpr (PROBE < 2) {
         row_max(s_nxt, mx);
-        move_reference(mx);
+        move_reference(mx, s_nxt);
       }
     };
     // sub-tile 2T+1: its successor is the first half of stage T+1
@@ -1574,7 +1621,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_g96x2_kernel(AttnParams p) {
       pv_phase(vf, pf);
       if constexpr (PROBE < 2) {
         row_max(s_nxt, mx);
-        move_reference(mx);
+        move_reference(mx, s_nxt);
       }
       const int t = sl0;
       sl0 = sl1; sl1 = sl2; sl2 = t;
@@ -1590,7 +1637,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_g96x2_kernel(AttnParams p) {
     s_mma(kfa, s0);
     k_fetch(0, 1, kfb);                // K(1): same stage
     row_max(s0, mx);
-    move_reference(mx);
+    move_reference(mx, s0);
     int i = 0;
     for (; i + 2 < nt; i += 2) {
       even(s0, s1);

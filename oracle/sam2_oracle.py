@@ -334,9 +334,30 @@ def rope_attention(P, pre: str, q: Tensor, k: Tensor, v: Tensor, heads: int, the
                    num_k_exclude_rope: int = 0, pmask: Optional[Tensor] = None) -> Tensor:
     """RoPEAttention.forward (transformer.py:288-331), batch-first [B, L, C]; the table is recomputed for the query
     grid (302-305) and tiled over the keys (rope_k_repeat)."""
-    q, k, v = lin(P, pre + ".q_proj", q), lin(P, pre + ".k_proj", k), lin(P, pre + ".v_proj", v)
+    fold = OPERAND_DTYPE is not None and heads == 1 and v.shape[-1] != P[pre + ".v_proj.weight"].shape[0]
+    v_in = v
+    q, k = lin(P, pre + ".q_proj", q), lin(P, pre + ".k_proj", k)
+    v = None if fold else lin(P, pre + ".v_proj", v)
     B, Lq, C = q.shape
     D = C // heads
+    if fold:
+        # Operand-rounding emulation of the memory cross-attention AS THE HIP PATH EVALUATES IT (DESIGN.md section 3, attn_kv64x2_kernel):
+        # the values carry no RoPE and softmax rows sum to one, so P (M Wv^T + bv) Wo^T + bo = (P M) (Wo Wv)^T + (Wo bv + bo) exactly;
+        # the kernel contracts P with the 64-channel memory rows M themselves and one K = 64 GEMM applies the composed weight (multiplied
+        # in fp32, rounded once).  Same function, different ROUNDING POINTS (P M is rounded where v and o would be) -- with plain fp32
+        # operands the two forms agree to round-off (tests/test_oracle_golden.py), so this branch only exists under `operand_rounding`.
+        side = int(round(math.sqrt(Lq)))
+        cos, sin = axial_rope_table(D, side, side, theta)
+        qh, kh = q[:, None], k[:, None]
+        qh = rope_rotate(qh, cos, sin)
+        n_rope = kh.shape[-2] - num_k_exclude_rope
+        if n_rope > 0:
+            r = n_rope // Lq
+            kh = torch.cat([rope_rotate(kh[:, :, :n_rope], cos.repeat(r, 1), sin.repeat(r, 1)), kh[:, :, n_rope:]], dim=2)
+        o64 = softmax_attention(qh, kh, v_in[:, None], pmask)[:, 0]                      # [B, Lq, 64]
+        Wc = P[pre + ".out_proj.weight"] @ P[pre + ".v_proj.weight"]
+        bc = P[pre + ".out_proj.weight"] @ P[pre + ".v_proj.bias"] + P[pre + ".out_proj.bias"]
+        return _rop(o64) @ _rop(Wc).t() + bc
 
     def split(t):
         return t.reshape(B, t.shape[1], heads, D).transpose(1, 2)

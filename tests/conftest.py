@@ -22,6 +22,7 @@ AT_SIZE = ("512_slices", "config3_volume_at_size")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "tight: also runs against the operand-rounding oracle at one tight bar for fp16 and bf16 (tests/test_modules_gpu.py)")
 
 
 def pytest_collection_modifyitems(session, config, items):
@@ -36,6 +37,35 @@ def pytest_collection_modifyitems(session, config, items):
         return (r, i)
 
     items[:] = [it for _, it in sorted(enumerate(items), key=key)]
+
+
+def pytest_sessionstart(session):
+    want = os.environ.get("MSAM2_EXPECT_OP16")
+    if want:                                            # the bf16 child suite: make sure it really runs on the bf16 library
+        import medical_sam2_amd.ops as ops
+        assert str(ops.OP16).endswith(want), f"expected a {want} library behind MSAM2_LIB_PATH, loaded one computes on {ops.OP16}"
+
+
+def pytest_collection_finish(session):
+    """GPU session that includes the bf16 child suite: start the child NOW so that it runs beside the fp16 tests instead of after them
+    (tests/test_bf16_build_gpu.py, collected last, waits for it).  Not inside the child itself, not on a box without a GPU."""
+    if os.environ.get("MSAM2_BF16_CHILD") or os.environ.get("MSAM2_LIB_PATH") or session.config.option.collectonly:
+        return
+    wanted = [it for it in session.items if "test_bf16_build_gpu" in it.nodeid]
+    if not wanted or len(session.items) < 20:          # (a run of that file alone starts the child itself)
+        return
+    import torch
+    if not torch.cuda.is_available():
+        return
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_bf16_build_gpu as b
+    session.config._msam2_bf16_child = b.start_child()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    child = getattr(session.config, "_msam2_bf16_child", None)
+    if child is not None and child.poll() is None:     # the session ended early (-x): do not leave the child running
+        child.terminate()
 
 
 @pytest.fixture(scope="session")

