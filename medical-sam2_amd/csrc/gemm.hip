@@ -1285,6 +1285,237 @@ static bool gemm_try_wstat(const GemmParams& p, hipStream_t s, bool apf) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// W-STATIONARY, 256 ROWS PER STEP (round 4).  What the counters said about gemm_wstat_kernel (profiles/r03_gemm_qkv*):
+// its L2 -> LDS traffic is right (W once per workgroup, A streamed) but a step is only 8 MFMAs per wave between two workgroup barriers
+// -- 256 matrix cycles against a ~2 000-cycle step -- and every MFMA needs 1.5 fragment reads (32 x 64 wave tiles).  Here a workgroup
+// works on TWO of its 128-row units at a time: 8 waves as 4 x 2, each a 64 x 64 block (16 MFMAs per wave and 64-deep k-step, one
+// fragment read per MFMA as in the tiled kernels: half the barriers and 2/3 of the LDS reads per flop), W panel resident (NK x 16 KiB),
+// A through an LDS-DMA ring of 32 KiB stages (256 rows x 64 k) that runs on across tile boundaries -- two stages at K = 384 (the
+// workgroup then owns all 160 KiB), three at K = 256.  The two units of a pair are whatever the workgroup's strided list holds next
+// (rows grp + u * groups), so the work split over the groups is as fine as the 128-row kernel's; an odd unit left over is paired with
+// itself and its twin's results are dropped.  Deferred epilogue as there: the finished 64 x 64 accumulators stay in a second register
+// set and one 32 x 32 block is retired in each of the next tile's first four k-steps.  Counted vmcnt waits (loads, LDS-DMA and stores
+// share one in-order counter): the ops younger than step s's four pieces are the pieces of step s+1 (three-stage ring only) and the
+// stores retired in the one or two iterations since.  Same k order per accumulator as every other GEMM kernel: bit-identical results.
+// ------------------------------------------------------------------------------------------------------------------
+template <int NK, int ACT, bool NT>
+__global__ __launch_bounds__(512, 1) void gemm_wstat256_kernel(GemmParams p, int n_panels, int groups) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BN = 128, BK = 64;
+  constexpr int KT_BYTES = BN * BK * 2;             // one k-tile of the W image: 16 KiB
+  constexpr int W_BYTES = NK * KT_BYTES;
+  constexpr int A_STAGE = 2 * KT_BYTES;             // 256 rows x 64 k: 32 KiB
+  constexpr int NST = (160 * 1024 - W_BYTES) / A_STAGE >= 3 ? 3 : 2;
+  constexpr int LPA = 4;                            // A pieces (1 KiB each) per wave and step: 32 pieces over 8 waves
+  constexpr int SPR = 8;                            // stores per retired 32x32 block
+  static_assert(NK >= 4, "one 32x32 block is retired in each of a tile's first four k-steps");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // [W image: NK k-tiles | A ring: NST stages]
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;          // 4 row slabs of 64 (slabs 0, 1: unit a; 2, 3: unit b) x 2 column halves of 64
+  const int half = wave >> 2;                       // which unit of the pair this wave loads (DMA) -- waves 0-3: a, 4-7: b
+  const int r = lane & 31, h = lane >> 5, odd = lane & 1;
+  int panel, grp;                                   // XCD-aware placement: see gemm_wstat_kernel
+  {
+    const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+    const int F = 32 / n_panels, R = 32 - F * n_panels;
+    if (l < F * n_panels) {
+      grp = xcd * F + l / n_panels;
+      panel = l % n_panels;
+    } else {
+      const int q = (l - F * n_panels) + R * xcd;
+      grp = 8 * F + q / n_panels;
+      panel = q % n_panels;
+    }
+  }
+  const int n_units = p.M / 128;
+  const int my_units = grp < min(groups, n_units) ? (n_units - grp + groups - 1) / groups : 0;     // units grp, grp + groups, ...
+  if (my_units == 0) return;
+  const int n_pairs = (my_units + 1) >> 1;
+  const int total = n_pairs * NK;
+  const int64_t n0 = (int64_t)panel * BN;
+  auto unit_row = [&](int pair, int hf) -> int {    // first row of unit `hf` of pair `pair` (an odd unit left over is its own twin)
+    int u = 2 * pair + hf;
+    if (u >= my_units) u = 2 * pair;
+    return (grp + u * groups) * 128;
+  };
+
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+  // a piece = 8 rows x 128 B = one DMA instruction; 128-byte-row images, chunk c of row r in slot c ^ ((r >> 1) & 7) (as gemm_glds_kernel)
+  unsigned offsA[LPA], offsW[2];
+#pragma unroll
+  for (int i = 0; i < LPA; ++i) {
+    const int row = ((wave & 3) * LPA + i) * 8 + (lane >> 3);            // row inside this wave's unit (0..127)
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    offsA[i] = (unsigned)((int64_t)row * p.lda * 2 + chunk * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave * 2 + i) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    offsW[i] = (unsigned)((n0 + row) * p.ldw * 2 + chunk * 16);
+  }
+  unsigned char* const ring = lds + W_BYTES;
+  auto issue_a = [&](int s) {
+    const int pair = s / NK, kt = s - pair * NK;
+    const unsigned so = (unsigned)(((int64_t)unit_row(pair, half) * p.lda + (int64_t)kt * BK) * 2);
+    unsigned char* base = ring + (s % NST) * A_STAGE + wave * (LPA * 1024);   // stage rows wave * 32 ..: unit a = rows 0..127, b = 128..255
+#pragma unroll
+    for (int i = 0; i < LPA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(base + i * 1024), 16, offsA[i], so, 0, 0);
+  };
+  float bias_j[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bias_j[j] = p.bias ? p.bias[n0 + wn * 64 + j * 32 + r] : 0.f;
+  asm volatile("" : "+v"(bias_j[0]), "+v"(bias_j[1])::"memory");       // waited for HERE, before any DMA is in flight (see gemm_wstat_kernel)
+  // ---- prologue: the whole W panel, then the first NST - 1 steps of A (W is older than step 0: waiting for step 0 covers it)
+#pragma unroll
+  for (int kt = 0; kt < NK; ++kt)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(lds + kt * KT_BYTES + (wave * 2 + i) * 1024), 16,
+                                               offsW[i], (unsigned)kt * BK * 2, 0, 0);
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < total) issue_a(s);
+
+  int offA[2], swzA[2], offB[2], swzB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ra = wm * 64 + i * 32 + r, rb = wn * 64 + i * 32 + r;
+    offA[i] = ra * 128;
+    swzA[i] = (ra >> 1) & 7;
+    offB[i] = rb * 128;
+    swzB[i] = (rb >> 1) & 7;
+  }
+  const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((int64_t)p.M * p.ldc * 2), 0x00020000);
+  const int ldc_b = (int)p.ldc * 2;
+  const int vcol = (int)(n0 + wn * 64 + (r & ~1)) * 2;
+  // one 32x32 block (i, j) of a finished tile; row0 = first row of this wave's 64-row slab
+  auto retire = [&](const f32x16& blk, int i, int j, int row0) {
+    const int vbase = (row0 + i * 32 + 4 * h + odd) * ldc_b + vcol + j * 64;
+#pragma unroll
+    for (int k = 0; k < SPR; ++k) {
+      const int e0 = 2 * k, ro = (e0 & 3) + 8 * (e0 >> 2);
+      float x0 = blk[e0] + bias_j[j], x1 = blk[e0 + 1] + bias_j[j];
+      if constexpr (ACT == 1) {
+        const f32x2 gp = gelu_erf2(f32x2{x0, x1});
+        x0 = gp[0];
+        x1 = gp[1];
+      } else if constexpr (ACT == 2) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
+      op16x2 own;
+      own[0] = f2op(x0);
+      own[1] = f2op(x1);
+      const unsigned P = __builtin_bit_cast(unsigned, own);
+      const unsigned Nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)P, 0xB1, 0xf, 0xf, false);
+      const unsigned outw = __builtin_amdgcn_perm(Nb, P, odd ? 0x03020706u : 0x05040100u);
+      __builtin_amdgcn_raw_buffer_store_b32(outw, c_rsrc, vbase + ro * ldc_b, 0, NT ? 2 : 0);
+    }
+  };
+  // stores this wave issued in iteration s (a block of the previous tile is retired in the first four k-steps of every tile but the first)
+  auto stores_in = [&](int s) -> int { return (s >= NK && (s % NK) < 4) ? SPR : 0; };
+
+  auto tile = [&](f32x16 (&cur)[2][2], f32x16 (&prev)[2][2], int pair, int prev_row0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cur[i][j][e] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) {
+      const int s = pair * NK + kt;
+      int n = s >= 1 ? stores_in(s - 1) : 0;
+      if constexpr (NST == 3) n += (s + 1 < total ? LPA : 0) + (s >= 2 ? stores_in(s - 2) : 0);
+      wstat_wait_dyn(n);
+      __builtin_amdgcn_s_barrier();                     // step s is complete for every wave; the stage of step s - 1 is free again
+      if (s + NST - 1 < total) issue_a(s + NST - 1);
+      const unsigned char* sa = ring + (s % NST) * A_STAGE;
+      const unsigned char* sw = lds + kt * KT_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        op16x8 af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          af[i] = *reinterpret_cast<const op16x8*>(sa + offA[i] + (((2 * ks + h) ^ swzA[i]) << 4));
+          bf[i] = *reinterpret_cast<const op16x8*>(sw + offB[i] + (((2 * ks + h) ^ swzB[i]) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) cur[i][j] = MSAM2_MFMA_32x32x16(af[i], bf[j], cur[i][j], 0, 0, 0);
+      }
+      if (pair > 0 && kt < 4) retire(prev[kt >> 1][kt & 1], kt >> 1, kt & 1, prev_row0);
+    }
+  };
+
+  f32x16 accA[2][2], accB[2][2];
+  int row_prev = 0;
+  for (int pair = 0; pair < n_pairs; pair += 2) {
+    tile(accA, accB, pair, row_prev);
+    row_prev = unit_row(pair, wm >> 1) + (wm & 1) * 64;
+    if (pair + 1 < n_pairs) {
+      tile(accB, accA, pair + 1, row_prev);
+      row_prev = unit_row(pair + 1, wm >> 1) + (wm & 1) * 64;
+    }
+  }
+  // the last tile's epilogue (the twin of an odd unit left over is dropped)
+  if (2 * (n_pairs - 1) + (wm >> 1) < my_units) {
+    if (n_pairs & 1) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) retire(accA[b >> 1][b & 1], b >> 1, b & 1, row_prev);
+    } else {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) retire(accB[b >> 1][b & 1], b >> 1, b & 1, row_prev);
+    }
+  }
+#endif
+}
+
+template <int NK, int ACT, bool NT>
+static void launch_wstat256(const GemmParams& p, int n_panels, int groups, hipStream_t s) {
+  constexpr int W_BYTES = NK * 128 * 64 * 2;
+  constexpr int NST = (160 * 1024 - W_BYTES) / (32 * 1024) >= 3 ? 3 : 2;
+  constexpr int LDS = W_BYTES + NST * 32 * 1024;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_wstat256_kernel<NK, ACT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_wstat256_kernel<NK, ACT, NT>), dim3(256), dim3(512), LDS, s, p, n_panels, groups);
+}
+
+// same problem class as gemm_try_wstat; MSAM2_GEMM_WSTAT256=0 keeps the 128-row kernel
+static bool gemm_try_wstat256(const GemmParams& p, hipStream_t s) {
+  static const bool off = getenv("MSAM2_GEMM_WSTAT256") && getenv("MSAM2_GEMM_WSTAT256")[0] == '0';
+  if (off) return false;
+  if (!p.out_is_16bit || p.res || p.colscale || p.rope_cos || p.pool_W || p.Q2 || p.res_mod) return false;
+  if (!(p.K == 256 || p.K == 384) || p.N % 128 != 0 || p.M % 128 != 0 || p.M < 8192 || !(p.act == 0 || p.act == 1 || p.act == 2)) return false;
+  if ((p.ldc & 1) || ((uintptr_t)p.C & 3) || (int64_t)p.M * p.ldc * 2 >= (1ll << 31) || (int64_t)p.M * p.lda * 2 >= (1ll << 31) ||
+      (int64_t)p.N * p.ldw * 2 >= (1ll << 31)) return false;
+  const int n_panels = p.N / 128;
+  if (n_panels > 32) return false;
+  const int groups = min(256 / n_panels, p.M / 128);
+#define WS256(NKV, ACTV) \
+  do { \
+    if (p.store_nt) launch_wstat256<NKV, ACTV, true>(p, n_panels, groups, s); \
+    else launch_wstat256<NKV, ACTV, false>(p, n_panels, groups, s); \
+  } while (0)
+  if (p.K == 384) {
+    if (p.act == 0) WS256(6, 0);
+    else if (p.act == 1) WS256(6, 1);
+    else WS256(6, 2);
+  } else {
+    if (p.act == 0) WS256(4, 0);
+    else if (p.act == 1) WS256(4, 1);
+    else WS256(4, 2);
+  }
+#undef WS256
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Skinny GEMM for M <= 32 (decoder tokens, hyper-network / IoU / object-pointer MLPs: 4..32 rows): one workgroup per 32
 // output columns, its 4 waves split K, operand fragments come straight from global memory (row r, 8 consecutive k = one
 // 16-byte load per lane per operand per MFMA, all independent => the whole reduction is in flight at once), partial 32x32
@@ -1448,6 +1679,7 @@ static int gemm_launch(const void* A, int64_t lda, const void* W, int64_t ldw, c
     const char* ew = getenv("MSAM2_GEMM_WSTAT");
     const int wstat_mode = ew ? atoi(ew) : -1;
     const bool want = wstat_mode == 1 || wstat_mode == 2 || wstat_mode < 0 || (wstat_mode == 3 && (act == 0 || act == 2));
+    if (want && !var && dma_ok && wstat_mode < 0 && gemm_try_wstat256(p, s)) return msam2_check_launch("gemm(w-stationary, 256 rows)");
     if (want && !var && dma_ok && gemm_try_wstat(p, s, wstat_mode == 2)) return msam2_check_launch("gemm(w-stationary)");
   }
   const int vv = var ? atoi(var) : (tiles <= 256 && K >= 1024 ? 8 : (K % 64 == 0 && K >= 384 ? 2 : 5));

@@ -175,7 +175,10 @@ def segment_volume(model, volume: torch.Tensor, prompts: Dict[int, dict], fill_h
     output_dict = {"cond_frame_outputs": chain_cond, "non_cond_frame_outputs": {}}
     masks: Dict[int, torch.Tensor] = {}
     sub = chain_subgroup(layout, group) if (distributed and kv_split) else None       # collective over `group`: every rank calls it
-    split_ctx = KVSplit(model, sub) if (distributed and kv_split and ge - gb > 1) else None
+    from . import parallel as _par
+    # (a group of one rank splits nothing -- except under FORCE_SINGLE_RANK_COLLECTIVES, the RCCL test of a one-GPU box, where the
+    #  key-split path runs with this rank owning every split so that its exchange goes through the real backend)
+    split_ctx = KVSplit(model, sub) if (distributed and kv_split and (ge - gb > 1 or (_par.FORCE_SINGLE_RANK_COLLECTIVES and n_obj == oe - ob))) else None
     if stats is not None:
         stats["chain_layout"] = {"objects": [ob, oe], "group_ranks": [gb, ge], "groups": len({span for _, span in layout}),
                                  "key_split_ranks": ge - gb if split_ctx is not None else 1}

@@ -39,7 +39,19 @@ def pytest_collection_modifyitems(session, config, items):
     items[:] = [it for _, it in sorted(enumerate(items), key=key)]
 
 
+def host_cpu_share() -> int:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import host_cpu_share as f
+    return f()
+
+
 def pytest_sessionstart(session):
+    # The CPU oracle is most of the GPU suite's wall time.  torch sizes its thread pool by the HOST's hardware threads (256 on the GPU
+    # box) although the cgroup grants 16: on all 256 the oracle runs 3x slower than on 16 (tests/probes/cpu_threads_probe.py).  The
+    # fp16 session and the bf16 child suite that runs beside it (tests/test_bf16_build_gpu.py) share the CPUs half and half.
+    import torch
+    share = host_cpu_share()
+    torch.set_num_threads(max(1, share // 2 if (os.environ.get("MSAM2_BF16_CHILD") and share >= 8) else share))
     want = os.environ.get("MSAM2_EXPECT_OP16")
     if want:                                            # the bf16 child suite: make sure it really runs on the bf16 library
         import medical_sam2_amd.ops as ops
@@ -60,12 +72,26 @@ def pytest_collection_finish(session):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import test_bf16_build_gpu as b
     session.config._msam2_bf16_child = b.start_child()
+    share = host_cpu_share()
+    if share >= 8:
+        torch.set_num_threads(share // 2)               # the child takes the other half
 
 
 def pytest_sessionfinish(session, exitstatus):
     child = getattr(session.config, "_msam2_bf16_child", None)
     if child is not None and child.poll() is None:     # the session ended early (-x): do not leave the child running
         child.terminate()
+
+
+@pytest.fixture(autouse=True)
+def _all_cpus_once_the_child_is_done(request):
+    """the bf16 child suite has ended: the oracle of the remaining fp16 tests (the at-size volumes come last) gets every CPU again"""
+    child = getattr(request.config, "_msam2_bf16_child", None)
+    if child is not None and child.poll() is not None and not getattr(request.config, "_msam2_threads_restored", False):
+        import torch
+        torch.set_num_threads(host_cpu_share())
+        request.config._msam2_threads_restored = True
+    yield
 
 
 @pytest.fixture(scope="session")

@@ -89,10 +89,26 @@ def rank_device(rank: int) -> int:
     return rank if real_devices() else 0
 
 
+def host_cpu_share() -> int:
+    """CPUs this process may actually use: the cgroup quota when there is one (the GPU box gives 16 of its 256 hardware threads), else the
+    affinity mask -- bench.host_cpu_share's rule.  torch sizes its pool by the host's hardware threads; on all 256 the oracle runs 3x
+    slower than on 16 (tests/probes/cpu_threads_probe.py)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def init_test_process_group(rank: int, world: int):
     """process group of a spawned test worker: backend nccl (= RCCL over xGMI) with one device per rank under MSAM2_TEST_REAL_DEVICES=1,
     otherwise gloo with every rank on device 0.  MASTER_ADDR / MASTER_PORT are in the environment."""
     import torch.distributed as dist
+    torch.set_num_threads(max(1, host_cpu_share() // world))
     torch.cuda.set_device(rank_device(rank))
     if real_devices():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank_device(rank)))

@@ -9,7 +9,7 @@ import torch
 import torch.multiprocessing as mp
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from helpers import all_gather_flat, init_test_process_group, rank_device  # noqa: E402
+from helpers import all_gather_flat, host_cpu_share, init_test_process_group, rank_device  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
@@ -150,6 +150,7 @@ def _full_worker(rank, world, port, q):
     import torch.distributed as dist
     torch.set_grad_enabled(False)
     torch.cuda.set_device(rank_device(rank))
+    torch.set_num_threads(max(1, host_cpu_share() // world))
     import medical_sam2_amd.build_sam as bs
     import medical_sam2_amd.synthetic as syn
     import medical_sam2_amd.training as T
@@ -237,6 +238,7 @@ def _bptt_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
     torch.cuda.set_device(rank_device(rank))
+    torch.set_num_threads(max(1, host_cpu_share() // world))
     torch.set_grad_enabled(False)
     import medical_sam2_amd.training as T
     import medical_sam2_amd.training_3d as t3

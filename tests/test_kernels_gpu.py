@@ -77,6 +77,38 @@ def test_gemm_exact_integers(ops, M, N, K):
     assert torch.equal(out.cpu().double(), ref), (out.cpu().double() - ref).abs().max()
 
 
+@pytest.mark.parametrize("M,N,K,act", [(8192, 1152, 384, 0), (8320, 256, 256, 0), (16384, 1536, 384, 2), (12800, 2048, 256, 2), (8192, 128, 384, 0),
+                                       (9088, 768, 256, 0)])
+def test_gemm_w_stationary_kernels_exact(ops, M, N, K, act):
+    """The W-stationary persistent kernels (gemm_wstat256_kernel: 256 rows per step, round 4; gemm_wstat_kernel): 16-bit output, K = 256 /
+    384, M >= 8192 -- the qkv / fc1 projections of Hiera stage 3 and the memory attention's linear1.  Sparse small-integer operands keep
+    every output an integer below 256 (exact in fp16 AND bf16), so the comparison is bit-exact whatever the operand type: a wrong
+    row / column / k mapping, a lost k-step, a unit paired with the wrong twin or a dropped tail unit cannot pass.  Shapes: even and odd
+    numbers of 128-row units per workgroup (a left-over unit is paired with itself), one unit per workgroup, one panel, 16 panels."""
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    a = torch.zeros(M, K)
+    w = torch.zeros(N, K)
+    cols = torch.randint(0, K, (M, 6), generator=g)
+    a.scatter_(1, cols, torch.randint(-3, 4, (M, 6), generator=g).float())
+    colsw = torch.randint(0, K, (N, 6), generator=g)
+    w.scatter_(1, colsw, torch.randint(-3, 4, (N, 6), generator=g).float())
+    a[:, 0] = (torch.arange(M) % 3).float()                   # structure a row / column swap or a k-permutation cannot preserve
+    w[:, 0] = (torch.arange(N) % 4).float() - 1
+    a[:, K - 1] = ((torch.arange(M) // 128) % 5).float() - 2  # differs from one 128-row unit to the next
+    w[:, K - 1] = 1.0
+    bias = torch.randint(-4, 5, (N,), generator=g).float()
+    ref = a.double() @ w.double().t() + bias.double()
+    if act == 2:
+        ref = ref.clamp_min(0)
+    assert ref.abs().max() < 256
+    out = ops.gemm(bf(a).to(DEV), bf(w).to(DEV), bias.to(DEV), act=act, out_dtype=OP16())
+    assert out.dtype == OP16() and torch.equal(out.cpu().double(), ref), (out.cpu().double() - ref).abs().max()
+    # strided output (a column block of a wider buffer), untouched outside
+    buf = torch.full((M, N + 16), 5.0, dtype=OP16(), device=DEV)
+    ops.gemm(bf(a).to(DEV), bf(w).to(DEV), bias.to(DEV), act=act, out=buf[:, 8:N + 8])
+    assert torch.equal(buf[:, 8:N + 8].cpu().double(), ref) and (buf[:, :8] == 5).all() and (buf[:, N + 8:] == 5).all()
+
+
 def test_gemm_epilogues(ops):
     M, N, K = 200, 192, 96
     a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.2))

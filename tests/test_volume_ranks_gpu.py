@@ -10,7 +10,7 @@ import torch
 import torch.multiprocessing as mp
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from helpers import init_test_process_group, rank_device  # noqa: E402
+from helpers import host_cpu_share, init_test_process_group, rank_device  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
@@ -42,6 +42,7 @@ def _worker(rank, world, port, q, CASES=CASES):
     import torch.distributed as dist
     torch.set_grad_enabled(False)
     torch.cuda.set_device(rank_device(rank))
+    torch.set_num_threads(max(1, host_cpu_share() // world))
     import medical_sam2_amd.parallel as par
     import medical_sam2_amd.volume as vol
     m = _model()
