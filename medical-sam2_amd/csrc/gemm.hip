@@ -1311,6 +1311,9 @@ __global__ __launch_bounds__(512, 1) void gemm_wstat256_kernel(GemmParams p, int
   static_assert(NK >= 4, "one 32x32 block is retired in each of a tile's first four k-steps");
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // [W image: NK k-tiles | A ring: NST stages]
   const int tid = threadIdx.x;
+  // diagnostic ladder (MSAM2_WS256_PROBE, host side; 0 in production): 1 no A DMA inside the loop, 2 + no retire, 3 + fragments read once,
+  // 4 + no barrier -- what each piece of the step costs
+  const int probe = p.add_cols;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;          // 4 row slabs of 64 (slabs 0, 1: unit a; 2, 3: unit b) x 2 column halves of 64
   const int half = wave >> 2;                       // which unit of the pair this wave loads (DMA) -- waves 0-3: a, 4-7: b
@@ -1392,6 +1395,7 @@ __global__ __launch_bounds__(512, 1) void gemm_wstat256_kernel(GemmParams p, int
   const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((int64_t)p.M * p.ldc * 2), 0x00020000);
   const int ldc_b = (int)p.ldc * 2;
   const int vcol = (int)(n0 + wn * 64 + (r & ~1)) * 2;
+  unsigned sink = 0;
   // one 32x32 block (i, j) of a finished tile; row0 = first row of this wave's 64-row slab
   auto retire = [&](const f32x16& blk, int i, int j, int row0) {
     const int vbase = (row0 + i * 32 + 4 * h + odd) * ldc_b + vcol + j * 64;
@@ -1410,12 +1414,18 @@ __global__ __launch_bounds__(512, 1) void gemm_wstat256_kernel(GemmParams p, int
       const unsigned P = __builtin_bit_cast(unsigned, own);
       const unsigned Nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)P, 0xB1, 0xf, 0xf, false);
       const unsigned outw = __builtin_amdgcn_perm(Nb, P, odd ? 0x03020706u : 0x05040100u);
-      __builtin_amdgcn_raw_buffer_store_b32(outw, c_rsrc, vbase + ro * ldc_b, 0, NT ? 2 : 0);
+      if (probe == 5) sink ^= outw;                     // diagnostic: the epilogue's vector work without its stores
+      else __builtin_amdgcn_raw_buffer_store_b32(outw, c_rsrc, vbase + ro * ldc_b, 0, NT ? 2 : 0);
     }
   };
   // stores this wave issued in iteration s (a block of the previous tile is retired in the first four k-steps of every tile but the first)
   auto stores_in = [&](int s) -> int { return (s >= NK && (s % NK) < 4) ? SPR : 0; };
 
+  op16x8 keep_a[2], keep_b[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) keep_a[i][e] = keep_b[i][e] = (op16)0.f;
   auto tile = [&](f32x16 (&cur)[2][2], f32x16 (&prev)[2][2], int pair, int prev_row0) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1426,11 +1436,12 @@ __global__ __launch_bounds__(512, 1) void gemm_wstat256_kernel(GemmParams p, int
 #pragma unroll
     for (int kt = 0; kt < NK; ++kt) {
       const int s = pair * NK + kt;
-      int n = s >= 1 ? stores_in(s - 1) : 0;
-      if constexpr (NST == 3) n += (s + 1 < total ? LPA : 0) + (s >= 2 ? stores_in(s - 2) : 0);
+      int n = (s >= 1 && probe < 2) ? stores_in(s - 1) : 0;
+      if (probe == 5) n = 0;
+      if constexpr (NST == 3) n += ((s + 1 < total && (probe < 1 || probe == 5 || s + 1 < NST - 1)) ? LPA : 0) + ((s >= 2 && probe < 2) ? stores_in(s - 2) : 0);
       wstat_wait_dyn(n);
-      __builtin_amdgcn_s_barrier();                     // step s is complete for every wave; the stage of step s - 1 is free again
-      if (s + NST - 1 < total) issue_a(s + NST - 1);
+      if (probe < 4 || probe == 5) __builtin_amdgcn_s_barrier();      // step s is complete for every wave; the stage of step s - 1 is free again
+      if (s + NST - 1 < total && (probe < 1 || probe == 5)) issue_a(s + NST - 1);
       const unsigned char* sa = ring + (s % NST) * A_STAGE;
       const unsigned char* sw = lds + kt * KT_BYTES;
 #pragma unroll
@@ -1438,15 +1449,22 @@ __global__ __launch_bounds__(512, 1) void gemm_wstat256_kernel(GemmParams p, int
         op16x8 af[2], bf[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          af[i] = *reinterpret_cast<const op16x8*>(sa + offA[i] + (((2 * ks + h) ^ swzA[i]) << 4));
-          bf[i] = *reinterpret_cast<const op16x8*>(sw + offB[i] + (((2 * ks + h) ^ swzB[i]) << 4));
+          if (probe < 3 || probe == 5 || (s == 0 && ks == 0)) {
+            af[i] = *reinterpret_cast<const op16x8*>(sa + offA[i] + (((2 * ks + h) ^ swzA[i]) << 4));
+            bf[i] = *reinterpret_cast<const op16x8*>(sw + offB[i] + (((2 * ks + h) ^ swzB[i]) << 4));
+            keep_a[i] = af[i];
+            keep_b[i] = bf[i];
+          } else {
+            af[i] = keep_a[i];
+            bf[i] = keep_b[i];
+          }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) cur[i][j] = MSAM2_MFMA_32x32x16(af[i], bf[j], cur[i][j], 0, 0, 0);
       }
-      if (pair > 0 && kt < 4) retire(prev[kt >> 1][kt & 1], kt >> 1, kt & 1, prev_row0);
+      if (pair > 0 && kt < 4 && (probe < 2 || probe == 5)) retire(prev[kt >> 1][kt & 1], kt >> 1, kt & 1, prev_row0);
     }
   };
 
@@ -1470,6 +1488,7 @@ __global__ __launch_bounds__(512, 1) void gemm_wstat256_kernel(GemmParams p, int
       for (int b = 0; b < 4; ++b) retire(accB[b >> 1][b & 1], b >> 1, b & 1, row_prev);
     }
   }
+  if (probe == 5 && sink == 0x12345u) ((unsigned*)p.C)[0] = sink;   // keeps the diagnostic's vector work alive
 #endif
 }
 
@@ -1486,10 +1505,13 @@ static void launch_wstat256(const GemmParams& p, int n_panels, int groups, hipSt
   hipLaunchKernelGGL((gemm_wstat256_kernel<NK, ACT, NT>), dim3(256), dim3(512), LDS, s, p, n_panels, groups);
 }
 
-// same problem class as gemm_try_wstat; MSAM2_GEMM_WSTAT256=0 keeps the 128-row kernel
+// same problem class as gemm_try_wstat.  OPT-IN (MSAM2_GEMM_WSTAT256=1): measured round 4 (tools/wstat_ab.py, three boxes) the 256-row
+// kernel is as fast as the 128-row one at K = 256 and 5-15 % slower at K = 384, where its A ring has only two stages -- the hypothesis
+// it was built on (barriers per MFMA) was wrong.  What it is kept for is its diagnostic ladder (MSAM2_WS256_PROBE, tools/ws256_probe.sh),
+// which says where a W-stationary launch spends its time: DESIGN.md section 3.2.
 static bool gemm_try_wstat256(const GemmParams& p, hipStream_t s) {
-  static const bool off = getenv("MSAM2_GEMM_WSTAT256") && getenv("MSAM2_GEMM_WSTAT256")[0] == '0';
-  if (off) return false;
+  static const bool on = getenv("MSAM2_GEMM_WSTAT256") && getenv("MSAM2_GEMM_WSTAT256")[0] == '1';
+  if (!on) return false;
   if (!p.out_is_16bit || p.res || p.colscale || p.rope_cos || p.pool_W || p.Q2 || p.res_mod) return false;
   if (!(p.K == 256 || p.K == 384) || p.N % 128 != 0 || p.M % 128 != 0 || p.M < 8192 || !(p.act == 0 || p.act == 1 || p.act == 2)) return false;
   if ((p.ldc & 1) || ((uintptr_t)p.C & 3) || (int64_t)p.M * p.ldc * 2 >= (1ll << 31) || (int64_t)p.M * p.lda * 2 >= (1ll << 31) ||
@@ -1497,10 +1519,13 @@ static bool gemm_try_wstat256(const GemmParams& p, hipStream_t s) {
   const int n_panels = p.N / 128;
   if (n_panels > 32) return false;
   const int groups = min(256 / n_panels, p.M / 128);
+  GemmParams pp = p;
+  static const int probe = getenv("MSAM2_WS256_PROBE") ? atoi(getenv("MSAM2_WS256_PROBE")) : 0;
+  pp.add_cols = probe;
 #define WS256(NKV, ACTV) \
   do { \
-    if (p.store_nt) launch_wstat256<NKV, ACTV, true>(p, n_panels, groups, s); \
-    else launch_wstat256<NKV, ACTV, false>(p, n_panels, groups, s); \
+    if (p.store_nt) launch_wstat256<NKV, ACTV, true>(pp, n_panels, groups, s); \
+    else launch_wstat256<NKV, ACTV, false>(pp, n_panels, groups, s); \
   } while (0)
   if (p.K == 384) {
     if (p.act == 0) WS256(6, 0);

@@ -109,6 +109,19 @@ def test_gemm_w_stationary_kernels_exact(ops, M, N, K, act):
     assert torch.equal(buf[:, 8:N + 8].cpu().double(), ref) and (buf[:, :8] == 5).all() and (buf[:, N + 8:] == 5).all()
 
 
+def test_gemm_w_stationary_256_row_kernel_in_a_child_process():
+    """gemm_wstat256_kernel is opt-in (MSAM2_GEMM_WSTAT256=1, read once per process: as fast as the 128-row kernel at K = 256, slower at
+    K = 384; kept for its diagnostic ladder): the exact cases above through it, in a child process."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import subprocess, sys
+    env = dict(_os.environ, MSAM2_GEMM_WSTAT256="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", _os.path.abspath(__file__), "-q", "-m", "gpu", "-k", "test_gemm_w_stationary_kernels_exact",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900,
+                       cwd=_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout + r.stderr)[-1500:]
+
+
 def test_gemm_epilogues(ops):
     M, N, K = 200, 192, 96
     a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.2))

@@ -1,5 +1,5 @@
-"""A/B of the W-stationary GEMM kernels on the step's short-reduction 16-bit projections: gemm_wstat256_kernel (256 rows per step, default)
-against gemm_wstat_kernel (MSAM2_GEMM_WSTAT256=0) and the tiled kernels (MSAM2_GEMM_WSTAT=0); one child process per variant (the switches
+"""A/B of the W-stationary GEMM kernels on the step's short-reduction 16-bit projections: gemm_wstat256_kernel (256 rows per step, MSAM2_GEMM_WSTAT256=1)
+against gemm_wstat_kernel (the default) and the tiled kernels (MSAM2_GEMM_WSTAT=0); one child process per variant (the switches
 are read once per process), alternating, HIP-event timing of 30 back-to-back launches, median of 5.
 usage: wstat_ab.py [rounds]"""
 import os, subprocess, sys
@@ -37,6 +37,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 else:
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     for rnd in range(rounds):
-        for label, env in (("wstat256", {}), ("wstat128", {"MSAM2_GEMM_WSTAT256": "0"}), ("tiled", {"MSAM2_GEMM_WSTAT": "0"})):
+        for label, env in (("wstat256", {"MSAM2_GEMM_WSTAT256": "1"}), ("wstat128", {}), ("tiled", {"MSAM2_GEMM_WSTAT": "0"})):
             print(f"== {label} (round {rnd})", flush=True)
             subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, **env), check=True)
