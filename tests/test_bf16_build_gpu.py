@@ -21,14 +21,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "medical-sam2_amd", "libmsam2_hip_bf16.so")
 LOG = os.path.join(ROOT, "gpurun_out", "bf16_suite.log")
-# What the bf16 library re-runs: every file whose result depends on the operand type -- kernels, modules (incl. the tight operand-rounding
-# comparison), end to end, the unit-round-off scaling test, backward, gradient goldens, BPTT, the autograd bridge.  Left to the fp16 run
-# only: what adds nothing at another operand type -- the size-independent properties and the graph bit-identity files, the 28-slice bank
-# bookkeeping chain, the two at-size volumes (a minute of CPU oracle each) -- and the multi-process files, which spawn their own children.
+# What the bf16 library re-runs: every single-process parity file -- kernels, modules (incl. the tighter operand-rounding comparison), end to
+# end (incl. the 28-slice bank chain and the 64-slice volume at size), the unit-round-off scaling test, properties, graphs, backward,
+# gradient goldens, BPTT, the autograd bridge, the captured training step.  Left to the fp16 run only: the 512-slice volume (half a
+# minute of CPU oracle that would compete with the fp16 session's own) and the multi-process files, which spawn their own children.
 FILES = ["tests/test_kernels_gpu.py", "tests/test_modules_gpu.py", "tests/test_e2e_gpu.py", "tests/test_operand_rounding_gpu.py",
-         "tests/test_backward_gpu.py", "tests/test_backward_encoder_gpu.py", "tests/test_grads_golden.py", "tests/test_bptt_gpu.py",
-         "tests/test_autograd_gpu.py"]
-SKIP = "not 512_slices and not config3_volume_at_size and not long_chain_steady_state"
+         "tests/test_properties_gpu.py", "tests/test_graphs_gpu.py", "tests/test_eval_seg.py", "tests/test_backward_gpu.py",
+         "tests/test_backward_encoder_gpu.py", "tests/test_grads_golden.py", "tests/test_bptt_gpu.py", "tests/test_autograd_gpu.py",
+         "tests/test_train_graph_gpu.py"]
+SKIP = "not 512_slices"
 
 
 def start_child():
