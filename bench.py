@@ -207,10 +207,8 @@ def pmc_traffic():
     here = os.path.dirname(os.path.abspath(__file__))
     tot = 0.0
     for name, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
-        path = os.path.join(here, "profiles", f"r03_attnkv64_pmc_{name}.csv")
-        if not os.path.exists(path):
-            path = os.path.join(here, "profiles", f"r02_attnkv64_pmc_{name}.csv")
-        if not os.path.exists(path):
+        path = next((q for q in (os.path.join(here, "profiles", f"{r}_attnkv64_pmc_{name}.csv") for r in ("r04", "r03", "r02")) if os.path.exists(q)), None)
+        if path is None:
             return None
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
                 if r.get("Counter_Name") == name and "attn_kv64x2_kernel" in r.get("Kernel_Name", "")]
