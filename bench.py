@@ -326,8 +326,8 @@ GEMM_ENTRY_POINTS = ("gemm", "gemm_rope", "gemm_pool2x2", "gemm_qkv_pool2x2", "g
 
 def time_gemm_family(m, imgs, pts, labels, memory, memory_pos, device):
     """Every GEMM launch of one eager step (all five entry points of ops: plain, +RoPE store, pooled shortcut, pooled qkv, token rows),
-    grouped by (entry point, M, N, K, output type, residual, activation); one representative call per group is re-launched 10 times on
-    its own live operands and timed with HIP events on the launch stream.  `achieved` = the step's GEMM flops (2 M N K per launch)
+    grouped by (entry point, M, N, K, output type, residual, activation); one representative call per group is re-launched 20 times on
+    its own live operands -- as ONE hipGraph replay, so that host launch time does not enter -- and timed with HIP events on the launch stream.  `achieved` = the step's GEMM flops (2 M N K per launch)
     over the sum of count x average launch time: the flop-weighted rate of the family against the dense MFMA peak."""
     import medical_sam2_amd.ops as ops
     from medical_sam2_amd._lib import lib, check
@@ -365,9 +365,29 @@ def time_gemm_family(m, imgs, pts, labels, memory, memory_pos, device):
         for _ in range(3):
             fn(*a, **kw)
         torch.cuda.synchronize()
+        # The `reps` launches are replayed from a hipGraph: launched one by one from Python a call costs ~18 us of host time, which
+        # is what the table showed for every shape under 18 us in round 3 (30 of the 50 shapes; in the step's graph they take 5-8 us)
+        run = None
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fn(*a, **kw)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                for _ in range(reps):
+                    fn(*a, **kw)
+            run = gr.replay
+        except Exception:  # noqa: BLE001 -- fall back to eager launches
+            torch.cuda.synchronize()
+            run = lambda: [fn(*a, **kw) for _ in range(reps)]
+        run()
+        torch.cuda.synchronize()
+        stream = torch.cuda.current_stream().cuda_stream
         check(lib().msam2_event_record(e0, stream))
-        for _ in range(reps):
-            fn(*a, **kw)
+        run()
         check(lib().msam2_event_record(e1, stream))
         ms = ctypes.c_float()
         check(lib().msam2_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
@@ -392,6 +412,7 @@ def time_gemm_family(m, imgs, pts, labels, memory, memory_pos, device):
             "traffic": None, "what": "all GEMM launches of one step (flop-weighted): sum of 2MNK over sum of launches x stand-alone average launch time",
             "gemm_ms_per_step": tot_t * 1e3, "flops_per_step": tot_f, "launches_per_step": sum(r["launches_per_step"] for r in rows),
             "distinct_shapes": len(rows), "top_shapes": rows[:8],
+            "ladder": "profiles/r04_gemm_wstat_ladder.txt: the same launch with pieces removed (a third epilogue + output stores, a third fixed cost, ~9 us of matrix work)",
             "pmc": "profiles/r03_gemm_16384x1536x384_pmc_*.csv, profiles/r03_gemm_16384x384x1536_pmc_*.csv (stage-3 fc1 / fc2 on the tiled kernel), "
                    "profiles/r03_gemm_qkv16384x1152x384_{wstat,tiled}_pmc_*.csv (the W-stationary kernel against the tiled one): HBM bytes, L2 "
                    "requests / hit rate, MFMA-busy, wait cycles; summary in profiles/README.md"}
