@@ -30,6 +30,7 @@ LIB = os.path.join(ROOT, "medical-sam2_amd", "libmsam2_hip_bf16.so")
 # power of two) or a dropped term is far outside (0.75, 1.15).
 FD_LO, FD_HI = 0.75, 1.15
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def _run_at_size():
@@ -107,16 +108,69 @@ def _run_at_size():
     assert all(o.skipped_elements == 0 for o in opts.values())
 
 
-def test_configs4_hiera_bplus_train_iteration_at_1024_b4_bf16():
+def _run_encoder_gradients_at_size():
+    """configs[4]'s model AT SIZE against the oracle ("the at-size configs[4] test has no oracle comparison at all"):
+    hiera_b+, one 1024 x 1024 slice -- the three FPN outputs and the gradient of a random linear functional of them with respect to all
+    ~250 image-encoder parameters and the two folded high-resolution convs, against torch.autograd through the fp32 oracle
+    (oracle.forward_image).  Same statement as tests/test_backward_encoder_gpu.py::test_image_encoder_backward_vs_autograd, which runs at
+    256 x 256: here the windows are the 1024^2 ones (64 x 64 tokens in stage 3, 14 x 14 windows padded to 70) and the global blocks see
+    4096 tokens."""
+    import medical_sam2_amd.backward_encoder as be
+    import medical_sam2_amd.build_sam as bs
+    import medical_sam2_amd.synthetic as syn
+    import medical_sam2_amd.weights as wts
+    from oracle import sam2_oracle as O
+    from helpers import btol
+    dev = torch.device("cuda", 0)
+    S = 1024
+    W = wts.init_weights("hiera_b+", 3)
+    m = bs.build_sam2("sam2_hiera_b+", device="cpu", hydra_overrides_extra=[f"++model.image_size={S}"])
+    m.load_state_dict(W, strict=True)
+    m = m.to(dev).eval()
+    cfg = O.model_config("hiera_b+", S)
+    img, _, _ = syn.image_batch([10], S)
+    train = lambda k: k.startswith("image_encoder.") or k.startswith("sam_mask_decoder.conv_s")
+    rel = lambda a, b: float((a.detach().double().cpu() - b.detach().double().cpu()).norm() / b.detach().double().cpu().norm().clamp_min(1e-30))
+    with torch.enable_grad():
+        P = {k: (v.clone().requires_grad_(True) if train(k) else v) for k, v in W.items()}
+        bo = O.forward_image(P, cfg, img)
+        dys = [torch.randn(*f.shape, generator=torch.Generator().manual_seed(60 + l)) * 0.05 for l, f in enumerate(bo["backbone_fpn"])]
+        sum((f * d).sum() for f, d in zip(bo["backbone_fpn"], dys)).backward()
+    with torch.no_grad():
+        out, st = be.image_encoder_forward_saved(m, img.to(dev))
+        fe = [rel(out["backbone_fpn"][l], bo["backbone_fpn"][l]) for l in range(3)]
+        d_fpn = [d.permute(0, 2, 3, 1).reshape(-1, d.shape[1]).contiguous().to(dev) for d in dys]
+        grads = be.image_encoder_backward(m, st, d_fpn)
+    missing = {k for k in P if train(k) and P[k].grad is not None and P[k].grad.abs().sum() > 0} - set(grads)
+    assert not missing, sorted(missing)[:10]
+    num = sum((grads[k].double().cpu() - P[k].grad.double()).pow(2).sum().item() for k in grads)
+    den = sum(P[k].grad.double().pow(2).sum().item() for k in grads)
+    errs = sorted(((rel(grads[k], P[k].grad), k) for k in grads), reverse=True)
+    print(f"configs[4] at size, one slice vs oracle autograd: FPN features {fe}; {len(grads)} parameter gradients: overall relative L2 "
+          f"{(num / den) ** 0.5:.4f}, worst {errs[:4]}")
+    assert all(e < btol(3e-3) for e in fe), fe
+    assert len(grads) > 240 and (num / den) ** 0.5 < btol(2e-2) and errs[0][0] < btol(8e-2, 2.5), errs[:6]
+
+
+def _in_bf16_child(fn, test_name):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import medical_sam2_amd.ops as ops
     if ops.OP16 == torch.bfloat16:
-        _run_at_size()
+        fn()
         return
     assert os.path.exists(LIB), "libmsam2_hip_bf16.so is built by __graft_entry__.build()"
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-s", "-p", "no:cacheprovider"], cwd=ROOT,
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-s", "-k", test_name, "-p", "no:cacheprovider"], cwd=ROOT,
                        env=dict(os.environ, MSAM2_LIB_PATH=LIB), capture_output=True, text=True, timeout=1200)
-    tail = "\n".join((r.stdout + r.stderr).splitlines()[-25:])
+    keep = [l for l in (r.stdout + r.stderr).splitlines() if "configs[4] at size" in l or "iteration " in l or "losses:" in l]
+    tail = "\n".join(keep + (r.stdout + r.stderr).splitlines()[-25:])
     print(tail)
     assert r.returncode == 0 and " passed" in r.stdout, tail
+
+
+def test_configs4_hiera_bplus_train_iteration_at_1024_b4_bf16():
+    _in_bf16_child(_run_at_size, "test_configs4_hiera_bplus_train_iteration_at_1024_b4_bf16")
+
+
+def test_configs4_hiera_bplus_encoder_gradients_at_1024_vs_oracle_autograd_bf16():
+    _in_bf16_child(_run_encoder_gradients_at_size, "test_configs4_hiera_bplus_encoder_gradients_at_1024_vs_oracle_autograd_bf16")
