@@ -54,6 +54,7 @@ SIGNATURES = {
     "msam2_fourier_pe_grid": (c_i, [c_p, c_p, c_l, c_l, c_l, c_p]),
     "msam2_hiera_pos_embed": (c_i, [c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_l, c_p]),
     "msam2_im2col_patch7x7s4": (c_i, [c_p, c_p, c_l, c_l, c_p]),
+    "msam2_patch_embed7x7s4": (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_p]),
     "msam2_im2col3x3s2": (c_i, [c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_p]),
     "msam2_conv3x3s2_ln_gelu": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_i, c_f, c_f, c_p]),
     "msam2_dwconv7x7_ln": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_p]),

@@ -21,6 +21,7 @@ import os as _os
 _POOL_GEMM = _os.environ.get("MSAM2_NO_POOL_GEMM") is None   # experiment switches
 _QPOOL_GEMM = _os.environ.get("MSAM2_NO_QPOOL_GEMM") is None
 _FUSED_MLP = _os.environ.get("MSAM2_NO_FUSED_MLP") is None
+_FUSED_PATCH = _os.environ.get("MSAM2_NO_FUSED_PATCH") is None
 
 
 class PatchEmbed(nn.Module):
@@ -40,9 +41,23 @@ class PatchEmbed(nn.Module):
             return w
         return self._wc.get("w", [self.proj.weight], build)
 
+    def _weight_perm(self):
+        """the conv weight in the one-kernel patch embedding's reduction order: [ceil32(E), 176], k' = (c * 7 + ky) * 8 + kx, zero at kx = 7
+        and in the padding (ops.patch_embed: 8 consecutive k' = 8 consecutive pixels of one image row)"""
+        def build():
+            w = self.proj.weight.detach()
+            E = w.shape[0]
+            wp = torch.zeros((E + 31) // 32 * 32, 22, 8, dtype=OP16, device=w.device)
+            wp[:E, :21, :7] = w.reshape(E, 21, 7).to(OP16)
+            return wp.reshape(-1, 176).contiguous()
+        return self._wc.get("wp", [self.proj.weight], build)
+
     def tokens(self, x: torch.Tensor, pos: Optional[torch.Tensor] = None) -> torch.Tensor:
         """[B,3,S,S] -> fp32 tokens [B*(S/4)^2, E] (+ position table broadcast over the batch)."""
         x = x.to(F32).contiguous()
+        E = self.proj.weight.shape[0]
+        if _FUSED_PATCH and ops.patch_embed_supported(x.shape[-1], E) and x.shape[-1] == x.shape[-2] and (pos is None or pos.shape[0] == (x.shape[-1] // 4) ** 2):
+            return ops.patch_embed(x, self._weight_perm(), v_f32(self._wc, "b", self.proj.bias), None if pos is None else pos.to(F32).contiguous())
         cols = ops.im2col_patch(x)
         return ops.gemm(cols, self._weight(), v_f32(self._wc, "b", self.proj.bias), residual=pos,
                         res_mod=pos.shape[0] if pos is not None else 0, out_dtype=F32)

@@ -461,6 +461,28 @@ def im2col_patch(img: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def patch_embed_supported(S: int, E: int) -> bool:
+    """the one-kernel patch embedding (msam2_patch_embed7x7s4) takes this problem: whole 32-token wave blocks per token row, E <= 128"""
+    So = S // 4
+    return S % 4 == 0 and So % 32 == 0 and (So <= 128 or So % 128 == 0) and E <= 128
+
+
+def patch_embed(img: torch.Tensor, w_perm: torch.Tensor, bias: torch.Tensor, pos: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """img fp32 [B,3,S,S] -> fp32 tokens [B*(S/4)^2, E] = conv7x7/s4/p3 + bias (+ pos [(S/4)^2, E], broadcast over the batch) in ONE kernel, no
+    im2col map.  w_perm: 16-bit [ceil(E/32)*32, 176] in the kernel's reduction order (modeling.encoder.PatchEmbed._weight_perm)."""
+    _req(img.dtype == F32 and img.is_contiguous() and img.shape[1] == 3 and img.shape[2] == img.shape[3], "patch_embed: [B,3,S,S] fp32")
+    B, _, S, _ = img.shape
+    E = bias.shape[0]
+    _req(patch_embed_supported(S, E), "patch_embed: unsupported size (use im2col_patch + gemm)")
+    _req(w_perm.dtype == OP16 and w_perm.is_contiguous() and tuple(w_perm.shape) == ((E + 31) // 32 * 32, 176), "patch_embed: w_perm [ceil32(E), 176] 16-bit")
+    _req(bias.dtype == F32 and bias.is_contiguous(), "patch_embed: fp32 bias")
+    if pos is not None:
+        _req(pos.dtype == F32 and pos.is_contiguous() and tuple(pos.shape) == ((S // 4) ** 2, E), "patch_embed: pos fp32 [(S/4)^2, E]")
+    out = torch.empty(B * (S // 4) ** 2, E, dtype=F32, device=img.device)
+    check(lib().msam2_patch_embed7x7s4(_p(img), _p(w_perm), _p(bias), _p(pos), _p(out), B, S, E, _stream()))
+    return out
+
+
 def im2col3x3s2(x: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
     """bf16 NHWC -> [B*(H/2)*(W/2), ld] patches, columns (ky,kx,c), ld = 9*C rounded up to a multiple of 8 (zero filled)."""
     C = x.shape[-1]

@@ -122,6 +122,39 @@ def test_gemm_w_stationary_256_row_kernel_in_a_child_process():
     assert r.returncode == 0 and " passed" in r.stdout, (r.stdout + r.stderr)[-1500:]
 
 
+@pytest.mark.parametrize("B,S,E", [(2, 256, 96), (1, 1024, 96), (2, 128, 112), (1, 512, 32), (3, 256, 128)])
+def test_patch_embed_one_kernel(ops, B, S, E):
+    """msam2_patch_embed7x7s4 (round 4): Conv2d(3, E, k7, s4, p3) + bias + position table in ONE kernel, the reduction re-ordered to
+    (c, ky, kx padded to 8) so that MFMA fragments are contiguous pixels of the staged image rows.  Against F.conv2d on the 16-bit-rounded
+    operands in float64 (exact products, fp32 accumulation: 1e-5) and against the two-launch path it replaces (im2col + GEMM).  Sizes:
+    64 / 256 / 32 / 128 tokens per row (one or two 128-token segments, partial workgroups), E = 96 (hiera_t / s), 112 (hiera_b+: the
+    fourth 32-column tile half used), 32, 128; borders (the 3-pixel padding) on every side."""
+    g = torch.Generator().manual_seed(S + E)
+    img = torch.randn(B, 3, S, S, generator=g)
+    img[:, :, :5, :] *= 3.0                                    # structure at the borders: a padding or row / column offset error shows
+    img[:, :, :, -5:] -= 2.0
+    w = torch.randn(E, 3, 7, 7, generator=g) * 0.1
+    bias = torch.randn(E, generator=g)
+    So = S // 4
+    pos = torch.randn(So * So, E, generator=g)
+    assert ops.patch_embed_supported(S, E)
+    wp = torch.zeros((E + 31) // 32 * 32, 22, 8)
+    wp[:E, :21, :7] = w.reshape(E, 21, 7)
+    wp = bf(wp.reshape(-1, 176)).contiguous()
+    ref = torch.nn.functional.conv2d(bf(img).double(), bf(w).double(), bias.double(), stride=4, padding=3).permute(0, 2, 3, 1).reshape(-1, E)
+    out = ops.patch_embed(img.to(DEV), wp.to(DEV), bias.to(DEV), pos.to(DEV))
+    want = ref + pos.double().repeat(B, 1)
+    close(out, want.float(), 2e-5, 2e-5, "patch_embed + pos")
+    out2 = ops.patch_embed(img.to(DEV), wp.to(DEV), bias.to(DEV))
+    close(out2, ref.float(), 2e-5, 2e-5, "patch_embed")
+    # the two-launch path (column order (c, ky, kx) padded to 160)
+    w160 = torch.zeros(E, 160)
+    w160[:, :147] = w.reshape(E, 147)
+    old = ops.gemm(ops.im2col_patch(img.to(DEV)), bf(w160).to(DEV), bias.to(DEV), out_dtype=torch.float32)
+    close(out2, old.cpu(), 2e-5, 2e-5, "patch_embed vs im2col + gemm")
+    assert not ops.patch_embed_supported(64, 96) and not ops.patch_embed_supported(1024, 160)
+
+
 def test_gemm_epilogues(ops):
     M, N, K = 200, 192, 96
     a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.2))
