@@ -45,32 +45,43 @@ extern "C" int msam2_im2col_patch7x7s4(const float* img, void* out, int64_t B, i
 // ------------------------------------------------------------------------------------------------------------------
 // PatchEmbed as ONE kernel (round 4): Conv2d(3, E, k7, s4, p3) + bias + position table, fp32 image in, fp32 tokens out, no im2col map.
 // The two-launch form writes an 84 MB [tokens, 160] patch matrix (4 x 1024^2) with a gather kernel that runs at 1.8 TB/s and reads it
-// back in the GEMM: 74 + 48 us for 150 MB of algorithmic traffic (50 MB image, 100 MB tokens).  Here a workgroup stages the 3 x 7 image
-// rows of a token-row segment (<= 128 tokens: 4 * nt + 8 pixels per row) in LDS as 16-bit values and the MFMA A fragments are read
-// straight from that image: the weight's reduction is RE-ORDERED to k' = (c * 7 + ky) * 8 + kx with a zero tap at kx = 7 (176 = 11 k-steps
-// of 16; tools: PatchEmbed._weight_perm), so the 8 consecutive k of a fragment are 8 consecutive pixels of one (c, ky) row, starting at
-// the token's window (pixel 4 t of the staged row: 8-byte aligned -> two ds_read_b64, 32 lanes x 8 B contiguous: conflict free).
+// back in the GEMM: 74 + 48 us in the step.  Here a workgroup stages the 3 x 7 image rows of a token-row segment (NTOK = 32 / 64 / 128
+// tokens: 4 NTOK + 4 pixels per row) in LDS as 16-bit values and the MFMA A fragments are read straight from that image: the weight's
+// reduction is RE-ORDERED to k' = (c * 7 + ky) * 8 + 1 + kx with a zero tap in FRONT of every run of seven (176 = 11 k-steps of 16;
+// PatchEmbed._weight_perm), so the 8 consecutive k' of a fragment are 8 consecutive pixels of one (c, ky) row starting at the pixel
+// before the token's window -- column 4 t of the staged row, whose column 0 is the 16-byte-aligned pixel 4 tx0 - 4: an aligned float4
+// of the image becomes one 8-byte LDS write, a fragment two 8-byte reads (32 lanes x 8 B contiguous: conflict free).
 // Wave w of the workgroup owns tokens 32 w .. 32 w + 31.  The permuted weight ([n][176], 34 KB at E = 96) is copied into LDS once per
 // workgroup with a 368-byte row pitch (23 sixteen-byte chunks: odd, so the 16 rows of a ds_read_b128 lane group fall into 16 different
-// bank groups) and its fragments are read per use -- in registers they cost 132 VGPRs and left one workgroup per CU, which cannot hide
-// the staging latency; the workgroup walks segments with a grid stride.  Output straight from the accumulator
-// layout: one dword per lane, 32 consecutive channels of a token = 128-byte row segments, bias and the position row (token index within
-// its image: the batch-broadcast table of Hiera._get_pos_embed) added in the store.
+// bank groups) and its fragments are read per use -- in registers they cost 132 VGPRs and left one workgroup per CU; the workgroup walks
+// segments with a grid stride.  What the first versions taught (tools/patch_embed_bench.py, 4 x 1024^2, E = 96; im2col + GEMM: 103 us):
+//   * a rolled load -> convert -> ds_write staging loop pays the memory latency once per iteration: 105 us; all of a thread's image
+//     loads issued at once: 93 us; the next segment's loads in flight under the current one's MFMAs and stores: no further change;
+//   * 8-byte instead of 2-byte LDS writes: no change;
+//   * the position table: loads and stores share ONE in-order counter (vmcnt), so a load issued behind a store waits for that store's
+//     round trip -- as 48 interleaved load / add / store triples per lane the table cost 54 of 92 us; with every position value
+//     loaded before the first store: **60 us** (E = 112: 72 against 112).  Loading them before the MFMAs as well costs 50 registers,
+//     the second workgroup per CU, and gains nothing.
+// Output straight from the accumulator layout: one dword per lane, 32 consecutive channels of a token = 128-byte row segments, bias
+// and the position row (token index within its image: the batch-broadcast table of Hiera._get_pos_embed) added in the store.
 // ------------------------------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, int NTOK>
 __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ img, const op16* __restrict__ wp, const float* __restrict__ bias,
-                                                          const float* __restrict__ pos, float* __restrict__ out, int B, int S, int E, int nt) {
+                                                          const float* __restrict__ pos, float* __restrict__ out, int B, int S, int E) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int KS = 11, ROWS = 21;                       // k-steps of 16; (c, ky) rows of the staged image
+  constexpr int nt = NTOK;                                // tokens per segment
+  constexpr int P = 4 * nt + 8;                           // staged row pitch in pixels (16-bit each): 4 nt + 4 used, rows stay 16-byte aligned
+  constexpr int WP = 368;                                 // LDS row pitch of the weight image in bytes
+  constexpr int F4 = nt + 1;                              // aligned float4 loads per row: pixels 4 tx0 - 4 .. 4 tx0 + 4 nt - 1
+  constexpr int TOTAL = ROWS * F4, ITERS = (TOTAL + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int r = lane & 31, h = lane >> 5;
   const int So = S / 4, segs_per_row = So / nt;
-  const int P = 4 * nt + 8;                                 // staged row pitch in pixels (16-bit each); >= 4 * nt + 3 needed, + pad
-  constexpr int WP = 368;                                   // LDS row pitch of the weight image in bytes
-  unsigned char* swt = smem;                                // [NT * 32][WP]
+  unsigned char* swt = smem;                              // [NT * 32][WP]
   op16* simg = reinterpret_cast<op16*>(smem + NT * 32 * WP);
-  for (int i = tid; i < NT * 32 * 22; i += 256) {           // 22 chunks of 16 bytes per 176-element row
+  for (int i = tid; i < NT * 32 * 22; i += 256) {         // 22 chunks of 16 bytes per 176-element row
     const int n = i / 22, c = i - n * 22;
     *reinterpret_cast<uint4*>(swt + n * WP + c * 16) = *reinterpret_cast<const uint4*>(wp + (int64_t)n * 176 + c * 8);
   }
@@ -78,49 +89,66 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
 #pragma unroll
   for (int j = 0; j < NT; ++j) bj[j] = (j * 32 + r < E) ? bias[j * 32 + r] : 0.f;
   const int n_seg = B * So * segs_per_row;
-  const int f4_per_row = nt + 1;                            // aligned float4 loads covering pixels 4 tx0 - 4 .. 4 tx0 + 4 nt - 1
+  // the image loads of segment i + 1 are issued before segment i is computed and stored (ITERS float4 per thread)
+  f32x4 v[ITERS];
+  auto load_segment = [&](int seg) __attribute__((always_inline)) {
+    const int sx = seg % segs_per_row, ty = (seg / segs_per_row) % So, b = seg / (segs_per_row * So);
+    const int tx0 = sx * nt;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int i = tid + it * 256;
+      const int row = i / F4, m = i - row * F4;
+      const int c = row / 7, ky = row - c * 7;
+      const int y = 4 * ty - 3 + ky, x = 4 * tx0 - 4 + 4 * m;
+      v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < TOTAL && y >= 0 && y < S && x >= 0 && x < S) v[it] = *reinterpret_cast<const f32x4*>(img + (((int64_t)b * 3 + c) * S + y) * S + x);
+    }
+  };
+  if ((int)blockIdx.x < n_seg) load_segment(blockIdx.x);
   for (int seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
     const int sx = seg % segs_per_row, ty = (seg / segs_per_row) % So, b = seg / (segs_per_row * So);
     const int tx0 = sx * nt;
-    __syncthreads();                                        // every wave is done reading the previous segment's image
-    // ---- stage: LDS column j of row (c, ky) <-> pixel x = 4 tx0 - 3 + j, y = 4 ty - 3 + ky; outside the image: 0
-    for (int i = tid; i < ROWS * f4_per_row; i += 256) {
-      const int row = i / f4_per_row, m = i - row * f4_per_row;
-      const int c = row / 7, ky = row - c * 7;
-      const int y = 4 * ty - 3 + ky, x = 4 * tx0 - 4 + 4 * m;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (y >= 0 && y < S && x >= 0 && x < S) v = *reinterpret_cast<const f32x4*>(img + (((int64_t)b * 3 + c) * S + y) * S + x);
-      op16* dst = simg + row * P + 4 * m - 1;               // pixel x -> column x - (4 tx0 - 3) = 4 m - 1
-      if (m > 0) dst[0] = f2op(v[0]);
-      dst[1] = f2op(v[1]);
-      dst[2] = f2op(v[2]);
-      dst[3] = f2op(v[3]);
-    }
-    for (int i = tid; i < ROWS * 5; i += 256) {             // columns 4 nt + 3 .. 4 nt + 7: read by the zero tap only, keep them finite
-      const int row = i / 5, j = i - row * 5;
-      simg[row * P + 4 * nt + 3 + j] = (op16)0.f;
+    // ---- stage: LDS column j of row (c, ky) <-> pixel x = 4 tx0 - 4 + j, y = 4 ty - 3 + ky; outside the image: 0
+    __syncthreads();                                      // every wave is done reading the previous segment's image (and the weights are in)
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int i = tid + it * 256;
+      const int row = i / F4, m = i - row * F4;
+      if (i < TOTAL) {
+        op16x4 w4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w4[q] = f2op(v[it][q]);
+        *reinterpret_cast<op16x4*>(simg + row * P + 4 * m) = w4;
+      }
     }
     __syncthreads();
+    if (seg + (int)gridDim.x < n_seg) load_segment(seg + gridDim.x);      // in flight under this segment's MFMAs and stores
     if (wave * 32 < nt) {
       f32x16 acc[NT];
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-      const int t = wave * 32 + r;                          // this lane's token within the segment (A operand row)
+      const int t = wave * 32 + r;                        // this lane's token within the segment (A operand row)
+      // all A fragments first (one LDS latency for the tile instead of one per k-step): the window of token t is columns 4 t .. 4 t + 7
+      // = pixels 4 (tx0 + t) - 4 .. + 3, the first of which meets the zero tap
+      op16x8 afr[KS];
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const int R = 2 * s + h;                            // (c, ky) row of this half's 8 taps; row 21 does not exist: zero fragment
-        op16x8 af;
-        if (R < ROWS) {
+        const int R = 2 * s + h;                          // (c, ky) row of this half's 8 taps; row 21 does not exist: zero fragment
+        if (R < ROWS) {                                   // (8-byte aligned only: two ds_read_b64)
           const op16* src = simg + R * P + 4 * t;
           const op16x4 lo = *reinterpret_cast<const op16x4*>(src), hi = *reinterpret_cast<const op16x4*>(src + 4);
-          af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3];
-          af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
+          afr[s][0] = lo[0]; afr[s][1] = lo[1]; afr[s][2] = lo[2]; afr[s][3] = lo[3];
+          afr[s][4] = hi[0]; afr[s][5] = hi[1]; afr[s][6] = hi[2]; afr[s][7] = hi[3];
         } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) af[e] = (op16)0.f;
+          for (int e = 0; e < 8; ++e) afr[s][e] = (op16)0.f;
         }
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const op16x8 af = afr[s];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const op16x8 wf = *reinterpret_cast<const op16x8*>(swt + (j * 32 + r) * WP + (s * 16 + h * 8) * 2);
@@ -130,6 +158,16 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
       // ---- store: lane = channel, accumulator register e = token row (e & 3) + 8 (e >> 2) + 4 h
       const int64_t tok0 = ((int64_t)b * So + ty) * So + tx0 + wave * 32;      // first token of this wave, global
       const int64_t ptok0 = (int64_t)ty * So + tx0 + wave * 32;                // ... within its image (position table row)
+      float pv[NT][16];                                   // every position value is loaded BEFORE the first store (header comment)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = j * 32 + r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+          pv[j][e] = (pos && n < E) ? pos[(ptok0 + row) * E + n] : 0.f;
+        }
+      }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int n = j * 32 + r;
@@ -137,9 +175,7 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-            float v = acc[j][e] + bj[j];
-            if (pos) v += pos[(ptok0 + row) * E + n];
-            out[(tok0 + row) * E + n] = v;
+            out[(tok0 + row) * E + n] = acc[j][e] + bj[j] + pv[j][e];
           }
         }
       }
@@ -149,7 +185,7 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
 }
 
 // img fp32 [B, 3, S, S] -> out fp32 [B * (S/4)^2, E] = conv7x7s4p3(img) + bias (+ pos[token within image], pos fp32 [(S/4)^2, E] or null).
-// w_perm: 16-bit [ceil(E / 32) * 32, 176], reduction order k' = (c * 7 + ky) * 8 + kx, zero at kx = 7 and in the padding rows / columns.
+// w_perm: 16-bit [ceil(E / 32) * 32, 176], reduction order k' = (c * 7 + ky) * 8 + 1 + kx, zero at k' % 8 == 0 and in the padding rows / columns.
 // Requires (S/4) % 32 == 0 and E <= 128.
 extern "C" int msam2_patch_embed7x7s4(const float* img, const void* w_perm, const float* bias, const float* pos, float* out, int64_t B,
                                       int64_t S, int64_t E, void* stream) {
@@ -157,26 +193,35 @@ extern "C" int msam2_patch_embed7x7s4(const float* img, const void* w_perm, cons
   MSAM2_REQUIRE(S % 4 == 0 && (S / 4) % 32 == 0 && E <= 128, "patch_embed: needs (S / 4) %% 32 == 0 and E <= 128 (S=%lld E=%lld)", (long long)S, (long long)E);
   MSAM2_REQUIRE((((uintptr_t)img | (uintptr_t)w_perm) & 15) == 0, "patch_embed: image and weights must be 16-byte aligned");
   MSAM2_REQUIRE(B * (S / 4) * (S / 4) * E < (1ll << 40), "patch_embed: problem too large");
-  const int So = (int)(S / 4), nt = So >= 128 ? 128 : So;   // So % 32 == 0: a segment is 32 .. 128 tokens and divides the row when So <= 128
-  MSAM2_REQUIRE(So % nt == 0, "patch_embed: the token row must split into whole segments (S/4 = %d)", So);
+  const int So = (int)(S / 4);
+  const int nt = So % 128 == 0 ? 128 : (So % 64 == 0 ? 64 : 32);     // tokens per segment: whole segments per token row
   const int n_seg = (int)B * So * (So / nt);
   const int NTn = (int)((E + 31) / 32);
   const int lds = NTn * 32 * 368 + 21 * (4 * nt + 8) * 2;
   const dim3 grid((unsigned)min(n_seg, 1024)), block(256);
-  static bool attr_set = false;
-  if (!attr_set) {     // (NT = 4, hiera_b+: 69 KB of dynamic LDS)
-    hipFuncSetAttribute((const void*)patch_embed_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    hipFuncSetAttribute((const void*)patch_embed_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    hipFuncSetAttribute((const void*)patch_embed_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    hipFuncSetAttribute((const void*)patch_embed_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    attr_set = true;
-  }
+#define PE_LAUNCH(NTV, TOKV) \
+  do { \
+    static bool attr_set = false; \
+    if (!attr_set) {     /* (NT = 4, hiera_b+: 69 KB of dynamic LDS) */ \
+      hipFuncSetAttribute((const void*)patch_embed_kernel<NTV, TOKV>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+      attr_set = true; \
+    } \
+    hipLaunchKernelGGL((patch_embed_kernel<NTV, TOKV>), grid, block, lds, (hipStream_t)stream, img, (const op16*)w_perm, bias, pos, out, (int)B, (int)S, (int)E); \
+  } while (0)
+#define PE_TOK(NTV) \
+  do { \
+    if (nt == 128) PE_LAUNCH(NTV, 128); \
+    else if (nt == 64) PE_LAUNCH(NTV, 64); \
+    else PE_LAUNCH(NTV, 32); \
+  } while (0)
   switch (NTn) {
-    case 1: hipLaunchKernelGGL((patch_embed_kernel<1>), grid, block, lds, (hipStream_t)stream, img, (const op16*)w_perm, bias, pos, out, (int)B, (int)S, (int)E, nt); break;
-    case 2: hipLaunchKernelGGL((patch_embed_kernel<2>), grid, block, lds, (hipStream_t)stream, img, (const op16*)w_perm, bias, pos, out, (int)B, (int)S, (int)E, nt); break;
-    case 3: hipLaunchKernelGGL((patch_embed_kernel<3>), grid, block, lds, (hipStream_t)stream, img, (const op16*)w_perm, bias, pos, out, (int)B, (int)S, (int)E, nt); break;
-    default: hipLaunchKernelGGL((patch_embed_kernel<4>), grid, block, lds, (hipStream_t)stream, img, (const op16*)w_perm, bias, pos, out, (int)B, (int)S, (int)E, nt); break;
+    case 1: PE_TOK(1); break;
+    case 2: PE_TOK(2); break;
+    case 3: PE_TOK(3); break;
+    default: PE_TOK(4); break;
   }
+#undef PE_TOK
+#undef PE_LAUNCH
   return msam2_check_launch("patch_embed7x7s4");
 }
 

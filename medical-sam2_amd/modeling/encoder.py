@@ -42,13 +42,14 @@ class PatchEmbed(nn.Module):
         return self._wc.get("w", [self.proj.weight], build)
 
     def _weight_perm(self):
-        """the conv weight in the one-kernel patch embedding's reduction order: [ceil32(E), 176], k' = (c * 7 + ky) * 8 + kx, zero at kx = 7
-        and in the padding (ops.patch_embed: 8 consecutive k' = 8 consecutive pixels of one image row)"""
+        """the conv weight in the one-kernel patch embedding's reduction order: [ceil32(E), 176], k' = (c * 7 + ky) * 8 + 1 + kx, zero at
+        k' % 8 == 0 and in the padding (ops.patch_embed: 8 consecutive k' = 8 consecutive pixels of one image row, the first of them the
+        16-byte-aligned pixel in front of the window)"""
         def build():
             w = self.proj.weight.detach()
             E = w.shape[0]
             wp = torch.zeros((E + 31) // 32 * 32, 22, 8, dtype=OP16, device=w.device)
-            wp[:E, :21, :7] = w.reshape(E, 21, 7).to(OP16)
+            wp[:E, :21, 1:] = w.reshape(E, 21, 7).to(OP16)
             return wp.reshape(-1, 176).contiguous()
         return self._wc.get("wp", [self.proj.weight], build)
 

@@ -464,12 +464,12 @@ def im2col_patch(img: torch.Tensor) -> torch.Tensor:
 def patch_embed_supported(S: int, E: int) -> bool:
     """the one-kernel patch embedding (msam2_patch_embed7x7s4) takes this problem: whole 32-token wave blocks per token row, E <= 128"""
     So = S // 4
-    return S % 4 == 0 and So % 32 == 0 and (So <= 128 or So % 128 == 0) and E <= 128
+    return S % 4 == 0 and So % 32 == 0 and E <= 128
 
 
 def patch_embed(img: torch.Tensor, w_perm: torch.Tensor, bias: torch.Tensor, pos: Optional[torch.Tensor] = None) -> torch.Tensor:
     """img fp32 [B,3,S,S] -> fp32 tokens [B*(S/4)^2, E] = conv7x7/s4/p3 + bias (+ pos [(S/4)^2, E], broadcast over the batch) in ONE kernel, no
-    im2col map.  w_perm: 16-bit [ceil(E/32)*32, 176] in the kernel's reduction order (modeling.encoder.PatchEmbed._weight_perm)."""
+    im2col map.  w_perm: 16-bit [ceil(E/32)*32, 176] in the kernel's reduction order, zero tap first (modeling.encoder.PatchEmbed._weight_perm)."""
     _req(img.dtype == F32 and img.is_contiguous() and img.shape[1] == 3 and img.shape[2] == img.shape[3], "patch_embed: [B,3,S,S] fp32")
     B, _, S, _ = img.shape
     E = bias.shape[0]

@@ -139,7 +139,7 @@ def test_patch_embed_one_kernel(ops, B, S, E):
     pos = torch.randn(So * So, E, generator=g)
     assert ops.patch_embed_supported(S, E)
     wp = torch.zeros((E + 31) // 32 * 32, 22, 8)
-    wp[:E, :21, :7] = w.reshape(E, 21, 7)
+    wp[:E, :21, 1:] = w.reshape(E, 21, 7)
     wp = bf(wp.reshape(-1, 176)).contiguous()
     ref = torch.nn.functional.conv2d(bf(img).double(), bf(w).double(), bias.double(), stride=4, padding=3).permute(0, 2, 3, 1).reshape(-1, E)
     out = ops.patch_embed(img.to(DEV), wp.to(DEV), bias.to(DEV), pos.to(DEV))

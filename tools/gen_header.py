@@ -11,7 +11,7 @@ DOC = {
     "msam2_version": "Library version (major*10000 + minor*100 + patch).",
     "msam2_operand_is_fp16": "16-bit operand type of this build: 1 = IEEE fp16 (default), 0 = bf16 (built with -DMSAM2_OPERAND_BF16).  All\n`*_is_16bit` flags below select between that type and fp32.",
     "msam2_last_error": "Message of the last failing call on this thread.  Errors never cross the ABI as exceptions: every entry returns\n0 on success, <0 on failure (reference behaviour: AT_ASSERTM -> RuntimeError, connected_components.cu:215-228; the\nPython wrapper re-raises as RuntimeError).",
-    "msam2_patch_embed7x7s4": "PatchEmbed.forward (backbones/utils.py:84-95: Conv2d(3, E, k7, s4, p3), NHWC out) plus the position table added at hieradet.py:283\n(x = x + self._get_pos_embed(x.shape[1:3])) as ONE kernel: fp32 image in, fp32 tokens out, no im2col map.  w_perm: the conv weight in the\nkernel's reduction order, 16-bit [ceil(E/32)*32, 176], k' = (c*7 + ky)*8 + kx with a zero tap at kx = 7; pos: fp32 [(S/4)^2, E] or NULL.\nNeeds (S/4) % 32 == 0 and E <= 128; other sizes use msam2_im2col_patch7x7s4 + msam2_gemm.",
+    "msam2_patch_embed7x7s4": "PatchEmbed.forward (backbones/utils.py:84-95: Conv2d(3, E, k7, s4, p3), NHWC out) plus the position table added at hieradet.py:283\n(x = x + self._get_pos_embed(x.shape[1:3])) as ONE kernel: fp32 image in, fp32 tokens out, no im2col map.  w_perm: the conv weight in the\nkernel's reduction order, 16-bit [ceil(E/32)*32, 176], k' = (c*7 + ky)*8 + 1 + kx with a zero tap in front of each run of 7; pos: fp32 [(S/4)^2, E] or NULL.\nNeeds (S/4) % 32 == 0 and E <= 128; other sizes use msam2_im2col_patch7x7s4 + msam2_gemm.",
     "msam2_gemm_pool2x2": "Hiera's pooled shortcut `do_pool(self.proj(x_norm), self.pool)` (hieradet.py:141-145, 23-34) as one GEMM: C (fp32)\n[B*(H/2)*(W/2), N] = maxpool2x2(A W^T + bias) over the [B,H,W] token image A; the un-pooled map is never written.",
     "msam2_gemm_qkv_pool2x2": "Fused qkv projection of a q-pooling Hiera block (hieradet.py:61-70 with do_pool, 23-34): k/v columns to QKV in image order,\nQ2 = maxpool2x2 of the q columns; the un-pooled q is neither written nor read back.",
     "msam2_gemm_tokens": "Token-side linear layers of the two-way decoder (transformer.py:165-196, 239-263): M <= 32 rows, A in fp32 from the residual\nstream, columns < add_cols computed from A + A2 (queries + query_pe), add and 16-bit conversion fused into the operand load.",
