@@ -228,7 +228,7 @@ __device__ __forceinline__ void gemm_epilogue_spec(const GemmParams& p, f32x16 (
 //   [1,0,3,2]) and packs a dword: even lanes store (col r, r+1) of row(e), odd lanes (col r-1, r) of row(e+1).
 // Rows past M fall outside the buffer descriptor's num_records and are dropped by the hardware range check (the row term is in
 // the per-lane voffset because soffset is not range-checked on gfx9); columns past N are masked per lane.
-template <int FM, int FN, int ACT, int RES /* 0 none, 1 f32 */, bool OUT16, bool ROPE = false>
+template <int FM, int FN, int ACT, int RES /* 0 none, 1 f32 */, bool OUT16, bool ROPE = false, int TBMAX = 2>
 __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x16 (&acc)[FM][FN], int64_t row0, int64_t col0, int lane) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int ES = OUT16 ? 2 : 4;
@@ -255,29 +255,41 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x16
   if constexpr (!OUT16) {
     const int vbase = (int)((row0 + 4 * h) * p.ldc + col0 + r) * 4;
     const int rbase = (int)((row0 + 4 * h) * p.ldr + col0 + r) * 4;
+    // Residual loads and output stores share ONE in-order counter (vmcnt): a load issued behind a store waits for that store's round trip.
+    // Tile by tile (16 loads, 16 stores, 16 loads, ...) the 2 x 2 tiles of a wave serialised three store round trips inside every
+    // epilogue (round 4, found on the patch-embedding kernel: conv.hip); the tiles are now handled TB at a time -- all their residual
+    // loads, then all their stores -- TB = 2 (32 extra registers) in the four-workgroups-per-CU kernel, all four tiles (TBMAX = 4) where the
+    // register budget allows.
+    constexpr int TB = (RES == 1 && FM * FN >= 2 && (FM * FN) % 2 == 0) ? ((TBMAX >= 4 && (FM * FN) % 4 == 0) ? 4 : 2) : 1;
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+    for (int t0 = 0; t0 < FM * FN; t0 += TB) {
+      float rv[TB][16];
+      if constexpr (RES == 1) {
 #pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        float rv[16];
-        if constexpr (RES == 1) {
+        for (int u = 0; u < TB; ++u) {
+          const int i = (t0 + u) / FN, j = (t0 + u) % FN;
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int ro = i * 32 + (e & 3) + 8 * (e >> 2);
-            rv[e] = colok[j] ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, rbase + ro * ldr_b + j * 128, 0, 0)) : 0.f;
+            rv[u][e] = colok[j] ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, rbase + ro * ldr_b + j * 128, 0, 0)) : 0.f;
           }
         }
+      }
+#pragma unroll
+      for (int u = 0; u < TB; ++u) {
+        const int i = (t0 + u) / FN, j = (t0 + u) % FN;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int ro = i * 32 + (e & 3) + 8 * (e >> 2);
           float y = fn(acc[i][j][e], j);
-          if constexpr (RES == 1) y += rv[e];
+          if constexpr (RES == 1) y += rv[u][e];
           if (colok[j]) {
             if (p.store_nt) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), c_rsrc, vbase + ro * ldc_b + j * 128, 0, 2);
             else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), c_rsrc, vbase + ro * ldc_b + j * 128, 0, 0);
           }
         }
       }
+    }
   } else {
     static_assert(!OUT16 || RES == 0, "16-bit outputs carry no residual on the direct path");
     const int vbase = (int)((row0 + 4 * h + odd) * p.ldc + col0 + (r & ~1)) * 2;
@@ -445,7 +457,7 @@ __device__ __forceinline__ void gemm_epilogue_qpool(const GemmParams& p, f32x16 
 #endif
 }
 
-template <int FM, int FN>
+template <int FM, int FN, int TBMAX = 2>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[FM][FN], float* scr, int64_t row0, int64_t col0,
                                               int lane) {
   if (p.pool_W) {
@@ -467,7 +479,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         else gemm_epilogue_direct<FM, FN, 0, 0, true>(p, acc, row0, col0, lane);
         return;
       case 0 * 4 + 0 + 0: gemm_epilogue_direct<FM, FN, 0, 0, false>(p, acc, row0, col0, lane); return;  // linear -> fp32
-      case 0 * 4 + 2 + 0: gemm_epilogue_direct<FM, FN, 0, 1, false>(p, acc, row0, col0, lane); return;  // + fp32 residual -> fp32
+      case 0 * 4 + 2 + 0: gemm_epilogue_direct<FM, FN, 0, 1, false, false, TBMAX>(p, acc, row0, col0, lane); return;  // + fp32 residual -> fp32
       case 1 * 4 + 0 + 1: gemm_epilogue_direct<FM, FN, 1, 0, true>(p, acc, row0, col0, lane); return;   // GELU -> 16-bit
       case 2 * 4 + 0 + 1: gemm_epilogue_direct<FM, FN, 2, 0, true>(p, acc, row0, col0, lane); return;   // ReLU -> 16-bit
       default: break;
@@ -714,7 +726,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
     }
   }
   __builtin_amdgcn_s_barrier();
-  gemm_epilogue<2, 2>(p, acc, reinterpret_cast<float*>(lds) + wave * 32 * 68, m0 + wm * 64, n0 + wn * 64, lane);
+  gemm_epilogue<2, 2, 4>(p, acc, reinterpret_cast<float*>(lds) + wave * 32 * 68, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

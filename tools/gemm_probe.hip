@@ -47,6 +47,14 @@ int main(int argc, char** argv) {
   for (int b = 0; b < nb; ++b) { hist[std::min(9, (int)((st[b * 8] - t0) * 10 / (t3 - t0 + 1)))]++; xcc[st[b * 8 + 5] & 15]++; }
   printf("start-time histogram:"); for (int i = 0; i < 10; ++i) printf(" %d", hist[i]); printf("\nper-XCC workgroups:");
   for (int i = 0; i < 8; ++i) printf(" %d", xcc[i]); printf("\n");
+  {  // workgroups per CU (HW_ID: cu 11:8, sh 12, se 15:13) -- how a grid smaller than the chip's slots is spread
+    std::vector<int> keys(nb);
+    for (int b = 0; b < nb; ++b) keys[b] = (int)(((st[b * 8 + 5] & 15) << 16) | (st[b * 8 + 4] & 0xFF00));
+    std::sort(keys.begin(), keys.end());
+    int distinct = 0, mx = 0, run = 0;
+    for (int b = 0; b < nb; ++b) { run = (b && keys[b] == keys[b - 1]) ? run + 1 : 1; if (run == 1) ++distinct; mx = std::max(mx, run); }
+    printf("workgroups on %d distinct CUs, at most %d on one CU\n", distinct, mx);
+  }
   // the first and last few workgroups in start order
   std::vector<int> ord(nb); for (int i = 0; i < nb; ++i) ord[i] = i;
   std::sort(ord.begin(), ord.end(), [&](int x, int y) { return st[x * 8] < st[y * 8]; });

@@ -35,6 +35,7 @@ def short(name):
 
 def main():
     d, steps = sys.argv[1], int(sys.argv[2])
+    seq_out = sys.argv[3] if len(sys.argv) > 3 else None      # optional: the ordered kernel list of the last replay (start us, us, name)
     rows = load(d)
     names = [r[2] for r in rows]
     n = len(names)
@@ -55,6 +56,12 @@ def main():
             ksum += (b - a) / 1e3
             if i:
                 gap += max(0.0, (a - seq[i - 1][1]) / 1e3)
+    if seq_out:
+        last = tail[(steps - 1) * K:]
+        with open(seq_out, "w") as f:
+            f.write(f"# ordered kernels of one replay of the benchmark step ({K} launches): index, start (us from the first), duration (us), kernel\n")
+            for i, (a, b, nm) in enumerate(last):
+                f.write(f"{i:3d} {(a - last[0][0]) / 1e3:8.1f} {(b - a) / 1e3:7.1f}  {short(nm)}\n")
     wall = sum((tail[(s + 1) * K - 1][1] - tail[s * K][0]) / 1e3 for s in range(steps)) / steps
     print(f"kernels per replay {K}; kernel time {ksum / steps:.1f} us; gaps between consecutive kernels {gap / steps:.1f} us; "
           f"first start -> last end {wall:.1f} us (average of the last {steps} replays)")
