@@ -101,6 +101,8 @@ SIGNATURES = {
     "msam2_token_mlp3": (c_i, [c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_p]),
     "msam2_hyper_masks": (c_i, [c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_p]),
     "msam2_prompt_points": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_f, c_p]),
+    "msam2_prompt_points_padded": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_f, c_p]),
+    "msam2_token_mlp3_packed": (c_i, [c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_p]),
     "msam2_select_mask": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_f, c_f, c_p]),
     "msam2_gather_rows": (c_i, [c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_p]),
     "msam2_obj_ptr_mix": (c_i, [c_p, c_p, c_p, c_l, c_l, c_p]),

@@ -552,12 +552,16 @@ extern "C" int msam2_hyper_masks(const float* hyper, const void* upscaled, float
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void prompt_points_kernel(const float* __restrict__ xy, const int* __restrict__ labels, const float* __restrict__ gauss,
                                      const float* __restrict__ point_emb, const float* __restrict__ not_a_point,
-                                     float* __restrict__ out, int n_pts, int C, float inv_size) {
+                                     float* __restrict__ out, int n_out, int p_in, int p_out, int C, float inv_size) {
   const int pt = blockIdx.x;
-  if (pt >= n_pts) return;
+  if (pt >= n_out) return;
   const int nf = C / 2;
-  const int lab = labels[pt];
-  const float cx = 2.f * ((xy[2 * pt] + 0.5f) * inv_size) - 1.f, cy = 2.f * ((xy[2 * pt + 1] + 0.5f) * inv_size) - 1.f;
+  const int set = pt / p_out, j = pt - set * p_out;
+  const bool pad = j >= p_in;                              // the padding point of prompt_encoder.py:87-91: (0, 0) with label -1
+  const int src = set * p_in + j;
+  const int lab = pad ? -1 : labels[src];
+  const float px = pad ? 0.f : xy[2 * src], py = pad ? 0.f : xy[2 * src + 1];
+  const float cx = 2.f * ((px + 0.5f) * inv_size) - 1.f, cy = 2.f * ((py + 0.5f) * inv_size) - 1.f;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     const int f = c % nf;
     const float a = 6.283185307179586f * (cx * gauss[f] + cy * gauss[nf + f]);
@@ -574,8 +578,20 @@ extern "C" int msam2_prompt_points(const float* xy, const int* labels, const flo
   MSAM2_REQUIRE(xy && labels && gauss && point_emb && not_a_point && out, "prompt_points: null tensor");
   MSAM2_REQUIRE(n_points > 0 && C % 2 == 0, "prompt_points: bad shape");
   hipLaunchKernelGGL(prompt_points_kernel, dim3((unsigned)n_points), dim3(128), 0, (hipStream_t)stream, xy, labels, gauss,
-                     point_emb, not_a_point, out, (int)n_points, (int)C, 1.0f / image_size);
+                     point_emb, not_a_point, out, (int)n_points, (int)n_points, (int)n_points, (int)C, 1.0f / image_size);
   return msam2_check_launch("prompt_points");
+}
+
+// the same with `n_pad` padding points appended to each of the `n_sets` prompt sets inside the kernel (no zeros / full / cat launches):
+// xy [n_sets, P, 2], labels [n_sets, P] -> out [n_sets, P + n_pad, C]
+extern "C" int msam2_prompt_points_padded(const float* xy, const int* labels, const float* gauss, const float* point_emb,
+                                          const float* not_a_point, float* out, int64_t n_sets, int64_t P, int64_t n_pad, int64_t C,
+                                          float image_size, void* stream) {
+  MSAM2_REQUIRE(xy && labels && gauss && point_emb && not_a_point && out, "prompt_points_padded: null tensor");
+  MSAM2_REQUIRE(n_sets > 0 && P > 0 && n_pad >= 0 && C % 2 == 0 && n_sets * (P + n_pad) < (1ll << 31), "prompt_points_padded: bad shape");
+  hipLaunchKernelGGL(prompt_points_kernel, dim3((unsigned)(n_sets * (P + n_pad))), dim3(128), 0, (hipStream_t)stream, xy, labels, gauss,
+                     point_emb, not_a_point, out, (int)(n_sets * (P + n_pad)), (int)P, (int)(P + n_pad), (int)C, 1.0f / image_size);
+  return msam2_check_launch("prompt_points_padded");
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -737,7 +753,8 @@ __global__ __launch_bounds__(1024) void token_mlp3_kernel(const float* __restric
                                                           const float* __restrict__ b1, const op16* __restrict__ w2,
                                                           const float* __restrict__ b2, const op16* __restrict__ w3,
                                                           const float* __restrict__ b3, const int* __restrict__ out_dim,
-                                                          const int* __restrict__ sigmoid, float* __restrict__ out, int B) {
+                                                          const int* __restrict__ sigmoid, float* __restrict__ out, int B,
+                                                          const int* __restrict__ out_off, const int* __restrict__ out_ld) {
   constexpr int C = 256, RPW = 16;                            // 16 waves x 16 rows per layer, 8 rows (8 loads) in flight per wave
   __shared__ float act[2][C];
   const int g = blockIdx.x, b = blockIdx.y;
@@ -747,6 +764,9 @@ __global__ __launch_bounds__(1024) void token_mlp3_kernel(const float* __restric
   const op16* ws[3] = {w1 + (int64_t)g * C * C, w2 + (int64_t)g * C * C, w3 + (int64_t)g * C * C};
   const float* bs[3] = {b1 + g * C, b2 + g * C, b3 + g * C};
   const int n_out = out_dim[g];
+  // packed output (out_off != nullptr): head g writes its n_out values of batch element b at out[out_off[g] + b * out_ld[g] + o], so that
+  // heads of different widths land in contiguous tensors of their own (no slicing copies behind the kernel)
+  float* orow = out_off ? out + out_off[g] + (int64_t)b * out_ld[g] : out + ((int64_t)b * gridDim.x + g) * C;
 #pragma unroll
   for (int layer = 0; layer < 3; ++layer) {
     const float* xin = act[layer & 1];
@@ -764,7 +784,7 @@ __global__ __launch_bounds__(1024) void token_mlp3_kernel(const float* __restric
         s = wave_sum(s) + bs[layer][o0 + u];
         if (lane == 0) {
           if (layer < 2) act[(layer + 1) & 1][o0 + u] = fmaxf(s, 0.f);
-          else if (o0 + u < n_out) out[((int64_t)b * gridDim.x + g) * C + o0 + u] = sigmoid[g] ? 1.f / (1.f + __expf(-s)) : s;
+          else if (o0 + u < n_out) orow[o0 + u] = sigmoid[g] ? 1.f / (1.f + __expf(-s)) : s;
         }
       }
     }
@@ -772,13 +792,31 @@ __global__ __launch_bounds__(1024) void token_mlp3_kernel(const float* __restric
   }
 }
 
-extern "C" int msam2_token_mlp3(const float* hs, int64_t hs_batch_stride, int64_t hs_token_stride, const int* token_index,
-                                const void* w1, const float* b1, const void* w2, const float* b2, const void* w3, const float* b3,
-                                const int* out_dim, const int* sigmoid_flag, float* out, int64_t G, int64_t B, int64_t C, void* stream) {
+static int token_mlp3_launch(const float* hs, int64_t hs_batch_stride, int64_t hs_token_stride, const int* token_index, const void* w1,
+                             const float* b1, const void* w2, const float* b2, const void* w3, const float* b3, const int* out_dim,
+                             const int* sigmoid_flag, float* out, const int* out_off, const int* out_ld, int64_t G, int64_t B, int64_t C,
+                             void* stream) {
   MSAM2_REQUIRE(hs && token_index && w1 && b1 && w2 && b2 && w3 && b3 && out_dim && sigmoid_flag && out, "token_mlp3: null tensor");
   MSAM2_REQUIRE(C == 256 && G > 0 && B > 0 && G < 65536 && B < 65536, "token_mlp3: built for width 256");
   hipLaunchKernelGGL(token_mlp3_kernel, dim3((unsigned)G, (unsigned)B), dim3(1024), 0, (hipStream_t)stream, hs, hs_batch_stride,
                      hs_token_stride, token_index, (const op16*)w1, b1, (const op16*)w2, b2, (const op16*)w3, b3, out_dim, sigmoid_flag,
-                     out, (int)B);
+                     out, (int)B, out_off, out_ld);
   return msam2_check_launch("token_mlp3");
+}
+
+extern "C" int msam2_token_mlp3(const float* hs, int64_t hs_batch_stride, int64_t hs_token_stride, const int* token_index,
+                                const void* w1, const float* b1, const void* w2, const float* b2, const void* w3, const float* b3,
+                                const int* out_dim, const int* sigmoid_flag, float* out, int64_t G, int64_t B, int64_t C, void* stream) {
+  return token_mlp3_launch(hs, hs_batch_stride, hs_token_stride, token_index, w1, b1, w2, b2, w3, b3, out_dim, sigmoid_flag, out, nullptr,
+                           nullptr, G, B, C, stream);
+}
+
+// the same with a packed output: head g writes out[out_offset[g] + b * out_stride[g] + o], o < out_dim[g] (int32 device arrays of G entries)
+extern "C" int msam2_token_mlp3_packed(const float* hs, int64_t hs_batch_stride, int64_t hs_token_stride, const int* token_index,
+                                       const void* w1, const float* b1, const void* w2, const float* b2, const void* w3, const float* b3,
+                                       const int* out_dim, const int* sigmoid_flag, float* out, const int* out_offset, const int* out_stride,
+                                       int64_t G, int64_t B, int64_t C, void* stream) {
+  MSAM2_REQUIRE(out_offset && out_stride, "token_mlp3_packed: null offset / stride table");
+  return token_mlp3_launch(hs, hs_batch_stride, hs_token_stride, token_index, w1, b1, w2, b2, w3, b3, out_dim, sigmoid_flag, out, out_offset,
+                           out_stride, G, B, C, stream);
 }

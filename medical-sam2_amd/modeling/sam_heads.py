@@ -45,13 +45,13 @@ class PromptEncoder(nn.Module):
         h, w = self.image_embedding_size
         return nchw_view(self.dense_pe_tokens(), 1, h, w)
 
-    def _points(self, xy: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    def _points(self, xy: torch.Tensor, labels: torch.Tensor, n_pad: int = 0) -> torch.Tensor:
         assert self.input_image_size[0] == self.input_image_size[1]
         wc = self._wc
         emb = wc.get("pemb", [m.weight for m in self.point_embeddings],
                      lambda: torch.cat([m.weight.detach() for m in self.point_embeddings], 0).float().contiguous())
         return ops.prompt_points(xy.to(F32), labels.to(torch.int32), self.pe_layer.positional_encoding_gaussian_matrix.to(F32), emb,
-                                 v_f32(wc, "nap", self.not_a_point_embed.weight), float(self.input_image_size[0]))
+                                 v_f32(wc, "nap", self.not_a_point_embed.weight), float(self.input_image_size[0]), n_pad=n_pad)
 
     def _embed_masks_tokens(self, masks: torch.Tensor) -> torch.Tensor:
         """mask_downscaling (two k2/s2 convs + LN + GELU, then 1x1) -> fp32 tokens [n*h*w, embed_dim]."""
@@ -90,17 +90,19 @@ class PromptEncoder(nn.Module):
         bs = self._get_batch_size(points, boxes, masks)
         dev = self.no_mask_embed.weight.device
         xy_parts, lab_parts = [], []
+        n_pad = 0
         if points is not None:
             coords, labels = points
             xy_parts.append(coords.to(F32))
             lab_parts.append(labels.to(torch.int32))
-            if boxes is None:  # padding point, label -1 (prompt_encoder.py:87-91)
-                xy_parts.append(torch.zeros(bs, 1, 2, device=dev))
-                lab_parts.append(torch.full((bs, 1), -1, dtype=torch.int32, device=dev))
+            if boxes is None:  # padding point, label -1 (prompt_encoder.py:87-91): appended inside the kernel
+                n_pad = 1
         if boxes is not None:  # box corners are points with labels 2 / 3 (prompt_encoder.py:103-112)
             xy_parts.append(boxes.to(F32).reshape(-1, 2, 2))
             lab_parts.append(torch.tensor([[2, 3]], dtype=torch.int32, device=dev).expand(bs, 2))
-        if xy_parts:
+        if len(xy_parts) == 1:
+            sparse = self._points(xy_parts[0].contiguous(), lab_parts[0].contiguous(), n_pad)
+        elif xy_parts:
             sparse = self._points(torch.cat(xy_parts, 1).contiguous(), torch.cat(lab_parts, 1).contiguous())
         else:
             sparse = torch.empty((bs, 0, self.embed_dim), device=dev)
@@ -312,9 +314,7 @@ class MaskDecoder(nn.Module):
         out_tok = wc.get("otok", [self.obj_score_token.weight, self.iou_token.weight, self.mask_tokens.weight],
                          lambda: torch.cat([self.obj_score_token.weight, self.iou_token.weight, self.mask_tokens.weight], 0).detach().float())
         T = out_tok.shape[0] + sparse.shape[1]
-        tokens = torch.empty(B, T, C, dtype=F32, device=src_tokens.device)
-        tokens[:, : out_tok.shape[0]] = out_tok          # data movement: assemble the query token list
-        tokens[:, out_tok.shape[0]:] = sparse
+        tokens = torch.cat([out_tok.unsqueeze(0).expand(B, -1, -1), sparse], 1)          # data movement: the query token list (one launch)
         hs, keys = self.transformer.run(src_tokens, pe_tokens, tokens.view(B * T, C), B, T, h * w)
         hs = hs.view(B, T, C)
         up = self.output_upscaling
@@ -355,11 +355,19 @@ class MaskDecoder(nn.Module):
                         torch.tensor([int(m.sigmoid_output) for m in heads], dtype=torch.int32, device=dev))
             tok, od, sg = wc.get("heads_const", [], consts)
             w1, b1, w2, b2, w3, b3 = wc.get("heads", params, pack)
-            y = ops.token_mlp3(hs, tok, w1, b1, w2, b2, w3, b3, od, sg)          # [B, G, 256]
             nm = self.num_mask_tokens
-            hyper = y[:, :nm, : C // 8].contiguous()
-            iou = y[:, nm, : heads[nm].layers[2].out_features].contiguous()
-            obj = y[:, nm + 1, : heads[nm + 1].layers[2].out_features].contiguous()
+            n_hyper, n_iou, n_obj = C // 8, heads[nm].layers[2].out_features, heads[nm + 1].layers[2].out_features
+
+            def layout():   # packed result: hyper [B, nm, C/8] | iou [B, n_iou] | obj [B, n_obj], each contiguous (no slicing copies)
+                dev = hs.device
+                off = [g * n_hyper for g in range(nm)] + [B * nm * n_hyper, B * nm * n_hyper + B * n_iou]
+                ld = [nm * n_hyper] * nm + [n_iou, n_obj]
+                return torch.tensor(off, dtype=torch.int32, device=dev), torch.tensor(ld, dtype=torch.int32, device=dev)
+            off, ld = wc.get(f"heads_layout{B}", [], layout)
+            y = ops.token_mlp3(hs, tok, w1, b1, w2, b2, w3, b3, od, sg, packed=(off, ld, B * (nm * n_hyper + n_iou + n_obj)))
+            hyper = y[: B * nm * n_hyper].view(B, nm, n_hyper)
+            iou = y[B * nm * n_hyper: B * (nm * n_hyper + n_iou)].view(B, n_iou)
+            obj = y[B * (nm * n_hyper + n_iou):].view(B, n_obj)
         else:
             hyper = torch.empty(B, self.num_mask_tokens, C // 8, dtype=F32, device=u.device)
             for i, m in enumerate(self.output_hypernetworks_mlps):
@@ -408,7 +416,7 @@ class MaskDecoder(nn.Module):
         # broadcast vector inside the kernel)
         e3 = tokens_of(emb).view(B, h * w, C)
         if dense.stride(2) == 0 and dense.stride(3) == 0:
-            d3 = dense[:, :, 0, 0].contiguous().unsqueeze(1).expand(B, h * w, C)
+            d3 = dense[:, :, 0, 0].unsqueeze(1).expand(B, h * w, C)            # strides (0 | C, 0, 1): broadcast inside the kernel
         else:
             d3 = tokens_of(dense).view(B, h * w, C)
         src = ops.add_cast(e3, d3, 1.0, F32).view(B * h * w, C)
@@ -423,7 +431,8 @@ class MaskDecoder(nn.Module):
         if multimask_output:
             masks, iou_pred = masks[:, 1:, :, :], iou_pred[:, 1:]
         elif self.dynamic_multimask_via_stability and not self.training:
-            obj_pos = torch.ones_like(object_score_logits[:, 0])  # no object gating at this level
+            nb = object_score_logits.shape[0]                       # no object gating at this level: a cached vector of ones
+            obj_pos = self._wc.get(f"ones{nb}", [], lambda: torch.ones(nb, dtype=F32, device=object_score_logits.device))
             low, sel, iou_sel = ops.select_mask(masks.contiguous(), iou_pred.contiguous(), obj_pos, False, True,
                                                 self.dynamic_multimask_stability_delta, self.dynamic_multimask_stability_thresh)
             masks, iou_pred = low, iou_sel

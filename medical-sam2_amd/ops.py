@@ -525,13 +525,13 @@ def hyper_masks(hyper: torch.Tensor, up: torch.Tensor, n: int, P: int) -> torch.
     return masks
 
 
-def prompt_points(xy: torch.Tensor, labels: torch.Tensor, gauss, point_emb, not_a_point, image_size: float) -> torch.Tensor:
-    """xy fp32 [n,P,2], labels int32 [n,P] -> fp32 [n,P,C]."""
+def prompt_points(xy: torch.Tensor, labels: torch.Tensor, gauss, point_emb, not_a_point, image_size: float, n_pad: int = 0) -> torch.Tensor:
+    """xy fp32 [n,P,2], labels int32 [n,P] -> fp32 [n,P + n_pad,C]; the last n_pad points of every set are the padding point ((0,0), label -1)."""
     n, P = labels.shape
     C = point_emb.shape[1]
-    out = torch.empty(n, P, C, dtype=F32, device=xy.device)
-    check(lib().msam2_prompt_points(_p(xy.contiguous()), _p(labels.contiguous()), _p(gauss), _p(point_emb), _p(not_a_point), _p(out),
-                                    n * P, C, float(image_size), _stream()))
+    out = torch.empty(n, P + n_pad, C, dtype=F32, device=xy.device)
+    check(lib().msam2_prompt_points_padded(_p(xy.contiguous()), _p(labels.contiguous()), _p(gauss), _p(point_emb), _p(not_a_point), _p(out),
+                                           n, P, n_pad, C, float(image_size), _stream()))
     return out
 
 
@@ -670,12 +670,22 @@ def non_overlap(masks: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def token_mlp3(hs: torch.Tensor, tok: torch.Tensor, w1, b1, w2, b2, w3, b3, out_dim: torch.Tensor, sigmoid: torch.Tensor) -> torch.Tensor:
-    """G three-layer ReLU MLPs of width 256 on tokens tok[g] of hs fp32 [B, T, 256] -> fp32 [B, G, 256] (first out_dim[g] valid)."""
+def token_mlp3(hs: torch.Tensor, tok: torch.Tensor, w1, b1, w2, b2, w3, b3, out_dim: torch.Tensor, sigmoid: torch.Tensor,
+               packed=None):
+    """G three-layer ReLU MLPs of width 256 on tokens tok[g] of hs fp32 [B, T, 256] -> fp32 [B, G, 256] (first out_dim[g] valid).
+    packed = (out_offset, out_stride, total): int32 [G] device tables + the element count of the flat fp32 result, head g of batch element b
+    at [out_offset[g] + b * out_stride[g] : + out_dim[g]] -- heads of different widths as contiguous tensors without slicing copies."""
     B, T, C = hs.shape
     G = tok.shape[0]
     _req(hs.dtype == F32 and hs.stride(2) == 1 and C == 256, "token_mlp3: hs must be fp32 [B,T,256] with contiguous channels")
     _req(w1.dtype == OP16 and w1.shape == (G, C, C) and w1.is_contiguous() and w2.shape == (G, C, C) and w3.shape == (G, C, C), "token_mlp3 weights")
+    if packed is not None:
+        off, ld, total = packed
+        _req(off.dtype == torch.int32 and ld.dtype == torch.int32 and off.numel() == G and ld.numel() == G, "token_mlp3: packed tables are int32 [G]")
+        out = torch.empty(total, dtype=F32, device=hs.device)
+        check(lib().msam2_token_mlp3_packed(_p(hs), hs.stride(0), hs.stride(1), _p(tok), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3),
+                                            _p(out_dim), _p(sigmoid), _p(out), _p(off), _p(ld), G, B, C, _stream()))
+        return out
     out = torch.empty(B, G, C, dtype=F32, device=hs.device)
     check(lib().msam2_token_mlp3(_p(hs), hs.stride(0), hs.stride(1), _p(tok), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3),
                                  _p(out_dim), _p(sigmoid), _p(out), G, B, C, _stream()))

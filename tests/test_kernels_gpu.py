@@ -648,6 +648,11 @@ def test_hyper_masks_prompt_select(ops):
     e = O.random_fourier_pe(W, (xy[1] + 0.5) / 1024.0)
     e = e + torch.stack([emb[0], emb[3]])
     close(out[1], e, 5e-4, 0, "prompt points row1")
+    # the padding point appended inside the kernel (prompt_encoder.py:87-91) == the oracle's prompt encoder on the un-padded points
+    padded = ops.prompt_points(xy[:, :1].contiguous().to(DEV), lab[:, :1].contiguous().to(DEV), W[pe + ".pe_layer.positional_encoding_gaussian_matrix"].to(DEV),
+                               emb.to(DEV), W[pe + ".not_a_point_embed.weight"].to(DEV), 1024.0, n_pad=1)
+    assert padded.shape == (2, 2, emb.shape[1])
+    close(padded, ref, 5e-4, 0, "prompt points + in-kernel padding point")
     # selection
     masks, ious, obj = rnd(3, 4, 16, 16, seed=3), torch.rand(3, 4, generator=torch.Generator().manual_seed(4)), torch.tensor([1.0, -1.0, 2.0])
     masks[2, 0] = masks[2, 0] * 0.01  # unstable single mask -> dynamic fallback
@@ -743,6 +748,13 @@ def test_token_mlp3(ops):
         if sg[g]:
             o = torch.sigmoid(o)
         close(y[:, g, : od[g]], o, 2e-4, 2e-4, f"token_mlp3 head {g}")
+    # packed output: hyper [B, 4, 32] | iou [B, 4] | obj [B, 1] as contiguous tensors, bit-equal to the slices of the [B, G, 256] form
+    off = torch.tensor([0, 32, 64, 96, B * 128, B * 128 + B * 4], dtype=torch.int32)
+    ld = torch.tensor([128, 128, 128, 128, 4, 1], dtype=torch.int32)
+    flat = ops.token_mlp3(hs.to(DEV), tok.to(DEV), w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV), w3.to(DEV), b3.to(DEV), od.to(DEV), sg.to(DEV),
+                          packed=(off.to(DEV), ld.to(DEV), B * 133))
+    assert torch.equal(flat[: B * 128].view(B, 4, 32), y[:, :4, :32]) and torch.equal(flat[B * 128: B * 132].view(B, 4), y[:, 4, :4])
+    assert torch.equal(flat[B * 132:].view(B, 1), y[:, 5, :1])
 
 
 def test_hip_graph_replay(ops):

@@ -85,7 +85,9 @@ DOC = {
     "msam2_convt2x2_shuffle": "ConvTranspose2d(k2,s2) tail of the mask decoder up-scaling: pixel shuffle of the GEMM output + bias + high-res\nskip feature, then LayerNorm2d + GELU or GELU (mask_decoder.py:244-247).",
     "msam2_token_mlp3": "The mask decoder's token heads in one launch (mask_decoder.py:249-266; MLP = sam2_utils.py:108-132): G independent\n3-layer ReLU MLPs of width 256 (4 hyper-networks, IoU head with sigmoid, object-score head), each on one token of every batch element.",
     "msam2_hyper_masks": "masks = hyper_in @ upscaled_embedding (mask_decoder.py:249-256).",
+    "msam2_token_mlp3_packed": "msam2_token_mlp3 with a packed output: head g writes out[out_offset[g] + b * out_stride[g] + o] for o < out_dim[g], so that the hyper-network\nvectors, the IoU predictions and the object score land in contiguous tensors of their own (mask_decoder.py:249-266 slices them apart).",
     "msam2_prompt_points": "Point / box-corner prompt embeddings (prompt_encoder.py:79-114; position_encoding.py:153-158).",
+    "msam2_prompt_points_padded": "msam2_prompt_points with the padding point of prompt_encoder.py:87-91 ((0, 0), label -1: points without a box) appended to every prompt\nset inside the kernel: xy [n_sets, P, 2], labels [n_sets, P] -> out [n_sets, P + n_pad, C] (replaces torch.zeros / torch.ones + two torch.cat).",
     "msam2_select_mask": "Mask selection without a host round trip: best-IoU multimask or dynamic multimask via stability\n(mask_decoder.py:147-168,269-317) and object-score gating (sam2_base.py:354-385).",
     "msam2_gather_rows": "Pick the SAM output token of the selected mask (sam2_base.py:375-383).",
     "msam2_obj_ptr_mix": "obj_ptr = lam*obj_ptr + (1-lam)*no_obj_ptr with the hard lam of fixed_no_obj_ptr (sam2_base.py:389-400).",
