@@ -29,6 +29,7 @@ SIGNATURES = {
     "msam2_mlp_fused_permute_w2": (c_i, [c_p, c_p, c_l, c_l, c_p]),
     "msam2_ln_mlp_residual_fwd": (c_i, [c_p, c_l, c_l, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
     "msam2_layernorm": (c_i, [c_p, c_i, c_l, c_p, c_p, c_p, c_i, c_l, c_l, c_l, c_f, c_i, c_p]),
+    "msam2_layernorm_dual": (c_i, [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_l, c_l, c_f, c_p]),
     "msam2_attention_workspace_bytes": (c_z, [c_l, c_l, c_l, c_l, c_i]),
     "msam2_attention_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_f, c_i, c_p, c_z, c_p]),
     "msam2_attention_fwd_lse": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_f, c_i, c_p, c_z, c_p, c_p]),
@@ -59,6 +60,7 @@ SIGNATURES = {
     "msam2_conv3x3s2_ln_gelu": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_i, c_f, c_f, c_p]),
     "msam2_dwconv7x7_ln": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_p]),
     "msam2_convt2x2_shuffle": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_p]),
+    "msam2_convt2x2_shuffle_f32skip": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_p]),
     "msam2_space_to_depth": (c_i, [c_p, c_i, c_p, c_l, c_l, c_l, c_l, c_l, c_l, c_p]),
     "msam2_aa_downsample": (c_i, [c_p, c_p, c_l, c_l, c_l, c_l, c_f, c_f, c_p]),
     "msam2_gate_rows": (c_i, [c_p, c_p, c_f, c_l, c_l, c_p]),

@@ -2096,6 +2096,183 @@ static int launch_attn_win(const AttnParams& p, int Bz, hipStream_t s) {
   return msam2_check_launch("window_attention_fwd(win)");
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Hiera windows of 16 keys (4 x 4: the stage-2 blocks and the q-pooled stage 2 -> 3 block): one WAVE per unit of KW = 32 / Lk = 2 consecutive
+// windows and one head (attn_tinywin_kernel, round 4; NT = 2 = one 64-key window per wave is built for experiments only).
+// The tiled kernel gave each such window a workgroup of one wave with a two-stage LDS ring: five waves per CU, 9 KB in flight per wave,
+// 39 / 67 us for 100 / 126 MB (stage-2 block, the q-pooled stage 2 -> 3 block; now 26 / 33 us).  Here a wave issues EVERY load of its unit
+// first -- its 32 query rows straight into the MFMA operand layout (6 x 16 B per lane), the unit's 32 * NT key and value rows as 16-byte
+// chunks (6 * NT per operand and lane) -- 18-30 KB in flight per wave and 12-16 waves per CU, then writes V into its PRIVATE LDS tile (no workgroup
+// barrier anywhere; K never touches LDS: lane (r, h) loads key r's chunks 2 * st + h, the operand layout itself) and runs one or two 32-key steps.  With KW > 1 the 32 x 32 score tile is block diagonal: a query sees
+// the keys of its own window, the other block is masked (the MFMAs are free here: the launch moves bytes).
+// V tile [32 * NT][192 B], plain (transposed reads: the four rows of a read sit in four different 64-byte bank groups).  Windows must tile the image
+// exactly (no padded tokens); anything else stays on the tiled kernel.
+// ------------------------------------------------------------------------------------------------------------------
+template <int D, int NT>
+__global__ __launch_bounds__(256) void attn_tinywin_kernel(AttnParams p, int n_units, int KW) {
+  static_assert(D == 96, "LDS bank analysis of the 192-byte rows is for D = 96");
+  constexpr int RB = D * 2, CPR = D / 8, DSTEPS = D / 16, DBLK = D / 32, BK = 32;
+  constexpr int ROWS = BK * NT, PER = ROWS * CPR / 64;         // K / V chunks per lane and operand (6 * NT)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int z = blockIdx.x * 4 + wave;                         // (unit, head)
+  if (z >= n_units * p.H) return;                              // (no workgroup barrier below)
+  const int head = z % p.H, unit = z / p.H;
+  const int nw = p.nwy * p.nwx;
+  unsigned char* vsm = smem + wave * (ROWS * RB);
+
+  // ---- this lane's query row: window unit * KW + r / Lq, token r % Lq of it
+  const int nq = KW * p.Lq;
+  const bool qvalid = r < nq;
+  const int qwin = qvalid ? r / p.Lq : 0;
+  int64_t qoff = 0;
+  int qb_ = 0;
+  {
+    const int gw = unit * KW + qwin;
+    qb_ = gw / nw;
+    const int w = gw - qb_ * nw, wy = w / p.nwx, wx = w - wy * p.nwx;
+    bool v_;
+    qoff = win_token_offset(qvalid ? r - qwin * p.Lq : 0, p.ws_q, wy, wx, p.hq, p.wq, v_);
+  }
+  const op16* qrow = p.q + (int64_t)qb_ * p.q_bs + (int64_t)head * p.q_hs + qoff * p.q_ts;
+  op16x8 qf[DSTEPS];
+#pragma unroll
+  for (int st = 0; st < DSTEPS; ++st) qf[st] = __builtin_bit_cast(op16x8, *reinterpret_cast<const uint4*>(qrow + st * 16 + h * 8));
+
+  // ---- the unit's K rows straight into the MFMA operand layout (lane (r, h): key 32 * tile + r, chunks 2 * st + h), its V rows as
+  //      16-byte chunks for the transposed reads: every load issued before the first LDS write
+  auto key_row = [&](int row, int& b) -> int64_t {
+    const int wi = row / p.Lk, t = row - wi * p.Lk;
+    const int gw = unit * KW + wi;
+    b = gw / nw;
+    const int w = gw - b * nw, wy = w / p.nwx, wx = w - wy * p.nwx;
+    bool v_;
+    return win_token_offset(t, p.ws_k, wy, wx, p.hk, p.wk, v_);
+  };
+  op16x8 kf[NT][DSTEPS];
+#pragma unroll
+  for (int tile = 0; tile < NT; ++tile) {
+    int b;
+    const int64_t tok = key_row(tile * BK + r, b);
+    const op16* krow = p.k + (int64_t)b * p.k_bs + (int64_t)head * p.k_hs + tok * p.k_ts;
+#pragma unroll
+    for (int st = 0; st < DSTEPS; ++st) kf[tile][st] = __builtin_bit_cast(op16x8, *reinterpret_cast<const uint4*>(krow + st * 16 + h * 8));
+  }
+  uint4 rv[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = lane + 64 * i;
+    const int row = c / CPR, dc = (c - row * CPR) * 8;
+    int b;
+    const int64_t tok = key_row(row, b);
+    rv[i] = *reinterpret_cast<const uint4*>(p.v + (int64_t)b * p.v_bs + (int64_t)head * p.v_hs + tok * p.v_ts + dc);
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = lane + 64 * i;
+    const int row = c / CPR, cc = c - row * CPR;
+    *reinterpret_cast<uint4*>(vsm + row * RB + (cc << 4)) = rv[i];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the wave reads only what it wrote itself
+
+  f32x16 o[DBLK];
+#pragma unroll
+  for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int li = lane & 15;
+  const int v_off = (4 * h + (li >> 2)) * RB + (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
+#pragma unroll
+  for (int tile = 0; tile < NT; ++tile) {
+    const int key0 = tile * BK;
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < DSTEPS; ++st) s = MSAM2_MFMA_32x32x16(kf[tile][st], qf[st], s, 0, 0, 0);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (KW > 1 && key / p.Lk != qwin) s[e] = -INFINITY;      // the other windows of the unit
+      mx = fmaxf(mx, s[e]);
+    }
+    mx = half_max(mx) * p.scale_log2;
+    const float m_new = fmaxf(m_run, mx);                      // finite: every tile holds keys of the query's window
+    if (NT > 1 && tile > 0) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+    }
+    m_run = m_new;
+    float psum = 0.f;
+    op16x8 pf[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], p.scale_log2, -m_run));
+      psum += pe;
+      pf[e >> 3][e & 7] = f2op_fast(pe);
+    }
+    l_run += psum;
+#pragma unroll
+    for (int d = 0; d < DBLK; ++d) {
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        typedef __attribute__((ext_vector_type(8))) short short8_t;
+        const unsigned char* a0 = vsm + (key0 + 16 * st) * RB + v_off + d * 64;
+        const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0));
+        const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0 + 8 * RB));
+        short8_t vv8;
+        vv8[0] = lo[0]; vv8[1] = lo[1]; vv8[2] = lo[2]; vv8[3] = lo[3];
+        vv8[4] = hi[0]; vv8[5] = hi[1]; vv8[6] = hi[2]; vv8[7] = hi[3];
+        o[d] = MSAM2_MFMA_32x32x16(__builtin_bit_cast(op16x8, vv8), pf[st], o[d], 0, 0, 0);
+      }
+    }
+  }
+  const float inv = 1.f / half_sum(l_run);
+  if (qvalid) {
+    op16* ob = p.o + (int64_t)qb_ * p.o_bs + (int64_t)head * p.o_hs + qoff * p.o_ts;
+#pragma unroll
+    for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        op16x4 wv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wv[e] = f2op(o[d][4 * g + e] * inv);
+        *reinterpret_cast<op16x4*>(ob + d * 32 + 8 * g + 4 * h) = wv;
+      }
+  }
+}
+
+// windows of 16 keys (two per wave), tiling both token images exactly, D = 96.  (The 64-key windows of the q-pooled stage 1 -> 2 block run
+// through the same code as NT = 2 -- `MSAM2_TINYWIN_64=1` -- but measured no better than the tiled kernel there: 72-77 us against 69 us,
+// 251 MB; they stay on the tiled kernel.)
+static bool attn_tinywin_applies(const AttnParams& p) {
+  const char* off = getenv("MSAM2_NO_TINYWIN");
+  if (off && off[0] == '1') return false;
+  const bool exact = p.hk % p.ws_k == 0 && p.wk % p.ws_k == 0 && p.hq % p.ws_q == 0 && p.wq % p.ws_q == 0;
+  if (!exact) return false;
+  if (p.Lk == 64) {
+    const char* on = getenv("MSAM2_TINYWIN_64");
+    return on && on[0] == '1' && p.Lq <= 32;
+  }
+  return p.Lk == 16 && 2 * p.Lq <= 32 && (p.nwy * p.nwx) % 2 == 0;
+}
+
+static int launch_attn_tinywin(const AttnParams& p, int Bz, hipStream_t s) {
+  const int KW = p.Lk == 16 ? 2 : 1, n_units = Bz / KW;
+  const int64_t waves = (int64_t)n_units * p.H;
+  const unsigned grid = (unsigned)((waves + 3) / 4);
+  if (p.Lk == 16) hipLaunchKernelGGL((attn_tinywin_kernel<96, 1>), dim3(grid), dim3(256), 4 * 32 * 192, s, p, n_units, KW);
+  else hipLaunchKernelGGL((attn_tinywin_kernel<96, 2>), dim3(grid), dim3(256), 4 * 64 * 192, s, p, n_units, KW);
+  return msam2_check_launch("window_attention_fwd(tiny windows)");
+}
+
 // softmax(Q K^T * scale) V with 256-wide q / k rows and 64-wide value rows (attn_kv64_kernel): the memory cross-attention with the
 // value projection folded out of the attention (O' = P M; the caller applies W_v and b_v behind it).  o: [.., 64] rows; workspace and
 // merge as msam2_attention_fwd with D = 64 (msam2_attention_workspace_bytes(B, H, Lq, 64, splits), msam2_attention_merge(.., D = 64, ..)).
@@ -2221,7 +2398,9 @@ extern "C" int msam2_window_attention_fwd(const void* q, int64_t q_token_stride,
   hipStream_t s = (hipStream_t)stream;
   const int Bz = (int)B * nwy * nwx;
   switch (D) {
-    case 96: return attn_win_applies(p) ? launch_attn_win(p, Bz, s) : dispatch_nw<96, true>(p, Bz, s);
+    case 96:
+      if (attn_win_applies(p)) return launch_attn_win(p, Bz, s);
+      return attn_tinywin_applies(p) ? launch_attn_tinywin(p, Bz, s) : dispatch_nw<96, true>(p, Bz, s);
     case 64: return dispatch_nw<64, true>(p, Bz, s);
     default: return dispatch_nw<128, true>(p, Bz, s);
   }

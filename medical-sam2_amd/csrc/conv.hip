@@ -439,8 +439,8 @@ __global__ void pixel_shuffle_kernel(const op16* __restrict__ g, const float* __
 // Eight channels per lane (16-byte loads / stores), C / 8 lanes per output pixel, 512 / C pixels per wave: the one-channel-per-lane form
 // above moves 128 bytes per wave instruction (32 us per call at the decoder's shapes); LayerNorm statistics are reduced over the
 // pixel's C / 8 lanes with xor-shuffles.  C in {32, 64}.
-template <int C>
-__global__ void pixel_shuffle8_kernel(const op16* __restrict__ g, const float* __restrict__ bias, const op16* __restrict__ skip,
+template <int C, typename TS>
+__global__ void pixel_shuffle8_kernel(const op16* __restrict__ g, const float* __restrict__ bias, const TS* __restrict__ skip,
                                       const float* __restrict__ ln_w, const float* __restrict__ ln_b, op16* __restrict__ y, int B, int h,
                                       int w) {
   constexpr int G = C / 8;                                   // lanes per pixel
@@ -456,11 +456,20 @@ __global__ void pixel_shuffle8_kernel(const op16* __restrict__ g, const float* _
   const int64_t tok = ((int64_t)b * h + Y / 2) * w + X / 2;
   const int sub = (Y & 1) * 2 + (X & 1);
   const op16x8 gv = *reinterpret_cast<const op16x8*>(g + tok * 4 * C + sub * C + c0);
-  const op16x8 sv = *reinterpret_cast<const op16x8*>(skip + pp * C + c0);
+  float sk[8];
+  if constexpr (sizeof(TS) == 4) {                            // fp32 skip (the FPN's own output type): no 16-bit copy pass in front of this kernel
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(skip + pp * C + c0), s1 = *reinterpret_cast<const f32x4*>(skip + pp * C + c0 + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sk[e] = e < 4 ? s0[e] : s1[e - 4];
+  } else {
+    const op16x8 sv = *reinterpret_cast<const op16x8*>(skip + pp * C + c0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sk[e] = op2f(sv[e]);
+  }
   const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + c0), b1 = *reinterpret_cast<const f32x4*>(bias + c0 + 4);
   float v[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = op2f(gv[e]) + (e < 4 ? b0[e] : b1[e - 4]) + op2f(sv[e]);
+  for (int e = 0; e < 8; ++e) v[e] = op2f(gv[e]) + (e < 4 ? b0[e] : b1[e - 4]) + sk[e];
   if (ln_w) {
     float s = 0.f;
 #pragma unroll
@@ -489,8 +498,9 @@ __global__ void pixel_shuffle8_kernel(const op16* __restrict__ g, const float* _
   *reinterpret_cast<op16x8*>(y + pix * C + c0) = o;
 }
 
-extern "C" int msam2_convt2x2_shuffle(const void* gemm_out, const float* bias, const void* skip, const float* ln_w,
-                                      const float* ln_b, void* y, int64_t B, int64_t h, int64_t w, int64_t C, void* stream) {
+template <typename TS>
+static int convt2x2_shuffle_launch(const void* gemm_out, const float* bias, const TS* skip, const float* ln_w, const float* ln_b, void* y,
+                                   int64_t B, int64_t h, int64_t w, int64_t C, void* stream) {
   MSAM2_REQUIRE(gemm_out && bias && skip && y, "convt2x2_shuffle: null tensor");
   MSAM2_REQUIRE(C > 0 && C <= 64, "convt2x2_shuffle: C must be <= 64");
   const int64_t pix = B * 4 * h * w;
@@ -498,17 +508,29 @@ extern "C" int msam2_convt2x2_shuffle(const void* gemm_out, const float* bias, c
   if (al && (C == 64 || C == 32)) {
     const int64_t threads = pix * (C / 8);
     if (C == 64)
-      hipLaunchKernelGGL((pixel_shuffle8_kernel<64>), dim3(cdiv(threads, 256)), dim3(256), 0, (hipStream_t)stream, (const op16*)gemm_out, bias,
-                         (const op16*)skip, ln_w, ln_b, (op16*)y, (int)B, (int)h, (int)w);
+      hipLaunchKernelGGL((pixel_shuffle8_kernel<64, TS>), dim3(cdiv(threads, 256)), dim3(256), 0, (hipStream_t)stream, (const op16*)gemm_out, bias,
+                         skip, ln_w, ln_b, (op16*)y, (int)B, (int)h, (int)w);
     else
-      hipLaunchKernelGGL((pixel_shuffle8_kernel<32>), dim3(cdiv(threads, 256)), dim3(256), 0, (hipStream_t)stream, (const op16*)gemm_out, bias,
-                         (const op16*)skip, ln_w, ln_b, (op16*)y, (int)B, (int)h, (int)w);
+      hipLaunchKernelGGL((pixel_shuffle8_kernel<32, TS>), dim3(cdiv(threads, 256)), dim3(256), 0, (hipStream_t)stream, (const op16*)gemm_out, bias,
+                         skip, ln_w, ln_b, (op16*)y, (int)B, (int)h, (int)w);
     return msam2_check_launch("convt2x2_shuffle");
   }
+  MSAM2_REQUIRE(sizeof(TS) == 2, "convt2x2_shuffle: the fp32-skip form needs C = 32 / 64 and 16-byte aligned tensors");
   const int ppw = (!ln_w && C <= 32 && 64 % C == 0) ? (int)(64 / C) : 1;
   hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(cdiv(cdiv(pix, ppw) * 64, 256)), dim3(256), 0, (hipStream_t)stream, (const op16*)gemm_out,
                      bias, (const op16*)skip, ln_w, ln_b, (op16*)y, (int)B, (int)h, (int)w, (int)C, ppw);
   return msam2_check_launch("convt2x2_shuffle");
+}
+
+extern "C" int msam2_convt2x2_shuffle(const void* gemm_out, const float* bias, const void* skip, const float* ln_w,
+                                      const float* ln_b, void* y, int64_t B, int64_t h, int64_t w, int64_t C, void* stream) {
+  return convt2x2_shuffle_launch<op16>(gemm_out, bias, (const op16*)skip, ln_w, ln_b, y, B, h, w, C, stream);
+}
+
+// the same with the high-resolution skip features in fp32 (as the FPN returns them): C = 32 / 64
+extern "C" int msam2_convt2x2_shuffle_f32skip(const void* gemm_out, const float* bias, const float* skip, const float* ln_w,
+                                              const float* ln_b, void* y, int64_t B, int64_t h, int64_t w, int64_t C, void* stream) {
+  return convt2x2_shuffle_launch<float>(gemm_out, bias, skip, ln_w, ln_b, y, B, h, w, C, stream);
 }
 
 // masks[n, k, p] = sum_c hyper[n, k, c] * up[n, p, c]   (mask_decoder.py:249-256), C = 32, K mask tokens; fp32 out

@@ -27,7 +27,8 @@ struct Vec4<op16> {
 // counter): 9.8 us for 16384 x 384, 3.8 TB/s on a copy-shaped kernel.
 template <typename TI, typename TO, int CHUNKS>
 __global__ void layernorm_kernel(const TI* __restrict__ x, int64_t ldx, const float* __restrict__ w, const float* __restrict__ b,
-                                 TO* __restrict__ y, int64_t ldy, int64_t rows, int C, float eps, int act) {
+                                 TO* __restrict__ y, int64_t ldy, int64_t rows, int C, float eps, int act, op16* __restrict__ y2 = nullptr,
+                                 int64_t ldy2 = 0) {
   typedef typename Vec4<TI>::type VI;
   typedef typename Vec4<TO>::type VO;
   const int64_t row = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
@@ -100,6 +101,12 @@ __global__ void layernorm_kernel(const TI* __restrict__ x, int64_t ldx, const fl
         o[e] = f2out<TO>(u);
       }
       *reinterpret_cast<VO*>(yr + ch * 4) = o;
+      if (y2) {                                              // second, 16-bit copy of the same row (msam2_layernorm_dual): the GEMM operand of the next layer
+        op16x4 o2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o2[e] = f2op((float)o[e]);
+        *reinterpret_cast<op16x4*>(y2 + row * ldy2 + ch * 4) = o2;
+      }
     }
   }
 }
@@ -179,6 +186,28 @@ extern "C" int msam2_layernorm(const void* x, int in_is_16bit, int64_t ldx, cons
 #undef LN_LAUNCH
   }
   return msam2_check_launch("layernorm");
+}
+
+// LayerNorm with TWO outputs: the fp32 rows (the residual stream the next block adds to) and their 16-bit copy (the operand of the next
+// block's projections) from one pass -- replaces msam2_layernorm + msam2_add_cast where both are needed (two-way decoder, transformer.py:190-196).
+extern "C" int msam2_layernorm_dual(const float* x, int64_t ldx, const float* weight, const float* bias, float* y, int64_t ldy, void* y16,
+                                    int64_t ldy16, int64_t rows, int64_t C, float eps, void* stream) {
+  MSAM2_REQUIRE(x && y && y16 && weight && bias, "layernorm_dual: null tensor");
+  MSAM2_REQUIRE(rows > 0 && C > 0 && C <= 1024 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldy16 % 4 == 0,
+                "layernorm_dual: rows=%lld C=%lld unsupported (C <= 1024, multiples of 4)", (long long)rows, (long long)C);
+  MSAM2_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)weight | (uintptr_t)bias) & 15) == 0 && ((uintptr_t)y16 & 7) == 0, "layernorm_dual: alignment");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(cdiv(rows * 16, 256)), block(256);
+  const int chunks = (int)((C / 4 + 15) / 16);
+#define LN_D(CH) \
+  hipLaunchKernelGGL((layernorm_kernel<float, float, CH>), grid, block, 0, s, x, ldx, weight, bias, y, ldy, rows, (int)C, eps, 0, (op16*)y16, ldy16)
+  if (chunks <= 2) LN_D(2);
+  else if (chunks <= 4) LN_D(4);
+  else if (chunks <= 6) LN_D(6);
+  else if (chunks <= 12) LN_D(12);
+  else LN_D(16);
+#undef LN_D
+  return msam2_check_launch("layernorm_dual");
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -157,8 +157,9 @@ class TwoWayAttentionBlock(nn.Module):
         n = getattr(self, name)
         return ops.layernorm(x, v_f32(self._wc, name + "w", n.weight), v_f32(self._wc, name + "b", n.bias), n.eps, out_dtype=F32)
 
-    def run(self, queries, keys, query_pe, key_pe, B, T, L):
-        """queries/query_pe fp32 [B*T, C]; keys fp32 [B*L, C]; key_pe fp32 [L, C] (shared over the batch)."""
+    def run(self, queries, keys, query_pe, key_pe, B, T, L, keys_b=None):
+        """queries/query_pe fp32 [B*T, C]; keys fp32 [B*L, C]; key_pe fp32 [L, C] (shared over the batch); keys_b: the 16-bit copy of keys when
+        the caller has it (the previous block's norm4 writes both).  Returns (queries, keys, 16-bit keys)."""
         C = queries.shape[1]
         q3 = lambda t, n: t.view(B, n, -1)
         sa, ca, ia, wc = self.self_attn, self.cross_attn_token_to_image, self.cross_attn_image_to_token, self._wc
@@ -181,7 +182,8 @@ class TwoWayAttentionBlock(nn.Module):
         queries = self._ln("norm1", queries)
         # tokens -> image.  The three image-side projections of the block (k, v of this attention and q of the image -> token attention
         # further down: `keys` does not change in between) are one GEMM
-        keys_b = to_bf16(keys)
+        if keys_b is None:
+            keys_b = to_bf16(keys)
         Cc, Ci2 = ca.internal_dim, ia.internal_dim
         kvq = _image_side_projections(wc, "ikvq", keys_b, key_pe, L, [ca.k_proj, ca.v_proj, ia.q_proj], [True, False, True])
         k_img, v_img, q_img = kvq[:, :Cc], kvq[:, Cc:2 * Cc], kvq[:, 2 * Cc:2 * Cc + Ci2]
@@ -207,15 +209,16 @@ class TwoWayAttentionBlock(nn.Module):
         else:
             qb = ops.add_cast(queries.view(1, B * T, C), query_pe.view(1, B * T, C), 1.0, OP16)[0]
             o = ia.core(q3(q_img, L), q3(ia.proj("k", qb), T), q3(ia.proj("v", to_bf16(queries)), T))
-        keys = self._ln("norm4", ia.out(o, keys))
-        return queries, keys
+        n4 = self.norm4          # fp32 rows (the residual stream) and their 16-bit copy (the next projections' operand) from one launch
+        keys, keys16 = ops.layernorm_dual(ia.out(o, keys), v_f32(wc, "norm4w", n4.weight), v_f32(wc, "norm4b", n4.bias), n4.eps)
+        return queries, keys, keys16
 
     def forward(self, queries, keys, query_pe, key_pe):
         B, T, C = queries.shape
         L = keys.shape[1]
         assert key_pe.shape[0] == 1 or B == 1, "key_pe is the batch-shared dense position encoding"
-        q, k = self.run(queries.to(F32).reshape(B * T, C).contiguous(), keys.to(F32).reshape(B * L, C).contiguous(),
-                        query_pe.to(F32).reshape(B * T, C).contiguous(), key_pe.to(F32).reshape(-1, C)[:L].contiguous(), B, T, L)
+        q, k, _ = self.run(queries.to(F32).reshape(B * T, C).contiguous(), keys.to(F32).reshape(B * L, C).contiguous(),
+                           query_pe.to(F32).reshape(B * T, C).contiguous(), key_pe.to(F32).reshape(-1, C)[:L].contiguous(), B, T, L)
         return q.view(B, T, C), k.view(B, L, C)
 
 
@@ -238,10 +241,14 @@ class TwoWayTransformer(nn.Module):
         """keys fp32 [B*L, C] tokens of the image embedding; key_pe fp32 [L, C]; tokens fp32 [B*T, C]."""
         C = tokens.shape[1]
         queries, qpe = tokens, tokens
+        keys16 = None
         for layer in self.layers:
-            queries, keys = layer.run(queries, keys, qpe, key_pe, B, T, L)
+            queries, keys, keys16 = layer.run(queries, keys, qpe, key_pe, B, T, L, keys16)
+        if keys16 is None:
+            keys16 = to_bf16(keys)
+        self._keys16 = keys16          # the up-scaling GEMM behind the transformer takes the same operand (MaskDecoder.predict_masks_tokens)
         fa = self.final_attn_token_to_image
-        kv_img = _image_side_projections(self._wc, "fkv", to_bf16(keys), key_pe, L, [fa.k_proj, fa.v_proj], [True, False])
+        kv_img = _image_side_projections(self._wc, "fkv", keys16, key_pe, L, [fa.k_proj, fa.v_proj], [True, False])
         Cf = fa.internal_dim
         q3 = lambda t, n: t.view(B, n, -1)
         if B * T <= 32 and fa.internal_dim % 32 == 0:
@@ -307,7 +314,7 @@ class MaskDecoder(nn.Module):
     def predict_masks_tokens(self, src_tokens: torch.Tensor, pe_tokens: torch.Tensor, sparse: torch.Tensor, feat_s0: torch.Tensor,
                              feat_s1: torch.Tensor, B: int, h: int, w: int):
         """src_tokens fp32 [B*h*w, C] (= image embedding + dense prompt); pe_tokens fp32 [h*w, C]; sparse fp32 [B,P,C];
-        feat_s0 bf16 [B*16hw, C/8], feat_s1 bf16 [B*4hw, C/4] token-major.  Returns (masks [B,4,4h,4w] fp32, iou [B,4],
+        feat_s0 [B*16hw, C/8], feat_s1 [B*4hw, C/4] token-major, 16-bit or fp32.  Returns (masks [B,4,4h,4w] fp32, iou [B,4],
         mask_tokens_out [B,4,C], object_score_logits [B,1])."""
         wc = self._wc
         C = self.transformer_dim
@@ -319,7 +326,11 @@ class MaskDecoder(nn.Module):
         hs = hs.view(B, T, C)
         up = self.output_upscaling
         dc1_w = wc.get("dc1", [up[0].weight], lambda: up[0].weight.detach().permute(2, 3, 1, 0).reshape(-1, C).to(OP16).contiguous())
-        g = ops.gemm(to_bf16(keys), dc1_w)
+        keys16 = getattr(self.transformer, "_keys16", None)
+        if keys16 is None or keys16.shape != keys.shape:
+            keys16 = to_bf16(keys)
+        self.transformer._keys16 = None
+        g = ops.gemm(keys16, dc1_w)
         u = ops.convt2x2_shuffle(g, v_f32(wc, "dc1b", up[0].bias), feat_s1, v_f32(wc, "lnw", up[1].weight), v_f32(wc, "lnb", up[1].bias), B, h, w)
         dc2_w = wc.get("dc2", [up[3].weight], lambda: up[3].weight.detach().permute(2, 3, 1, 0).reshape(-1, C // 4).to(OP16).contiguous())
         g = ops.gemm(u, dc2_w)
@@ -422,7 +433,9 @@ class MaskDecoder(nn.Module):
         src = ops.add_cast(e3, d3, 1.0, F32).view(B * h * w, C)
         pe = tokens_of(image_pe.to(F32))[: h * w]
         f0, f1 = high_res_features
-        return self.predict_masks_tokens(src, pe, sparse_prompt_embeddings.to(F32), to_bf16(tokens_of(f0)), to_bf16(tokens_of(f1)), B, h, w)
+        # the skip features stay fp32 token-major (the up-scaling tail reads them as they are) when their widths are the kernel's 32 / 64
+        skip = lambda f: tokens_of(f) if (f.dtype == F32 and f.shape[1] in (32, 64)) else to_bf16(tokens_of(f))
+        return self.predict_masks_tokens(src, pe, sparse_prompt_embeddings.to(F32), skip(f0), skip(f1), B, h, w)
 
     def forward(self, image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings, multimask_output: bool,
                 repeat_image: bool, cell_nums=None, high_res_features: Optional[List[torch.Tensor]] = None):

@@ -140,6 +140,18 @@ def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: fl
     return y.reshape(x.shape)
 
 
+def layernorm_dual(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float):
+    """fp32 [rows, C] -> (LayerNorm rows in fp32, the same rows in the 16-bit operand type) from one launch"""
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C)
+    _req(x2.dtype == F32 and x2.stride(1) == 1 and C % 4 == 0, "layernorm_dual: fp32 rows, C % 4 == 0")
+    y = torch.empty(x2.shape, dtype=F32, device=x.device)
+    y16 = torch.empty(x2.shape, dtype=OP16, device=x.device)
+    check(lib().msam2_layernorm_dual(_p(x2), x2.stride(0), _p(weight), _p(bias), _p(y), y.stride(0), _p(y16), y16.stride(0), x2.shape[0], C, eps,
+                                     _stream()))
+    return y.reshape(x.shape), y16.reshape(x.shape)
+
+
 def ln_mlp_residual_supported(dim: int) -> bool:
     return bool(lib().msam2_ln_mlp_residual_supported(dim))
 
@@ -511,10 +523,15 @@ def dwconv7x7_ln(x: torch.Tensor, B: int, H: int, W: int, w_tap_major, bias, ln_
 
 
 def convt2x2_shuffle(g: torch.Tensor, bias, skip: torch.Tensor, ln_w, ln_b, B: int, h: int, w: int) -> torch.Tensor:
+    """skip: the high-resolution features, 16-bit or (C = 32 / 64) fp32 as the FPN returns them -- no 16-bit copy pass in front"""
     C = g.shape[1] // 4
-    _req(g.dtype == OP16 and skip.dtype == OP16 and g.is_contiguous() and skip.is_contiguous(), "convt2x2_shuffle: 16-bit contiguous")
+    _req(g.dtype == OP16 and skip.dtype in (OP16, F32) and g.is_contiguous() and skip.is_contiguous(), "convt2x2_shuffle: contiguous 16-bit g, 16-bit / fp32 skip")
     y = torch.empty(B * 4 * h * w, C, dtype=OP16, device=g.device)
-    check(lib().msam2_convt2x2_shuffle(_p(g), _p(bias), _p(skip), _p(ln_w), _p(ln_b), _p(y), B, h, w, C, _stream()))
+    if skip.dtype == F32:
+        _req(C in (32, 64), "convt2x2_shuffle: fp32 skip features need C = 32 / 64")
+        check(lib().msam2_convt2x2_shuffle_f32skip(_p(g), _p(bias), _p(skip), _p(ln_w), _p(ln_b), _p(y), B, h, w, C, _stream()))
+    else:
+        check(lib().msam2_convt2x2_shuffle(_p(g), _p(bias), _p(skip), _p(ln_w), _p(ln_b), _p(y), B, h, w, C, _stream()))
     return y
 
 

@@ -325,6 +325,11 @@ def test_layernorm(ops, rows, C, eps, act):
     out = ops.layernorm(bf(x).to(DEV), w.to(DEV), b.to(DEV), eps, act=act, out_dtype=OP16())
     refb = O.lnorm(P, "n", bf(x).float(), eps)
     close(out, O.gelu(refb) if act else refb, 2e-3, 8e-3, "layernorm bf16")
+    if not act and C % 4 == 0:
+        # two outputs from one launch: the fp32 rows bit-equal to the one-output call, the 16-bit rows = their rounding
+        one = ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), eps, out_dtype=torch.float32)
+        y32, y16 = ops.layernorm_dual(x.to(DEV), w.to(DEV), b.to(DEV), eps)
+        assert torch.equal(y32, one) and y16.dtype == OP16() and torch.equal(y16, one.to(OP16()))
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -627,6 +632,10 @@ def test_convtranspose_via_gemm_shuffle(ops, cin, cout, ln):
     out = ops.convt2x2_shuffle(g, b.to(DEV), skip.permute(0, 2, 3, 1).contiguous().to(DEV), lw.to(DEV) if ln else None,
                                lb.to(DEV) if ln else None, B, h, w)
     close(out, ref, 0.03, 0.02, "convT shuffle")
+    # the skip features in fp32 (as the FPN returns them): same result as from their 16-bit copy when the values are 16-bit representable
+    out32 = ops.convt2x2_shuffle(g, b.to(DEV), skip.float().permute(0, 2, 3, 1).contiguous().to(DEV), lw.to(DEV) if ln else None,
+                                 lb.to(DEV) if ln else None, B, h, w)
+    assert torch.equal(out32, out)
 
 
 def test_hyper_masks_prompt_select(ops):

@@ -20,6 +20,7 @@ DOC = {
     "msam2_ln_mlp_residual_supported": "1 when msam2_ln_mlp_residual_fwd is built for this width (96 / 192: Hiera stages 1 and 2).",
     "msam2_mlp_fused_permute_w2": "Kernel-ready copy of the second MLP weight for msam2_ln_mlp_residual_fwd: the hidden index of every 32-block permuted to the k order\nin which the fc1 accumulator is consumed as an MFMA operand.",
     "msam2_ln_mlp_residual_fwd": "The MLP half of MultiScaleBlock.forward as ONE kernel (hieradet.py:166-167: x = x + self.mlp(self.norm2(x)); sam2_utils.py:108-132 with\nnn.GELU): LayerNorm, fc1, exact-erf GELU, fc2 and the residual add; the 4x hidden activation never leaves the registers.  Block-level\nfused entry for the two high-resolution stages (dim 96 / 192), where the three separate launches are bound by the hidden map's HBM\nround trip.",
+    "msam2_layernorm_dual": "nn.LayerNorm on fp32 rows with two outputs from one pass: the fp32 rows (residual stream) and their 16-bit copy (operand of the next\nprojection) -- norm4 of the two-way block (transformer.py:190-196), whose output `keys` is both.",
     "msam2_layernorm": "Row LayerNorm (fp32 statistics) on [rows, C], optional GELU: nn.LayerNorm at hieradet.py:138,166,\nmemory_attention.py:60,73,94,162, transformer.py:173-194,116; LayerNorm2d (sam2_utils.py:137-149) on NHWC tokens.",
     "msam2_attention_workspace_bytes": "Scratch needed by msam2_attention_fwd when splits > 1 (fp32 partial O, running max, partial sum).",
     "msam2_attention_merge": "Second half of a split-KV attention call issued with a NEGATIVE split count (the split pass alone, partials left in the\nworkspace): combines the per-split (max, sum, O) triples into o.  Lets a host time / overlap the two kernels separately.",
@@ -82,6 +83,7 @@ DOC = {
     "msam2_im2col3x3s2": "im2col of the 64->256 k3/s2/p1 mask down-sampler conv (memory_encoder.py:41-49).",
     "msam2_conv3x3s2_ln_gelu": "One MaskDownSampler stage: Conv2d(k3,s2,p1) + LayerNorm2d + GELU (memory_encoder.py:37-54), with the scaled\nsigmoid / binarisation of the mask logits (sam2_base.py:686-696) fused into the first stage.",
     "msam2_dwconv7x7_ln": "CXBlock head: depth-wise 7x7 conv + LayerNorm2d (memory_encoder.py:99-101).",
+    "msam2_convt2x2_shuffle_f32skip": "msam2_convt2x2_shuffle with the high-resolution skip features (mask_decoder.py:244-247: feat_s1 / feat_s0) read in fp32, the type the FPN\nreturns them in (C = 32 / 64): no 16-bit copy of the two largest feature maps in front of the decoder.",
     "msam2_convt2x2_shuffle": "ConvTranspose2d(k2,s2) tail of the mask decoder up-scaling: pixel shuffle of the GEMM output + bias + high-res\nskip feature, then LayerNorm2d + GELU or GELU (mask_decoder.py:244-247).",
     "msam2_token_mlp3": "The mask decoder's token heads in one launch (mask_decoder.py:249-266; MLP = sam2_utils.py:108-132): G independent\n3-layer ReLU MLPs of width 256 (4 hyper-networks, IoU head with sigmoid, object-score head), each on one token of every batch element.",
     "msam2_hyper_masks": "masks = hyper_in @ upscaled_embedding (mask_decoder.py:249-256).",

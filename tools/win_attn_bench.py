@@ -50,7 +50,8 @@ for name, hw, dim, heads, ws, pool in (CASES if __name__ == "__main__" else []):
     res = []
     for v1 in ("1", "0"):
         os.environ["MSAM2_WIN_V1"] = v1
+        os.environ["MSAM2_NO_TINYWIN"] = v1          # the tiled pass also switches the tiny-window kernel (16 / 64-key windows) off
         t = timeit(lambda: ops.window_attention(qkv, B, hw, hw, heads, ws, bias, q_pooled=qp))
         res.append(t)
     print(f"{name:8s} tokens {T:7d} dim {dim:4d} heads {heads} ws {ws:2d} pool {int(pool)}: tiled {res[0] * 1e6:7.1f} us ({by / res[0] / 1e12:5.2f} TB/s)   "
-          f"whole-window {res[1] * 1e6:7.1f} us ({by / res[1] / 1e12:5.2f} TB/s = {by / res[1] / 8e12 * 100:4.1f} % of 8 TB/s)", flush=True)
+          f"whole-window / tiny-window {res[1] * 1e6:7.1f} us ({by / res[1] / 1e12:5.2f} TB/s = {by / res[1] / 8e12 * 100:4.1f} % of 8 TB/s)", flush=True)
