@@ -28,6 +28,7 @@ SIGNATURES = {
     "msam2_ln_mlp_residual_supported": (c_i, [c_l]),
     "msam2_mlp_fused_permute_w2": (c_i, [c_p, c_p, c_l, c_l, c_p]),
     "msam2_ln_mlp_residual_fwd": (c_i, [c_p, c_l, c_l, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "msam2_ln_mlp_residual_fwd_dual": (c_i, [c_p, c_l, c_l, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "msam2_layernorm": (c_i, [c_p, c_i, c_l, c_p, c_p, c_p, c_i, c_l, c_l, c_l, c_f, c_i, c_p]),
     "msam2_layernorm_dual": (c_i, [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_l, c_l, c_f, c_p]),
     "msam2_attention_workspace_bytes": (c_z, [c_l, c_l, c_l, c_l, c_i]),

@@ -29,6 +29,7 @@ struct MlpFusedParams {
   const op16* w2p;       // [DIM, 4*DIM], hidden index permuted inside every 32-block (see mlp_fused_permute)
   int64_t T;
   float eps;
+  op16* out16;           // optional second output: the same rows in the 16-bit operand type (a stage's last block: the FPN's lateral GEMM operand)
 };
 
 template <int RB>
@@ -226,6 +227,12 @@ __global__ __launch_bounds__(256, OCC) void mlp_fused_kernel(MlpFusedParams p) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) o[e] = accy[tb][d0 + d][4 * g + e] + bv[e] + xv[d][g][e];
               *reinterpret_cast<f32x4*>(yr + ch) = o;
+              if (p.out16) {
+                op16x4 o2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o2[e] = f2op(o[e]);
+                *reinterpret_cast<op16x4*>(p.out16 + tok[tb] * DIM + ch) = o2;
+              }
             }
         }
       }
@@ -270,15 +277,29 @@ static int launch_mlp_fused(const MlpFusedParams& p, hipStream_t s) {
 
 // out[T, dim] (fp32) = x + fc2(GELU(fc1(LayerNorm(x)))) with x fp32 [T, dim] contiguous, w1 16-bit [4 dim, dim], w2p 16-bit [dim, 4 dim]
 // permuted by msam2_mlp_fused_permute_w2, biases / LayerNorm parameters fp32.  dim in {96, 192}.
-extern "C" int msam2_ln_mlp_residual_fwd(const float* x, int64_t T, int64_t dim, const float* ln_w, const float* ln_b, float eps, const void* w1,
-                                         const float* b1, const void* w2p, const float* b2, float* out, void* stream) {
+static int ln_mlp_residual_launch(const float* x, int64_t T, int64_t dim, const float* ln_w, const float* ln_b, float eps, const void* w1,
+                                  const float* b1, const void* w2p, const float* b2, float* out, void* out16, void* stream) {
   MSAM2_REQUIRE(x && out && ln_w && ln_b && w1 && b1 && w2p && b2 && T > 0, "ln_mlp_residual: null tensor / empty problem");
   MSAM2_REQUIRE(msam2_ln_mlp_residual_supported(dim), "ln_mlp_residual: dim %lld not built (96 / 192)", (long long)dim);
-  MSAM2_REQUIRE((((uintptr_t)x | (uintptr_t)out | (uintptr_t)w1 | (uintptr_t)w2p | (uintptr_t)ln_w | (uintptr_t)ln_b | (uintptr_t)b1 | (uintptr_t)b2) & 15) == 0,
-                "ln_mlp_residual: 16-byte aligned tensors");
+  MSAM2_REQUIRE((((uintptr_t)x | (uintptr_t)out | (uintptr_t)w1 | (uintptr_t)w2p | (uintptr_t)ln_w | (uintptr_t)ln_b | (uintptr_t)b1 | (uintptr_t)b2) & 15) == 0 &&
+                    ((uintptr_t)out16 & 7) == 0, "ln_mlp_residual: 16-byte aligned tensors");
   MSAM2_REQUIRE(x != out, "ln_mlp_residual: in-place not supported (a token's residual is re-read in the store)");
-  MlpFusedParams p = {x, out, ln_w, ln_b, b1, b2, (const op16*)w1, (const op16*)w2p, T, eps};
+  MlpFusedParams p = {x, out, ln_w, ln_b, b1, b2, (const op16*)w1, (const op16*)w2p, T, eps, (op16*)out16};
   hipStream_t s = (hipStream_t)stream;
   if (dim == 96) return launch_mlp_fused<96, 192, 4>(p, s);
   return launch_mlp_fused<192, 96, 2>(p, s);
+}
+
+extern "C" int msam2_ln_mlp_residual_fwd(const float* x, int64_t T, int64_t dim, const float* ln_w, const float* ln_b, float eps, const void* w1,
+                                         const float* b1, const void* w2p, const float* b2, float* out, void* stream) {
+  return ln_mlp_residual_launch(x, T, dim, ln_w, ln_b, eps, w1, b1, w2p, b2, out, nullptr, stream);
+}
+
+// the same with the result also written in the 16-bit operand type (out16 [T, dim]): the last block of a Hiera stage, whose output is the
+// operand of the FPN's lateral 1x1 convolution (image_encoder.py:95-110) -- no cast pass over the largest feature maps
+extern "C" int msam2_ln_mlp_residual_fwd_dual(const float* x, int64_t T, int64_t dim, const float* ln_w, const float* ln_b, float eps,
+                                              const void* w1, const float* b1, const void* w2p, const float* b2, float* out, void* out16,
+                                              void* stream) {
+  MSAM2_REQUIRE(out16, "ln_mlp_residual_dual: null 16-bit output");
+  return ln_mlp_residual_launch(x, T, dim, ln_w, ln_b, eps, w1, b1, w2p, b2, out, out16, stream);
 }

@@ -185,8 +185,10 @@ class MultiScaleBlock(nn.Module):
         return (D, Dp, wc.get("qkvw_p", [a.qkv.weight], qkv_w), wc.get("qkvb_p", [a.qkv.bias], qkv_b),
                 wc.get("ow_p", [a.proj.weight], proj_w))
 
-    def run(self, t: torch.Tensor, B: int, H: int, W: int) -> Tuple[torch.Tensor, int, int]:
-        """fp32 tokens [B*H*W, dim] -> (fp32 tokens [B*H'*W', dim_out], H', W')."""
+    def run(self, t: torch.Tensor, B: int, H: int, W: int, emit16: bool = False) -> Tuple[torch.Tensor, int, int]:
+        """fp32 tokens [B*H*W, dim] -> (fp32 tokens [B*H'*W', dim_out], H', W').  emit16 (a stage's last block): `self.out16` also holds the
+        result in the 16-bit operand type when the block's last kernel could write it in the same store (else None)."""
+        self.out16 = None
         wc, a = self._wc, self.attn
         heads, dim_out = a.num_heads, self.dim_out
         D, Dp, qkv_w, qkv_b, proj_w = self._packed_attn_weights()
@@ -225,7 +227,9 @@ class MultiScaleBlock(nn.Module):
             w2p = mlp._wc.get("w1p", [mlp.layers[1].weight], lambda: ops.mlp_fused_permute_w2(mlp.layers[1].weight.detach().to(OP16).contiguous()))
             t = ops.ln_mlp_residual(t, v_f32(wc, "n2w", self.norm2.weight), v_f32(wc, "n2b", self.norm2.bias), 1e-6,
                                     w_bf16(mlp._wc, "w0", mlp.layers[0].weight), v_f32(mlp._wc, "b0", mlp.layers[0].bias), w2p,
-                                    v_f32(mlp._wc, "b1", mlp.layers[1].bias))
+                                    v_f32(mlp._wc, "b1", mlp.layers[1].bias), also16=emit16)
+            if emit16:
+                t, self.out16 = t
             return t, Hq, Wq
         xn2 = ops.layernorm(t, v_f32(wc, "n2w", self.norm2.weight), v_f32(wc, "n2b", self.norm2.bias), 1e-6)
         t = self.mlp.run(xn2, residual=t, out_dtype=F32)
@@ -291,9 +295,14 @@ class Hiera(nn.Module):
         t = self.patch_embed.tokens(x, self._pos_tokens(h, w))
         outputs = []
         for i, blk in enumerate(self.blocks):
-            t, h, w = blk.run(t, B, h, w)
-            if i == self.stage_ends[-1] or (i in self.stage_ends and self.return_interm_layers):
-                outputs.append(nchw_view(t, B, h, w))
+            is_out = i == self.stage_ends[-1] or (i in self.stage_ends and self.return_interm_layers)
+            t, h, w = blk.run(t, B, h, w, emit16=is_out)
+            if is_out:
+                v = nchw_view(t, B, h, w)
+                # the 16-bit token-major copy the block's last kernel wrote beside the fp32 rows (stages 1 / 2): FpnNeck takes it as its lateral
+                # GEMM operand instead of casting the map again (a private attribute of this tensor object; any other consumer ignores it)
+                v._op16_tokens, blk.out16 = blk.out16, None
+                outputs.append(v)
         return outputs
 
 
@@ -327,6 +336,10 @@ class FpnNeck(nn.Module):
         prev = None
         n = len(self.convs) - 1
         td = self.fpn_top_down_levels
+        def operand(x):            # the stage output as the lateral GEMM's 16-bit operand
+            x16 = getattr(x, "_op16_tokens", None)
+            ok = x16 is not None and x16.dtype == OP16 and x16.shape == (x.shape[0] * x.shape[2] * x.shape[3], x.shape[1])
+            return x16 if ok else to_bf16(tokens_of(x))
         for i in range(n, -1, -1):
             B, C, H, W = xs[i].shape
             conv = self.convs[n - i].conv
@@ -337,10 +350,10 @@ class FpnNeck(nn.Module):
                 ).to(OP16).contiguous())
                 b = self._wc.get(f"cb{i}", [conv.bias, pc.weight, pc.bias], lambda: (
                     pc.weight.detach().float().reshape(pc.weight.shape[0], -1) @ conv.bias.detach().float() + pc.bias.detach().float()).contiguous())
-                lat = ops.gemm(to_bf16(tokens_of(xs[i])), w, b, out_dtype=F32)
+                lat = ops.gemm(operand(xs[i]), w, b, out_dtype=F32)
                 prev = None
             else:
-                lat = ops.gemm(to_bf16(tokens_of(xs[i])), w_bf16(self._wc, f"w{i}", conv.weight), v_f32(self._wc, f"b{i}", conv.bias),
+                lat = ops.gemm(operand(xs[i]), w_bf16(self._wc, f"w{i}", conv.weight), v_f32(self._wc, f"b{i}", conv.bias),
                                out_dtype=F32)
                 if i in td and prev is not None:
                     ops.upsample2x_add_(lat, prev, B, H, W)

@@ -165,12 +165,18 @@ def mlp_fused_permute_w2(w2: torch.Tensor) -> torch.Tensor:
 
 
 def ln_mlp_residual(x: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, eps: float, w1: torch.Tensor, b1: torch.Tensor, w2p: torch.Tensor,
-                    b2: torch.Tensor) -> torch.Tensor:
-    """fp32 [T, dim] = x + fc2(GELU(fc1(LayerNorm(x)))) in one kernel (dim 96 / 192; w2p from mlp_fused_permute_w2)."""
+                    b2: torch.Tensor, also16: bool = False):
+    """fp32 [T, dim] = x + fc2(GELU(fc1(LayerNorm(x)))) in one kernel (dim 96 / 192; w2p from mlp_fused_permute_w2).
+    also16: returns (fp32 rows, the same rows in the 16-bit operand type) -- written by the same store."""
     T, dim = x.shape
     _req(x.dtype == F32 and x.is_contiguous() and w1.dtype == OP16 and w2p.dtype == OP16 and w1.shape == (4 * dim, dim) and w2p.shape == (dim, 4 * dim)
          and w1.is_contiguous() and w2p.is_contiguous(), "ln_mlp_residual: x fp32 [T, dim], w1 [4 dim, dim], w2p [dim, 4 dim] 16-bit contiguous")
     out = torch.empty_like(x)
+    if also16:
+        out16 = torch.empty(x.shape, dtype=OP16, device=x.device)
+        check(lib().msam2_ln_mlp_residual_fwd_dual(_p(x), T, dim, _p(ln_w), _p(ln_b), float(eps), _p(w1), _p(b1), _p(w2p), _p(b2), _p(out), _p(out16),
+                                                   _stream()))
+        return out, out16
     check(lib().msam2_ln_mlp_residual_fwd(_p(x), T, dim, _p(ln_w), _p(ln_b), float(eps), _p(w1), _p(b1), _p(w2p), _p(b2), _p(out), _stream()))
     return out
 

@@ -805,3 +805,7 @@ def test_ln_mlp_residual_fused(ops, dim, T):
     hid = ops.gemm(xn, bf(P["m.layers.0.weight"]).to(DEV), d(P["m.layers.0.bias"]), act=ops.ACT_GELU)
     three = ops.gemm(hid, bf(P["m.layers.1.weight"]).to(DEV), d(P["m.layers.1.bias"]), residual=d(x), out_dtype=torch.float32)
     close(out, three, btol(4e-3), btol(2e-3), "fused vs three launches")
+    # second, 16-bit output of the same store (msam2_ln_mlp_residual_fwd_dual): fp32 rows unchanged, 16-bit rows = their rounding
+    o32, o16 = ops.ln_mlp_residual(d(x), d(P["n.weight"]), d(P["n.bias"]), 1e-6, bf(P["m.layers.0.weight"]).to(DEV), d(P["m.layers.0.bias"]), w2p,
+                                   d(P["m.layers.1.bias"]), also16=True)
+    assert torch.equal(o32, out) and o16.dtype == OP16() and torch.equal(o16, out.to(OP16()))
