@@ -2072,6 +2072,12 @@ __global__ __launch_bounds__(512) void attn_win_kernel(AttnParams p) {
 #endif
 }
 
+// (Round 4, not kept: a variant that pipelines the gather against the key tiles -- chunk c = round * threads + tid is key-major, a barrier per
+//  round, the tiles that are whole run while later rounds are in flight -- was built three ways and measured with tools/win_probe.hip's stamps:
+//  all rounds issued up front by LDS-DMA with per-round vmcnt waits: a CU's memory pipe serves its waves one after the other, not round by
+//  round, so round 0 of the last wave lands at 6.5 us and the whole gather takes 13.5 us instead of 7.4 (24.5 us per launch against 22.6);
+//  the same through staging registers, all rounds or a two-round ring: 143-165 registers live beside the accumulators, i.e. one workgroup
+//  per CU (two rounds of workgroups) or spills, and a scratch reload waits on the same in-order counter as the gather.  DESIGN.md 3.3.)
 // whole-window kernel: windows of 33 .. 256 queries whose K + V images (Lk + ceil8(Lk) rows of 192 B) let two workgroups share a CU
 static bool attn_win_applies(const AttnParams& p) {
   const char* off = getenv("MSAM2_WIN_V1");
