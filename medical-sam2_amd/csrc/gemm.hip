@@ -1572,22 +1572,24 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
   const int64_t arow = (int64_t)min(r, p.M - 1) * p.lda + h * 8;
   const op16* ap = p.A + arow;
   const float* ap32 = p.A32 + arow;
-  const float* ap2 = (F32A && p.A2 && n0 < p.add_cols) ? p.A2 + arow : nullptr;   // workgroup-uniform: add_cols is a multiple of 32
+  const bool add2 = F32A && p.A2 && n0 < p.add_cols;          // workgroup-uniform: add_cols is a multiple of 32
+  const float* ap2 = add2 ? p.A2 + arow : ap32;               // always a valid address: the loads below are unconditional
+  const float a2s = add2 ? 1.f : 0.f;
   const op16* wp = p.W + min(n0 + r, (int64_t)p.N - 1) * p.ldw + h * 8;
+  // (round 4: no conditional loads anywhere in this kernel.  Each `if (x) v = load` had become a basic block of its own with a full
+  //  vmcnt wait behind it -- one exposed L2 latency per k-step of the tail loop and per bias / residual element of the store: most of
+  //  the ~6 us this launch-bound kernel took)
   auto load_a = [&](int step) -> op16x8 {
     if constexpr (!F32A) {
       return *reinterpret_cast<const op16x8*>(ap + step * 16);
     } else {
       f32x4 lo = *reinterpret_cast<const f32x4*>(ap32 + step * 16), hi = *reinterpret_cast<const f32x4*>(ap32 + step * 16 + 4);
-      if (ap2) {
-        lo += *reinterpret_cast<const f32x4*>(ap2 + step * 16);
-        hi += *reinterpret_cast<const f32x4*>(ap2 + step * 16 + 4);
-      }
+      const f32x4 lo2 = *reinterpret_cast<const f32x4*>(ap2 + step * 16), hi2 = *reinterpret_cast<const f32x4*>(ap2 + step * 16 + 4);
       op16x8 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        o[e] = f2op(lo[e]);
-        o[4 + e] = f2op(hi[e]);
+        o[e] = f2op(add2 ? lo[e] + lo2[e] : lo[e]);
+        o[4 + e] = f2op(add2 ? hi[e] + hi2[e] : hi[e]);
       }
       return o;
     }
@@ -1595,40 +1597,65 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  int st = s0;
-  for (; st + 8 <= s1; st += 8) {
+  for (int st = s0; st < s1; st += 8) {                       // 8 k-steps of loads in flight; steps past s1 are clamped and not multiplied
     op16x8 a[8], w[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      a[u] = load_a(st + u);
-      w[u] = *reinterpret_cast<const op16x8*>(wp + (st + u) * 16);
+      const int su = min(st + u, s1 - 1);
+      a[u] = load_a(su);
+      w[u] = *reinterpret_cast<const op16x8*>(wp + su * 16);
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc = MSAM2_MFMA_32x32x16(a[u], w[u], acc, 0, 0, 0);
-  }
-  for (; st < s1; ++st) {
-    const op16x8 a = load_a(st);
-    const op16x8 w = *reinterpret_cast<const op16x8*>(wp + st * 16);
-    acc = MSAM2_MFMA_32x32x16(a, w, acc, 0, 0, 0);
+    for (int u = 0; u < 8; ++u)
+      if (st + u < s1) acc = MSAM2_MFMA_32x32x16(a[u], w[u], acc, 0, 0, 0);
   }
 #pragma unroll
   for (int e = 0; e < 16; ++e) part[wave][(e & 3) + 8 * (e >> 2) + 4 * h][r] = acc[e];
-  __syncthreads();
+  // bias / column scale / residual of this thread's four outputs: loaded (clamped, unconditional per tensor) before the barrier
+  int rowv[4], colv[4];
+  float bv[4], cv[4], rv[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int idx = t * 256 + tid;
-    const int row = idx >> 5, col = idx & 31;
+    rowv[t] = idx >> 5;
+    colv[t] = idx & 31;
+    bv[t] = 0.f; cv[t] = 1.f; rv[t] = 0.f;
+  }
+  if (p.bias) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bv[t] = p.bias[min(n0 + colv[t], (int64_t)p.N - 1)];
+  }
+  if (p.colscale) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) cv[t] = p.colscale[min(n0 + colv[t], (int64_t)p.N - 1)];
+  }
+  if (p.res) {
+    int64_t at[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int rc = min(rowv[t], p.M - 1);
+      const int64_t rr = p.res_mod > 0 ? (int64_t)((unsigned)rc % (unsigned)p.res_mod) : rc;
+      at[t] = rr * p.ldr + min(n0 + colv[t], (int64_t)p.N - 1);
+    }
+    if (p.res_is_16bit) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) rv[t] = op2f(reinterpret_cast<const op16*>(p.res)[at[t]]);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) rv[t] = reinterpret_cast<const float*>(p.res)[at[t]];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int row = rowv[t], col = colv[t];
     const int64_t n = n0 + col;
     if (row < p.M && n < p.N) {
-      float x = part[0][row][col] + part[1][row][col] + part[2][row][col] + part[3][row][col] + (p.bias ? p.bias[n] : 0.f);
+      float x = part[0][row][col] + part[1][row][col] + part[2][row][col] + part[3][row][col] + bv[t];
       if (p.act == 1) x = gelu_erf(x);
       else if (p.act == 2) x = fmaxf(x, 0.f);
       else if (p.act == 3) x = 1.f / (1.f + __expf(-x));
-      if (p.colscale) x *= p.colscale[n];
-      if (p.res) {
-        const int64_t rr = p.res_mod > 0 ? (int64_t)((unsigned)row % (unsigned)p.res_mod) : row;
-        x += p.res_is_16bit ? op2f(reinterpret_cast<const op16*>(p.res)[rr * p.ldr + n]) : reinterpret_cast<const float*>(p.res)[rr * p.ldr + n];
-      }
+      x = x * cv[t] + rv[t];
       if (p.out_is_16bit) reinterpret_cast<op16*>(p.C)[(int64_t)row * p.ldc + n] = f2op(x);
       else reinterpret_cast<float*>(p.C)[(int64_t)row * p.ldc + n] = x;
     }
