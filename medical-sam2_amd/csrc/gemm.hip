@@ -301,8 +301,46 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x16
       pos_base = (int)((unsigned)l_base % (unsigned)p.rope_npos);
       hp = p.rope_D >> 1;
     }
+    // column side of the rotation, once per lane: channel pair inside its head (one integer division instead of one per output pair)
+    int pr_j[ROPE ? FN : 1];
+    bool colrot[ROPE ? FN : 1];
+    if constexpr (ROPE) {
+      int m = (int)((unsigned)((int)col0 + (r & ~1)) % (unsigned)p.rope_D);
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+      for (int j = 0; j < FN; ++j) {
+        pr_j[j] = m >> 1;
+        colrot[j] = (int)col0 + j * 32 + (r & ~1) < p.rope_cols && colok[j];
+        m += 32;
+        while (m >= p.rope_D) m -= p.rope_D;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      // RoPE factors of this 32-row block: ALL of them loaded (unconditionally, index clamped) before its first store.  Loaded where they
+      // were used -- one `if (rotates) { c = cos[..]; s = sin[..]; }` per pair of outputs, each followed by a store -- every one of the
+      // FN * 8 loads waited for the previous store's round trip (vmcnt is one in-order counter; round 4): the RoPE projections ran at a
+      // third of the plain ones' rate.
+      float rc[ROPE ? FN : 1][ROPE ? 8 : 1], rs[ROPE ? FN : 1][ROPE ? 8 : 1];
+      bool rot[ROPE ? FN : 1][ROPE ? 8 : 1];
+      if constexpr (ROPE) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int e0 = 2 * k, ro = i * 32 + (e0 & 3) + 8 * (e0 >> 2);
+          int l = l_base + ro, pos = pos_base + ro;
+          // (ro < 128 <= period / npos is checked on the host: one wrap suffices)
+          if (l >= p.rope_period) { l -= p.rope_period; pos = (int)((unsigned)l % (unsigned)p.rope_npos); }
+          else if (pos >= p.rope_npos) pos -= p.rope_npos;
+          const bool rowrot = l < p.rope_n;
+          const int prow = pos * hp;
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            rot[j][k] = rowrot && colrot[j];
+            const int at = rot[j][k] ? prow + pr_j[j] : 0;
+            rc[j][k] = p.rope_cos[at];
+            rs[j][k] = p.rope_sin[at];
+          }
+        }
+      }
 #pragma unroll
       for (int j = 0; j < FN; ++j)
 #pragma unroll
@@ -336,14 +374,8 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x16
           const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xf, 0xf, false));
           float lo = odd ? recv : x0, hi = odd ? x1 : recv;
           if constexpr (ROPE) {
-            const int ncol = (int)col0 + j * 32 + (r & ~1);
-            int l = l_base + ro, pos = pos_base + ro;
-            // (ro < 128 <= period / npos is checked on the host: one wrap suffices)
-            if (l >= p.rope_period) { l -= p.rope_period; pos = (int)((unsigned)l % (unsigned)p.rope_npos); }
-            else if (pos >= p.rope_npos) pos -= p.rope_npos;
-            if (ncol < p.rope_cols && l < p.rope_n && colok[j]) {
-              const int pr = (ncol % p.rope_D) >> 1;
-              const float c = p.rope_cos[(int64_t)pos * hp + pr], sn = p.rope_sin[(int64_t)pos * hp + pr];
+            if (rot[j][k]) {
+              const float c = rc[j][k], sn = rs[j][k];
               const float re = lo, im = hi;
               lo = re * c - im * sn;
               hi = re * sn + im * c;
@@ -354,6 +386,7 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x16
           pk[1] = f2op(hi);
           if (colok[j]) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk), c_rsrc, vbase + ro * ldc_b + j * 64, 0, 0);
         }
+    }
   }
 #endif
 }
