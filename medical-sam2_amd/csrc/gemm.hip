@@ -411,11 +411,14 @@ __device__ __forceinline__ void gemm_epilogue_pool(const GemmParams& p, f32x16 (
   const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((int64_t)p.M >> 2) * p.ldc * 4), 0x00020000);
   const int vbase = (int)(((row0 >> 2) + h) * p.ldc + col0 + r) * 4;
   const int ldc_b = (int)p.ldc * 4;
+  float bias_j[FN];                                          // every bias value before the first store (one in-order counter for loads and stores)
+#pragma unroll
+  for (int j = 0; j < FN; ++j) bias_j[j] = p.bias ? p.bias[min(col0 + j * 32 + r, (int64_t)p.N - 1)] : 0.f;
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
     const int64_t n = col0 + j * 32 + r;
     const bool ok = n < p.N;
-    const float b = (p.bias && ok) ? p.bias[n] : 0.f;
+    const float b = bias_j[j];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -439,12 +442,37 @@ __device__ __forceinline__ void gemm_epilogue_qpool(const GemmParams& p, f32x16 
   const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((int64_t)p.M * p.ldc * 2), 0x00020000);
   const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.Q2, 0, (int)(((int64_t)p.M >> 2) * p.ldq * 2), 0x00020000);
   auto swap = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)); };
+  float bias_j[FN];                                          // every bias value before the first store (one in-order counter for loads and stores)
+#pragma unroll
+  for (int j = 0; j < FN; ++j) bias_j[j] = p.bias ? p.bias[min(col0 + j * 32 + r, (int64_t)p.N - 1)] : 0.f;
+  // image-order pixel row of sub-pixel (0, 0) of every pooled pixel this lane holds (pooled pixels row0/4 + h + 8 i + 2 g): ONE pair of
+  // 32-bit divisions for the first, the others by stepping through the pooled image -- was gemm_a_row per (j, i, g): FN * 8 * two 64-bit
+  // divisions per lane, the larger part of this epilogue's vector work (round 4)
+  int top_ig[FM][4];
+  {
+    const int w2 = p.pool_W >> 1, h2 = p.pool_H >> 1;
+    const unsigned pix0 = (unsigned)(row0 >> 2) + (unsigned)h;
+    const int x0 = (int)(pix0 % (unsigned)w2);
+    const unsigned t0 = pix0 / (unsigned)w2;
+    const int y0 = (int)(t0 % (unsigned)h2), b0 = (int)(t0 / (unsigned)h2);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        int x = x0 + 8 * i + 2 * g, y = y0, bb = b0;
+        while (x >= w2) {
+          x -= w2;
+          if (++y >= h2) { y = 0; ++bb; }
+        }
+        top_ig[i][g] = (bb * p.pool_H + 2 * y) * p.pool_W + 2 * x;
+      }
+  }
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
     const int64_t ncol = col0 + j * 32;                      // first column of this fragment (wave-uniform)
     const int64_t n = ncol + r;
     const bool ok = n < p.N;
-    const float b = (p.bias && ok) ? p.bias[n] : 0.f;
+    const float b = bias_j[j];
     if (ncol < p.poolq_cols) {
 #pragma unroll
       for (int i = 0; i < FM; ++i)
@@ -469,7 +497,7 @@ __device__ __forceinline__ void gemm_epilogue_qpool(const GemmParams& p, f32x16 
           // logical rows row0 + 32 i + 8 g + 4 h + {0,1,2,3} = sub-pixels (dy, dx) of ONE pooled pixel
           const int64_t m = row0 + i * 32 + 8 * g + 4 * h;
           const bool live = m < p.M;
-          const int64_t top = gemm_a_row(p, live ? m : 0);    // pixel row of (dy, dx) = (0, 0); (0,1) = +1, (1,0) = +W, (1,1) = +W+1
+          const int64_t top = top_ig[i][g];                   // pixel row of (dy, dx) = (0, 0); (0,1) = +1, (1,0) = +W, (1,1) = +W+1
 #pragma unroll
           for (int dy = 0; dy < 2; ++dy) {
             const float x0 = acc[i][j][4 * g + 2 * dy] + b, x1 = acc[i][j][4 * g + 2 * dy + 1] + b;
