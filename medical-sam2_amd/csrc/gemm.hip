@@ -584,25 +584,41 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
   const int nk = p.ksplit_tiles > 0 ? min(nk_all, kt0 + p.ksplit_tiles) : nk_all;
   if (kt0 >= nk) return;
 
+  // Row bases once (gemm_a_row is two 64-bit divisions for pooled row orders), loads unconditional with clamped addresses and the
+  // out-of-range chunks zeroed afterwards: `if (in range) v = load` gave every chunk a basic block and a full vmcnt wait of its own --
+  // three exposed latencies per k-tile of a kernel whose reductions are 3-5 tiles long (round 4).
+  const op16* a_base[A_PER];
+  const op16* w_base[W_PER];
+  bool a_in[A_PER], w_in[W_PER];
+#pragma unroll
+  for (int i = 0; i < A_PER; ++i) {
+    const int c = min(tid + i * NT, A_CHUNKS - 1);
+    const int row = c >> 2;
+    a_in[i] = tid + i * NT < A_CHUNKS && m0 + row < p.M;
+    a_base[i] = p.A + gemm_a_row(p, min(m0 + row, (int64_t)p.M - 1)) * p.lda + (c & 3) * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < W_PER; ++i) {
+    const int c = min(tid + i * NT, W_CHUNKS - 1);
+    const int row = c >> 2;
+    w_in[i] = tid + i * NT < W_CHUNKS && n0 + row < p.N;
+    w_base[i] = p.W + min(n0 + row, (int64_t)p.N - 1) * p.ldw + (c & 3) * 8;
+  }
   auto gload = [&](int kt) {
     const int k0 = kt * GEMM_BK;
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
-      const int c = tid + i * NT;
-      const int row = c >> 2, kc = (c & 3) * 8;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (c < A_CHUNKS && m0 + row < p.M && k0 + kc < p.K)
-        v = *reinterpret_cast<const uint4*>(p.A + gemm_a_row(p, m0 + row) * p.lda + k0 + kc);
-      ra[i] = v;
+      const int kc = (min(tid + i * NT, A_CHUNKS - 1) & 3) * 8;
+      const bool kin = k0 + kc < p.K;                       // (K % 8 == 0: a chunk is inside or outside as a whole)
+      const uint4 v = *reinterpret_cast<const uint4*>(a_base[i] + (kin ? k0 : 0));
+      ra[i] = (a_in[i] && kin) ? v : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < W_PER; ++i) {
-      const int c = tid + i * NT;
-      const int row = c >> 2, kc = (c & 3) * 8;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (c < W_CHUNKS && n0 + row < p.N && k0 + kc < p.K)
-        v = *reinterpret_cast<const uint4*>(p.W + (n0 + row) * p.ldw + k0 + kc);
-      rw[i] = v;
+      const int kc = (min(tid + i * NT, W_CHUNKS - 1) & 3) * 8;
+      const bool kin = k0 + kc < p.K;
+      const uint4 v = *reinterpret_cast<const uint4*>(w_base[i] + (kin ? k0 : 0));
+      rw[i] = (w_in[i] && kin) ? v : make_uint4(0, 0, 0, 0);
     }
   };
   auto lstore = [&](int buf) {
