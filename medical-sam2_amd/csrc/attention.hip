@@ -307,19 +307,48 @@ __global__ void attn_merge_kernel(AttnParams p, int Bz) {
   const int head = (gw / p.Lq) % p.H;
   const int z = gw / ((int64_t)p.Lq * p.H);
   float M = -INFINITY;
-  for (int s = 0; s < p.splits; ++s) M = fmaxf(M, p.ml_part[((int64_t)s * rows + gw) * 2]);
   const int d0 = lane * 4;
   float L = 0.f;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < p.splits; ++s) {
-    const float m = p.ml_part[((int64_t)s * rows + gw) * 2], l = p.ml_part[((int64_t)s * rows + gw) * 2 + 1];
-    if (m == -INFINITY) continue;
-    const float w = l * __builtin_amdgcn_exp2f(m - M);
-    L += w;
-    if (d0 < D) {
-      const op16x4 t = *reinterpret_cast<const op16x4*>(p.o_part + ((int64_t)s * rows + gw) * D + d0);
+  constexpr int G = 8;
+  if (p.splits <= G) {
+    // every (max, sum) pair and every partial row of this query loaded up front (split index clamped: unconditional loads).  The serial
+    // form below is a chain of 3 * splits dependent loads -- 12 memory latencies for 4 splits: the whole duration of a launch whose 40 MB
+    // the chip moves in 6 us (round 4).  Same arithmetic in the same order: bit-identical.
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    f32x2_ ml[G];
+    op16x4 t[G];
+    const int d0c = d0 < D ? d0 : 0;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] += w * op2f(t[e]);
+    for (int u = 0; u < G; ++u) {
+      const int64_t at = (int64_t)min(u, p.splits - 1) * rows + gw;
+      ml[u] = *reinterpret_cast<const f32x2_*>(p.ml_part + at * 2);
+      t[u] = *reinterpret_cast<const op16x4*>(p.o_part + at * D + d0c);
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u)
+      if (u < p.splits) M = fmaxf(M, ml[u][0]);
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      if (u < p.splits && ml[u][0] != -INFINITY) {
+        const float w = ml[u][1] * __builtin_amdgcn_exp2f(ml[u][0] - M);
+        L += w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += w * op2f(t[u][e]);
+      }
+    }
+  } else {
+    for (int s = 0; s < p.splits; ++s) M = fmaxf(M, p.ml_part[((int64_t)s * rows + gw) * 2]);
+    for (int s = 0; s < p.splits; ++s) {
+      const float m = p.ml_part[((int64_t)s * rows + gw) * 2], l = p.ml_part[((int64_t)s * rows + gw) * 2 + 1];
+      if (m == -INFINITY) continue;
+      const float w = l * __builtin_amdgcn_exp2f(m - M);
+      L += w;
+      if (d0 < D) {
+        const op16x4 t = *reinterpret_cast<const op16x4*>(p.o_part + ((int64_t)s * rows + gw) * D + d0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += w * op2f(t[e]);
+      }
     }
   }
   if (p.lse && lane == 0) p.lse[gw] = M + __log2f(L);

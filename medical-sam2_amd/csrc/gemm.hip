@@ -1651,7 +1651,6 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
   const float* ap32 = p.A32 + arow;
   const bool add2 = F32A && p.A2 && n0 < p.add_cols;          // workgroup-uniform: add_cols is a multiple of 32
   const float* ap2 = add2 ? p.A2 + arow : ap32;               // always a valid address: the loads below are unconditional
-  const float a2s = add2 ? 1.f : 0.f;
   const op16* wp = p.W + min(n0 + r, (int64_t)p.N - 1) * p.ldw + h * 8;
   // (round 4: no conditional loads anywhere in this kernel.  Each `if (x) v = load` had become a basic block of its own with a full
   //  vmcnt wait behind it -- one exposed L2 latency per k-step of the tail loop and per bias / residual element of the store: most of
@@ -1665,7 +1664,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
       op16x8 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        o[e] = f2op(add2 ? lo[e] + lo2[e] : lo[e]);
+        o[e] = f2op(add2 ? lo[e] + lo2[e] : lo[e]);        // (without an addend the second operand is the first one re-read: an L1 hit)
         o[4 + e] = f2op(add2 ? hi[e] + hi2[e] : hi[e]);
       }
       return o;
@@ -1674,18 +1673,25 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  for (int st = s0; st < s1; st += 8) {                       // 8 k-steps of loads in flight; steps past s1 are clamped and not multiplied
-    op16x8 a[8], w[8];
+  // U k-steps of loads in flight; steps past s1 are clamped (re-read, not multiplied).  U = 4 when a wave owns at most 4 steps (K <= 256:
+  // the token-side projections), so that the clamping does not double their loads
+  auto run = [&](auto u_tag) __attribute__((always_inline)) {
+    constexpr int U = decltype(u_tag)::value;
+    for (int st = s0; st < s1; st += U) {
+      op16x8 a[U], w[U];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int su = min(st + u, s1 - 1);
-      a[u] = load_a(su);
-      w[u] = *reinterpret_cast<const op16x8*>(wp + su * 16);
+      for (int u = 0; u < U; ++u) {
+        const int su = min(st + u, s1 - 1);
+        a[u] = load_a(su);
+        w[u] = *reinterpret_cast<const op16x8*>(wp + su * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (st + u < s1) acc = MSAM2_MFMA_32x32x16(a[u], w[u], acc, 0, 0, 0);
     }
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (st + u < s1) acc = MSAM2_MFMA_32x32x16(a[u], w[u], acc, 0, 0, 0);
-  }
+  };
+  if (per <= 4) run(std::integral_constant<int, 4>{});
+  else run(std::integral_constant<int, 8>{});
 #pragma unroll
   for (int e = 0; e < 16; ++e) part[wave][(e & 3) + 8 * (e >> 2) + 4 * h][r] = acc[e];
   // bias / column scale / residual of this thread's four outputs: loaded (clamped, unconditional per tensor) before the barrier
