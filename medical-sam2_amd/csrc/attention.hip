@@ -2652,6 +2652,134 @@ __global__ void attn_fewkeys_kernel(const op16* q, const op16* k, const op16* v,
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// tokens -> image attention of the two-way decoder (a handful of queries against 4096 image keys, 8 heads of 16 channels) on the matrix
+// pipe: ONE 1024-thread workgroup per (batch, head) serves ALL its queries (round 4).  attn_fewq_kernel gives every (batch, head, query) a
+// workgroup of its own, so the head's K and V (262 KB) are read once per query -- 9 times -- by 288 workgroups in two rounds: 23 us.
+// Here wave w owns keys [w * Lk / 16, ...): per 32-key step ONE MFMA gives the scores of all (<= 32) queries (S^T = K Q^T, the 16 channels
+// are the whole reduction), the softmax runs per lane (lane = query), and O^T += V^T P^T is two more MFMAs with V^T read transposed from
+// a private LDS tile ([32 keys][64 B]: 32 channel slots, the upper 16 zero, so that attn_win_kernel's transposed-read addressing applies
+// unchanged).  Every K fragment and V chunk of the wave's key range is loaded up front (8 + 8 loads per lane in flight).  The 16 waves'
+// (max, sum, O) are merged through LDS by the first 16 * Lq threads.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void attn_fewq16_kernel(const op16* __restrict__ q, const op16* __restrict__ k, const op16* __restrict__ v,
+                                                           op16* __restrict__ o, int64_t q_bs, int64_t q_ts, int64_t k_bs, int64_t k_ts,
+                                                           int64_t v_bs, int64_t v_ts, int64_t o_bs, int64_t o_ts, int H, int Lq, int Lk,
+                                                           float scale_log2) {
+  constexpr int D = 16, RB = 64, BK = 32, NW = 16, MAXS = 8;  // MAXS 32-key steps per wave: Lk <= 16 * 8 * 32 = 4096 (launcher)
+  __shared__ __attribute__((aligned(16))) unsigned char vt[NW][BK * RB];        // per-wave V tile
+  __shared__ float part[NW][32][18];                                          // per wave and query: m, l, O[0..15]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int b = blockIdx.x / H, head = blockIdx.x - b * H;
+  const op16* qb = q + (int64_t)b * q_bs + head * D;
+  const op16* kb = k + (int64_t)b * k_bs + head * D;
+  const op16* vb = v + (int64_t)b * v_bs + head * D;
+  // upper 16 channel slots of every V row: zero, once
+  {
+    unsigned char* t = vt[wave];
+    *reinterpret_cast<uint4*>(t + (lane >> 1) * RB + 32 + (lane & 1) * 16) = make_uint4(0, 0, 0, 0);
+  }
+  // query fragment (B operand): lane (r = query, h) holds channels 8 h .. 8 h + 7
+  op16x8 qf;
+  {
+    uint4 t = make_uint4(0, 0, 0, 0);
+    const uint4 ld = *reinterpret_cast<const uint4*>(qb + (int64_t)min(r, Lq - 1) * q_ts + h * 8);
+    if (r < Lq) t = ld;
+    qf = __builtin_bit_cast(op16x8, t);
+  }
+  // this wave's keys: steps of 32, every load issued before the first use (row indices clamped; masked below)
+  const int per = (Lk + NW - 1) / NW;                         // keys per wave
+  const int key_lo = wave * per, key_hi = min(Lk, key_lo + per);
+  const int nsteps = max(0, (key_hi - key_lo + BK - 1) / BK);
+  uint4 kfr[MAXS], vch[MAXS];
+#pragma unroll
+  for (int st = 0; st < MAXS; ++st) {
+    const int kk = min(key_lo + st * BK + r, Lk - 1);                           // K fragment row (A operand): key r of the step
+    kfr[st] = *reinterpret_cast<const uint4*>(kb + (int64_t)kk * k_ts + h * 8);
+    const int kv = min(key_lo + st * BK + (lane >> 1), Lk - 1);                 // V chunk: key lane / 2, channel half lane & 1
+    vch[st] = *reinterpret_cast<const uint4*>(vb + (int64_t)kv * v_ts + (lane & 1) * 8);
+  }
+  f32x16 oacc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int li = lane & 15;
+  const int v_off = (4 * h + (li >> 2)) * RB + (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
+#pragma unroll
+  for (int st = 0; st < MAXS; ++st) {
+    if (st < nsteps) {                                                           // (wave-uniform)
+      const int key0 = key_lo + st * BK;
+      *reinterpret_cast<uint4*>(vt[wave] + (lane >> 1) * RB + (lane & 1) * 16) = vch[st];
+      f32x16 sacc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+      sacc = MSAM2_MFMA_32x32x16(__builtin_bit_cast(op16x8, kfr[st]), qf, sacc, 0, 0, 0);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (key >= key_hi) sacc[e] = -INFINITY;
+        mx = fmaxf(mx, sacc[e]);
+      }
+      mx = half_max(mx) * scale_log2;                                            // finite: every step holds >= 1 key of the range
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[e] *= alpha;
+      m_run = m_new;
+      float psum = 0.f;
+      op16x8 pf[2];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[e], scale_log2, -m_run));
+        psum += pe;
+        pf[e >> 3][e & 7] = f2op_fast(pe);
+      }
+      l_run += psum;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // the wave's own V tile is in LDS
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        typedef __attribute__((ext_vector_type(8))) short short8_t;
+        const unsigned char* a0 = vt[wave] + (16 * s2) * RB + v_off;
+        const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0));
+        const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0 + 8 * RB));
+        short8_t vv8;
+        vv8[0] = lo[0]; vv8[1] = lo[1]; vv8[2] = lo[2]; vv8[3] = lo[3];
+        vv8[4] = hi[0]; vv8[5] = hi[1]; vv8[6] = hi[2]; vv8[7] = hi[3];
+        oacc = MSAM2_MFMA_32x32x16(__builtin_bit_cast(op16x8, vv8), pf[s2], oacc, 0, 0, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // tile read before the next step overwrites it
+    }
+  }
+  // ---- per wave: (m, l, O rows d = (e & 3) + 8 (e >> 2) + 4 h for e < 8) of query r; merged by thread (query, channel)
+  const float l_tot = half_sum(l_run);
+  {
+    float* pp = part[wave][r];
+    if (h == 0) { pp[0] = m_run; pp[1] = l_tot; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pp[2 + (e & 3) + 8 * (e >> 2) + 4 * h] = oacc[e];
+  }
+  __syncthreads();
+  if (tid < Lq * D) {
+    const int qi = tid / D, d = tid - qi * D;
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) M = fmaxf(M, part[w][qi][0]);
+    float L = 0.f, acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float mw = part[w][qi][0];
+      const float wgt = (mw == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw - M);
+      L += part[w][qi][1] * wgt;
+      acc += part[w][qi][2 + d] * wgt;
+    }
+    o[(int64_t)b * o_bs + (int64_t)qi * o_ts + head * D + d] = f2op(acc / L);
+  }
+}
+
+
 extern "C" int msam2_attention_small_fwd(const void* q, int64_t q_bs, int64_t q_ts, const void* k, int64_t k_bs, int64_t k_ts,
                                          const void* v, int64_t v_bs, int64_t v_ts, void* o, int64_t o_bs, int64_t o_ts,
                                          int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t D, float scale, void* stream) {
@@ -2671,6 +2799,15 @@ extern "C" int msam2_attention_small_fwd(const void* q, int64_t q_bs, int64_t q_
       hipLaunchKernelGGL((attn_fewkeys_kernel<32>), g1, dim3(256), 0, s, (const op16*)q, (const op16*)k, (const op16*)v, (op16*)o, q_bs,
                          q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts, (int)B, (int)H, (int)Lq, (int)Lk, sl);
     return msam2_check_launch("attention_small(fewkeys)");
+  }
+  {
+    const char* off = getenv("MSAM2_NO_FEWQ16");
+    if (D == 16 && Lq <= 32 && Lk >= 1024 && Lk <= 4096 && !(off && off[0] == '1') && q_ts % 8 == 0 && k_ts % 8 == 0 && v_ts % 8 == 0 &&
+        q_bs % 8 == 0 && k_bs % 8 == 0 && v_bs % 8 == 0 && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0) {
+      hipLaunchKernelGGL(attn_fewq16_kernel, dim3((unsigned)(B * H)), dim3(1024), 0, s, (const op16*)q, (const op16*)k, (const op16*)v, (op16*)o,
+                         q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts, (int)H, (int)Lq, (int)Lk, sl);
+      return msam2_check_launch("attention_small(fewq, matrix pipe)");
+    }
   }
   if (Lk >= 1024 && B * H * Lq <= 4096) {
     dim3 g2((unsigned)(B * H * Lq));

@@ -488,7 +488,7 @@ def test_window_attention_vs_oracle(ops, B, Hh, Ww, heads, ws, pool):
 
 
 @pytest.mark.parametrize("B,Lq,Lk,heads,C", [(2, 8, 256, 8, 128), (2, 256, 8, 8, 128), (3, 7, 7, 8, 256), (1, 9, 4096, 8, 128),
-                                            (2, 8, 1500, 8, 256)])
+                                            (2, 8, 1500, 8, 256), (4, 9, 4096, 8, 128), (2, 5, 3000, 8, 128), (1, 32, 1024, 4, 64)])
 def test_attention_small(ops, B, Lq, Lk, heads, C):
     q, k, v = bf(rnd(B, Lq, C, seed=1)), bf(rnd(B, Lk, C, seed=2)), bf(rnd(B, Lk, C, seed=3))
     D = C // heads
