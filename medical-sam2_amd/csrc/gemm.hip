@@ -58,14 +58,14 @@ struct GemmParams {
 // A row (in elements of lda) that logical GEMM row m reads
 __device__ __forceinline__ int64_t gemm_a_row(const GemmParams& p, int64_t m) {
   if (p.pool_W == 0) return m;
-  const int s = (int)(m & 3);
-  const int64_t pix = m >> 2;
-  const int w2 = p.pool_W >> 1, h2 = p.pool_H >> 1;
-  const int x2 = (int)(pix % w2);
-  const int64_t t = pix / w2;
-  const int y2 = (int)(t % h2);
-  const int64_t b = t / h2;
-  return (b * p.pool_H + 2 * y2 + (s >> 1)) * p.pool_W + 2 * x2 + (s & 1);
+  // 32-bit arithmetic (M < 2^31 is checked on the host): the 64-bit form cost four ~100-instruction divisions per thread in the prologue
+  // of every tile of the pooled GEMMs, whose main loop is 3-12 k-steps (round 4)
+  const unsigned mu = (unsigned)m;
+  const unsigned s = mu & 3u, pix = mu >> 2;
+  const unsigned w2 = (unsigned)p.pool_W >> 1, h2 = (unsigned)p.pool_H >> 1;
+  const unsigned t = pix / w2, x2 = pix - t * w2;
+  const unsigned b = t / h2, y2 = t - b * h2;
+  return (int64_t)((b * (unsigned)p.pool_H + 2 * y2 + (s >> 1)) * (unsigned)p.pool_W + 2 * x2 + (s & 1));
 }
 
 #ifdef MSAM2_GSTAMP
