@@ -228,24 +228,22 @@ extern "C" int msam2_patch_embed7x7s4(const float* img, const void* w_perm, cons
 // 3x3 / stride 2 / pad 1 im2col on NHWC op16: [B,H,W,C] -> [B*(H/2)*(W/2), ld], column order (ky, kx, c), zero fill
 // up to ld (>= 9*C, multiple of 8).  One thread per 8-byte group of 4 channels (C % 4 == 0).
 __global__ void im2col3x3s2_kernel(const op16* __restrict__ x, op16* __restrict__ out, int B, int H, int W, int C, int ld) {
-  const int Ho = H / 2, Wo = W / 2;
-  const int gpr = ld / 4;  // 4-element groups per output row
-  const int64_t total = (int64_t)B * Ho * Wo * gpr;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int g = i % gpr;
-    int64_t t = i / gpr;
-    const int xo = t % Wo;
-    t /= Wo;
-    const int yo = t % Ho;
-    const int b = t / Ho;
-    const int col = g * 4;
-    op16x4 v = {f2op(0.f), f2op(0.f), f2op(0.f), f2op(0.f)};
-    if (col < 9 * C) {
-      const int k = col / C, c = col % C;
-      const int y = 2 * yo - 1 + k / 3, xx = 2 * xo - 1 + k % 3;
-      if (y >= 0 && y < H && xx >= 0 && xx < W) v = *reinterpret_cast<const op16x4*>(x + (((int64_t)b * H + y) * W + xx) * C + c);
-    }
-    *reinterpret_cast<op16x4*>(out + i * 4) = v;
+  // 32-bit index arithmetic (the group count is checked on the host): as int64 the seven divisions / remainders per 8-byte group were the
+  // kernel (round 4); the load is unconditional (clamped) and zeroed afterwards
+  const unsigned Ho = H / 2, Wo = W / 2;
+  const unsigned gpr = ld / 4;  // 4-element groups per output row
+  const unsigned total = (unsigned)B * Ho * Wo * gpr;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned t0 = i / gpr, g = i - t0 * gpr;
+    const unsigned t1 = t0 / Wo, xo = t0 - t1 * Wo;
+    const unsigned b = t1 / Ho, yo = t1 - b * Ho;
+    const unsigned col = g * 4;
+    const unsigned k = min(col / (unsigned)C, 8u), c = col - (col / (unsigned)C) * C;
+    const int y = 2 * (int)yo - 1 + (int)(k / 3), xx = 2 * (int)xo - 1 + (int)(k % 3);
+    const bool in = col < 9u * C && y >= 0 && y < H && xx >= 0 && xx < W;
+    const op16x4 ld4 = *reinterpret_cast<const op16x4*>(x + (((int64_t)b * H + min(max(y, 0), H - 1)) * W + min(max(xx, 0), W - 1)) * C + (col < 9u * C ? c : 0));
+    const op16x4 zero = {f2op(0.f), f2op(0.f), f2op(0.f), f2op(0.f)};
+    *reinterpret_cast<op16x4*>(out + (int64_t)i * 4) = in ? ld4 : zero;
   }
 }
 
@@ -253,6 +251,7 @@ extern "C" int msam2_im2col3x3s2(const void* x, void* out, int64_t B, int64_t H,
   MSAM2_REQUIRE(x && out && B > 0 && C > 0 && C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && ld >= 9 * C && ld % 8 == 0,
                 "im2col3x3s2: bad arguments");
   const int64_t total = B * (H / 2) * (W / 2) * (ld / 4);
+  MSAM2_REQUIRE(total < (1ll << 31), "im2col3x3s2: more than 2^31 output groups");
   hipLaunchKernelGGL(im2col3x3s2_kernel, dim3((unsigned)min((int64_t)16384, (total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, (const op16*)x, (op16*)out, (int)B, (int)H, (int)W, (int)C, (int)ld);
   return msam2_check_launch("im2col3x3s2");

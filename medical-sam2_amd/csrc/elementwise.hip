@@ -361,10 +361,29 @@ __global__ void upsample2x_add_kernel(float* __restrict__ y, const float* __rest
   }
 }
 
+// four channels per thread, 32-bit index arithmetic (C % 4 == 0, fewer than 2^31 groups, 16-byte aligned tensors): the one-element form
+// spends four 64-bit divisions on every 4 bytes it moves (14.9 us for the FPN's one top-down step; round 4)
+__global__ void upsample2x_add4_kernel(float* __restrict__ y, const float* __restrict__ top, unsigned B, unsigned H, unsigned W, unsigned C4) {
+  const unsigned total = B * H * W * C4;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned t0 = i / C4, c = i - t0 * C4;
+    const unsigned t1 = t0 / W, xx = t0 - t1 * W;
+    const unsigned b = t1 / H, yy = t1 - b * H;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(y + (int64_t)i * 4);
+    const f32x4 tp = *reinterpret_cast<const f32x4*>(top + ((int64_t)(b * (H / 2) + yy / 2) * (W / 2) + xx / 2) * (C4 * 4) + c * 4);
+    *reinterpret_cast<f32x4*>(y + (int64_t)i * 4) = a + tp;
+  }
+}
+
 extern "C" int msam2_upsample2x_add(void* y, const void* top, int64_t B, int64_t H, int64_t W, int64_t C, void* stream) {
   MSAM2_REQUIRE(y && top, "upsample2x_add: null tensor");
   MSAM2_REQUIRE(H % 2 == 0 && W % 2 == 0 && B > 0 && C > 0, "upsample2x_add: bad shape");
   const int64_t total = B * H * W * C;
+  if (C % 4 == 0 && total / 4 < (1ll << 31) && (((uintptr_t)y | (uintptr_t)top) & 15) == 0) {
+    hipLaunchKernelGGL(upsample2x_add4_kernel, dim3((unsigned)min((int64_t)16384, (total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (float*)y, (const float*)top, (unsigned)B, (unsigned)H, (unsigned)W, (unsigned)(C / 4));
+    return msam2_check_launch("upsample2x_add");
+  }
   hipLaunchKernelGGL(upsample2x_add_kernel, dim3((unsigned)min((int64_t)8192, (total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, (float*)y, (const float*)top, (int)B, (int)H, (int)W, (int)C);
   return msam2_check_launch("upsample2x_add");
