@@ -38,28 +38,31 @@ __device__ __forceinline__ int mlp_swz(int c, int r) {
   else return (c & ~7) | ((c & 7) ^ ((r >> 1) & 7));
 }
 
-template <int DIM, int HC, int TB, int OCC = 1>
-__global__ __launch_bounds__(256, OCC) void mlp_fused_kernel(MlpFusedParams p) {
+// NWV waves per workgroup (4 or 8).  With 8 (round 4) the workgroup still owns ONE weight ring in LDS, a wave carries TB = half as many
+// token blocks, and every SIMD holds two waves: one wave's GELU / LayerNorm vector work and LDS reads run under the other's MFMAs, and a
+// wave's registers (<= 256) no longer spill (the 4-wave form at dim 192 spilled 21-35 registers of a 512-register budget).
+template <int DIM, int HC, int TB, int OCC = 1, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64, OCC) void mlp_fused_kernel(MlpFusedParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int HID = 4 * DIM, NCH = HID / HC, KS1 = DIM / 16, DB = DIM / 32, HB = HC / 32;
   constexpr int RB1 = DIM * 2, RB2 = HC * 2;                 // LDS row bytes of the W1 chunk [HC][DIM] and the W2 chunk [DIM][HC]
   constexpr int CPR1 = DIM / 8, CPR2 = HC / 8;               // 16-byte chunks per row
   constexpr int W1B = HC * RB1, W2B = DIM * RB2, BUF = W1B + W2B;
-  constexpr int PIECES1 = W1B / 1024, PIECES2 = W2B / 1024, PW1 = PIECES1 / 4, PW2 = PIECES2 / 4;
+  constexpr int PIECES1 = W1B / 1024, PIECES2 = W2B / 1024, PW1 = (PIECES1 + NWV - 1) / NWV, PW2 = (PIECES2 + NWV - 1) / NWV;
   static_assert((RB1 == 192 || RB1 == 384) && (RB2 == 192 || RB2 == 384), "row swizzles are built for 192 / 384-byte rows");
-  static_assert(PIECES1 % 4 == 0 && PIECES2 % 4 == 0 && 2 * BUF + (3 * DIM + HID) * 4 <= 160 * 1024, "LDS budget");
+  static_assert(2 * BUF + (3 * DIM + HID) * 4 <= 160 * 1024, "LDS budget");   // (pieces are dealt j * NWV + wave: a last, partial round is guarded)
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   float* prm = reinterpret_cast<float*>(smem + 2 * BUF);     // [gamma DIM | beta DIM | b2 DIM | b1 HID]
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int r = lane & 31, h = lane >> 5;
-  for (int i = tid; i < DIM; i += 256) {
+  for (int i = tid; i < DIM; i += NWV * 64) {
     prm[i] = p.ln_w[i];
     prm[DIM + i] = p.ln_b[i];
     prm[2 * DIM + i] = p.b2[i];
   }
-  for (int i = tid; i < HID; i += 256) prm[3 * DIM + i] = p.b1[i];
+  for (int i = tid; i < HID; i += NWV * 64) prm[3 * DIM + i] = p.b1[i];
 
   // ---- weight stream: per-lane source offsets of this wave's DMA pieces (chunk-independent part), scalar chunk offset added per issue
   const auto w1_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, HID * DIM * 2, 0x00020000);
@@ -67,31 +70,41 @@ __global__ __launch_bounds__(256, OCC) void mlp_fused_kernel(MlpFusedParams p) {
   unsigned off1[PW1], off2[PW2];
 #pragma unroll
   for (int j = 0; j < PW1; ++j) {
-    const int f = (wave * PW1 + j) * 64 + lane, row = f / CPR1, c = f % CPR1;
+    const int f = min(j * NWV + wave, PIECES1 - 1) * 64 + lane, row = f / CPR1, c = f % CPR1;
     off1[j] = (unsigned)(row * RB1 + mlp_swz<RB1>(c, row) * 16);                       // W1 rows are DIM * 2 bytes in memory too
   }
 #pragma unroll
   for (int j = 0; j < PW2; ++j) {
-    const int f = (wave * PW2 + j) * 64 + lane, row = f / CPR2, c = f % CPR2;
+    const int f = min(j * NWV + wave, PIECES2 - 1) * 64 + lane, row = f / CPR2, c = f % CPR2;
     off2[j] = (unsigned)(row * HID * 2 + mlp_swz<RB2>(c, row) * 16);
   }
   auto issue = [&](int chunk, int buf) {
-    unsigned char* d1 = smem + buf * BUF + wave * PW1 * 1024;
-    unsigned char* d2 = smem + buf * BUF + W1B + wave * PW2 * 1024;
+    unsigned char* d1 = smem + buf * BUF;
+    unsigned char* d2 = smem + buf * BUF + W1B;
     const unsigned s1 = (unsigned)chunk * HC * RB1, s2 = (unsigned)chunk * HC * 2;
 #pragma unroll
     for (int j = 0; j < PW1; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w1_rsrc, (__attribute__((address_space(3))) void*)(d1 + j * 1024), 16, off1[j], s1, 0, 0);
+      if (j * NWV + wave < PIECES1)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w1_rsrc, (__attribute__((address_space(3))) void*)(d1 + (j * NWV + wave) * 1024), 16, off1[j], s1, 0, 0);
 #pragma unroll
     for (int j = 0; j < PW2; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w2_rsrc, (__attribute__((address_space(3))) void*)(d2 + j * 1024), 16, off2[j], s2, 0, 0);
+      if (j * NWV + wave < PIECES2)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w2_rsrc, (__attribute__((address_space(3))) void*)(d2 + (j * NWV + wave) * 1024), 16, off2[j], s2, 0, 0);
   };
 
-  const int64_t pass_tokens = 128 * TB;
+  const int64_t pass_tokens = NWV * 32 * TB;
   const int64_t n_pass = (p.T + pass_tokens - 1) / pass_tokens;
   int64_t g_chunk = 0;                                       // running chunk count of this workgroup (buffer = parity)
-  if ((int64_t)blockIdx.x < n_pass) issue(0, 0);
-  __syncthreads();                                           // parameters visible (the DMA is waited for inside the loop)
+  // RESIDENT (two chunks = the whole of W1 and W2 fit the two ring buffers: dim 96): both chunks are loaded ONCE and stay; the pass loop
+  // then has no DMA, no wait and no barrier, so the 8 waves drift apart and one wave's LayerNorm prologue / store epilogue runs under the
+  // others' MFMAs (round 4).  Otherwise the ring streams chunk c + 1 under chunk c, one barrier per chunk.
+  constexpr bool RESIDENT = (NCH == 2) && NWV == 8;
+  if ((int64_t)blockIdx.x < n_pass) {
+    issue(0, 0);
+    if constexpr (RESIDENT) issue(1, 1);
+  }
+  if constexpr (RESIDENT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                           // parameters visible (streaming form: the DMA is waited for inside the loop)
 
   for (int64_t pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
     // ---- this wave's TB token blocks: LayerNorm -> 16-bit B fragments
@@ -147,10 +160,10 @@ __global__ __launch_bounds__(256, OCC) void mlp_fused_kernel(MlpFusedParams p) {
         for (int e = 0; e < 16; ++e) accy[tb][d][e] = 0.f;
 
     for (int chunk = 0; chunk < NCH; ++chunk, ++g_chunk) {
-      const int buf = (int)(g_chunk & 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of the chunk have landed
-      __builtin_amdgcn_s_barrier();                          // ... every wave's; the other buffer is no longer read
-      {
+      const int buf = RESIDENT ? chunk : (int)(g_chunk & 1);
+      if constexpr (!RESIDENT) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the chunk have landed
+        __builtin_amdgcn_s_barrier();                        // ... every wave's; the other buffer is no longer read
         const bool more_here = chunk + 1 < NCH;
         const bool more = more_here || (pass + gridDim.x < n_pass);
         if (more) issue(more_here ? chunk + 1 : 0, buf ^ 1);
@@ -262,16 +275,16 @@ extern "C" int msam2_mlp_fused_permute_w2(const void* w2, void* w2p, int64_t dim
 // 1 when msam2_ln_mlp_residual_fwd is built for this width (hidden = 4 * dim, exact-erf GELU): dim 96 and 192 (Hiera stages 1 / 2)
 extern "C" int msam2_ln_mlp_residual_supported(int64_t dim) { return dim == 96 || dim == 192; }
 
-template <int DIM, int HC, int TB, int OCC = 1>
+template <int DIM, int HC, int TB, int OCC = 1, int NWV = 4>
 static int launch_mlp_fused(const MlpFusedParams& p, hipStream_t s) {
   constexpr int LDS = 2 * (2 * HC * DIM * 2) + (3 * DIM + 4 * DIM) * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)mlp_fused_kernel<DIM, HC, TB, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)mlp_fused_kernel<DIM, HC, TB, OCC, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  const int64_t n_pass = (p.T + 128 * TB - 1) / (128 * TB);
-  hipLaunchKernelGGL((mlp_fused_kernel<DIM, HC, TB, OCC>), dim3((unsigned)min((int64_t)256 * OCC, n_pass)), dim3(256), LDS, s, p);
+  const int64_t n_pass = (p.T + NWV * 32 * TB - 1) / (NWV * 32 * TB);
+  hipLaunchKernelGGL((mlp_fused_kernel<DIM, HC, TB, OCC, NWV>), dim3((unsigned)min((int64_t)256 * OCC, n_pass)), dim3(NWV * 64), LDS, s, p);
   return msam2_check_launch("ln_mlp_residual_fwd");
 }
 
@@ -286,8 +299,13 @@ static int ln_mlp_residual_launch(const float* x, int64_t T, int64_t dim, const 
   MSAM2_REQUIRE(x != out, "ln_mlp_residual: in-place not supported (a token's residual is re-read in the store)");
   MlpFusedParams p = {x, out, ln_w, ln_b, b1, b2, (const op16*)w1, (const op16*)w2p, T, eps, (op16*)out16};
   hipStream_t s = (hipStream_t)stream;
-  if (dim == 96) return launch_mlp_fused<96, 192, 4>(p, s);
-  return launch_mlp_fused<192, 96, 2>(p, s);
+  static const bool four = [] { const char* e = getenv("MSAM2_MLP_WAVES4"); return e && e[0] == '1'; }();   // A/B: the 4-wave form
+  if (four) {
+    if (dim == 96) return launch_mlp_fused<96, 192, 4>(p, s);
+    return launch_mlp_fused<192, 96, 2>(p, s);
+  }
+  if (dim == 96) return launch_mlp_fused<96, 192, 2, 1, 8>(p, s);
+  return launch_mlp_fused<192, 96, 1, 1, 8>(p, s);
 }
 
 extern "C" int msam2_ln_mlp_residual_fwd(const float* x, int64_t T, int64_t dim, const float* ln_w, const float* ln_b, float eps, const void* w1,
