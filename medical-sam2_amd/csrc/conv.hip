@@ -281,34 +281,12 @@ __global__ void conv3x3s2_ln_gelu_kernel(const TI* __restrict__ x, const float* 
     float acc[COUT];
 #pragma unroll
     for (int co = 0; co < COUT; ++co) acc[co] = bias[co];
-    if constexpr (CIN <= 4) {
-      // the 9 * CIN taps loaded unconditionally (clamped), then transformed, then zeroed outside the image: with `continue` per tap every
-      // load was a basic block of its own behind a full wait -- nine exposed latencies per output pixel (round 4).  Same accumulation order.
-      float tv[9][CIN];
-      bool ok[9];
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int yy = 2 * yo - 1 + ky, xx = 2 * xo - 1 + kx;
-          ok[ky * 3 + kx] = yy >= 0 && yy < H && xx >= 0 && xx < W;
-          const TI* px = x + (((int64_t)b * H + min(max(yy, 0), H - 1)) * W + min(max(xx, 0), W - 1)) * CIN;
-#pragma unroll
-          for (int ci = 0; ci < CIN; ++ci) tv[ky * 3 + kx][ci] = (float)px[ci];
-        }
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) {
-          float v = tv[tap][ci];
-          if (mask_mode == 1) v = mscale / (1.f + __expf(-v)) + mbias;
-          else if (mask_mode == 2) v = (v > 0.f ? mscale : 0.f) + mbias;
-          if (ok[tap]) {
-#pragma unroll
-            for (int co = 0; co < COUT; ++co) acc[co] += v * ws[(co * CIN + ci) * 9 + tap];
-          }
-        }
-    } else {
+    // (Round 4 tried the taps loaded unconditionally -- clamped, all nine in flight, predicated FMAs -- and one 8-byte store per pixel:
+    //  19.3 -> 16.6 us at 4 x 1024^2.  The compiler orders that form's arithmetic differently: outputs moved by one 16-bit ulp in ~1e-4 of
+    //  the rows, and the BPTT fixture's chained gradient -- whose decoder input gradient moves 8.5 % per 0.05 % of its input, DESIGN 7.2 --
+    //  went from 0.8 % to 6 % off the reference's.  Both forms are within the kernel's own tolerance; the form the fixtures were validated
+    //  with stays.)
+    {
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       const int yy = 2 * yo - 1 + ky;
@@ -338,15 +316,8 @@ __global__ void conv3x3s2_ln_gelu_kernel(const TI* __restrict__ x, const float* 
     for (int co = 0; co < COUT; ++co) var += (acc[co] - mean) * (acc[co] - mean);
     const float rstd = 1.f / sqrtf(var / COUT + 1e-6f);
     op16* py = y + i * COUT;
-    if constexpr (COUT == 4) {                                 // one 8-byte store per pixel
-      op16x4 o;
 #pragma unroll
-      for (int co = 0; co < 4; ++co) o[co] = f2op(gelu_erf((acc[co] - mean) * rstd * ln_w[co] + ln_b[co]));
-      *reinterpret_cast<op16x4*>(py) = o;
-    } else {
-#pragma unroll
-      for (int co = 0; co < COUT; ++co) py[co] = f2op(gelu_erf((acc[co] - mean) * rstd * ln_w[co] + ln_b[co]));
-    }
+    for (int co = 0; co < COUT; ++co) py[co] = f2op(gelu_erf((acc[co] - mean) * rstd * ln_w[co] + ln_b[co]));
   }
 }
 

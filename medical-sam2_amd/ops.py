@@ -166,7 +166,8 @@ def mlp_fused_permute_w2(w2: torch.Tensor) -> torch.Tensor:
 
 def ln_mlp_residual(x: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, eps: float, w1: torch.Tensor, b1: torch.Tensor, w2p: torch.Tensor,
                     b2: torch.Tensor, also16: bool = False):
-    """fp32 [T, dim] = x + fc2(GELU(fc1(LayerNorm(x)))) in one kernel (dim 96 / 192; w2p from mlp_fused_permute_w2).
+    """fp32 [T, dim] = x + fc2(GELU(fc1(LayerNorm(x)))) in one kernel (dim 96 / 192, and 384 -- opt-in in the trunk: ln_mlp_residual_supported; w2p from
+    mlp_fused_permute_w2, whose layout depends on dim).
     also16: returns (fp32 rows, the same rows in the 16-bit operand type) -- written by the same store."""
     T, dim = x.shape
     _req(x.dtype == F32 and x.is_contiguous() and w1.dtype == OP16 and w2p.dtype == OP16 and w1.shape == (4 * dim, dim) and w2p.shape == (dim, 4 * dim)

@@ -783,7 +783,7 @@ def test_hip_graph_replay(ops):
     close(out, a.float().cpu() @ w.float().cpu().t(), 2e-4, 1e-5, "graph replay")
 
 
-@pytest.mark.parametrize("dim,T", [(96, 512), (96, 4096 + 77), (192, 256), (192, 3000)])
+@pytest.mark.parametrize("dim,T", [(96, 512), (96, 4096 + 77), (192, 256), (192, 3000), (384, 64), (384, 4096 + 37)])
 def test_ln_mlp_residual_fused(ops, dim, T):
     """msam2_ln_mlp_residual_fwd (LayerNorm + fc1 + exact-erf GELU + fc2 + residual in one kernel, hieradet.py:166-167) against the
     oracle's norm2 / MLP on the same 16-bit weights: ragged token counts (partial passes, clamped rows), several passes per workgroup."""

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Fused LN + MLP block (msam2_ln_mlp_residual_fwd) against the three-launch path at the Hiera stage-1 / stage-2 shapes (B = 4, 1024^2)."""
+"""Fused LN + MLP block (msam2_ln_mlp_residual_fwd) against the three-launch path at the Hiera stage-1 / stage-2 / stage-3 shapes (B = 4, 1024^2)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import medical_sam2_amd.ops as ops  # noqa: E402
 from tools.win_attn_bench import timeit  # noqa: E402  (graph-replay timer)
 g = torch.Generator().manual_seed(0)
-for dim, T in ((96, 262144), (192, 65536)):
+for dim, T in ((96, 262144), (192, 65536), (384, 16384)):
     x = torch.randn(T, dim, generator=g).cuda()
     lw, lb = torch.ones(dim).cuda(), torch.zeros(dim).cuda()
     w1 = (torch.randn(4 * dim, dim, generator=g) / dim ** 0.5).to(ops.OP16).cuda()
