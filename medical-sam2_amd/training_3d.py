@@ -34,6 +34,9 @@ from .ops import F32, OP16, _p, _stream
 from .training import DecoderAdam, upsampled_mask_loss
 
 GROUPS = ("decoder", "memory_attention", "memory_encoder", "obj_ptr_proj")
+# train_step_3d(bounded_tape=None): volumes longer than this many slices train on the bounded tape (the memory attention of a propagated
+# slice is run a second time in the backward: +1 forward of 4 layers per slice against O(slices x keys) of saved projections)
+BOUNDED_TAPE_FROM = 16
 
 
 def _pow2(t: torch.Tensor) -> float:
@@ -57,10 +60,15 @@ def _prompt_points(pr: dict):
 
 
 @torch.no_grad()
-def volume_forward_saved(model, volume: torch.Tensor, prompts: Dict[int, dict]):
+def volume_forward_saved(model, volume: torch.Tensor, prompts: Dict[int, dict], bounded_tape: bool = False):
     """The chain of `volume.segment_volume` (single rank) with a tape.  volume [T,3,S,S] normalised, prompts {slice: {"boxes": [n,4]} |
     {"point_coords", "point_labels"}}.  model.training decides dropout, mask binarisation for the memory encoder, the pointer selection
-    and the dynamic multimask fallback exactly as in `track_step`.  Returns (tape, {slice: low-res mask logits [n,1,S/4,S/4]})."""
+    and the dynamic multimask fallback exactly as in `track_step`.  Returns (tape, {slice: low-res mask logits [n,1,S/4,S/4]}).
+    bounded_tape: the memory attention's per-layer intermediates of a propagated slice (its projections of EVERY bank key, four layers:
+    O(slices x keys) over a volume -- func_3d/function.py:130-191 trains over `video_length` slices) are NOT kept; the tape keeps what
+    selects and re-creates them -- the bank selection (references to outputs the tape holds anyway) and the dropout stream position --
+    and `volume_backward` runs that slice's memory attention forward again, one slice at a time.  Same kernels on the same inputs: the
+    gradients are those of the full tape (tests/test_bptt_gpu.py)."""
     from .modeling.common import to_bf16, tokens_of, v_f32
     T, S = volume.shape[0], model.image_size
     cond_ids = sorted(prompts)
@@ -96,9 +104,18 @@ def volume_forward_saved(model, volume: torch.Tensor, prompts: Dict[int, dict]):
             labels = -torch.ones(n, 1, dtype=torch.int32, device=dev)
             spatial, ptrs = model._select_memory(t, od, T)
             memory, memory_pos, n_ptr_tok, _ = model._assemble_memory(spatial, ptrs, n, h, w, dev)
-            y, state = bwd.memory_attention_forward_saved(ma, feats[-1], pos[-1], memory, memory_pos, n_ptr_tok, dropout=ma.next_dropout())
+            drop = ma.next_dropout()
+            y, state = bwd.memory_attention_forward_saved(ma, feats[-1], pos[-1], memory, memory_pos, n_ptr_tok, dropout=drop)
             src = y.transpose(0, 1)
-            fr.update(state=state, spatial=[owner[id(o)] for _, o in spatial], ptrs=[owner[id(p)] for p in ptrs], n_ptr_tok=n_ptr_tok)
+            fr.update(spatial=[owner[id(o)] for _, o in spatial], ptrs=[owner[id(p)] for p in ptrs], n_ptr_tok=n_ptr_tok)
+            if bounded_tape:
+                # what re-creates the state: the selection itself (references, no copies), the dropout sub-stream of this forward; the
+                # position encoding of the top level is the same for every slice and kept once
+                fr.update(mem_sel=(spatial, ptrs), drop=drop)
+                tape.setdefault("top_pos", pos[-1])
+                del state
+            else:
+                fr.update(state=state)
         src = ops.add_cast(src.reshape(n, L, C), dense.view(1, 1, C).expand(n, L, C), 1.0, F32).view(n * L, C)
         se, _ = model.sam_prompt_encoder(points=(coords, labels), boxes=None, masks=None)
         se = se.to(F32)
@@ -206,7 +223,14 @@ def volume_backward(model, tape: dict, d_low: Dict[int, torch.Tensor]) -> Dict[s
             continue                                     # src = features + no_mem_embed: nothing trained upstream
         # 4. memory attention; its d memory goes back to the slices the bank was assembled from
         s_m = _pow2(d_src)
-        _, dmemory, _, g_mem = bwd.memory_attention_backward_saved(ma, fr["state"], (d_src * s_m).view(n, L, C).transpose(0, 1))
+        state = fr.get("state")
+        if state is None:                                # bounded tape: this slice's memory attention forward again (see volume_forward_saved)
+            spatial, ptrs = fr["mem_sel"]
+            memory, memory_pos, n_ptr_tok, _ = model._assemble_memory(spatial, ptrs, n, h, w, dev)
+            _, state = bwd.memory_attention_forward_saved(ma, fr["top"], tape["top_pos"], memory, memory_pos, n_ptr_tok, dropout=fr["drop"])
+            del memory, memory_pos
+        _, dmemory, _, g_mem = bwd.memory_attention_backward_saved(ma, state, (d_src * s_m).view(n, L, C).transpose(0, 1))
+        del state
         _acc(grads["memory_attention"], g_mem, 1.0 / (s_d * s_m))
         dmemory = dmemory.to(F32) / (s_d * s_m)                                          # [Nk, n, 64]
         for i, u in enumerate(fr["spatial"]):
@@ -221,7 +245,8 @@ def volume_backward(model, tape: dict, d_low: Dict[int, torch.Tensor]) -> Dict[s
 
 @torch.no_grad()
 def train_step_3d(model, optimizers: Dict[str, DecoderAdam], volume: torch.Tensor, prompts: Dict[int, dict], targets: Dict[int, torch.Tensor],
-                  pos_weight: float = 2.0, grads_out: Optional[dict] = None, data_parallel: bool = False, group=None):
+                  pos_weight: float = 2.0, grads_out: Optional[dict] = None, data_parallel: bool = False, group=None,
+                  bounded_tape: Optional[bool] = None):
     """One iteration of func_3d/function.py:58-191 on one volume.  targets {slice: [n,1,S,S] in {0,1}} for every slice.  optimizers maps
     "decoder" (the reference's optimizer1 / `sam_layers`) and "memory_attention" / "memory_encoder" / "obj_ptr_proj" (optimizer2 /
     `mem_layers`) to DecoderAdam instances over the respective module; missing groups are left alone.
@@ -231,9 +256,12 @@ def train_step_3d(model, optimizers: Dict[str, DecoderAdam], volume: torch.Tenso
     per group: "non_prompt" / "prompt") when given.
     data_parallel: one process per GPU, every rank on its OWN volume (volumes share nothing: SURVEY 8(e) row 1): the per-group
     gradients -- true gradients, no loss scale to agree on -- are summed over the ranks in place (`parallel.allreduce_gradients_async`,
-    all groups in flight together) and averaged inside the Adam kernel; the returned losses stay this rank's."""
-    tape, low = volume_forward_saved(model, volume, prompts)
+    all groups in flight together) and averaged inside the Adam kernel; the returned losses stay this rank's.
+    bounded_tape: see `volume_forward_saved`; None = on for volumes of more than BOUNDED_TAPE_FROM slices."""
     T = volume.shape[0]
+    if bounded_tape is None:
+        bounded_tape = T > BOUNDED_TAPE_FROM
+    tape, low = volume_forward_saved(model, volume, prompts, bounded_tape=bounded_tape)
     cond = set(prompts)
     n_c, n_nc = len(cond), T - len(cond)
     d_np, d_p = {}, {}

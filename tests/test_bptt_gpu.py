@@ -191,6 +191,60 @@ def test_chain_forward_and_bptt_gradients_match_reference_autograd():
     assert per_slice_ok and all(f[1] and f[2] and f[3] for f in failures), failures
 
 
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_bounded_tape_recomputes_the_memory_attention_state(dropout):
+    """volume_forward_saved(bounded_tape=True) keeps no per-layer memory-attention intermediates (O(slices x keys) over a volume:
+    func_3d/function.py:130-191 back-propagates through `video_length` slices) and volume_backward re-runs that slice's forward: same
+    kernels on the same inputs (and, in train mode, the same dropout sub-stream), so the gradients equal the full tape's up to the order of the backward's atomic
+    fp32 sums (the forward is bit-identical), and the tape is smaller."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import medical_sam2_amd.training_3d as t3
+    from medical_sam2_amd.training import upsampled_mask_loss
+    m, G, meta, volume, prompts, targets = _case()
+    ma = m.memory_attention
+    if dropout > 0:
+        for layer in ma.layers:
+            layer.dropout_value = dropout
+    T = meta["n_slices"]
+    n_nc = T - len(prompts)
+
+    def run(bounded):
+        ma.dropout_seed, ma._dropout_calls = 7, 0                         # replay the same dropout stream in both runs
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        with torch.no_grad():
+            tape, low = t3.volume_forward_saved(m, volume, prompts, bounded_tape=bounded)
+            held = torch.cuda.memory_allocated() - base                  # what the tape (and the outputs it references) keeps alive
+            d_np = {t: upsampled_mask_loss(low[t], targets[t], 0, meta["pos_weight"])[1] / n_nc for t in range(T) if t not in prompts}
+            g = t3.volume_backward(m, tape, d_np)
+        torch.cuda.synchronize()
+        n_states = sum(1 for fr in tape["frames"].values() if fr.get("state") is not None)
+        return g, {t: low[t].clone() for t in low}, held, n_states
+
+    g_full, low_full, held_full, st_full = run(False)
+    g_bnd, low_bnd, held_bnd, st_bnd = run(True)
+    assert st_full == n_nc and st_bnd == 0
+    assert held_bnd < held_full, (held_bnd, held_full)
+    print(f"tape bytes held after the forward: full {held_full / 2**20:.1f} MiB, bounded {held_bnd / 2**20:.1f} MiB ({T} slices, dropout {dropout})")
+    for t in low_full:
+        assert torch.equal(low_full[t], low_bnd[t]), t                  # same forward, same dropout masks
+    # The weight-gradient GEMMs split K over workgroups and add with fp32 atomics (gemm.hip: split-K): their sums differ from run to run in
+    # the order of the additions -- measured between two runs: 1.5e-4 on the decoder's up-scaling weight, 1.3e-3 on a decoder q projection
+    # (the residue of the softmax Jacobian's cancellation, 300-1000x smaller than its sibling value projection: test above), neither of
+    # which the recomputation touches.  Hence: each group's gradient as ONE vector to 1e-3, single tensors to 2 %.
+    for grp in t3.GROUPS:
+        assert set(g_full[grp]) == set(g_bnd[grp]) and len(g_full[grp]) > 0, grp
+        keys = [k for k in sorted(g_full[grp]) if not k.endswith("k_proj.bias")]   # (softmax is invariant to a key bias: round-off in both runs)
+        va = torch.cat([g_full[grp][k].double().reshape(-1) for k in keys])
+        vb = torch.cat([g_bnd[grp][k].double().reshape(-1) for k in keys])
+        e_grp = float((va - vb).norm() / va.norm())
+        e_one = max(float((g_full[grp][k].double() - g_bnd[grp][k].double()).norm() / g_full[grp][k].double().norm().clamp_min(1e-30)) for k in keys)
+        print(f"bounded vs full tape, {grp}: whole-group relative difference {e_grp:.2e}, worst single tensor {e_one:.2e}")
+        assert e_grp < 1e-3 and e_one < 2e-2, (grp, e_grp, e_one)
+
+
 def test_train_step_3d_updates_the_reference_groups():
     """train_step_3d: the memory groups step on the non-prompt gradient, the decoder on both; losses reported like function.py:171-175;
     a second step on the same volume lowers the non-prompt loss' decoder-side contribution (sanity of sign and scale)"""
