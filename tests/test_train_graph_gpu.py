@@ -105,4 +105,8 @@ def test_eager_forward_between_graph_replays_keeps_weight_copies_alive():
         share = {g: sum(a for a, _ in f) / sum(b for _, b in f) for g, f in frac.items()}
         print("graph vs eager after 4 iterations: worst |d| in units of lr", worst, "share of elements off by > lr/2", share)
         assert all(w <= 8.0 for w in worst.values()), worst       # 4 steps x at most 2 lr
-        assert all(s < 0.02 for s in share.values()), share
+        # The share of such elements is a property of the atomics' noise, not of the weight copies this test is about (a stale or freed
+        # copy moves EVERY element of a tensor, and by more than 2 lr per step): measured 0.020 / 0.024 / 0.022 (encoder / memory attention /
+        # decoder) on the bf16 library in one run and under 0.02 in others -- the earlier bar of 0.02 sat inside that spread and turned the
+        # driver's command red on an unlucky run.  0.05 keeps a factor of two over the measured spread and 20x under a corrupted tensor.
+        assert all(s < 0.05 for s in share.values()), share

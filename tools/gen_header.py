@@ -17,8 +17,8 @@ DOC = {
     "msam2_gemm_tokens": "Token-side linear layers of the two-way decoder (transformer.py:165-196, 239-263): M <= 32 rows, A in fp32 from the residual\nstream, columns < add_cols computed from A + A2 (queries + query_pe), add and 16-bit conversion fused into the operand load.",
     "msam2_gemm_rope": "Linear projection with the axial RoPE of RoPEAttention fused into the store (transformer.py:241-243 + 299-315,\nposition_encoding.py:200-216): C (16-bit) = rope(A W^T + bias) on columns < rope_cols (whole heads, adjacent channel pairs) of rows\nwhose position l = m % rows_per_batch is < n_rope, with table row l % n_pos of cos/sin [n_pos, head_dim/2] (rope_k_repeat).",
     "msam2_gemm": "C[M,N] = residual[m % res_mod] + colscale[n] * act(A[M,K] W[N,K]^T + bias[n]); A, W 16-bit (K contiguous), bias/colscale\nfp32, residual/C 16-bit or fp32.  act: 0 none, 1 exact-erf GELU, 2 ReLU, 3 sigmoid.\nReplaces every nn.Linear / 1x1 Conv2d / im2col'ed conv of the path: hieradet.py:61,79,141; sam2_utils.py:127-131;\ntransformer.py:241-243,261; memory_attention.py:96; image_encoder.py:112; mask_decoder.py:240-256;\nmemory_encoder.py:103-105,171-175; sam2_base.py:470-475.",
-    "msam2_ln_mlp_residual_supported": "1 when msam2_ln_mlp_residual_fwd is built for this width (96 / 192: Hiera stages 1 and 2).",
-    "msam2_mlp_fused_permute_w2": "Kernel-ready copy of the second MLP weight for msam2_ln_mlp_residual_fwd: the hidden index of every 32-block permuted to the k order\nin which the fc1 accumulator is consumed as an MFMA operand.",
+    "msam2_ln_mlp_residual_supported": "1 when the trunk should take msam2_ln_mlp_residual_fwd at this width (96 / 192: Hiera stages 1 and 2; 384 only with MSAM2_MLP_384=1 -- built and\ncallable, but slower than its three launches: DESIGN 3.5).",
+    "msam2_mlp_fused_permute_w2": "Kernel-ready copy of the second MLP weight for msam2_ln_mlp_residual_fwd: the hidden index of every 32-block permuted to the k order\nin which the fc1 accumulator is consumed as an MFMA operand (dim 96 / 192: [dim, hidden]; dim 384: chunk-major [hidden / 32][dim][32] in the\nkernel's LDS image -- opaque to the caller, same size).",
     "msam2_ln_mlp_residual_fwd_dual": "msam2_ln_mlp_residual_fwd with the result also written in the 16-bit operand type: the last block of a Hiera stage, whose output feeds the\nFPN's lateral 1x1 convolution (image_encoder.py:95-110) -- no cast pass over the stage-1 / stage-2 feature maps (100 MB + 50 MB at 4 x 1024^2).",
     "msam2_ln_mlp_residual_fwd": "The MLP half of MultiScaleBlock.forward as ONE kernel (hieradet.py:166-167: x = x + self.mlp(self.norm2(x)); sam2_utils.py:108-132 with\nnn.GELU): LayerNorm, fc1, exact-erf GELU, fc2 and the residual add; the 4x hidden activation never leaves the registers.  Block-level\nfused entry for the two high-resolution stages (dim 96 / 192), where the three separate launches are bound by the hidden map's HBM\nround trip.",
     "msam2_layernorm_dual": "nn.LayerNorm on fp32 rows with two outputs from one pass: the fp32 rows (residual stream) and their 16-bit copy (operand of the next\nprojection) -- norm4 of the two-way block (transformer.py:190-196), whose output `keys` is both.",
