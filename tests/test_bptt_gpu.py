@@ -224,25 +224,32 @@ def test_bounded_tape_recomputes_the_memory_attention_state(dropout):
         return g, {t: low[t].clone() for t in low}, held, n_states
 
     g_full, low_full, held_full, st_full = run(False)
+    g_again, low_again, _, _ = run(False)                                # the full tape a second time: what two runs of the SAME thing differ by
     g_bnd, low_bnd, held_bnd, st_bnd = run(True)
     assert st_full == n_nc and st_bnd == 0
     assert held_bnd < held_full, (held_bnd, held_full)
     print(f"tape bytes held after the forward: full {held_full / 2**20:.1f} MiB, bounded {held_bnd / 2**20:.1f} MiB ({T} slices, dropout {dropout})")
     for t in low_full:
-        assert torch.equal(low_full[t], low_bnd[t]), t                  # same forward, same dropout masks
-    # The weight-gradient GEMMs split K over workgroups and add with fp32 atomics (gemm.hip: split-K): their sums differ from run to run in
-    # the order of the additions -- measured between two runs: 1.5e-4 on the decoder's up-scaling weight, 1.3e-3 on a decoder q projection
-    # (the residue of the softmax Jacobian's cancellation, 300-1000x smaller than its sibling value projection: test above), neither of
-    # which the recomputation touches.  Hence: each group's gradient as ONE vector to 1e-3, single tensors to 2 %.
+        assert torch.equal(low_full[t], low_bnd[t]) and torch.equal(low_full[t], low_again[t]), t   # same forward, same dropout masks
+
+    def diff(ga, gb, grp):
+        keys = [k for k in sorted(ga[grp]) if not k.endswith("k_proj.bias")]   # (softmax is invariant to a key bias: round-off in every run)
+        va = torch.cat([ga[grp][k].double().reshape(-1) for k in keys])
+        vb = torch.cat([gb[grp][k].double().reshape(-1) for k in keys])
+        one = max(float((ga[grp][k].double() - gb[grp][k].double()).norm() / ga[grp][k].double().norm().clamp_min(1e-30)) for k in keys)
+        return float((va - vb).norm() / va.norm()), one
+
+    # The weight-gradient GEMMs split K over workgroups and add with fp32 atomics (gemm.hip: split-K), so two runs of the SAME tape differ in
+    # the order of those additions, amplified by the chain (measured, whole group / worst single tensor: 3e-4 / 3e-3 on fp16 operands,
+    # 9e-4 / 2.5e-2 on bf16 -- the decoder's q projections are the residue of a cancellation, test above).  The recomputed tape is held to
+    # that measured run-to-run difference (x 4, and a floor), not to a constant: a wrong bank, seed or state would differ by tens of per cent,
+    # and the forward above is compared bit for bit.
     for grp in t3.GROUPS:
         assert set(g_full[grp]) == set(g_bnd[grp]) and len(g_full[grp]) > 0, grp
-        keys = [k for k in sorted(g_full[grp]) if not k.endswith("k_proj.bias")]   # (softmax is invariant to a key bias: round-off in both runs)
-        va = torch.cat([g_full[grp][k].double().reshape(-1) for k in keys])
-        vb = torch.cat([g_bnd[grp][k].double().reshape(-1) for k in keys])
-        e_grp = float((va - vb).norm() / va.norm())
-        e_one = max(float((g_full[grp][k].double() - g_bnd[grp][k].double()).norm() / g_full[grp][k].double().norm().clamp_min(1e-30)) for k in keys)
-        print(f"bounded vs full tape, {grp}: whole-group relative difference {e_grp:.2e}, worst single tensor {e_one:.2e}")
-        assert e_grp < 1e-3 and e_one < 2e-2, (grp, e_grp, e_one)
+        n_grp, n_one = diff(g_full, g_again, grp)
+        e_grp, e_one = diff(g_full, g_bnd, grp)
+        print(f"{grp}: bounded vs full tape {e_grp:.2e} (worst tensor {e_one:.2e}); full vs full again {n_grp:.2e} ({n_one:.2e})")
+        assert e_grp < 4 * n_grp + 2e-4 and e_one < 4 * n_one + 2e-3, (grp, e_grp, n_grp, e_one, n_one)
 
 
 def test_train_step_3d_updates_the_reference_groups():
