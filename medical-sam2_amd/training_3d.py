@@ -108,11 +108,11 @@ def volume_forward_saved(model, volume: torch.Tensor, prompts: Dict[int, dict], 
             y, state = bwd.memory_attention_forward_saved(ma, feats[-1], pos[-1], memory, memory_pos, n_ptr_tok, dropout=drop)
             src = y.transpose(0, 1)
             fr.update(spatial=[owner[id(o)] for _, o in spatial], ptrs=[owner[id(p)] for p in ptrs], n_ptr_tok=n_ptr_tok)
+            # what re-creates the state: the selection itself (references, no copies), the dropout sub-stream of this forward; the
+            # position encoding of the top level is the same for every slice and kept once
+            fr.update(mem_sel=(spatial, ptrs), drop=drop)
+            tape.setdefault("top_pos", pos[-1])
             if bounded_tape:
-                # what re-creates the state: the selection itself (references, no copies), the dropout sub-stream of this forward; the
-                # position encoding of the top level is the same for every slice and kept once
-                fr.update(mem_sel=(spatial, ptrs), drop=drop)
-                tape.setdefault("top_pos", pos[-1])
                 del state
             else:
                 fr.update(state=state)

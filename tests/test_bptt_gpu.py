@@ -191,14 +191,36 @@ def test_chain_forward_and_bptt_gradients_match_reference_autograd():
     assert per_slice_ok and all(f[1] and f[2] and f[3] for f in failures), failures
 
 
+def _same_tree(a, b, path, out):
+    """every tensor of two nested state structures, bit for bit"""
+    if torch.is_tensor(a):
+        if not (torch.is_tensor(b) and a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b)):
+            out.append(path)
+    elif isinstance(a, dict):
+        if not isinstance(b, dict) or set(a) != set(b):
+            out.append(path + " (keys)")
+            return
+        for k in a:
+            _same_tree(a[k], b[k], f"{path}.{k}", out)
+    elif isinstance(a, (list, tuple)):
+        if not isinstance(b, (list, tuple)) or len(a) != len(b):
+            out.append(path + " (length)")
+            return
+        for i, (x, y) in enumerate(zip(a, b)):
+            _same_tree(x, y, f"{path}[{i}]", out)
+    elif a != b:
+        out.append(path)
+
+
 @pytest.mark.parametrize("dropout", [0.0, 0.1])
 def test_bounded_tape_recomputes_the_memory_attention_state(dropout):
     """volume_forward_saved(bounded_tape=True) keeps no per-layer memory-attention intermediates (O(slices x keys) over a volume:
-    func_3d/function.py:130-191 back-propagates through `video_length` slices) and volume_backward re-runs that slice's forward: same
-    kernels on the same inputs (and, in train mode, the same dropout sub-stream), so the gradients equal the full tape's up to the order of the backward's atomic
-    fp32 sums (the forward is bit-identical), and the tape is smaller."""
+    func_3d/function.py:130-191 back-propagates through `video_length` slices); volume_backward re-runs that slice's forward from the
+    stored bank selection and dropout sub-stream.  (1) The re-created state equals the state the forward had saved BIT FOR BIT, every
+    tensor of every layer, with and without dropout; (2) the tape is smaller; (3) the gradients agree with the full tape's."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    import medical_sam2_amd.backward as bwd
     import medical_sam2_amd.training_3d as t3
     from medical_sam2_amd.training import upsampled_mask_loss
     m, G, meta, volume, prompts, targets = _case()
@@ -209,47 +231,56 @@ def test_bounded_tape_recomputes_the_memory_attention_state(dropout):
     T = meta["n_slices"]
     n_nc = T - len(prompts)
 
-    def run(bounded):
-        ma.dropout_seed, ma._dropout_calls = 7, 0                         # replay the same dropout stream in both runs
+    def run(bounded, check_state=False):
+        ma.dropout_seed, ma._dropout_calls = 7, 0                         # replay the same dropout stream in every run
         torch.cuda.synchronize()
-        torch.cuda.reset_peak_memory_stats()
         base = torch.cuda.memory_allocated()
         with torch.no_grad():
             tape, low = t3.volume_forward_saved(m, volume, prompts, bounded_tape=bounded)
             held = torch.cuda.memory_allocated() - base                  # what the tape (and the outputs it references) keeps alive
+            n_states = sum(1 for fr in tape["frames"].values() if fr.get("state") is not None)
+            if check_state:                                              # exactly what volume_backward does on the bounded tape
+                n = tape["n"]
+                for t in tape["order"]:
+                    fr = tape["frames"][t]
+                    if fr["cond"]:
+                        continue
+                    spatial, ptrs = fr["mem_sel"]
+                    memory, memory_pos, n_ptr_tok, _ = m._assemble_memory(spatial, ptrs, n, fr["h"], fr["w"], fr["src"].device)
+                    _, again = bwd.memory_attention_forward_saved(ma, fr["top"], tape["top_pos"], memory, memory_pos, n_ptr_tok, dropout=fr["drop"])
+                    bad = []
+                    _same_tree(fr["state"], again, f"slice{t}", bad)
+                    assert not bad, bad[:8]
+                    assert len(fr["state"]["ctxs"]) == len(ma.layers)
             d_np = {t: upsampled_mask_loss(low[t], targets[t], 0, meta["pos_weight"])[1] / n_nc for t in range(T) if t not in prompts}
             g = t3.volume_backward(m, tape, d_np)
         torch.cuda.synchronize()
-        n_states = sum(1 for fr in tape["frames"].values() if fr.get("state") is not None)
         return g, {t: low[t].clone() for t in low}, held, n_states
 
-    g_full, low_full, held_full, st_full = run(False)
-    g_again, low_again, _, _ = run(False)                                # the full tape a second time: what two runs of the SAME thing differ by
+    g_full, low_full, held_full, st_full = run(False, check_state=True)
     g_bnd, low_bnd, held_bnd, st_bnd = run(True)
     assert st_full == n_nc and st_bnd == 0
     assert held_bnd < held_full, (held_bnd, held_full)
     print(f"tape bytes held after the forward: full {held_full / 2**20:.1f} MiB, bounded {held_bnd / 2**20:.1f} MiB ({T} slices, dropout {dropout})")
     for t in low_full:
-        assert torch.equal(low_full[t], low_bnd[t]) and torch.equal(low_full[t], low_again[t]), t   # same forward, same dropout masks
-
-    def diff(ga, gb, grp):
-        keys = [k for k in sorted(ga[grp]) if not k.endswith("k_proj.bias")]   # (softmax is invariant to a key bias: round-off in every run)
-        va = torch.cat([ga[grp][k].double().reshape(-1) for k in keys])
-        vb = torch.cat([gb[grp][k].double().reshape(-1) for k in keys])
-        one = max(float((ga[grp][k].double() - gb[grp][k].double()).norm() / ga[grp][k].double().norm().clamp_min(1e-30)) for k in keys)
-        return float((va - vb).norm() / va.norm()), one
-
-    # The weight-gradient GEMMs split K over workgroups and add with fp32 atomics (gemm.hip: split-K), so two runs of the SAME tape differ in
-    # the order of those additions, amplified by the chain (measured, whole group / worst single tensor: 3e-4 / 3e-3 on fp16 operands,
-    # 9e-4 / 2.5e-2 on bf16 -- the decoder's q projections are the residue of a cancellation, test above).  The recomputed tape is held to
-    # that measured run-to-run difference (x 4, and a floor), not to a constant: a wrong bank, seed or state would differ by tens of per cent,
-    # and the forward above is compared bit for bit.
+        assert torch.equal(low_full[t], low_bnd[t]), t                  # same forward, same dropout masks
+    # Gradients.  With the state bit-identical the two backward passes do the same arithmetic; what differs is the ORDER of the fp32
+    # atomic additions of the split-K weight-gradient GEMMs (gemm.hip), which follows the kernels' timing, amplified by this fixture's
+    # ill-conditioned chain (test above).  Two runs of the FULL tape differ by the same amount: measured whole-group 2.8e-4 .. 4.1e-4
+    # between two clean runs on fp16 operands (sometimes 1e-8, when the timing repeats), and no different with the allocator's free
+    # blocks filled with NaN or 3e4 before the backward (no uninitialised read: no NaN comes out).  Bounded vs full, measured: whole group
+    # 1.3e-4 .. 4.6e-4 (fp16), up to 3.2e-3 (bf16, dropout 0.1); worst single tensor 5e-3 / 2.6e-2 (the decoder's and the memory
+    # attention's q / k projections: residues of a cancellation).  The bars are 3x the largest of those; a wrong bank, seed or state
+    # (excluded bit for bit above) would differ by tens of per cent.
     for grp in t3.GROUPS:
         assert set(g_full[grp]) == set(g_bnd[grp]) and len(g_full[grp]) > 0, grp
-        n_grp, n_one = diff(g_full, g_again, grp)
-        e_grp, e_one = diff(g_full, g_bnd, grp)
-        print(f"{grp}: bounded vs full tape {e_grp:.2e} (worst tensor {e_one:.2e}); full vs full again {n_grp:.2e} ({n_one:.2e})")
-        assert e_grp < 4 * n_grp + 2e-4 and e_one < 4 * n_one + 2e-3, (grp, e_grp, n_grp, e_one, n_one)
+        keys = [k for k in sorted(g_full[grp]) if not k.endswith("k_proj.bias")]   # (softmax is invariant to a key bias: round-off in every run)
+        va = torch.cat([g_full[grp][k].double().reshape(-1) for k in keys])
+        vb = torch.cat([g_bnd[grp][k].double().reshape(-1) for k in keys])
+        e_grp = float((va - vb).norm() / va.norm())
+        e_one = max(float((g_full[grp][k].double() - g_bnd[grp][k].double()).norm() / g_full[grp][k].double().norm().clamp_min(1e-30)) for k in keys)
+        print(f"{grp}: bounded vs full tape, whole group {e_grp:.2e}, worst single tensor {e_one:.2e}")
+        assert e_grp < 1e-2 and e_one < 8e-2, (grp, e_grp, e_one)
 
 
 def test_train_step_3d_updates_the_reference_groups():
