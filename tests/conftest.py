@@ -51,7 +51,8 @@ def pytest_sessionstart(session):
     # fp16 session and the bf16 child suite that runs beside it (tests/test_bf16_build_gpu.py) share the CPUs half and half.
     import torch
     share = host_cpu_share()
-    torch.set_num_threads(max(1, share // 2 if (os.environ.get("MSAM2_BF16_CHILD") and share >= 8) else share))
+    beside = os.environ.get("MSAM2_BF16_CHILD") and os.environ.get("MSAM2_BF16_CHILD_BESIDE") == "1"
+    torch.set_num_threads(max(1, share // 2 if (beside and share >= 8) else share))
     want = os.environ.get("MSAM2_EXPECT_OP16")
     if want:                                            # the bf16 child suite: make sure it really runs on the bf16 library
         import medical_sam2_amd.ops as ops
@@ -61,6 +62,13 @@ def pytest_sessionstart(session):
 def pytest_collection_finish(session):
     """GPU session that includes the bf16 child suite: start the child NOW so that it runs beside the fp16 tests instead of after them
     (tests/test_bf16_build_gpu.py, collected last, waits for it).  Not inside the child itself, not on a box without a GPU."""
+    # Round 4, last session: OPT-IN (MSAM2_BF16_CHILD_BESIDE=1).  Two processes on one card made timing-dependent quantities part of the
+    # verdict: the atomics-order noise of the captured training step crossed its bar in the child on one run, and on another ONE key
+    # projection of the child's memory attention came out with different bits than the same launch a second earlier (never reproduced in
+    # 240 + 240 recomputations of a process alone on the card).  By default the child now runs AFTER the fp16 tests, alone on the card:
+    # ~2.5 minutes more wall time, far inside the driver's 900 s.
+    if os.environ.get("MSAM2_BF16_CHILD_BESIDE") != "1":
+        return
     if os.environ.get("MSAM2_BF16_CHILD") or os.environ.get("MSAM2_LIB_PATH") or session.config.option.collectonly:
         return
     wanted = [it for it in session.items if "test_bf16_build_gpu" in it.nodeid]
