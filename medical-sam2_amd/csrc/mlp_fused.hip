@@ -258,7 +258,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void mlp_fused_kernel(MlpFusedParams
 // dim 384 (Hiera stage 3: 11 blocks of hiera_s, 16384 tokens at 4 x 1024^2).  OPT-IN (MSAM2_MLP_384=1), NOT the default: correct
 // (tests/test_kernels_gpu.py::test_ln_mlp_residual_fused, dim 384) and, as it stands, SLOWER than the three launches it would replace
 // (LayerNorm 9 + fc1 33 + fc2 32 us in the step; 90 us as an isolated sequence; this kernel 110-118 us).  Why it was built: what bounds the
-// two GEMMs is what a CU can take in (DESIGN 3.2: ~33 GB/s per CU of activations out of the Infinity Cache, ~70 GB/s of weights out of its
+// two GEMMs is what a CU can take in (DESIGN 3.5: ~33 GB/s per CU of activations out of the Infinity Cache, ~70 GB/s of weights out of its
 // XCD's L2), and the 50 MB hidden map goes out and comes back through exactly that path; fused, a CU takes in 96 KB of activations and the
 // 2.36 MB of W1 | W2 from L2 (~33 us at 70 GB/s) and the hidden map never exists.  Why it does not pay yet (removal ladder, round 4,
 // 16384 tokens): row loads / residual / store in the token-per-lane layout 23 us, the 36 MFMAs per wave and chunk 41 us, LDS fragment
