@@ -265,13 +265,16 @@ def test_bounded_tape_recomputes_the_memory_attention_state(dropout):
     for t in low_full:
         assert torch.equal(low_full[t], low_bnd[t]), t                  # same forward, same dropout masks
     # Gradients.  With the state bit-identical the two backward passes do the same arithmetic; what differs is the ORDER of the fp32
-    # atomic additions of the split-K weight-gradient GEMMs (gemm.hip), which follows the kernels' timing, amplified by this fixture's
-    # ill-conditioned chain (test above).  Two runs of the FULL tape differ by the same amount: measured whole-group 2.8e-4 .. 4.1e-4
-    # between two clean runs on fp16 operands (sometimes 1e-8, when the timing repeats), and no different with the allocator's free
-    # blocks filled with NaN or 3e4 before the backward (no uninitialised read: no NaN comes out).  Bounded vs full, measured: whole group
-    # 1.3e-4 .. 4.6e-4 (fp16), up to 3.2e-3 (bf16, dropout 0.1); worst single tensor 5e-3 / 2.6e-2 (the decoder's and the memory
-    # attention's q / k projections: residues of a cancellation).  The bars are 3x the largest of those; a wrong bank, seed or state
-    # (excluded bit for bit above) would differ by tens of per cent.
+    # atomic additions inside the backward (split-K sums, the attention backward's key-side accumulation), which follows the kernels'
+    # timing: a last-bit difference of an fp32 sum flips the 16-bit rounding of single elements of the next GEMM's operand (one unit
+    # round-off: 5e-4 on fp16, 4e-3 on bf16) and the chain carries it on.  Two runs of the FULL tape differ by the same amount: measured
+    # whole-group 2.8e-4 .. 4.1e-4 between two clean runs on fp16 (1e-8 when the timing repeats), no different with the allocator's free
+    # blocks filled with NaN or 3e4 before the backward (no uninitialised read: no NaN comes out).  Bounded vs full, measured over a dozen
+    # runs: whole group <= 4.6e-4 (fp16), <= 1.2e-2 (bf16, dropout 0.1, obj_ptr_proj); worst single tensor 5e-3 / 2.6e-2 (q / k
+    # projections: residues of a cancellation).  The bars sit 3-6x over those; a wrong bank, seed or state (excluded bit for bit above)
+    # would differ by tens of per cent.
+    import medical_sam2_amd.ops as ops
+    bar_grp, bar_one = (3e-3, 5e-2) if ops.OP16 == torch.float16 else (4e-2, 2e-1)
     for grp in t3.GROUPS:
         assert set(g_full[grp]) == set(g_bnd[grp]) and len(g_full[grp]) > 0, grp
         keys = [k for k in sorted(g_full[grp]) if not k.endswith("k_proj.bias")]   # (softmax is invariant to a key bias: round-off in every run)
@@ -280,22 +283,25 @@ def test_bounded_tape_recomputes_the_memory_attention_state(dropout):
         e_grp = float((va - vb).norm() / va.norm())
         e_one = max(float((g_full[grp][k].double() - g_bnd[grp][k].double()).norm() / g_full[grp][k].double().norm().clamp_min(1e-30)) for k in keys)
         print(f"{grp}: bounded vs full tape, whole group {e_grp:.2e}, worst single tensor {e_one:.2e}")
-        assert e_grp < 1e-2 and e_one < 8e-2, (grp, e_grp, e_one)
+        assert e_grp < bar_grp and e_one < bar_one, (grp, e_grp, e_one)
 
 
-def test_train_step_3d_updates_the_reference_groups():
+@pytest.mark.parametrize("bounded", [False, True])
+def test_train_step_3d_updates_the_reference_groups(bounded):
     """train_step_3d: the memory groups step on the non-prompt gradient, the decoder on both; losses reported like function.py:171-175;
-    a second step on the same volume lowers the non-prompt loss' decoder-side contribution (sanity of sign and scale)"""
+    a second step on the same volume lowers the non-prompt loss' decoder-side contribution (sanity of sign and scale).  On the full and
+    on the bounded tape (`bounded_tape`: the iteration's own switch; None = by volume length)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import medical_sam2_amd.training as tr
     import medical_sam2_amd.training_3d as t3
     m, G, meta, volume, prompts, targets = _case()
+    assert t3.BOUNDED_TAPE_FROM >= meta["n_slices"]                  # (the default would pick the full tape for this fixture)
     opts = {"decoder": tr.DecoderAdam(m.sam_mask_decoder, lr=1e-4), "memory_attention": tr.DecoderAdam(m.memory_attention, lr=1e-8),
             "memory_encoder": tr.DecoderAdam(m.memory_encoder, lr=1e-8), "obj_ptr_proj": tr.DecoderAdam(m.obj_ptr_proj, lr=1e-8)}
     before = {k: p.detach().clone() for k, p in m.named_parameters()}
     out = {}
-    r1 = t3.train_step_3d(m, opts, volume, prompts, targets, pos_weight=meta["pos_weight"], grads_out=out)
+    r1 = t3.train_step_3d(m, opts, volume, prompts, targets, pos_weight=meta["pos_weight"], grads_out=out, bounded_tape=bounded)
     assert abs(r1["non_prompt_loss"] - float(G["non_prompt_loss"][0])) < 1e-2 and abs(r1["prompt_loss"] - float(G["prompt_loss"][0])) < 1e-2
     changed = {k for k, p in m.named_parameters() if not torch.equal(p.detach(), before[k])}
     assert any(k.startswith("sam_mask_decoder.") for k in changed) and any(k.startswith("memory_encoder.") for k in changed)
@@ -304,5 +310,5 @@ def test_train_step_3d_updates_the_reference_groups():
     assert all(o.t == 1 for o in opts.values())
     losses = [r1["loss"]]
     for _ in range(3):
-        losses.append(t3.train_step_3d(m, opts, volume, prompts, targets, pos_weight=meta["pos_weight"])["loss"])
+        losses.append(t3.train_step_3d(m, opts, volume, prompts, targets, pos_weight=meta["pos_weight"], bounded_tape=bounded)["loss"])
     assert losses[-1] < losses[0], losses
